@@ -1,0 +1,368 @@
+"""TEST INFRASTRUCTURE — generates tests/golden/*.npz by RUNNING THE REFERENCE in the authoring
+container (through oracle/ref_shim.py: the reference's Python CPU branch, and its own
+op/rasterize.cpp compiled where it lies).  The fixtures are data only: seeded/closed-form
+inputs and the reference's outputs.  Re-run:  python oracle/make_golden.py
+
+Every input is a pure function of integer hashes (stylerenderer_amd/synth.py det_*), so
+the GPU box can rebuild identical inputs without any RNG agreement.
+"""
+import ctypes
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, HERE)
+sys.path.insert(0, ROOT)
+import build_ref  # noqa: E402
+import ref_shim  # noqa: E402
+from stylerenderer_amd import synth  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+T = torch.from_numpy
+
+
+def dn(shape, key):
+    return synth.det_normal(shape, key)
+
+
+def save(name, **arrays):
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **arrays)
+    print("%-28s %8.1f KB  %d arrays" % (name + ".npz", os.path.getsize(path) / 1024, len(arrays)))
+
+
+# ------------------------------------------------------------------------------- fused act
+def gold_fused_act(ns):
+    out = {}
+    for tag, shape in (("a", (2, 4, 5, 5)), ("b", (3, 8)), ("c", (2, 3, 7))):
+        x = dn(shape, 11)
+        x.reshape(-1)[::7] = 0.0                      # exact zeros: the x > 0 boundary
+        bias = dn((shape[1],), 12) * 0.5
+        # make x + bias hit exactly 0 somewhere
+        x.reshape(shape[0], shape[1], -1)[0, 1, 0] = -bias[1]
+        gy = dn(shape, 13)
+        ggx, ggb = dn(shape, 14), dn((shape[1],), 15)
+        xt, bt = T(x).requires_grad_(), T(bias).requires_grad_()
+        y = ns.op.fused_leaky_relu(xt, bt)            # CPU branch, reference op/fused_act.py:87-94
+        gx, gb = torch.autograd.grad(y, [xt, bt], T(gy), create_graph=True)
+        # double backward: d/d(gy) of <gx, ggx> + <gb, ggb>
+        gyt = T(gy).requires_grad_()
+        gx2, gb2 = torch.autograd.grad(ns.op.fused_leaky_relu(xt, bt), [xt, bt], gyt,
+                                       create_graph=True)
+        (ggo,) = torch.autograd.grad((gx2 * T(ggx)).sum() + (gb2 * T(ggb)).sum(), gyt)
+        out.update({tag + "_x": x, tag + "_bias": bias, tag + "_gy": gy, tag + "_ggx": ggx,
+                    tag + "_ggb": ggb, tag + "_y": y.detach().numpy(),
+                    tag + "_gx": gx.detach().numpy(), tag + "_gb": gb.detach().numpy(),
+                    tag + "_ggo": ggo.numpy()})
+    save("fused_act", **out)
+
+
+# ------------------------------------------------------------------------------- upfirdn2d
+UFD_CASES = [
+    # tag, in shape, taps, gain, up, down, pad
+    ("blur_up", (2, 3, 9, 9), (1, 3, 3, 1), 4.0, 1, 1, (1, 1)),       # Blur after convT (layers.py:272-275)
+    ("blur_d22", (2, 3, 8, 8), (1, 3, 3, 1), 1.0, 1, 1, (2, 2)),      # D: blur before 3x3 s2 conv
+    ("skip_up", (2, 3, 8, 8), (1, 3, 3, 1), 4.0, 2, 1, (2, 1)),       # ToRGB skip upsample
+    ("down_11", (2, 3, 8, 8), (1, 3, 3, 1), 1.0, 1, 2, (1, 1)),       # backward of skip_up / Downsample
+    ("down_22", (2, 3, 9, 9), (1, 3, 3, 1), 1.0, 1, 2, (2, 2)),
+    ("odd", (1, 2, 7, 5), (1, 3, 3, 1), 1.0, 1, 1, (1, 1)),
+    ("crop", (1, 2, 9, 9), (1, 3, 3, 1), 1.0, 1, 1, (-1, 2)),         # negative pad = crop
+    ("up3dn2", (1, 2, 6, 7), (1, 2, 1), 1.0, 3, 2, (2, 3)),           # generic path
+    ("big", (1, 1, 37, 70), (1, 3, 3, 1), 4.0, 1, 1, (1, 1)),         # spans several tiles
+]
+
+
+def gold_upfirdn2d(ns):
+    out = {}
+    for tag, shape, taps, gain, up, down, pad in UFD_CASES:
+        k = synth_kernel(taps, gain)
+        x = dn(shape, 21)
+        xt = T(x).requires_grad_()
+        y = ns.op.upfirdn2d(xt, T(k), up=up, down=down, pad=pad)     # upfirdn2d_native
+        gy = dn(tuple(y.shape), 22)
+        (gx,) = torch.autograd.grad(y, xt, T(gy))
+        out.update({tag + "_x": x, tag + "_k": k, tag + "_y": y.detach().numpy(), tag + "_gy": gy,
+                    tag + "_gx": gx.numpy(),
+                    tag + "_prm": np.array([up, down, pad[0], pad[1]], np.int64)})
+    # asymmetric, non-separable kernel pins the flip convention
+    k = np.arange(1, 10, dtype=np.float32).reshape(3, 3) / 45.0
+    x = dn((1, 2, 6, 6), 23)
+    xt = T(x).requires_grad_()
+    y = ns.op.upfirdn2d(xt, T(k), up=1, down=1, pad=(1, 1))
+    gy = dn(tuple(y.shape), 24)
+    (gx,) = torch.autograd.grad(y, xt, T(gy))
+    out.update({"asym_x": x, "asym_k": k, "asym_y": y.detach().numpy(), "asym_gy": gy,
+                "asym_gx": gx.numpy(), "asym_prm": np.array([1, 1, 1, 1], np.int64)})
+    save("upfirdn2d", **out)
+
+
+def synth_kernel(taps, gain):
+    k = np.asarray(taps, np.float32)
+    k2 = k[None, :] * k[:, None]
+    return (k2 / k2.sum() * np.float32(gain)).astype(np.float32)
+
+
+# ------------------------------------------------------------------------------- modulated conv
+def gold_modconv(ns):
+    out = {}
+    L = ns.layers
+    cases = [("plain", dict(in_channel=8, out_channel=6, kernel_size=3, style_dim=16)),
+             ("up", dict(in_channel=8, out_channel=6, kernel_size=3, style_dim=16, upsample=True)),
+             ("rgb", dict(in_channel=8, out_channel=3, kernel_size=1, style_dim=16, demodulate=False))]
+    for tag, kw in cases:
+        m = L.ModulatedConv2d(**kw)
+        synth.fill_state_dict(m.state_dict(), salt=31)
+        x = dn((2, 8, 8, 8), 32)
+        s = dn((2, 16), 33)
+        xt, st = T(x).requires_grad_(), T(s).requires_grad_()
+        y = m(xt, st)
+        gy = dn(tuple(y.shape), 34)
+        params = [m.weight, m.modulation.weight, m.modulation.bias]
+        grads = torch.autograd.grad(y, [xt, st] + params, T(gy))
+        out.update({tag + "_x": x, tag + "_s": s, tag + "_y": y.detach().numpy(), tag + "_gy": gy,
+                    tag + "_gx": grads[0].numpy(), tag + "_gs": grads[1].numpy(),
+                    tag + "_gw": grads[2].numpy(), tag + "_gmw": grads[3].numpy(),
+                    tag + "_gmb": grads[4].numpy()})
+    save("modconv", **out)
+
+
+# ------------------------------------------------------------------------------- generator
+def _noise_list(g, key):
+    noises = []
+    for i in range(g.num_layers):
+        res = (i + 5) // 2
+        noises.append(T(dn((1, 1, 2 ** res, 2 ** res), key + i)))
+    return noises
+
+
+def grad_digest(named_grads):
+    """Per-parameter (L2 norm, first 8 values) — compact pin of a whole gradient set."""
+    names = sorted(named_grads)
+    norms = np.array([float(named_grads[n].double().norm()) for n in names], np.float64)
+    heads = np.stack([np.pad(named_grads[n].reshape(-1)[:8].numpy(),
+                             (0, max(0, 8 - named_grads[n].numel()))) for n in names])
+    return names, norms, heads.astype(np.float32)
+
+
+def gold_generator(ns):
+    for tag, size, sdim, nmlp, batch in (("s8", 8, 64, 2, 2), ("s64", 64, 512, 8, 1)):
+        g = ns.model.Generator(size, sdim, nmlp)
+        synth.fill_state_dict(g.state_dict(), salt=41)
+        z = T(dn((batch, sdim), 42))
+        noise = _noise_list(g, 4300)
+        img, lat = g([z], return_latents=True, noise=noise)
+        arrays = {"image": img.detach().numpy(), "latent": lat.detach().numpy(),
+                  "n_params": np.array(sum(p.numel() for p in g.parameters())),
+                  "n_keys": np.array(len(g.state_dict()))}
+        if tag == "s8":
+            z2 = T(dn((batch, sdim), 44))
+            img2, _ = g([z, z2], inject_index=1, noise=noise)
+            arrays["image_mix"] = img2.detach().numpy()
+            img3, _ = g([z], randomize_noise=False)            # registered noise buffers
+            arrays["image_bufnoise"] = img3.detach().numpy()
+            # truncation
+            mean_lat = g.style(T(dn((4, sdim), 45))).mean(0, keepdim=True)
+            img4, _ = g([z], truncation=0.7, truncation_latent=mean_lat, noise=noise)
+            arrays["image_trunc"] = img4.detach().numpy()
+            arrays["trunc_latent"] = mean_lat.detach().numpy()
+            # first-order gradients of a fixed linear functional
+            proj = T(dn(tuple(img.shape), 46))
+            named = {n: p for n, p in g.named_parameters()}
+            used = {n: p for n, p in named.items()}
+            grads = torch.autograd.grad((img * proj).sum(), list(used.values()), allow_unused=True)
+            gd = {n: gr for n, gr in zip(used, grads) if gr is not None}
+            names, norms, heads = grad_digest(gd)
+            arrays.update({"grad_names": np.array(names), "grad_norms": norms, "grad_heads": heads,
+                           "unused": np.array(sorted(n for n, gr in zip(used, grads) if gr is None))})
+            # path-length regulariser (reference train.py:118-134 semantics), double backward
+            pl_noise = T(dn(tuple(img.shape), 47)) / np.sqrt(img.shape[2] * img.shape[3])
+            img5, lat5 = g([z], return_latents=True, noise=noise)
+            (gl,) = torch.autograd.grad((img5 * pl_noise).sum(), lat5, create_graph=True)
+            path_lengths = torch.sqrt(gl.pow(2).sum(2).mean(1))       # upstream StyleGAN2 form
+            flat = gl.view(gl.shape[0], -1)
+            path_lengths_ref = torch.sqrt((flat * flat).sum(1))        # train.py:129-131 form
+            mean0 = 0.0
+            path_mean = mean0 + 0.01 * (path_lengths_ref.mean() - mean0)
+            penalty = (path_lengths_ref - path_mean).pow(2).mean()
+            g.zero_grad()
+            penalty.backward()
+            gd2 = {n: p.grad for n, p in g.named_parameters() if p.grad is not None}
+            names2, norms2, heads2 = grad_digest(gd2)
+            arrays.update({"pl_lengths": path_lengths_ref.detach().numpy(),
+                           "pl_lengths_sg2": path_lengths.detach().numpy(),
+                           "pl_penalty": penalty.detach().numpy(),
+                           "pl_grad_names": np.array(names2), "pl_grad_norms": norms2,
+                           "pl_grad_heads": heads2})
+        save("generator_" + tag, **arrays)
+
+
+def gold_generator_with_map(ns):
+    size, sdim, nmlp, batch = 16, 64, 2, 2
+    g = ns.model.GeneratorWithMap(size, sdim, nmlp)
+    synth.fill_state_dict(g.state_dict(), salt=51)
+    v0, tri = synth.uv_ellipsoid(12, 10)
+    v = synth.random_poses(v0, batch, seed=7)
+    nrm = synth.vertex_normals(v, tri)
+    z = T(dn((batch, sdim), 52))
+    noise = _noise_list(g, 5300)
+    img, lat, maps = g([z], (T(v), T(nrm), T(tri)), return_normals=True, return_latents=True,
+                       noise=noise)
+    arrays = {"image": img.detach().numpy(), "latent": lat.detach().numpy(), "v": v, "nrm": nrm,
+              "tri": tri.astype(np.int32),
+              "n_params": np.array(sum(p.numel() for p in g.parameters()))}
+    for i, m in enumerate(maps):
+        arrays["normmap_%d" % i] = m.detach().numpy()
+    save("generator_map_s16", **arrays)
+
+
+def gold_discriminator(ns):
+    d = ns.model.Discriminator(16)
+    synth.fill_state_dict(d.state_dict(), salt=61)
+    x = T(dn((4, 3, 16, 16), 62)).requires_grad_()
+    y = d(x)
+    (gx,) = torch.autograd.grad(y.sum(), x, create_graph=True)
+    r1 = (gx * gx).reshape(4, -1).sum(1).mean()
+    d.zero_grad()
+    r1.backward()
+    gd = {n: p.grad for n, p in d.named_parameters() if p.grad is not None}
+    names, norms, heads = grad_digest(gd)
+    save("discriminator_s16", x=x.detach().numpy(), y=y.detach().numpy(), gx=gx.detach().numpy(),
+         r1=r1.detach().numpy(), r1_grad_names=np.array(names), r1_grad_norms=norms,
+         r1_grad_heads=heads, n_params=np.array(sum(p.numel() for p in d.parameters())))
+
+
+# ------------------------------------------------------------------------------- rasterizer
+def _ref_forward_with_z(capi, v, tri, h, w, persp, eps):
+    """Calls the reference's rasterize_cpu<float> loops through the extern "C" shim so the
+    z-buffer is visible."""
+    b, nv = v.shape[0], v.shape[1]
+    nf = tri.shape[-2]
+    idx = np.zeros((b, h, w, 3), np.int64)
+    c = np.zeros((b, h, w, 3), np.float32)
+    zb = np.full((b, h, w), -np.finfo(np.float32).max, np.float32)
+    P = lambda a: ctypes.c_void_p(a.ctypes.data)  # noqa: E731
+    fn = capi.ref_rasterize_cpu_f32
+    fn.restype = ctypes.c_int64
+    fn.argtypes = [ctypes.c_int64] * 5 + [ctypes.c_int] * 3 + [ctypes.c_void_p] * 5 + [ctypes.c_float]
+    fn(b, nv, nf, h, w, 0, int(tri.ndim == 2), int(persp), P(v), P(tri), P(idx), P(c), P(zb),
+       np.float32(eps))
+    return idx, c, zb
+
+
+def adversarial_mesh():
+    """16x16 screen.  Pixel centre i sits at NDC (2i+1)/16 - 1."""
+    def px(i):
+        return (2 * i + 1) / 16.0 - 1.0
+
+    def py(j):                       # screen y is flipped
+        return 1.0 - (2 * j + 1) / 16.0
+
+    V, F = [], []
+
+    def tri(p0, p1, p2):
+        base = len(V)
+        V.extend([p0, p1, p2])
+        F.append((base, base + 1, base + 2))
+
+    # two triangles sharing the diagonal edge through pixel centres, same depth -> tie, lowest id wins
+    tri((px(1), py(1), 0.25), (px(1), py(6), 0.25), (px(6), py(6), 0.25))
+    tri((px(1), py(1), 0.25), (px(6), py(6), 0.25), (px(6), py(1), 0.25))
+    # coplanar overlapping pair at equal depth, the later one must lose everywhere they overlap
+    tri((px(8), py(1), -0.5), (px(8), py(7), -0.5), (px(14), py(7), -0.5))
+    tri((px(9), py(2), -0.5), (px(9), py(7), -0.5), (px(14), py(7), -0.5))
+    # a nearer triangle overwriting part of the first pair, and a farther one hidden behind it
+    tri((px(2), py(3), 0.75), (px(2), py(6), 0.75), (px(5), py(6), 0.75))
+    tri((px(2), py(3), -0.75), (px(2), py(6), -0.75), (px(5), py(6), -0.75))
+    # zero-area triangle collapsed to a segment lying on pixel centres (row 10)
+    tri((px(2), py(10), 0.1), (px(5), py(10), 0.2), (px(9), py(10), 0.3))
+    # zero-area triangle collapsed to a point exactly on a pixel centre
+    tri((px(12), py(10), 0.4), (px(12), py(10), 0.4), (px(12), py(10), 0.4))
+    # back-facing (clockwise) triangle: culled
+    tri((px(1), py(12), 0.0), (px(6), py(14), 0.0), (px(1), py(14), 0.0))
+    # sliver + sub-pixel triangle (bbox may be empty)
+    tri((px(9) + 0.01, py(12), 0.0), (px(9) + 0.02, py(14), 0.0), (px(9) + 0.03, py(14), 0.0))
+    tri((px(11) + 0.01, py(12) - 0.01, 0.0), (px(11) + 0.02, py(12) - 0.03, 0.0),
+        (px(11) + 0.04, py(12) - 0.03, 0.0))
+    # partly off-screen
+    tri((px(12), py(12), 0.0), (px(12), py(20), 0.0), (px(20), py(20), 0.0))
+    v = np.asarray(V, np.float32)
+    f = np.asarray(F, np.int64)
+    f = np.concatenate([f, [[0, 1, len(V)]], [[-1, 2, 3]]], 0)       # out-of-range ids: skipped
+    return v, f
+
+
+def gold_raster(ns):
+    capi = build_ref.load_capi()
+    rop = ns.rasterize_op
+    # (i) the reference's only known-answer test (op/rasterize.py:83-107), float64
+    v = np.array([[[-1, -1, 0], [-1, 1, 0], [1, 0, 0]]], np.float64)
+    f = np.array([[2, 1, 0]], np.int64)
+    t = np.array([[[1, 0], [0, 1], [0, 0]]], np.float64)
+    vt, tt = T(v).requires_grad_(), T(t).requires_grad_()
+    o = ns.op.rasterize(vt, tt, T(f), 5)
+    idx, coeff = rop.forward(T(v), T(f), 5, 0, False, 1e-6)
+    go = synth.det_normal((1, 5, 5, 2), 71).astype(np.float64)
+    gv, gt = torch.autograd.grad(o, [vt, tt], T(go))
+    save("raster_kat", v=v, f=f, tex=t, out=o.detach().numpy(), index=idx.numpy().astype(np.int32),
+         coeff=coeff.numpy(), grad_out=go, grad_v=gv.numpy(), grad_tex=gt.numpy(),
+         dcoeff=rop.backward(T(v), idx, False, 1e-6).numpy())
+
+    # (ii) ellipsoid, per-sample pose, fp32
+    v0, tri = synth.uv_ellipsoid(20, 18)
+    vb = synth.random_poses(v0, 2, seed=3)
+    nrm = synth.vertex_normals(vb, tri)
+    for res in (32, 64):
+        idx, c, zb = _ref_forward_with_z(capi, vb, tri, res, res, False, 1e-6)
+        idx2, c2 = rop.forward(T(vb), T(tri), res, 0, False, 1e-6)
+        assert np.array_equal(idx, idx2.numpy()) and np.array_equal(c, c2.numpy())
+        vt, tt = T(vb).requires_grad_(), T(nrm).requires_grad_()
+        o = ns.op.rasterize(vt, tt, T(tri), res)
+        go = synth.det_normal(tuple(o.shape), 72)
+        gv, gt = torch.autograd.grad(o, [vt, tt], T(go))
+        save("raster_ellipsoid_%d" % res, v=vb, tri=tri.astype(np.int32), tex=nrm,
+             index=idx.astype(np.int32), coeff=c, zbuf=zb, out=o.detach().numpy(), grad_out=go,
+             grad_v=gv.numpy(), grad_tex=gt.numpy(),
+             dcoeff=rop.backward(T(vb), T(idx), False, 1e-6).numpy())
+    # perspective variant (z < 0)
+    vp = vb.copy()
+    vp[..., 2] -= 3.0
+    idx, c, zb = _ref_forward_with_z(capi, vp, tri, 32, 32, True, 1e-6)
+    save("raster_perspective_32", v=vp, tri=tri.astype(np.int32), index=idx.astype(np.int32),
+         coeff=c, zbuf=zb, dcoeff=rop.backward(T(vp), T(idx), True, 1e-6).numpy())
+
+    # (iii) adversarial cases
+    va, fa = adversarial_mesh()
+    vab = np.stack([va, va * np.float32(0.9)], 0)
+    idx, c, zb = _ref_forward_with_z(capi, vab, fa, 16, 16, False, 1e-6)
+    save("raster_adversarial_16", v=vab, tri=fa.astype(np.int32), index=idx.astype(np.int32),
+         coeff=c, zbuf=zb, dcoeff=rop.backward(T(vab), T(idx), False, 1e-6).numpy())
+    # per-sample topology [b,f,3] and back-facing-only mesh (everything culled -> zeros)
+    fb = np.stack([fa, fa[::-1].copy()], 0)
+    idx, c, zb = _ref_forward_with_z(capi, vab, fb, 16, 16, False, 1e-6)
+    flipped = tri[:, ::-1].copy()
+    idx_bf, c_bf, zb_bf = _ref_forward_with_z(capi, vb, flipped, 32, 32, False, 1e-6)
+    save("raster_misc", v=vab, tri_b=fb.astype(np.int32), index_b=idx.astype(np.int32), coeff_b=c,
+         zbuf_b=zb, v_bf=vb, tri_bf=flipped.astype(np.int32), index_bf=idx_bf.astype(np.int32),
+         coeff_bf=c_bf, covered_bf=np.array(int((idx_bf != 0).any(-1).sum())))
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    ns = ref_shim.load()
+    torch.manual_seed(0)
+    which = sys.argv[1:] or ["fused", "ufd", "modconv", "gen", "gwm", "disc", "raster"]
+    table = {"fused": gold_fused_act, "ufd": gold_upfirdn2d, "modconv": gold_modconv,
+             "gen": gold_generator, "gwm": gold_generator_with_map, "disc": gold_discriminator,
+             "raster": gold_raster}
+    with torch.no_grad():
+        pass
+    for k in which:
+        table[k](ns)
+
+
+if __name__ == "__main__":
+    main()
