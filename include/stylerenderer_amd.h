@@ -1,0 +1,149 @@
+/*
+ * stylerenderer_amd — C ABI of the MI355X-native (gfx950) StyleRenderer generator hot path.
+ *
+ * One shared library, libstylerenderer_hip.so, built from the .hip sources under stylerenderer_amd/csrc.
+ * Every entry point is extern "C", takes plain device pointers + sizes + an explicit HIP
+ * stream, allocates nothing, keeps no state and never synchronises the host (all calls are
+ * hipGraph-capturable).  Each function states which reference interface it replaces
+ * (paths relative to the reference repository WestlyPark/StyleRenderer).
+ *
+ * Ownership: the caller allocates every buffer (inputs contiguous, fp32 unless noted).
+ * Errors: 0 on success; a negative SR_E* code for a rejected argument; a positive value is the
+ * hipError_t of a failed launch.  sr_error_string() maps either to text.  (The reference's
+ * native functions return `bool` and never check anything, op/upfirdn2d_kernel.cu:205-257.)
+ *
+ * Threading: any host thread; the kernels are enqueued on `stream` (pass the framework's
+ * current stream — the reference uses c10::cuda::getCurrentCUDAStream for two ops,
+ * op/fused_bias_act_kernel.cu:78-80, and the legacy default stream for the rasterizer,
+ * op/rasterize.cu:89-92, which is deliberately not reproduced).
+ */
+#ifndef STYLERENDERER_AMD_H_
+#define STYLERENDERER_AMD_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* sr_stream_t; /* hipStream_t */
+
+#define SR_OK 0
+#define SR_EINVAL (-1)   /* bad size / null pointer / unsupported combination */
+#define SR_ERANGE (-2)   /* size exceeds what the kernel indexes */
+
+const char* sr_error_string(int code);
+/* ABI version of this header; bumped on any signature change. */
+int sr_abi_version(void);
+
+/* ---------------------------------------------------------------------------------------
+ * fused bias + activation
+ * Replaces  bool fused_bias_act_op(float* y, const float* x, const float* b, const float* ref,
+ *             int act, int grad, float alpha, float scale, int size_x, int step_b, int size_b,
+ *             int use_bias, int use_ref, int use_cuda)   reference op/fused_bias_act_kernel.cu:71-76
+ * (arithmetic: op/fused_bias_act_kernel.cu:15-42).  out[i] = f(x[i] + b[(i / step_b) % size_b]) * scale,
+ * f selected by act*10+grad: 30 lrelu(x), 31 lrelu'(ref)*x, 32/12 zero, else identity.
+ * Sizes are 64-bit here (the reference's `int` caps tensors at 2^31 elements). */
+int sr_fused_bias_act(float* y, const float* x, const float* b, const float* ref, int act, int grad,
+                      float alpha, float scale, int64_t size_x, int64_t step_b, int64_t size_b,
+                      int use_bias, int use_ref, sr_stream_t stream);
+
+/* Backward of the fused activation with the bias gradient reduced in the same pass.
+ * Replaces the pair {fused_bias_act(gy, empty, out, 3, 1, ..) ; grad_input.sum(dims != 1)}
+ * of reference op/fused_act.py:29-38.  x layout [n, c, inner]:
+ *   gx[i]    = (out[i] > 0 ? gy[i] : alpha * gy[i]) * scale
+ *   gb[ch]   = sum over n, inner of gx                      (deterministic two-stage tree)
+ * `partial` is caller scratch of sr_fused_act_bwd_scratch_floats(n, c, inner) floats. */
+int64_t sr_fused_act_bwd_scratch_floats(int64_t n, int64_t c, int64_t inner);
+int sr_fused_act_bwd(float* gx, float* gb, const float* gy, const float* out, float alpha,
+                     float scale, int64_t n, int64_t c, int64_t inner, float* partial,
+                     sr_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
+ * upfirdn2d: zero-insert upsample -> pad/crop -> 2-D FIR (correlation with the flipped kernel)
+ * -> decimate.  Replaces  bool upfirdn2d_op(float* out, const float* x, const float* k,
+ *             UpFirDn2DKernelParams& p, int mode, int use_cuda)
+ * reference op/upfirdn2d_kernel.cu:205-206 with the struct of op/upfirdn2d.cpp:2-22 flattened into
+ * scalars (minor_dim is always 1 in the reference's callers, op/upfirdn2d.py:99,122, and is not
+ * carried).  x is [major, in_h, in_w], out is [major, out_h, out_w] with
+ * out = (in*up + pad0 + pad1 - k) / down + 1  (op/upfirdn2d.py:103-104); the caller passes the
+ * out sizes it allocated and they are checked.  `k` is the [kh, kw] kernel in DEVICE memory. */
+int sr_upfirdn2d(float* out, const float* x, const float* k, int64_t major, int in_h, int in_w,
+                 int out_h, int out_w, int kh, int kw, int up_x, int up_y, int down_x, int down_y,
+                 int pad_x0, int pad_x1, int pad_y0, int pad_y1, sr_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
+ * 3DMM triangle rasterizer (z-buffered, deterministic; results equal the reference's
+ * SEQUENTIAL CPU loops bit for bit: op/rasterize.cpp:21-67).
+ * Replaces  bool rasterize_gpu<scalar,index>(b, nv, nf, h, w, repeat_v, repeat_f, perspective,
+ *             const scalar* v, const index* f, index* i, scalar* c, scalar* zB, scalar eps)
+ * reference op/rasterize.cu:84-88.
+ *   v     [b, nv, 3] (or [nv, 3] when repeat_v)         tri  int64 [nf, 3] (or [b, nf, 3])
+ *   index int64 [b, h, w, 3]   coeff [b, h, w, 3]       zbuf [b, h, w] or NULL
+ * Unlike the reference the outputs need NOT be pre-initialised: every pixel is written
+ * (uncovered: index 0, coeff 0, zbuf -MAX).  `work` is caller scratch of
+ * sr_rasterize_scratch_bytes(b, h, w, is_double) bytes.
+ * Optional fused attribute interpolation (reference op/rasterize.py:29-37): when `tex` != NULL,
+ * attr[b,h,w,c] = sum_k tex[index_k, :] * coeff_k  with tex [b*nv (or nv), c]. */
+int64_t sr_rasterize_scratch_bytes(int64_t b, int64_t h, int64_t w, int is_double);
+int sr_rasterize_forward_f32(int64_t b, int64_t nv, int64_t nf, int64_t h, int64_t w, int repeat_v,
+                             int repeat_f, int perspective, const float* v, const int64_t* tri,
+                             int64_t* index, float* coeff, float* zbuf, float eps,
+                             const float* tex, int64_t tex_c, float* attr, void* work,
+                             sr_stream_t stream);
+int sr_rasterize_forward_f64(int64_t b, int64_t nv, int64_t nf, int64_t h, int64_t w, int repeat_v,
+                             int repeat_f, int perspective, const double* v, const int64_t* tri,
+                             int64_t* index, double* coeff, double* zbuf, double eps,
+                             const double* tex, int64_t tex_c, double* attr, void* work,
+                             sr_stream_t stream);
+
+/* d(coeff)/d(vertex) per pixel.  Replaces  bool rasterize_gpu_backward<scalar,index>(b, n, h, w,
+ *   repeat_v, perspective, const scalar* v, const index* i, scalar* dcoeff, scalar eps)
+ * reference op/rasterize.cu:124-127 (arithmetic op/rasterize.h:169-228).  dcoeff [b,h,w,3,9];
+ * every pixel is written (zeros where the reference leaves its torch::zeros untouched). */
+int sr_rasterize_backward_f32(int64_t b, int64_t n, int64_t h, int64_t w, int repeat_v,
+                              int perspective, const float* v, const int64_t* index, float* dcoeff,
+                              float eps, sr_stream_t stream);
+int sr_rasterize_backward_f64(int64_t b, int64_t n, int64_t h, int64_t w, int repeat_v,
+                              int perspective, const double* v, const int64_t* index,
+                              double* dcoeff, double eps, sr_stream_t stream);
+
+/* Fused backward of `rasterize` (reference op/rasterize.py:39-80: dcoeff, [1x3]@[3x9], and two
+ * sparse scatter matmuls) without materialising dcoeff or a COO matrix:
+ *   grad_v  [rows, 3] += sum_pixels (grad_out . tex[index_i]) * dcoeff[i, :]
+ *   grad_tex[rows, c] += grad_out * coeff_k
+ * rows = b*nv.  Both outputs must be zeroed by the caller; either may be NULL.  Accumulation
+ * uses fp32/fp64 atomics (summation order is not fixed — the reference's sparse mm is not
+ * ordered either). */
+int sr_rasterize_grad_f32(int64_t b, int64_t nv, int64_t h, int64_t w, int repeat_v, int perspective,
+                          const float* v, const float* tex, int64_t tex_c, const int64_t* index,
+                          const float* coeff, const float* grad_out, float* grad_v,
+                          float* grad_tex, float eps, sr_stream_t stream);
+int sr_rasterize_grad_f64(int64_t b, int64_t nv, int64_t h, int64_t w, int repeat_v, int perspective,
+                          const double* v, const double* tex, int64_t tex_c, const int64_t* index,
+                          const double* coeff, const double* grad_out, double* grad_v,
+                          double* grad_tex, double eps, sr_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Dense contraction of the modulated convolution on the matrix cores (exact fp32 MFMA).
+ * The reference has no native code here: it calls torch's F.conv2d / F.conv_transpose2d with
+ * groups = batch on per-sample weight copies (reference layers.py:293-323).  These entry points
+ * are what a host binding calls instead.
+ *
+ *   out[b,n,oy,ox] = oscale[b,n] * sum_{ky,kx,c} wt[ky*k+kx][c][n] * iscale[b,c] * in[b,c,iy,ix] + obias[n]
+ *
+ *   in  [B, C, IH, IW]   out [B, N, OH, OW]   wt [k*k, C, N]  (N contiguous)
+ *   iscale [B, C] | NULL   oscale [B, N] | NULL   obias [N] | NULL
+ *   transposed = 0: correlation, iy = oy*stride + ky - pad   (k in {1,3}, stride in {1,2})
+ *   transposed = 1: k = 3, stride = 2, pad = 0: out[2y+ky, 2x+kx] += in[y,x] * wt[ky*3+kx]
+ *                   (OH = 2*IH + 1), the stride-2 transposed conv of the upsampling layers. */
+int sr_conv2d_mfma(float* out, const float* in, const float* wt, const float* iscale,
+                   const float* oscale, const float* obias, int64_t B, int64_t C, int64_t N,
+                   int64_t IH, int64_t IW, int64_t OH, int64_t OW, int ksize, int stride, int pad,
+                   int transposed, sr_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* STYLERENDERER_AMD_H_ */

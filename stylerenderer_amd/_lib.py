@@ -1,0 +1,85 @@
+"""ctypes binding of libstylerenderer_hip.so (the C ABI declared in include/stylerenderer_amd.h).
+
+The product path for device tensors goes through this module only.  There is no fallback:
+if the shared library is missing or does not export a declared symbol, `lib()` raises.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libstylerenderer_hip.so")
+
+_i = ctypes.c_int
+_l = ctypes.c_int64
+_f = ctypes.c_float
+_d = ctypes.c_double
+_p = ctypes.c_void_p
+
+# name -> (restype, argtypes); mirrors include/stylerenderer_amd.h line by line
+SIGNATURES = {
+    "sr_error_string": (ctypes.c_char_p, [_i]),
+    "sr_abi_version": (_i, []),
+    "sr_fused_bias_act": (_i, [_p, _p, _p, _p, _i, _i, _f, _f, _l, _l, _l, _i, _i, _p]),
+    "sr_fused_act_bwd_scratch_floats": (_l, [_l, _l, _l]),
+    "sr_fused_act_bwd": (_i, [_p, _p, _p, _p, _f, _f, _l, _l, _l, _p, _p]),
+    "sr_upfirdn2d": (_i, [_p, _p, _p, _l] + [_i] * 14 + [_p]),
+    "sr_rasterize_scratch_bytes": (_l, [_l, _l, _l, _i]),
+    "sr_rasterize_forward_f32": (_i, [_l] * 5 + [_i] * 3 + [_p] * 5 + [_f, _p, _l, _p, _p, _p]),
+    "sr_rasterize_forward_f64": (_i, [_l] * 5 + [_i] * 3 + [_p] * 5 + [_d, _p, _l, _p, _p, _p]),
+    "sr_rasterize_backward_f32": (_i, [_l] * 4 + [_i] * 2 + [_p] * 3 + [_f, _p]),
+    "sr_rasterize_backward_f64": (_i, [_l] * 4 + [_i] * 2 + [_p] * 3 + [_d, _p]),
+    "sr_rasterize_grad_f32": (_i, [_l] * 4 + [_i] * 2 + [_p, _p, _l] + [_p] * 5 + [_f, _p]),
+    "sr_conv2d_mfma": (_i, [_p] * 6 + [_l] * 7 + [_i] * 4 + [_p]),
+    "sr_rasterize_grad_f64": (_i, [_l] * 4 + [_i] * 2 + [_p, _p, _l] + [_p] * 5 + [_d, _p]),
+}
+
+_lib = None
+
+
+class NativeLibraryError(RuntimeError):
+    pass
+
+
+def lib():
+    """Loads the HIP library once.  Raises NativeLibraryError when it is absent or incomplete."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.isfile(LIB_PATH):
+        raise NativeLibraryError(
+            "stylerenderer_amd: %s not found. Build it with `python -c 'import __graft_entry__ as g; "
+            "g.build()'` (hipcc --offload-arch=gfx950). There is no CPU/PyTorch fallback for device "
+            "tensors." % LIB_PATH)
+    try:
+        handle = ctypes.CDLL(LIB_PATH)
+    except OSError as e:
+        raise NativeLibraryError("stylerenderer_amd: cannot load %s: %s" % (LIB_PATH, e))
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(handle, name)
+        except AttributeError:
+            raise NativeLibraryError("stylerenderer_amd: %s does not export %s" % (LIB_PATH, name))
+        fn.restype = res
+        fn.argtypes = args
+    _lib = handle
+    return _lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = lib().sr_error_string(rc)
+        raise RuntimeError("%s failed: %s (code %d)" % (what or "stylerenderer_amd call",
+                                                        msg.decode() if msg else "?", rc))
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL).  Zero-size tensors map to NULL."""
+    if t is None or t.numel() == 0:
+        return None
+    return t.data_ptr()
+
+
+def current_stream(device=None):
+    import torch
+
+    return torch.cuda.current_stream(device).cuda_stream

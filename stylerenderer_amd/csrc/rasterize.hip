@@ -1,0 +1,685 @@
+// Deterministic z-buffer triangle rasterizer for gfx950, bit-exact against the reference's
+// SEQUENTIAL CPU loops (reference op/rasterize.cpp:21-67, arithmetic op/rasterize.h:10-228).
+//
+// The reference's CUDA kernel (op/rasterize.cu:40-83) is racy: atomicMax on the depth followed by
+// a non-atomic re-read and unordered stores of weights/ids (op/rasterize.h:143-154), launched as
+// only `b` blocks on the legacy default stream.  This file is a different algorithm:
+//
+//   pass 1  k_depth_keys   one lane per (sample, triangle), ~b*nf lanes (>> 256 CUs x 64): exact
+//           triangle setup, bbox walk, and ONE 64-bit atomicMax per covered pixel on the packed key
+//           (orderable(z) << 32) | (0xFFFFFFFE - t).  max key == "largest z, ties -> lowest
+//           triangle id" == the outcome of the CPU's in-order `if (zB < z)` sweep.
+//   pass 2  k_resolve      one lane per pixel: decode the winner, redo its setup with the same
+//           device functions (IEEE ops, no contraction => same bits as pass 1 and as x86), write
+//           ids (+ nv*batch), weights, depth and, optionally, interpolated attributes.  Every
+//           pixel is written, so no pre-initialised outputs and no float atomics are needed.
+//   fp64    a 64-bit depth cannot share a word with the id: pass 1a atomicMax(orderable(z)),
+//           pass 1b atomicMin(t) among lanes whose depth equals the maximum, then pass 2.
+//
+// Bit-exactness rules: compiled with -ffp-contract=off (x86-64 baseline has no
+// FMA), correctly-rounded fp32 division (hipcc default, kept explicit in the build), f32
+// subnormals preserved (hipcc default kernel mode), `x - .5` evaluated in fp32 (equal to the
+// reference's double-literal form for every float input), (h, w) passed swapped into the setup
+// exactly like the reference's call sites, float->int64 casts with x86 semantics.
+//
+// Backward: k_dcoeff (API parity with rasterize_gpu_backward, coalesced through LDS) and
+// k_grad_fused (dcoeff never materialised; atomics scatter straight to grad_v / grad_tex).
+#include <float.h>
+
+#include "common.h"
+
+namespace {
+
+template <typename R> struct Lim;
+template <> struct Lim<float> {
+    static __host__ __device__ float lowest() { return -FLT_MAX; }
+};
+template <> struct Lim<double> {
+    static __host__ __device__ double lowest() { return -DBL_MAX; }
+};
+
+// Triangle state held as named scalars (never arrays: runtime-indexed arrays would be demoted
+// to scratch memory).  p*: vertices (x, y in screen space after setup, z untouched);
+// e0..e2 edge constants, e3..e5 d/dx, e6..e8 d/dy; area = |signed area sum|.
+template <typename R>
+struct Tri {
+    R p0, p1, p2, p3, p4, p5, p6, p7, p8;
+    R e0, e1, e2, e3, e4, e5, e6, e7, e8;
+    R area;
+    int x0, x1, y0, y1;
+};
+
+// (int64_t) cast as x86-64 cvtts[sd]2si performs it: NaN / out of range -> INT64_MIN.
+template <typename R>
+__device__ __forceinline__ long long to_i64_x86(R f) {
+    if (f >= (R)-9223372036854775808.0 && f < (R)9223372036854775808.0) return (long long)f;
+    return (long long)0x8000000000000000ULL;
+}
+
+template <typename R> __device__ __forceinline__ R r_ceil(R x);
+template <> __device__ __forceinline__ float r_ceil<float>(float x) { return ceilf(x); }
+template <> __device__ __forceinline__ double r_ceil<double>(double x) { return ceil(x); }
+template <typename R> __device__ __forceinline__ R r_floor(R x);
+template <> __device__ __forceinline__ float r_floor<float>(float x) { return floorf(x); }
+template <> __device__ __forceinline__ double r_floor<double>(double x) { return floor(x); }
+
+// One vertex to screen space; false = rejected by the perspective near test.
+template <typename R>
+__device__ __forceinline__ bool to_screen(R& x, R& y, const R z, R sw, R sh, bool perspective, R eps) {
+    if (perspective) {
+        if (z >= -eps) return false;
+        x = x / -z;
+        y = y / -z;
+    }
+    const R sx = (1 + x) * sw / 2;
+    const R sy = (1 - y) * sh / 2;
+    x = sx - (R)0.5;
+    y = sy - (R)0.5;
+    return true;
+}
+
+template <typename R>
+__device__ __forceinline__ void grow(R& lo, R& hi, R q) {
+    // `if (lo > q) lo = q; else if (hi < q) hi = q;` as value selects (reference op/rasterize.h:27-34)
+    const bool below = lo > q;
+    const bool above = !below && (hi < q);
+    lo = below ? q : lo;
+    hi = above ? q : hi;
+}
+
+// Triangle setup.  sw / sh are what the reference's barycentric() receives as (w, h): the callers
+// pass (h_arg, w_arg).  Returns false when the triangle is rejected.
+template <typename R>
+__device__ __forceinline__ bool tri_setup(Tri<R>& t, long long sw, long long sh, bool perspective,
+                                          R eps) {
+    const R fw = (R)sw, fh = (R)sh;
+    if (!to_screen<R>(t.p0, t.p1, t.p2, fw, fh, perspective, eps)) return false;
+    if (!to_screen<R>(t.p3, t.p4, t.p5, fw, fh, perspective, eps)) return false;
+    if (!to_screen<R>(t.p6, t.p7, t.p8, fw, fh, perspective, eps)) return false;
+    R lo_u = t.p0, hi_u = t.p0, lo_v = t.p1, hi_v = t.p1;
+    grow<R>(lo_u, hi_u, t.p3);
+    grow<R>(lo_v, hi_v, t.p4);
+    grow<R>(lo_u, hi_u, t.p6);
+    grow<R>(lo_v, hi_v, t.p7);
+    long long x0 = to_i64_x86<R>(r_ceil<R>(lo_u)), x1 = to_i64_x86<R>(r_floor<R>(hi_u));
+    long long y0 = to_i64_x86<R>(r_ceil<R>(lo_v)), y1 = to_i64_x86<R>(r_floor<R>(hi_v));
+    if (x0 < 0) x0 = 0;
+    if (x1 > sw - 1) x1 = sw - 1;
+    if (y0 < 0) y0 = 0;
+    if (y1 > sh - 1) y1 = sh - 1;
+    if (x1 < x0 || y1 < y0) return false;
+    t.x0 = (int)x0; t.x1 = (int)x1; t.y0 = (int)y0; t.y1 = (int)y1;
+
+    R m0 = t.p3 * t.p7, m1 = t.p4 * t.p6;
+    t.e0 = m0 - m1;
+    m0 = t.p1 * t.p6; m1 = t.p0 * t.p7;
+    t.e1 = m0 - m1;
+    m0 = t.p0 * t.p4; m1 = t.p1 * t.p3;
+    t.e2 = m0 - m1;
+    R det = t.e0 + t.e1;
+    det = det + t.e2;
+    if (det > eps) return false;
+    t.e3 = t.p4 - t.p7;
+    t.e4 = t.p7 - t.p1;
+    t.e5 = t.p1 - t.p4;
+    t.e6 = t.p6 - t.p3;
+    t.e7 = t.p0 - t.p6;
+    t.e8 = t.p3 - t.p0;
+    if (det < 0) {
+        t.e0 = -t.e0; t.e1 = -t.e1; t.e2 = -t.e2;
+        t.e3 = -t.e3; t.e4 = -t.e4; t.e5 = -t.e5;
+        t.e6 = -t.e6; t.e7 = -t.e7; t.e8 = -t.e8;
+        t.area = -det;
+    } else {
+        t.area = det;
+    }
+    return true;
+}
+
+template <typename R>
+__device__ __forceinline__ void edge_values(const Tri<R>& t, R px, R py, R& c0, R& c1, R& c2) {
+    R gx = t.e3 * px, gy = t.e6 * py;
+    R a = t.e0 + gx;
+    c0 = a + gy;
+    gx = t.e4 * px; gy = t.e7 * py;
+    a = t.e1 + gx;
+    c1 = a + gy;
+    gx = t.e5 * px; gy = t.e8 * py;
+    a = t.e2 + gx;
+    c2 = a + gy;
+}
+
+#define SR_SEL3(a0, a1, a2, n) ((n) == 0 ? (a0) : ((n) == 1 ? (a1) : (a2)))
+
+// Launders a value through an empty asm so that a later select between such values cannot be
+// folded back into a runtime-indexed load of the triangle struct (which would force the whole
+// struct into scratch memory).  Emits no instruction.
+__device__ __forceinline__ float opaque(float x) { asm volatile("" : "+v"(x)); return x; }
+__device__ __forceinline__ double opaque(double x) { asm volatile("" : "+v"(x)); return x; }
+
+// Barycentric weights from the edge values; false = pixel outside.
+template <typename R>
+__device__ __forceinline__ bool pixel_weights(const Tri<R>& t, R px, R py, R& c0, R& c1, R& c2, R eps) {
+    if (c0 < -eps || c1 < -eps || c2 < -eps) return false;
+    if (t.area > eps) {
+        R s = c0 + c1;
+        s = s + c2;
+        c0 = c0 / s;
+        c1 = c1 / s;
+        c2 = c2 / s;
+        return true;
+    }
+    // zero-area triangle: longest edge (segment) or a point (reference op/rasterize.h:87-121).
+    const R E3 = opaque(t.e3), E4 = opaque(t.e4), E5 = opaque(t.e5);
+    const R E6 = opaque(t.e6), E7 = opaque(t.e7), E8 = opaque(t.e8);
+    const R P0 = opaque(t.p0), P1 = opaque(t.p1), P3 = opaque(t.p3);
+    const R P4 = opaque(t.p4), P6 = opaque(t.p6), P7 = opaque(t.p7);
+    R l0, l1, l2;
+    {
+        R a = E3 * E3, b = E6 * E6;
+        l0 = a + b;
+        a = E4 * E4; b = E7 * E7;
+        l1 = a + b;
+        a = E5 * E5; b = E8 * E8;
+        l2 = a + b;
+    }
+    l0 = opaque(l0); l1 = opaque(l1); l2 = opaque(l2);
+    int i = (l0 > l1) ? 0 : 1;
+    const R li_len = (i == 0) ? l0 : l1;
+    i = (li_len > l2) ? i : 2;
+    const R lmax = (i == 2) ? l2 : li_len;
+    const int j = (i == 2) ? 0 : i + 1, k = (j == 2) ? 0 : j + 1;
+    const R e3i = SR_SEL3(E3, E4, E5, i), e6i = SR_SEL3(E6, E7, E8, i);
+    R ci, cj, ck;
+    bool inside;
+    if (lmax > eps) {
+        const R pkx = SR_SEL3(P0, P3, P6, k), pky = SR_SEL3(P1, P4, P7, k);
+        const R pjx = SR_SEL3(P0, P3, P6, j), pjy = SR_SEL3(P1, P4, P7, j);
+        R a = -(px - pkx) * e6i;
+        R b = (py - pky) * e3i;
+        const R lj = a + b;
+        a = (px - pjx) * e6i;
+        b = (py - pjy) * e3i;
+        const R lk = a - b;
+        const R li = lj + lk;
+        ci = 0;
+        cj = lj / li;
+        ck = lk / li;
+        inside = cj >= -eps && ck >= -eps;
+    } else {
+        const R pix_ = SR_SEL3(P0, P3, P6, i), piy_ = SR_SEL3(P1, P4, P7, i);
+        ci = 1;
+        cj = 0;
+        ck = 0;
+        const R dx = px - pix_, dy = py - piy_;
+        const R a = dx * dx, b = dy * dy;
+        inside = (a + b) < eps;
+    }
+    ci = opaque(ci); cj = opaque(cj); ck = opaque(ck);
+    c0 = (i == 0) ? ci : ((j == 0) ? cj : ck);
+    c1 = (i == 1) ? ci : ((j == 1) ? cj : ck);
+    c2 = (i == 2) ? ci : ((j == 2) ? cj : ck);
+    return inside;
+}
+
+template <typename R>
+__device__ __forceinline__ bool pixel_depth(const Tri<R>& t, R& c0, R& c1, R& c2, bool perspective,
+                                            R eps, R& z) {
+    if (perspective) {
+        c0 = c0 / t.p2;
+        c1 = c1 / t.p5;
+        c2 = c2 / t.p8;
+        R s = c0 + c1;
+        s = s + c2;
+        if (s >= -eps) return false;
+        c0 = c0 * s;
+        c1 = c1 * s;
+        c2 = c2 * s;
+        z = s;
+    } else {
+        const R a = c0 * t.p2, b = c1 * t.p5, d = c2 * t.p8;
+        const R s = a + b;
+        z = s + d;
+    }
+    return true;
+}
+
+// Total order on floats as unsigned integers; -0 is folded onto +0 so that equal depths tie.
+__device__ __forceinline__ unsigned ord32(float z) {
+    unsigned u = __float_as_uint(z);
+    if (u == 0x80000000u) u = 0u;
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ unsigned long long ord64(double z) {
+    unsigned long long u = (unsigned long long)__double_as_longlong(z);
+    if (u == 0x8000000000000000ULL) u = 0ULL;
+    return (u & 0x8000000000000000ULL) ? ~u : (u | 0x8000000000000000ULL);
+}
+__host__ __device__ inline unsigned long long key_init_f32() {
+    // orderable(-FLT_MAX) = ~0xFF7FFFFF = 0x00800000
+    return ((unsigned long long)0x00800000u << 32) | 0xFFFFFFFFull;
+}
+__host__ __device__ inline unsigned long long key_init_f64() { return 0x0010000000000000ULL; }
+
+template <typename R>
+__device__ __forceinline__ bool load_tri(Tri<R>& t, const R* __restrict__ vs,
+                                         const long long* __restrict__ fs, long long ti,
+                                         long long nv, long long& i0, long long& i1, long long& i2) {
+    i0 = fs[3 * ti];
+    i1 = fs[3 * ti + 1];
+    i2 = fs[3 * ti + 2];
+    if (i0 < 0 || i1 < 0 || i2 < 0 || i0 >= nv || i1 >= nv || i2 >= nv) return false;
+    t.p0 = vs[3 * i0]; t.p1 = vs[3 * i0 + 1]; t.p2 = vs[3 * i0 + 2];
+    t.p3 = vs[3 * i1]; t.p4 = vs[3 * i1 + 1]; t.p5 = vs[3 * i1 + 2];
+    t.p6 = vs[3 * i2]; t.p7 = vs[3 * i2 + 1]; t.p8 = vs[3 * i2 + 2];
+    return true;
+}
+
+__global__ __launch_bounds__(256) void k_fill_u64(unsigned long long* p, unsigned long long v,
+                                                  long long n) {
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) p[i] = v;
+}
+__global__ __launch_bounds__(256) void k_fill_u32(unsigned* p, unsigned v, long long n) {
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) p[i] = v;
+}
+
+// MODE 0: fp32 packed key.  MODE 1: fp64 depth max.  MODE 2: fp64 lowest id among depth-maxima.
+template <typename R, int MODE>
+__global__ __launch_bounds__(256) void k_depth_keys(long long b, long long nv, long long nf,
+                                                    long long h, long long w, bool repeat_v,
+                                                    bool repeat_f, bool perspective,
+                                                    const R* __restrict__ v,
+                                                    const long long* __restrict__ f,
+                                                    unsigned long long* __restrict__ keys,
+                                                    unsigned* __restrict__ tmin, R eps) {
+    const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= b * nf) return;
+    const long long s = g / nf, ti = g - s * nf;
+    const R* vs = repeat_v ? v : v + s * nv * 3;
+    const long long* fs = repeat_f ? f : f + s * nf * 3;
+    Tri<R> t;
+    long long i0, i1, i2;
+    if (!load_tri<R>(t, vs, fs, ti, nv, i0, i1, i2)) return;
+    if (!tri_setup<R>(t, h, w, perspective, eps)) return;
+    const long long hw = h * w;
+    unsigned long long* ks = keys + s * hw;
+    for (int y = t.y0; y <= t.y1; ++y)
+        for (int x = t.x0; x <= t.x1; ++x) {
+            const long long pix = x + (long long)y * w;
+            if (pix >= hw) continue;        // the reference would write out of bounds (w > h)
+            const R px = (R)x, py = (R)y;
+            R c0, c1, c2, z;
+            edge_values<R>(t, px, py, c0, c1, c2);
+            if (!pixel_weights<R>(t, px, py, c0, c1, c2, eps)) continue;
+            if (!pixel_depth<R>(t, c0, c1, c2, perspective, eps, z)) continue;
+            if (!(z == z)) continue;        // NaN never passes `zB < z`
+            if (MODE == 0) {
+                const unsigned long long key =
+                    ((unsigned long long)ord32((float)z) << 32) | (unsigned long long)(0xFFFFFFFEu - (unsigned)ti);
+                if (key > ks[pix]) atomicMax(&ks[pix], key);
+            } else if (MODE == 1) {
+                const unsigned long long key = ord64((double)z);
+                if (key > ks[pix]) atomicMax(&ks[pix], key);
+            } else {
+                const unsigned long long key = ord64((double)z);
+                if (key == ks[pix] && key > key_init_f64()) atomicMin(&tmin[s * hw + pix], (unsigned)ti);
+            }
+        }
+}
+
+template <typename R>
+__global__ __launch_bounds__(256) void k_resolve(long long b, long long nv, long long nf, long long h,
+                                                 long long w, bool repeat_v, bool repeat_f,
+                                                 bool perspective, const R* __restrict__ v,
+                                                 const long long* __restrict__ f,
+                                                 const unsigned long long* __restrict__ keys,
+                                                 const unsigned* __restrict__ tmin,
+                                                 long long* __restrict__ index, R* __restrict__ coeff,
+                                                 R* __restrict__ zbuf, const R* __restrict__ tex,
+                                                 long long tex_c, R* __restrict__ attr, R eps) {
+    const long long hw = h * w;
+    const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= b * hw) return;
+    const long long s = g / hw, pix = g - s * hw;
+    long long ti = -1;
+    if (sizeof(R) == 4) {
+        const unsigned long long key = keys[g];
+        if (key != key_init_f32()) ti = (long long)(0xFFFFFFFEu - (unsigned)(key & 0xFFFFFFFFull));
+    } else {
+        const unsigned tm = tmin[g];
+        if (tm != 0xFFFFFFFFu) ti = tm;
+    }
+    long long i0 = 0, i1 = 0, i2 = 0;
+    R c0 = 0, c1 = 0, c2 = 0;
+    R z = Lim<R>::lowest();
+    if (ti >= 0) {
+        const R* vs = repeat_v ? v : v + s * nv * 3;
+        const long long* fs = repeat_f ? f : f + s * nf * 3;
+        Tri<R> t;
+        load_tri<R>(t, vs, fs, ti, nv, i0, i1, i2);
+        tri_setup<R>(t, h, w, perspective, eps);
+        const int y = (int)(pix / w), x = (int)(pix - (long long)y * w);
+        const R px = (R)x, py = (R)y;
+        edge_values<R>(t, px, py, c0, c1, c2);
+        pixel_weights<R>(t, px, py, c0, c1, c2, eps);
+        pixel_depth<R>(t, c0, c1, c2, perspective, eps, z);
+        const long long shift = repeat_v ? 0 : nv * s;
+        i0 += shift; i1 += shift; i2 += shift;
+    }
+    if (index) {
+        index[3 * g] = i0;
+        index[3 * g + 1] = i1;
+        index[3 * g + 2] = i2;
+    }
+    if (coeff) {
+        coeff[3 * g] = c0;
+        coeff[3 * g + 1] = c1;
+        coeff[3 * g + 2] = c2;
+    }
+    if (zbuf) zbuf[g] = z;
+    if (attr) {
+        for (long long ch = 0; ch < tex_c; ++ch) {
+            const R a0 = tex[i0 * tex_c + ch] * c0;
+            const R a1 = tex[i1 * tex_c + ch] * c1;
+            const R a2 = tex[i2 * tex_c + ch] * c2;
+            const R s01 = a0 + a1;
+            attr[g * tex_c + ch] = s01 + a2;
+        }
+    }
+}
+
+// d(3 weights)/d(3 vertices x xyz) at one pixel (reference op/rasterize.h:169-228).  `g` = 27 values
+// [weight][vertex][component]; returns false (g untouched) for a degenerate triangle.
+template <typename R>
+__device__ __forceinline__ bool weight_jacobian(const R p[9], R px, R py, R sw, R sh, R g[27],
+                                                bool perspective, R eps) {
+    const R u = (px * 2 - sw + 1) / sw;
+    const R vv = (py * -2 + sh - 1) / sh;
+    R e[9], det;
+    R m0 = p[3] * p[7], m1 = p[4] * p[6];
+    e[0] = m0 - m1;
+    m0 = p[1] * p[6]; m1 = p[0] * p[7];
+    e[1] = m0 - m1;
+    m0 = p[0] * p[4]; m1 = p[1] * p[3];
+    e[2] = m0 - m1;
+    if (perspective) {
+        if (p[2] >= -eps || p[5] >= -eps || p[8] >= -eps) return false;
+        const R a = e[0] * p[2], b = e[1] * p[5], d = e[2] * p[8];
+        det = a + b;
+        det = det + d;
+        if (det >= -eps && det <= eps) return false;
+        e[0] = -e[0];
+        e[1] = -e[1];
+        e[2] = -e[2];
+        m0 = p[4] * p[8]; m1 = p[5] * p[7]; e[3] = m0 - m1;
+        m0 = p[2] * p[7]; m1 = p[1] * p[8]; e[4] = m0 - m1;
+        m0 = p[1] * p[5]; m1 = p[2] * p[4]; e[5] = m0 - m1;
+        m0 = p[5] * p[6]; m1 = p[3] * p[8]; e[6] = m0 - m1;
+        m0 = p[0] * p[8]; m1 = p[2] * p[6]; e[7] = m0 - m1;
+        m0 = p[2] * p[3]; m1 = p[0] * p[5]; e[8] = m0 - m1;
+    } else {
+        det = e[0] + e[1];
+        det = det + e[2];
+        e[3] = p[4] - p[7];
+        e[4] = p[7] - p[1];
+        e[5] = p[1] - p[4];
+        e[6] = p[6] - p[3];
+        e[7] = p[0] - p[6];
+        e[8] = p[3] - p[0];
+    }
+    if (!(det < -eps || det > eps)) return false;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) e[k] = e[k] / det;
+    R c[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const R gx = e[3 + k] * u, gy = e[6 + k] * vv;
+        const R a = e[k] + gx;
+        c[k] = a + gy;
+    }
+#pragma unroll
+    for (int l = 0; l < 27; ++l) {
+        const int wi = l / 9, comp = (l + 1) % 3, vert = (l / 3) % 3;
+        g[l] = -c[vert] * e[wi + comp * 3];
+    }
+    if (perspective) {
+        R s = c[0] + c[1];
+        s = s + c[2];
+#pragma unroll
+        for (int l = 0; l < 9; ++l) {
+            R tot = g[l] + g[l + 9];
+            tot = tot + g[l + 18];
+#pragma unroll
+            for (int wi = 0; wi < 3; ++wi) {
+                const R corr = c[wi] * tot / s;
+                if (l % 3 == 2) g[l + wi * 9] = (-g[l + wi * 9] - corr) / s;
+                else g[l + wi * 9] = (g[l + wi * 9] - corr) / s;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int l = 0; l < 9; ++l) g[2 + l * 3] = 0;
+    }
+    return true;
+}
+
+template <typename R>
+__device__ __forceinline__ bool load_pixel_tri(const long long* __restrict__ index, long long g,
+                                               long long rows, const R* __restrict__ v, R p[9],
+                                               long long ids[3]) {
+    ids[0] = index[3 * g];
+    ids[1] = index[3 * g + 1];
+    ids[2] = index[3 * g + 2];
+    if (ids[0] == ids[1] || ids[0] == ids[2] || ids[1] == ids[2]) return false;
+    if (ids[0] < 0 || ids[1] < 0 || ids[2] < 0 || ids[0] >= rows || ids[1] >= rows || ids[2] >= rows)
+        return false;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        p[k] = v[3 * ids[0] + k];
+        p[3 + k] = v[3 * ids[1] + k];
+        p[6 + k] = v[3 * ids[2] + k];
+    }
+    return true;
+}
+
+// dcoeff [b*h*w, 27]: 256 pixels per workgroup, staged through LDS so the 27-float records leave
+// as fully coalesced rows.
+template <typename R>
+__global__ __launch_bounds__(256) void k_dcoeff(long long b, long long n, long long h, long long w,
+                                                bool perspective, const R* __restrict__ v,
+                                                const long long* __restrict__ index,
+                                                R* __restrict__ dcoeff, R eps) {
+    __shared__ R s_g[256 * 27];
+    const long long hw = h * w, total = b * hw;
+    const long long base = (long long)blockIdx.x * 256;
+    const long long g = base + threadIdx.x;
+    R jac[27];
+#pragma unroll
+    for (int l = 0; l < 27; ++l) jac[l] = 0;
+    if (g < total) {
+        R p[9];
+        long long ids[3];
+        if (load_pixel_tri<R>(index, g, n * b, v, p, ids)) {
+            const long long pix = g % hw;
+            weight_jacobian<R>(p, (R)(pix % w), (R)(pix / w), (R)h, (R)w, jac, perspective, eps);
+        }
+    }
+#pragma unroll
+    for (int l = 0; l < 27; ++l) s_g[threadIdx.x * 27 + l] = jac[l];
+    __syncthreads();
+    const long long remain = total - base;
+    const int cnt = (int)((remain < 256 ? remain : 256) * 27);
+    for (int i = threadIdx.x; i < cnt; i += 256) dcoeff[base * 27 + i] = s_g[i];
+}
+
+template <typename R>
+__global__ __launch_bounds__(256) void k_grad_fused(long long b, long long nv, long long h,
+                                                    long long w, bool perspective,
+                                                    const R* __restrict__ v, const R* __restrict__ tex,
+                                                    long long tex_c, const long long* __restrict__ index,
+                                                    const R* __restrict__ coeff,
+                                                    const R* __restrict__ grad_out,
+                                                    R* __restrict__ grad_v, R* __restrict__ grad_tex,
+                                                    R eps) {
+    const long long hw = h * w, total = b * hw;
+    const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= total) return;
+    R p[9];
+    long long ids[3];
+    if (!load_pixel_tri<R>(index, g, nv * b, v, p, ids)) return;
+    const R* go = grad_out + g * tex_c;
+    if (grad_tex) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const R ck = coeff[3 * g + k];
+            if (ck != 0)
+                for (long long ch = 0; ch < tex_c; ++ch)
+                    unsafeAtomicAdd(&grad_tex[ids[k] * tex_c + ch], go[ch] * ck);
+        }
+    }
+    if (grad_v) {
+        R jac[27];
+        const long long pix = g % hw;
+        if (!weight_jacobian<R>(p, (R)(pix % w), (R)(pix / w), (R)h, (R)w, jac, perspective, eps)) return;
+        R dw[3] = {0, 0, 0};
+        for (long long ch = 0; ch < tex_c; ++ch) {
+            const R gch = go[ch];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) dw[k] += gch * tex[ids[k] * tex_c + ch];
+        }
+#pragma unroll
+        for (int j = 0; j < 9; ++j) {
+            const R val = dw[0] * jac[j] + dw[1] * jac[9 + j] + dw[2] * jac[18 + j];
+            if (val != 0) unsafeAtomicAdd(&grad_v[ids[j / 3] * 3 + (j % 3)], val);
+        }
+    }
+}
+
+template <typename R>
+int forward_impl(long long b, long long nv, long long nf, long long h, long long w, int repeat_v,
+                 int repeat_f, int perspective, const R* v, const long long* tri, long long* index,
+                 R* coeff, R* zbuf, R eps, const R* tex, long long tex_c, R* attr, void* work,
+                 hipStream_t st) {
+    if (b < 0 || nv < 0 || nf < 0 || h <= 0 || w <= 0) return SR_EINVAL;
+    if (nf >= 0xFFFFFFFELL) return SR_ERANGE;
+    if (b == 0) return SR_OK;
+    if (!work || (nf > 0 && (!v || !tri))) return SR_EINVAL;
+    if (attr && (!tex || tex_c <= 0)) return SR_EINVAL;
+    const long long npix = b * h * w;
+    if (eps < 0) eps = -eps;
+    unsigned long long* keys = reinterpret_cast<unsigned long long*>(work);
+    unsigned* tmin = reinterpret_cast<unsigned*>(keys + npix);
+    const bool is64 = sizeof(R) == 8;
+    hipLaunchKernelGGL(k_fill_u64, dim3(sr_stream_grid(npix, 256)), dim3(256), 0, st, keys,
+                       is64 ? key_init_f64() : key_init_f32(), npix);
+    if (is64)
+        hipLaunchKernelGGL(k_fill_u32, dim3(sr_stream_grid(npix, 256)), dim3(256), 0, st, tmin,
+                           0xFFFFFFFFu, npix);
+    const long long ntri = b * nf;
+    if (ntri > 0) {
+        const unsigned grid = (unsigned)sr_ceil_div(ntri, 256);
+        if (!is64) {
+            hipLaunchKernelGGL((k_depth_keys<R, 0>), dim3(grid), dim3(256), 0, st, b, nv, nf, h, w,
+                               repeat_v != 0, repeat_f != 0, perspective != 0, v, tri, keys, tmin, eps);
+        } else {
+            hipLaunchKernelGGL((k_depth_keys<R, 1>), dim3(grid), dim3(256), 0, st, b, nv, nf, h, w,
+                               repeat_v != 0, repeat_f != 0, perspective != 0, v, tri, keys, tmin, eps);
+            hipLaunchKernelGGL((k_depth_keys<R, 2>), dim3(grid), dim3(256), 0, st, b, nv, nf, h, w,
+                               repeat_v != 0, repeat_f != 0, perspective != 0, v, tri, keys, tmin, eps);
+        }
+    }
+    hipLaunchKernelGGL((k_resolve<R>), dim3((unsigned)sr_ceil_div(npix, 256)), dim3(256), 0, st, b, nv, nf,
+                       h, w, repeat_v != 0, repeat_f != 0, perspective != 0, v, tri, keys, tmin, index,
+                       coeff, zbuf, tex, tex_c, attr, eps);
+    return sr_launch_status();
+}
+
+template <typename R>
+int backward_impl(long long b, long long n, long long h, long long w, int perspective, const R* v,
+                  const long long* index, R* dcoeff, R eps, hipStream_t st) {
+    if (b < 0 || n < 0 || h < 0 || w < 0) return SR_EINVAL;
+    const long long total = b * h * w;
+    if (total == 0) return SR_OK;
+    if (!v || !index || !dcoeff) return SR_EINVAL;
+    if (eps < 0) eps = -eps;
+    hipLaunchKernelGGL((k_dcoeff<R>), dim3((unsigned)sr_ceil_div(total, 256)), dim3(256), 0, st, b, n, h,
+                       w, perspective != 0, v, index, dcoeff, eps);
+    return sr_launch_status();
+}
+
+template <typename R>
+int grad_impl(long long b, long long nv, long long h, long long w, int perspective, const R* v,
+              const R* tex, long long tex_c, const long long* index, const R* coeff, const R* grad_out,
+              R* grad_v, R* grad_tex, R eps, hipStream_t st) {
+    if (b < 0 || nv < 0 || h < 0 || w < 0 || tex_c <= 0) return SR_EINVAL;
+    const long long total = b * h * w;
+    if (total == 0 || (!grad_v && !grad_tex)) return SR_OK;
+    if (!v || !index || !grad_out || (grad_v && !tex) || (grad_tex && !coeff)) return SR_EINVAL;
+    if (eps < 0) eps = -eps;
+    hipLaunchKernelGGL((k_grad_fused<R>), dim3((unsigned)sr_ceil_div(total, 256)), dim3(256), 0, st, b, nv,
+                       h, w, perspective != 0, v, tex, tex_c, index, coeff, grad_out, grad_v, grad_tex, eps);
+    return sr_launch_status();
+}
+
+}  // namespace
+
+extern "C" int64_t sr_rasterize_scratch_bytes(int64_t b, int64_t h, int64_t w, int is_double) {
+    const int64_t npix = (b > 0 ? b : 0) * (h > 0 ? h : 0) * (w > 0 ? w : 0);
+    return npix * (is_double ? 12 : 8) + 16;
+}
+
+extern "C" int sr_rasterize_forward_f32(int64_t b, int64_t nv, int64_t nf, int64_t h, int64_t w,
+                                        int repeat_v, int repeat_f, int perspective, const float* v,
+                                        const int64_t* tri, int64_t* index, float* coeff, float* zbuf,
+                                        float eps, const float* tex, int64_t tex_c, float* attr,
+                                        void* work, sr_stream_t stream) {
+    return forward_impl<float>(b, nv, nf, h, w, repeat_v, repeat_f, perspective, v,
+                               reinterpret_cast<const long long*>(tri),
+                               reinterpret_cast<long long*>(index), coeff, zbuf, eps, tex, tex_c, attr,
+                               work, sr_stream(stream));
+}
+extern "C" int sr_rasterize_forward_f64(int64_t b, int64_t nv, int64_t nf, int64_t h, int64_t w,
+                                        int repeat_v, int repeat_f, int perspective, const double* v,
+                                        const int64_t* tri, int64_t* index, double* coeff,
+                                        double* zbuf, double eps, const double* tex, int64_t tex_c,
+                                        double* attr, void* work, sr_stream_t stream) {
+    return forward_impl<double>(b, nv, nf, h, w, repeat_v, repeat_f, perspective, v,
+                                reinterpret_cast<const long long*>(tri),
+                                reinterpret_cast<long long*>(index), coeff, zbuf, eps, tex, tex_c, attr,
+                                work, sr_stream(stream));
+}
+extern "C" int sr_rasterize_backward_f32(int64_t b, int64_t n, int64_t h, int64_t w, int repeat_v,
+                                         int perspective, const float* v, const int64_t* index,
+                                         float* dcoeff, float eps, sr_stream_t stream) {
+    (void)repeat_v;
+    return backward_impl<float>(b, n, h, w, perspective, v, reinterpret_cast<const long long*>(index),
+                                dcoeff, eps, sr_stream(stream));
+}
+extern "C" int sr_rasterize_backward_f64(int64_t b, int64_t n, int64_t h, int64_t w, int repeat_v,
+                                         int perspective, const double* v, const int64_t* index,
+                                         double* dcoeff, double eps, sr_stream_t stream) {
+    (void)repeat_v;
+    return backward_impl<double>(b, n, h, w, perspective, v, reinterpret_cast<const long long*>(index),
+                                 dcoeff, eps, sr_stream(stream));
+}
+extern "C" int sr_rasterize_grad_f32(int64_t b, int64_t nv, int64_t h, int64_t w, int repeat_v,
+                                     int perspective, const float* v, const float* tex, int64_t tex_c,
+                                     const int64_t* index, const float* coeff, const float* grad_out,
+                                     float* grad_v, float* grad_tex, float eps, sr_stream_t stream) {
+    (void)repeat_v;
+    return grad_impl<float>(b, nv, h, w, perspective, v, tex, tex_c,
+                            reinterpret_cast<const long long*>(index), coeff, grad_out, grad_v, grad_tex,
+                            eps, sr_stream(stream));
+}
+extern "C" int sr_rasterize_grad_f64(int64_t b, int64_t nv, int64_t h, int64_t w, int repeat_v,
+                                     int perspective, const double* v, const double* tex,
+                                     int64_t tex_c, const int64_t* index, const double* coeff,
+                                     const double* grad_out, double* grad_v, double* grad_tex,
+                                     double eps, sr_stream_t stream) {
+    (void)repeat_v;
+    return grad_impl<double>(b, nv, h, w, perspective, v, tex, tex_c,
+                             reinterpret_cast<const long long*>(index), coeff, grad_out, grad_v,
+                             grad_tex, eps, sr_stream(stream));
+}

@@ -1,0 +1,187 @@
+// upfirdn2d for gfx950: zero-insert upsample -> pad/crop -> 2-D FIR -> decimate.
+//
+// Replaces the reference's upfirdn2d_op and its six tiled "modes" + large fallback
+// (reference op/upfirdn2d_kernel.cu:79-257; mode table op/upfirdn2d.cpp:50-75).  MI355X-first design:
+//   * k_fir4_tile — the shape that carries all the bytes in the generator (Blur after the
+//     stride-2 transposed conv and its gradient: up = down = 1, 4x4 taps; reference layers.py:272-275):
+//     a 32x64 output tile per 256-thread workgroup, the 35x67 input halo tile staged once in LDS
+//     (9.5 KiB, rows padded to 68 floats so every lane's 8-float window is two aligned
+//     ds_read_b128), each lane producing a 2x4 output micro-tile from a register sliding window and
+//     writing 16-byte stores.  HBM traffic = 4*(N_in + N_out) bytes, the algorithmic minimum.
+//   * k_upfirdn_generic — any up/down/kernel/pad (ToRGB skip upsample up=2, its gradient down=2,
+//     odd kernels, crops): one output per lane, consecutive lanes on consecutive columns
+//     (coalesced), polyphase tap skipping instead of multiplying inserted zeros.
+// Taps are accumulated ky-major then kx in fp32 with separate multiply and add
+// (-ffp-contract=off), the order the oracle (oracle/ops_np.py) fixes, so HIP == oracle bitwise.
+#include "common.h"
+
+namespace {
+
+struct UfdParams {
+    int in_h, in_w, out_h, out_w, kh, kw;
+    int up_x, up_y, down_x, down_y, pad_x0, pad_y0;
+};
+
+__device__ __forceinline__ int floor_div(int a, int b) {
+    int q = a / b;
+    return (a % b != 0 && ((a < 0) != (b < 0))) ? q - 1 : q;
+}
+
+// ------------------------------------------------------------------------------ generic
+__global__ __launch_bounds__(256) void k_upfirdn_generic(float* __restrict__ out,
+                                                         const float* __restrict__ x,
+                                                         const float* __restrict__ k, UfdParams p,
+                                                         int64_t total) {
+    extern __shared__ float s_k[];      // flipped kernel
+    for (int i = threadIdx.x; i < p.kh * p.kw; i += blockDim.x) {
+        const int ky = i / p.kw, kx = i % p.kw;
+        s_k[i] = k[(p.kh - 1 - ky) * p.kw + (p.kw - 1 - kx)];
+    }
+    __syncthreads();
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int64_t plane_out = (int64_t)p.out_h * p.out_w;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const int64_t plane = i / plane_out;
+        const int rem = (int)(i - plane * plane_out);
+        const int oy = rem / p.out_w, ox = rem - oy * p.out_w;
+        const float* src = x + plane * (int64_t)p.in_h * p.in_w;
+        // tap ky touches upsampled row  oy*down - pad0 + ky ; only multiples of `up` hold data
+        const int my = oy * p.down_y - p.pad_y0, mx = ox * p.down_x - p.pad_x0;
+        int ky0 = (-my) % p.up_y;   // first ky with (my + ky) % up == 0
+        if (ky0 < 0) ky0 += p.up_y;
+        int kx0 = (-mx) % p.up_x;
+        if (kx0 < 0) kx0 += p.up_x;
+        float acc = 0.0f;
+        for (int ky = ky0; ky < p.kh; ky += p.up_y) {
+            const int iy = (my + ky) / p.up_y;          // exact: divisible by construction
+            if (iy < 0 || iy >= p.in_h) continue;
+            for (int kx = kx0; kx < p.kw; kx += p.up_x) {
+                const int ix = (mx + kx) / p.up_x;
+                if (ix < 0 || ix >= p.in_w) continue;
+                const float prod = src[(int64_t)iy * p.in_w + ix] * s_k[ky * p.kw + kx];
+                acc = acc + prod;
+            }
+        }
+        out[i] = acc;
+    }
+}
+
+// ------------------------------------------------------------------------------ 4x4, up=down=1
+constexpr int T_OH = 32, T_OW = 64, T_K = 4;
+constexpr int T_IH = T_OH + T_K - 1;        // 35
+constexpr int T_IW = T_OW + T_K - 1;        // 67
+constexpr int T_LD = 68;                    // LDS row pitch (floats), multiple of 4
+
+__global__ __launch_bounds__(256) void k_fir4_tile(float* __restrict__ out,
+                                                   const float* __restrict__ x,
+                                                   const float* __restrict__ k, int in_h, int in_w,
+                                                   int out_h, int out_w, int pad_x0, int pad_y0,
+                                                   int tiles_x, int tiles_y) {
+    __shared__ __attribute__((aligned(16))) float s_in[T_IH * T_LD];
+    __shared__ float s_k[16];
+    int bid = blockIdx.x;
+    const int tx_i = bid % tiles_x;
+    bid /= tiles_x;
+    const int ty_i = bid % tiles_y;
+    const int64_t plane = bid / tiles_y;
+    const int oy0 = ty_i * T_OH, ox0 = tx_i * T_OW;
+    const int iy0 = oy0 - pad_y0, ix0 = ox0 - pad_x0;
+    const float* src = x + plane * (int64_t)in_h * in_w;
+
+    if (threadIdx.x < 16) {
+        const int ky = threadIdx.x >> 2, kx = threadIdx.x & 3;
+        s_k[threadIdx.x] = k[(3 - ky) * 4 + (3 - kx)];
+    }
+    // stage the halo tile: consecutive lanes read consecutive columns of one row (coalesced)
+    for (int i = threadIdx.x; i < T_IH * T_LD; i += 256) {
+        const int r = i / T_LD, c = i - r * T_LD;
+        const int gy = iy0 + r, gx = ix0 + c;
+        float v = 0.0f;
+        if (c < T_IW && gy >= 0 && gy < in_h && gx >= 0 && gx < in_w) v = src[(int64_t)gy * in_w + gx];
+        s_in[i] = v;
+    }
+    __syncthreads();
+
+    float kf[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) kf[i] = s_k[i];
+
+    const int lx = (threadIdx.x & 15) * 4;       // 4 output columns per lane
+    const int ly = (threadIdx.x >> 4) * 2;       // 2 output rows per lane
+    float acc[2][4];
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[r][c] = 0.0f;
+
+    // rows ly .. ly+4 of the tile feed the two output rows; for bit-exact ky-major order each
+    // output row walks its own four input rows top to bottom.
+    float win[5][8];
+#pragma unroll
+    for (int r = 0; r < 5; ++r) {
+        const float4 a = *reinterpret_cast<const float4*>(&s_in[(ly + r) * T_LD + lx]);
+        const float4 b = *reinterpret_cast<const float4*>(&s_in[(ly + r) * T_LD + lx + 4]);
+        win[r][0] = a.x; win[r][1] = a.y; win[r][2] = a.z; win[r][3] = a.w;
+        win[r][4] = b.x; win[r][5] = b.y; win[r][6] = b.z; win[r][7] = b.w;
+    }
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int ky = 0; ky < 4; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 4; ++kx)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const float prod = win[r + ky][c + kx] * kf[ky * 4 + kx];
+                    acc[r][c] = acc[r][c] + prod;
+                }
+
+    float* dst = out + plane * (int64_t)out_h * out_w;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int oy = oy0 + ly + r;
+        if (oy >= out_h) continue;
+        const int ox = ox0 + lx;
+        float* q = dst + (int64_t)oy * out_w + ox;
+        if (ox + 3 < out_w && ((reinterpret_cast<uintptr_t>(q) & 15) == 0)) {
+            *reinterpret_cast<float4*>(q) = make_float4(acc[r][0], acc[r][1], acc[r][2], acc[r][3]);
+        } else {
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                if (ox + c < out_w) q[c] = acc[r][c];
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int sr_upfirdn2d(float* out, const float* x, const float* k, int64_t major, int in_h,
+                            int in_w, int out_h, int out_w, int kh, int kw, int up_x, int up_y,
+                            int down_x, int down_y, int pad_x0, int pad_x1, int pad_y0, int pad_y1,
+                            sr_stream_t stream) {
+    if (major < 0 || in_h < 0 || in_w < 0 || kh <= 0 || kw <= 0 || up_x <= 0 || up_y <= 0 ||
+        down_x <= 0 || down_y <= 0)
+        return SR_EINVAL;
+    // floor division like Python's // (reference op/upfirdn2d.py:103-104)
+    auto fdiv = [](int a, int b) { int q = a / b; return (a % b != 0 && (a < 0)) ? q - 1 : q; };
+    const int eh = fdiv(in_h * up_y + pad_y0 + pad_y1 - kh, down_y) + 1;
+    const int ew = fdiv(in_w * up_x + pad_x0 + pad_x1 - kw, down_x) + 1;
+    if (eh != out_h || ew != out_w) return SR_EINVAL;
+    if (major == 0 || out_h <= 0 || out_w <= 0) return SR_OK;
+    if (!out || !x || !k) return SR_EINVAL;
+    hipStream_t st = sr_stream(stream);
+    if (up_x == 1 && up_y == 1 && down_x == 1 && down_y == 1 && kh == 4 && kw == 4) {
+        const int tiles_x = (out_w + T_OW - 1) / T_OW, tiles_y = (out_h + T_OH - 1) / T_OH;
+        const int64_t blocks = (int64_t)tiles_x * tiles_y * major;
+        if (blocks < 0x7FFFFFFFLL) {
+            hipLaunchKernelGGL(k_fir4_tile, dim3((unsigned)blocks), dim3(256), 0, st, out, x, k, in_h, in_w,
+                               out_h, out_w, pad_x0, pad_y0, tiles_x, tiles_y);
+            return sr_launch_status();
+        }
+    }
+    UfdParams p{in_h, in_w, out_h, out_w, kh, kw, up_x, up_y, down_x, down_y, pad_x0, pad_y0};
+    const int64_t total = major * (int64_t)out_h * out_w;
+    hipLaunchKernelGGL(k_upfirdn_generic, dim3(sr_stream_grid(total, 256)), dim3(256),
+                       (size_t)kh * kw * sizeof(float), st, out, x, k, p, total);
+    return sr_launch_status();
+}

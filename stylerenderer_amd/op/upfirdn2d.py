@@ -1,0 +1,125 @@
+"""upfirdn2d — host side of csrc/upfirdn2d.hip.
+
+Interface parity with the reference (reference op/upfirdn2d.py):
+  upfirdn2d(input, kernel, up=1, down=1, pad=(0, 0))                        :145-156
+  gradient = the same operator with up<->down swapped, flipped taps and the padding of :111-114;
+  double-backward = the forward operator on the grad-of-grad (:63-85).
+`upfirdn2d_op(...)` is the tensor-level operator of the reference's pybind module
+(op/upfirdn2d.cpp:24-26) on top of the C ABI `sr_upfirdn2d`.
+
+Device tensors always run the HIP kernels.  CPU tensors take a plain PyTorch route, which is what
+the reference does for them (`upfirdn2d_native`, op/upfirdn2d.py:159-200); it is written here as a
+single strided transposed/regular convolution rather than the reference's view+pad sequence.
+"""
+import torch
+from torch.autograd import Function
+from torch.nn import functional as F
+
+from .. import _lib
+from ._dispatch import is_device_tensor, on_device_of, require_f32, stream_of
+
+
+def _out_size(n, up, down, p0, p1, k):
+    return (n * up + p0 + p1 - k) // down + 1
+
+
+def upfirdn2d_op(input, kernel, up_x, up_y, down_x, down_y, pad_x0, pad_x1, pad_y0, pad_y1):
+    """input [major, in_h, in_w, 1] (or [major, in_h, in_w]) -> [major, out_h, out_w, 1]."""
+    require_f32(input, "upfirdn2d")
+    x = input.contiguous()
+    k = kernel.contiguous()
+    if k.device != x.device:
+        k = k.to(x.device)
+    require_f32(k, "upfirdn2d kernel")
+    if x.dim() == 4 and x.size(3) != 1:
+        raise RuntimeError("upfirdn2d: minor dimension must be 1")
+    major, in_h, in_w = x.size(0), x.size(1), x.size(2)
+    kh, kw = k.shape
+    out_h = _out_size(in_h, up_y, down_y, pad_y0, pad_y1, kh)
+    out_w = _out_size(in_w, up_x, down_x, pad_x0, pad_x1, kw)
+    if out_h <= 0 or out_w <= 0:
+        raise RuntimeError("upfirdn2d: empty output (%d x %d)" % (out_h, out_w))
+    out = torch.empty((major, out_h, out_w, 1), dtype=x.dtype, device=x.device)
+    with on_device_of(x):
+        rc = _lib.lib().sr_upfirdn2d(_lib.ptr(out), _lib.ptr(x), _lib.ptr(k), major, in_h, in_w, out_h,
+                                     out_w, kh, kw, up_x, up_y, down_x, down_y, pad_x0, pad_x1,
+                                     pad_y0, pad_y1, stream_of(x))
+    _lib.check(rc, "sr_upfirdn2d")
+    return out
+
+
+class UpFirDn2dBackward(Function):
+    @staticmethod
+    def forward(ctx, grad_output, kernel, grad_kernel, up, down, pad, g_pad, in_size, out_size):
+        up_x, up_y = up
+        down_x, down_y = down
+        g_pad_x0, g_pad_x1, g_pad_y0, g_pad_y1 = g_pad
+        grad_output = grad_output.reshape(-1, out_size[0], out_size[1], 1)
+        grad_input = upfirdn2d_op(grad_output, grad_kernel, down_x, down_y, up_x, up_y,
+                                  g_pad_x0, g_pad_x1, g_pad_y0, g_pad_y1)
+        grad_input = grad_input.view(in_size[0], in_size[1], in_size[2], in_size[3])
+        ctx.save_for_backward(kernel)
+        ctx.up, ctx.down, ctx.pad = up, down, pad
+        ctx.in_size, ctx.out_size = in_size, out_size
+        return grad_input
+
+    @staticmethod
+    def backward(ctx, gradgrad_input):
+        (kernel,) = ctx.saved_tensors
+        gg = gradgrad_input.reshape(-1, ctx.in_size[2], ctx.in_size[3], 1)
+        out = upfirdn2d_op(gg, kernel, ctx.up[0], ctx.up[1], ctx.down[0], ctx.down[1], *ctx.pad)
+        out = out.view(ctx.in_size[0], ctx.in_size[1], ctx.out_size[0], ctx.out_size[1])
+        return out, None, None, None, None, None, None, None, None
+
+
+class UpFirDn2d(Function):
+    @staticmethod
+    def forward(ctx, input, kernel, up, down, pad):
+        up_x, up_y = up
+        down_x, down_y = down
+        pad_x0, pad_x1, pad_y0, pad_y1 = pad
+        kernel_h, kernel_w = kernel.shape
+        _, channel, in_h, in_w = input.shape
+        ctx.in_size = input.shape
+        out_h = _out_size(in_h, up_y, down_y, pad_y0, pad_y1, kernel_h)
+        out_w = _out_size(in_w, up_x, down_x, pad_x0, pad_x1, kernel_w)
+        ctx.out_size = (out_h, out_w)
+        ctx.up, ctx.down, ctx.pad = (up_x, up_y), (down_x, down_y), (pad_x0, pad_x1, pad_y0, pad_y1)
+        ctx.g_pad = (kernel_w - pad_x0 - 1,
+                     in_w * up_x - out_w * down_x + pad_x0 - up_x + 1,
+                     kernel_h - pad_y0 - 1,
+                     in_h * up_y - out_h * down_y + pad_y0 - up_y + 1)
+        ctx.save_for_backward(kernel, torch.flip(kernel, [0, 1]))
+        out = upfirdn2d_op(input.reshape(-1, in_h, in_w, 1), kernel, up_x, up_y, down_x, down_y,
+                           pad_x0, pad_x1, pad_y0, pad_y1)
+        return out.view(-1, channel, out_h, out_w)
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        kernel, grad_kernel = ctx.saved_tensors
+        grad_input = UpFirDn2dBackward.apply(grad_output, kernel, grad_kernel, ctx.up, ctx.down,
+                                             ctx.pad, ctx.g_pad, ctx.in_size, ctx.out_size)
+        return grad_input, None, None, None, None
+
+
+def _upfirdn2d_cpu(input, kernel, up, down, pad):
+    """CPU tensors: zero-insert + pad/crop + correlation with the flipped kernel + decimate."""
+    n, c, in_h, in_w = input.shape
+    kh, kw = kernel.shape
+    x = input.reshape(n * c, 1, in_h, in_w)
+    if up > 1:
+        z = x.new_zeros(n * c, 1, in_h * up, in_w * up)
+        z[:, :, ::up, ::up] = x
+        x = z
+    p0, p1 = pad
+    x = F.pad(x, [max(p0, 0), max(p1, 0), max(p0, 0), max(p1, 0)])
+    x = x[:, :, max(-p0, 0): x.shape[2] - max(-p1, 0), max(-p0, 0): x.shape[3] - max(-p1, 0)]
+    w = torch.flip(kernel, [0, 1]).view(1, 1, kh, kw).to(x.dtype)
+    y = F.conv2d(x, w)[:, :, ::down, ::down]
+    return y.reshape(n, c, y.shape[2], y.shape[3])
+
+
+def upfirdn2d(input, kernel, up=1, down=1, pad=(0, 0)):
+    if not is_device_tensor(input):
+        return _upfirdn2d_cpu(input, kernel, up, down, pad)
+    return UpFirDn2d.apply(input, kernel, (up, up), (down, down), (pad[0], pad[1], pad[0], pad[1]))

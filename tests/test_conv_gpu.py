@@ -1,0 +1,100 @@
+"""GPU: MFMA implicit-GEMM convolution against a float64 torch-CPU convolution (the third-party
+arithmetic the reference itself relies on).  Tolerance: the MFMA is an exact fp32
+fma chain, so the error is fp32 round-off of a K-term dot product: |err| <= 2e-6 * sum|a*b| here."""
+import numpy as np
+import pytest
+import torch
+from torch.nn import functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def ref_conv(x, w_oihw, iscale, oscale, obias, stride, pad, transposed):
+    """float64 CPU reference. w_oihw: [N, C, k, k] correlation weights (or, transposed, the
+    [C, N, k, k] layout conv_transpose2d takes)."""
+    x = x.double()
+    if iscale is not None:
+        x = x * iscale.double()[:, :, None, None]
+    if transposed:
+        y = F.conv_transpose2d(x, w_oihw.double(), stride=stride, padding=pad)
+    else:
+        y = F.conv2d(x, w_oihw.double(), stride=stride, padding=pad)
+    if oscale is not None:
+        y = y * oscale.double()[:, :, None, None]
+    if obias is not None:
+        y = y + obias.double()[None, :, None, None]
+    return y
+
+
+def to_taps(w, transposed):
+    """[N,C,k,k] (or [C,N,k,k] when transposed) -> [k*k, C, N]."""
+    if transposed:
+        c, n, k, _ = w.shape
+        return w.permute(2, 3, 0, 1).reshape(k * k, c, n).contiguous()
+    n, c, k, _ = w.shape
+    return w.permute(2, 3, 1, 0).reshape(k * k, c, n).contiguous()
+
+
+CASES = [
+    # B, C, N, H, W, k, stride, pad, transposed
+    (2, 8, 6, 8, 8, 3, 1, 1, False),
+    (3, 20, 130, 4, 4, 3, 1, 1, False),
+    (16, 16, 8, 4, 4, 3, 1, 1, False),
+    (2, 5, 7, 16, 16, 3, 1, 1, False),
+    (1, 9, 4, 37, 41, 3, 1, 1, False),
+    (2, 12, 140, 64, 64, 3, 1, 1, False),
+    (2, 8, 6, 9, 9, 3, 2, 0, False),
+    (2, 10, 5, 33, 33, 3, 2, 0, False),
+    (1, 7, 3, 65, 65, 3, 2, 0, False),
+    (2, 8, 6, 4, 4, 3, 2, 0, True),
+    (2, 8, 6, 8, 8, 3, 2, 0, True),
+    (1, 11, 9, 16, 16, 3, 2, 0, True),
+    (1, 6, 130, 32, 32, 3, 2, 0, True),
+    (2, 8, 3, 8, 8, 1, 1, 0, False),
+    (2, 16, 5, 32, 32, 1, 1, 0, False),
+    (2, 6, 4, 9, 9, 1, 2, 0, False),
+]
+
+
+@pytest.mark.parametrize("case", CASES)
+@pytest.mark.parametrize("scaled", [True, False])
+def test_conv_vs_float64(case, scaled):
+    from stylerenderer_amd.op.conv import conv2d_mfma
+
+    b, c, n, h, w, k, stride, pad, tr = case
+    g = torch.Generator().manual_seed(b * 1000 + c * 10 + n + h)
+    x = torch.randn(b, c, h, w, generator=g)
+    wgt = torch.randn((c, n, k, k) if tr else (n, c, k, k), generator=g)
+    isc = torch.randn(b, c, generator=g) if scaled else None
+    osc = torch.randn(b, n, generator=g) if scaled else None
+    bias = torch.randn(n, generator=g) if scaled else None
+    want = ref_conv(x, wgt, isc, osc, bias, stride, pad, tr)
+    dev = lambda t: None if t is None else t.to(DEV)  # noqa: E731
+    got = conv2d_mfma(dev(x), dev(to_taps(wgt, tr)), dev(isc), dev(osc), dev(bias), k, stride, pad, tr)
+    assert got.shape == want.shape
+    # bound: fp32 round-off against the sum of absolute products
+    absx = x.abs().double() * (isc.abs().double()[:, :, None, None] if scaled else 1.0)
+    mag = (F.conv_transpose2d(absx, wgt.abs().double(), stride=stride, padding=pad) if tr
+           else F.conv2d(absx, wgt.abs().double(), stride=stride, padding=pad))
+    if scaled:
+        mag = mag * osc.abs().double()[:, :, None, None] + bias.abs().double()[None, :, None, None]
+    err = (got.cpu().double() - want).abs()
+    assert float((err / (mag + 1e-30)).max()) < 2e-6
+
+
+def test_conv_full_width_layers_spotcheck():
+    """Generator-sized layers (512 -> 512 at 16x16, 128 -> 128 at 128x128): compare a strip of
+    outputs with float64."""
+    from stylerenderer_amd.op.conv import conv2d_mfma
+
+    for (b, c, n, res) in ((4, 512, 512, 16), (2, 128, 128, 128)):
+        g = torch.Generator().manual_seed(res)
+        x = torch.randn(b, c, res, res, generator=g)
+        wgt = torch.randn(n, c, 3, 3, generator=g) / np.sqrt(c * 9)
+        isc = torch.randn(b, c, generator=g)
+        osc = torch.rand(b, n, generator=g) + 0.5
+        got = conv2d_mfma(x.to(DEV), to_taps(wgt, False).to(DEV), isc.to(DEV), osc.to(DEV), None, 3, 1, 1)
+        want = ref_conv(x[:1], wgt, isc[:1], osc[:1], None, 1, 1, False)
+        err = (got[:1].cpu().double() - want).abs().max().item()
+        assert err < 2e-5 * want.abs().max().item()

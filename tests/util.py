@@ -1,0 +1,27 @@
+"""Helpers shared by the tests."""
+import numpy as np
+
+
+def bits_equal(a, b):
+    a = np.ascontiguousarray(a)
+    b = np.ascontiguousarray(b)
+    return a.shape == b.shape and a.dtype == b.dtype and np.array_equal(a.view(np.uint8), b.view(np.uint8))
+
+
+def max_ulp(a, b):
+    """Largest distance in float32 units-in-the-last-place between two arrays."""
+    a = np.ascontiguousarray(a, np.float32)
+    b = np.ascontiguousarray(b, np.float32)
+
+    def key(x):
+        i = x.view(np.int32).astype(np.int64)
+        return np.where(i < 0, np.int64(-(2 ** 31)) - i, i)
+
+    return int(np.abs(key(a) - key(b)).max()) if a.size else 0
+
+
+def rel_err(a, b):
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    den = max(float(np.abs(b).max()), 1e-30)
+    return float(np.abs(a - b).max()) / den
