@@ -143,6 +143,20 @@ int sr_conv2d_mfma(float* out, const float* in, const float* wt, const float* is
                    int64_t IH, int64_t IW, int64_t OH, int64_t OW, int ksize, int stride, int pad,
                    int transposed, sr_stream_t stream);
 
+/* Weight gradient of sr_conv2d_mfma (same geometry arguments):
+ *   dwt[ky*k+kx][c][n] = sum_{b, pixels} (xscale[b,c] * x[b,c,window]) * (gscale[b,n] * gy[b,n,pixel])
+ * x [B,C,IH,IW], gy [B,N,OH,OW], dwt [k*k, C, N]; xscale / gscale may be NULL.  The batch is folded
+ * into the reduction (the reference's grouped convolution would give per-sample gradients).
+ * `scratch`: sr_conv2d_wgrad_scratch_floats(...) floats of split-K partial sums, reduced in a
+ * fixed order (deterministic). */
+int64_t sr_conv2d_wgrad_scratch_floats(int64_t B, int64_t C, int64_t N, int64_t IH, int64_t IW,
+                                       int64_t OH, int64_t OW, int ksize, int stride, int pad,
+                                       int transposed);
+int sr_conv2d_wgrad_mfma(float* dwt, const float* x, const float* gy, const float* xscale,
+                         const float* gscale, int64_t B, int64_t C, int64_t N, int64_t IH,
+                         int64_t IW, int64_t OH, int64_t OW, int ksize, int stride, int pad,
+                         int transposed, float* scratch, sr_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -44,3 +44,30 @@ def conv2d_mfma(x, wt, iscale=None, oscale=None, obias=None, ksize=3, stride=1, 
                                        ksize, stride, pad, int(bool(transposed)), stream_of(x))
     _lib.check(rc, "sr_conv2d_mfma")
     return out
+
+
+def conv2d_wgrad_mfma(x, gy, xscale=None, gscale=None, ksize=3, stride=1, pad=1, transposed=False):
+    """dwt [k*k, C, N] = sum over batch and pixels of (xscale*x)[window] * (gscale*gy)."""
+    require_f32(x, "conv2d_wgrad_mfma")
+    require_f32(gy, "conv2d_wgrad_mfma grad")
+    x = x.contiguous()
+    gy = gy.contiguous()
+    b, c, ih, iw = x.shape
+    b2, n, oh, ow = gy.shape
+    if b2 != b or (oh, ow) != conv_out_size(ih, iw, ksize, stride, pad, transposed):
+        raise RuntimeError("conv2d_wgrad_mfma: shape mismatch x %s gy %s" % (tuple(x.shape), tuple(gy.shape)))
+    for t, shape, name in ((xscale, (b, c), "xscale"), (gscale, (b, n), "gscale")):
+        if t is not None and (tuple(t.shape) != shape or not t.is_contiguous() or t.dtype != torch.float32):
+            raise RuntimeError("conv2d_wgrad_mfma: %s must be contiguous float32 %s" % (name, shape))
+    L = _lib.lib()
+    nfl = L.sr_conv2d_wgrad_scratch_floats(b, c, n, ih, iw, oh, ow, ksize, stride, pad, int(bool(transposed)))
+    if nfl < 0:
+        raise RuntimeError("conv2d_wgrad_mfma: unsupported geometry")
+    scratch = torch.empty(nfl, dtype=torch.float32, device=x.device)
+    dwt = torch.empty((ksize * ksize, c, n), dtype=torch.float32, device=x.device)
+    with on_device_of(x):
+        rc = L.sr_conv2d_wgrad_mfma(_lib.ptr(dwt), _lib.ptr(x), _lib.ptr(gy), _lib.ptr(xscale),
+                                    _lib.ptr(gscale), b, c, n, ih, iw, oh, ow, ksize, stride, pad,
+                                    int(bool(transposed)), _lib.ptr(scratch), stream_of(x))
+    _lib.check(rc, "sr_conv2d_wgrad_mfma")
+    return dwt

@@ -98,3 +98,45 @@ def test_conv_full_width_layers_spotcheck():
         want = ref_conv(x[:1], wgt, isc[:1], osc[:1], None, 1, 1, False)
         err = (got[:1].cpu().double() - want).abs().max().item()
         assert err < 2e-5 * want.abs().max().item()
+
+
+@pytest.mark.parametrize("case", CASES)
+@pytest.mark.parametrize("scaled", [True, False])
+def test_wgrad_vs_float64(case, scaled):
+    """dL/dW of the same cases through float64 autograd on the CPU."""
+    from stylerenderer_amd.op.conv import conv2d_wgrad_mfma
+
+    b, c, n, h, w, k, stride, pad, tr = case
+    g = torch.Generator().manual_seed(b * 977 + c * 13 + n + h)
+    x = torch.randn(b, c, h, w, generator=g)
+    wgt = torch.randn((c, n, k, k) if tr else (n, c, k, k), generator=g).double().requires_grad_()
+    isc = torch.randn(b, c, generator=g) if scaled else None
+    osc = torch.randn(b, n, generator=g) if scaled else None
+    y = ref_conv(x, wgt, isc, osc, None, stride, pad, tr)
+    gy = torch.randn(y.shape, generator=g)
+    (gw,) = torch.autograd.grad(y, wgt, gy.double())
+    want = to_taps(gw, tr)
+    dev = lambda t: None if t is None else t.to(DEV)  # noqa: E731
+    got = conv2d_wgrad_mfma(dev(x), dev(gy), dev(isc), dev(osc), k, stride, pad, tr)
+    assert got.shape == want.shape
+    scale = want.abs().max().item() + 1e-30
+    # K = B * pixels terms per output, fp32 partial sums: relative to the largest gradient entry
+    assert float((got.cpu().double() - want).abs().max()) < 3e-5 * scale * max(1.0, np.sqrt(b * h * w) / 30)
+
+
+def test_wgrad_deterministic_and_large():
+    from stylerenderer_amd.op.conv import conv2d_wgrad_mfma
+
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(4, 128, 64, 64, generator=g).to(DEV)
+    gy = torch.randn(4, 128, 64, 64, generator=g).to(DEV)
+    xs = torch.randn(4, 128, generator=g).to(DEV)
+    gs = torch.randn(4, 128, generator=g).to(DEV)
+    a = conv2d_wgrad_mfma(x, gy, xs, gs)
+    b = conv2d_wgrad_mfma(x, gy, xs, gs)
+    assert torch.equal(a, b)
+    xd = (x * xs[:, :, None, None]).double().cpu()
+    gd = (gy * gs[:, :, None, None]).double().cpu()
+    want = torch.nn.grad.conv2d_weight(xd, (128, 128, 3, 3), gd, padding=1)
+    want = want.permute(2, 3, 1, 0).reshape(9, 128, 128)
+    assert float((a.cpu().double() - want).abs().max()) < 1e-4 * float(want.abs().max())
