@@ -1,0 +1,290 @@
+"""Layers of the StyleRenderer generator / discriminator on the MI355X-native operators.
+
+Same class names, constructor arguments, parameter / buffer names and shapes as the reference's
+layers.py (so reference checkpoints load unchanged), different execution:
+
+  * ModulatedConv2d (reference layers.py:259-323) never materialises per-sample weights.  The style
+    scales the activation tile inside the MFMA convolution kernel, the demodulation factor
+    rsqrt(sum (W*s)^2 + eps) = rsqrt(s^2 @ sum_k W^2 + eps) is a [B,Cin]x[Cin,Cout] product, and it
+    is applied in the kernel epilogue.  Identical algebra, fp32 round-off level differences
+    (tolerance stated in tests/test_model_gpu.py).
+  * the stride-2 transposed convolution of the upsampling layers runs as four output phases of
+    the same kernel, followed by the LDS-tiled FIR blur (op.upfirdn2d).
+  * CPU tensors follow the reference's own formulation (grouped F.conv2d), which is what the
+    reference executes for them; device tensors never take that route.
+"""
+import math
+
+import torch
+from torch import nn
+from torch.nn import functional as F
+
+from .op import FusedLeakyReLU, fused_leaky_relu, upfirdn2d
+from .op import conv as _conv
+
+
+def make_kernel(k):
+    k = torch.tensor(k, dtype=torch.float32)
+    if k.dim() == 1:
+        k = k[None, :] * k[:, None]
+    return k / k.sum()
+
+
+def _taps(w):
+    """[Cout, Cin, k, k] -> [k*k, Cin, Cout] (the layout of the MFMA kernels)."""
+    co, ci, kh, kw = w.shape
+    return w.permute(2, 3, 1, 0).reshape(kh * kw, ci, co).contiguous()
+
+
+class PixelNorm(nn.Module):
+    def __init__(self, eps=1e-8):
+        super().__init__()
+        self.eps = abs(eps)
+
+    def forward(self, input):
+        return input * torch.rsqrt(torch.mean(input * input, -1, keepdim=True) + self.eps)
+
+
+class Upsample(nn.Module):
+    def __init__(self, kernel, factor=2):
+        super().__init__()
+        self.factor = factor
+        self.register_buffer("kernel", make_kernel(kernel) * (factor ** 2))
+        p = self.kernel.shape[0] - factor
+        self.pad = ((p + 1) // 2 + factor - 1, p // 2)
+
+    def forward(self, input):
+        return upfirdn2d(input, self.kernel, up=self.factor, down=1, pad=self.pad)
+
+
+class Downsample(nn.Module):
+    def __init__(self, kernel, factor=2):
+        super().__init__()
+        self.factor = factor
+        self.register_buffer("kernel", make_kernel(kernel))
+        p = self.kernel.shape[0] - factor
+        self.pad = ((p + 1) // 2, p // 2)
+
+    def forward(self, input):
+        return upfirdn2d(input, self.kernel, up=1, down=self.factor, pad=self.pad)
+
+
+class Blur(nn.Module):
+    def __init__(self, kernel, pad, upsample_factor=1):
+        super().__init__()
+        kernel = make_kernel(kernel)
+        if upsample_factor > 1:
+            kernel = kernel * (upsample_factor ** 2)
+        self.register_buffer("kernel", kernel)
+        self.pad = pad
+
+    def forward(self, input):
+        return upfirdn2d(input, self.kernel, pad=self.pad)
+
+
+class EqualConv2d(nn.Module):
+    """Plain convolution with equalised learning rate (reference layers.py:204-221)."""
+
+    def __init__(self, in_channel, out_channel, kernel_size, stride=1, padding=0, bias=True):
+        super().__init__()
+        self.weight = nn.Parameter(torch.randn(out_channel, in_channel, kernel_size, kernel_size))
+        self.scale = 1 / math.sqrt(in_channel * kernel_size ** 2)
+        self.stride = stride
+        self.padding = padding
+        self.bias = nn.Parameter(torch.zeros(out_channel)) if bias else None
+
+    def _geom(self):
+        k = self.weight.shape[2]
+        return {(3, 1, 1): "c3", (3, 2, 0): "c3s2", (1, 1, 0): "c1", (1, 2, 0): "c1s2"}.get(
+            (k, self.stride, self.padding))
+
+    def forward(self, input):
+        geom = self._geom()
+        if input.device.type == "cuda" and geom is not None:
+            return _conv.conv2d(input, _taps(self.weight * self.scale), None, None, self.bias, geom)
+        return F.conv2d(input, self.weight * self.scale, bias=self.bias, stride=self.stride,
+                        padding=self.padding)
+
+    def __repr__(self):
+        return "%s(%d, %d, %d, stride=%d, padding=%d)" % (
+            self.__class__.__name__, self.weight.shape[1], self.weight.shape[0],
+            self.weight.shape[2], self.stride, self.padding)
+
+
+class EqualLinear(nn.Module):
+    def __init__(self, in_dim, out_dim, bias=True, bias_init=0, lr_mul=1, activation=None):
+        super().__init__()
+        self.weight = nn.Parameter(torch.randn(out_dim, in_dim).div_(lr_mul))
+        self.bias = nn.Parameter(torch.zeros(out_dim).fill_(bias_init)) if bias else None
+        self.activation = activation
+        self.scale = (1 / math.sqrt(in_dim)) * lr_mul
+        self.lr_mul = lr_mul
+
+    def forward(self, input):
+        if self.activation == "fused_lrelu":
+            out = F.linear(input, self.weight * self.scale)
+            return fused_leaky_relu(out, self.bias * self.lr_mul)
+        bias = self.bias * self.lr_mul if self.bias is not None else None
+        out = F.linear(input, self.weight * self.scale, bias=bias)
+        if self.activation == "relu":
+            out = F.relu(out)
+        elif self.activation == "lrelu":
+            out = F.leaky_relu(out, negative_slope=0.2)
+        elif self.activation == "selu":
+            out = F.selu(out)
+        elif self.activation == "tanh":
+            out = torch.tanh(out)
+        return out
+
+    def __repr__(self):
+        return "%s(%d, %d)" % (self.__class__.__name__, self.weight.shape[1], self.weight.shape[0])
+
+
+class ScaledLeakyReLU(nn.Module):
+    def __init__(self, negative_slope=0.2):
+        super().__init__()
+        self.negative_slope = negative_slope
+
+    def forward(self, input):
+        return F.leaky_relu(input, negative_slope=self.negative_slope) * math.sqrt(2)
+
+
+class ModulatedConv2d(nn.Module):
+    def __init__(self, in_channel, out_channel, kernel_size, style_dim, demodulate=True,
+                 upsample=False, downsample=False, blur_kernel=[1, 3, 3, 1]):
+        super().__init__()
+        self.eps = 1e-8
+        self.kernel_size = kernel_size
+        self.in_channel = in_channel
+        self.out_channel = out_channel
+        self.upsample = upsample
+        self.downsample = downsample
+        if upsample:
+            factor = 2
+            p = (len(blur_kernel) - factor) - (kernel_size - 1)
+            self.blur = Blur(blur_kernel, pad=((p + 1) // 2 + factor - 1, p // 2 + 1),
+                             upsample_factor=factor)
+        if downsample:
+            factor = 2
+            p = (len(blur_kernel) - factor) + (kernel_size - 1)
+            self.blur = Blur(blur_kernel, pad=((p + 1) // 2, p // 2))
+        self.scale = 1 / math.sqrt(in_channel * kernel_size ** 2)
+        self.padding = kernel_size // 2
+        self.weight = nn.Parameter(torch.randn(1, out_channel, in_channel, kernel_size, kernel_size))
+        self.modulation = EqualLinear(style_dim, in_channel, bias_init=1)
+        self.demodulate = demodulate
+
+    def __repr__(self):
+        return "%s(%d, %d, %d, upsample=%s, downsample=%s)" % (
+            self.__class__.__name__, self.in_channel, self.out_channel, self.kernel_size,
+            self.upsample, self.downsample)
+
+    # ---- device tensors: shared weights + operand scaling on the MFMA kernels
+    def _forward_mfma(self, input, style):
+        w = self.weight[0] * self.scale                                  # [Co, Ci, k, k]
+        s = self.modulation(style)                                       # [B, Ci]
+        d = None
+        if self.demodulate:
+            w2 = w.pow(2).sum((2, 3)).t()                                # [Ci, Co]
+            d = torch.rsqrt(torch.matmul(s * s, w2) + self.eps)          # [B, Co]
+        wt = _taps(w)
+        k = self.kernel_size
+        if self.upsample:
+            if k != 3:
+                raise RuntimeError("ModulatedConv2d: upsample supports kernel_size 3")
+            out = _conv.conv2d(input, wt, s, d, None, "t3s2")
+            return self.blur(out)
+        if self.downsample:
+            if k != 3:
+                raise RuntimeError("ModulatedConv2d: downsample supports kernel_size 3")
+            return _conv.conv2d(self.blur(input), wt, s, d, None, "c3s2")
+        if k == 3:
+            return _conv.conv2d(input, wt, s, d, None, "c3")
+        if k == 1:
+            return _conv.conv2d(input, wt, s, d, None, "c1")
+        raise RuntimeError("ModulatedConv2d: kernel_size %d is not supported on device" % k)
+
+    # ---- CPU tensors: the reference's grouped-convolution formulation (reference layers.py:293-323)
+    def _forward_grouped(self, input, style):
+        batch, in_channel, height, width = input.shape
+        k = self.kernel_size
+        s = self.modulation(style).view(batch, 1, in_channel, 1, 1)
+        weight = self.scale * self.weight * s
+        if self.demodulate:
+            weight = weight * torch.rsqrt(weight.pow(2).sum([2, 3, 4], keepdim=True) + self.eps)
+        if self.upsample:
+            wt = weight.transpose(1, 2).reshape(batch * in_channel, self.out_channel, k, k)
+            out = F.conv_transpose2d(input.reshape(1, batch * in_channel, height, width), wt,
+                                     padding=0, stride=2, groups=batch)
+            return self.blur(out.view(batch, self.out_channel, out.shape[2], out.shape[3]))
+        wflat = weight.view(batch * self.out_channel, in_channel, k, k)
+        if self.downsample:
+            x = self.blur(input)
+            out = F.conv2d(x.reshape(1, batch * in_channel, x.shape[2], x.shape[3]), wflat, padding=0,
+                           stride=2, groups=batch)
+        else:
+            out = F.conv2d(input.reshape(1, batch * in_channel, height, width), wflat,
+                           padding=self.padding, groups=batch)
+        return out.view(batch, self.out_channel, out.shape[2], out.shape[3])
+
+    def forward(self, input, style):
+        if input.device.type == "cuda":
+            return self._forward_mfma(input, style)
+        return self._forward_grouped(input, style)
+
+
+class NoiseInjection(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.weight = nn.Parameter(torch.zeros(1))
+
+    def forward(self, image, noise=None):
+        if noise is None:
+            batch, _, height, width = image.shape
+            noise = image.new_empty(batch, 1, height, width).normal_()
+        return image + self.weight * noise
+
+
+class ConstantInput(nn.Module):
+    def __init__(self, channel, size=4):
+        super().__init__()
+        self.input = nn.Parameter(torch.randn(1, channel, size, size))
+
+    def forward(self, input):
+        return self.input.repeat(input.shape[0], 1, 1, 1)
+
+
+class ConvLayer(nn.Sequential):
+    """[Blur] -> EqualConv2d -> [FusedLeakyReLU | ScaledLeakyReLU] (reference layers.py:341-378).
+    `activate` is 'lrelu' or anything else for "no activation"; the reference passes False from
+    ResBlock.skip, which its own code cannot digest — accepted here."""
+
+    def __init__(self, in_channel, out_channel, kernel_size, downsample=False,
+                 blur_kernel=[1, 3, 3, 1], bias=True, activate="lrelu"):
+        layers = []
+        if downsample:
+            factor = 2
+            p = (len(blur_kernel) - factor) + (kernel_size - 1)
+            layers.append(Blur(blur_kernel, pad=((p + 1) // 2, p // 2)))
+            stride, padding = 2, 0
+        else:
+            stride, padding = 1, kernel_size // 2
+        self.padding = padding
+        layers.append(EqualConv2d(in_channel, out_channel, kernel_size, padding=padding,
+                                  stride=stride, bias=bias))
+        if activate == "lrelu":
+            layers.append(FusedLeakyReLU(out_channel) if bias else ScaledLeakyReLU(0.2))
+        super().__init__(*layers)
+
+
+class ResBlock(nn.Module):
+    def __init__(self, in_channel, out_channel, blur_kernel=[1, 3, 3, 1], downsample=True):
+        super().__init__()
+        self.conv1 = ConvLayer(in_channel, in_channel, 3)
+        self.conv2 = ConvLayer(in_channel, out_channel, 3, downsample=downsample)
+        self.skip = ConvLayer(in_channel, out_channel, 1, downsample=downsample, activate=False,
+                              bias=False)
+
+    def forward(self, input):
+        out = self.conv2(self.conv1(input))
+        return (out + self.skip(input)) / math.sqrt(2)

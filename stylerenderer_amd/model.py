@@ -1,0 +1,258 @@
+"""Networks of the StyleRenderer hot path on the MI355X-native layers.
+
+Drop-in for the reference's model.py: same class names, constructor signatures, forward
+signatures and return tuples, and the same state_dict keys (incl. the reference's duplicated
+`to_rgbs` tail, SURVEY.md D5: the second half of `to_rgbs` is registered but never used, so
+reference checkpoints with 165 keys at 256x256 load with strict=True).
+
+  Generator         reference model.py:71-187
+  GeneratorWithMap  reference model.py:188-295   (rasterised normal maps modulate every layer)
+  Discriminator     reference model.py:296-336
+"""
+import math
+
+import numpy as np
+import torch
+from torch import nn
+
+from .layers import (Blur, ConstantInput, ConvLayer, EqualLinear, ModulatedConv2d, NoiseInjection,  # noqa: F401
+                     PixelNorm, ResBlock, Upsample)
+from .op import FusedLeakyReLU, rasterize
+
+CHANNEL_BASE = {4: 512, 8: 512, 16: 512, 32: 512, 64: 256, 128: 128, 256: 64, 512: 32, 1024: 16}
+
+
+def channel_table(channel_multiplier):
+    return {r: (c if r <= 32 else c * channel_multiplier) for r, c in CHANNEL_BASE.items()}
+
+
+class StyledConv(nn.Module):
+    """modulated conv -> noise -> bias + LeakyReLU (reference model.py:11-32)."""
+
+    def __init__(self, in_channel, out_channel, kernel_size, style_dim, upsample=False,
+                 blur_kernel=[1, 3, 3, 1], demodulate=True):
+        super().__init__()
+        self.conv = ModulatedConv2d(in_channel, out_channel, kernel_size, style_dim,
+                                    upsample=upsample, blur_kernel=blur_kernel, demodulate=demodulate)
+        self.noise = NoiseInjection()
+        self.bias = None
+        self.activate = FusedLeakyReLU(out_channel)
+
+    def forward(self, input, style, noise=None):
+        out = self.conv(input, style)
+        out = self.noise(out, noise=noise)
+        return self.activate(out)
+
+
+class StyledMapConv(nn.Module):
+    """StyledConv with a per-pixel affine from the rasterised normal map between the conv and
+    the noise (reference model.py:33-55)."""
+
+    def __init__(self, in_channel, out_channel, kernel_size, style_dim, upsample=False,
+                 blur_kernel=[1, 3, 3, 1], demodulate=True):
+        super().__init__()
+        self.conv = ModulatedConv2d(in_channel, out_channel, kernel_size, style_dim,
+                                    upsample=upsample, blur_kernel=blur_kernel, demodulate=demodulate)
+        self.noise = NoiseInjection()
+        self.bias = None
+        self.activate = FusedLeakyReLU(out_channel)
+
+    def forward(self, input, style, stylemap, noise=None):
+        out = self.conv(input, style)
+        out = out * stylemap[:, :1] + stylemap[:, 1:2]
+        out = self.noise(out, noise=noise)
+        return self.activate(out)
+
+
+class ToRGB(nn.Module):
+    def __init__(self, in_channel, style_dim, upsample=True, blur_kernel=[1, 3, 3, 1]):
+        super().__init__()
+        if upsample:
+            self.upsample = Upsample(blur_kernel)
+        self.conv = ModulatedConv2d(in_channel, 3, 1, style_dim, demodulate=False)
+        self.bias = nn.Parameter(torch.zeros(1, 3, 1, 1))
+
+    def forward(self, input, style, skip=None):
+        out = self.conv(input, style) + self.bias
+        if skip is not None:
+            out = out + self.upsample(skip)
+        return out
+
+
+class Generator(nn.Module):
+    def __init__(self, size, style_dim, n_mlp, channel_multiplier=2, blur_kernel=[1, 3, 3, 1],
+                 lr_mlp=0.01):
+        super().__init__()
+        self._build_trunk(size, style_dim, n_mlp, channel_multiplier, lr_mlp)
+        self._build_synthesis(StyledConv, style_dim, blur_kernel)
+
+    # -- registration order matters for state_dict key order; names match the reference
+    def _build_trunk(self, size, style_dim, n_mlp, channel_multiplier, lr_mlp):
+        self.size = size
+        self.style_dim = style_dim
+        mapping = [PixelNorm()]
+        mapping += [EqualLinear(style_dim, style_dim, lr_mul=lr_mlp, activation="fused_lrelu")
+                    for _ in range(n_mlp)]
+        self.style = nn.Sequential(*mapping)
+        self.channels = channel_table(channel_multiplier)
+        self.input = ConstantInput(self.channels[4])
+        self.to_rgb1 = ToRGB(self.channels[4], style_dim, upsample=False)
+        self.log_size = int(math.log(size, 2))
+        self.num_layers = (self.log_size - 2) * 2 + 1
+        self.n_latent = self.log_size * 2 - 2
+        self.convs = nn.ModuleList()
+        self.upsamples = nn.ModuleList()
+        self.to_rgbs = nn.ModuleList()
+        self.noises = nn.Module()
+        for layer_idx in range(self.num_layers):
+            res = (layer_idx + 5) // 2
+            self.noises.register_buffer("noise_%d" % layer_idx, torch.randn(1, 1, 2 ** res, 2 ** res))
+        # the ToRGB heads the forward pass uses (first half of `to_rgbs`)
+        for i in range(3, self.log_size + 1):
+            self.to_rgbs.append(ToRGB(self.channels[2 ** i], style_dim))
+
+    def _build_synthesis(self, conv_cls, style_dim, blur_kernel, per_resolution=None):
+        in_channel = self.channels[4]
+        self.conv1 = conv_cls(in_channel, in_channel, 3, style_dim, blur_kernel=blur_kernel)
+        for i in range(3, self.log_size + 1):
+            out_channel = self.channels[2 ** i]
+            self.convs.append(conv_cls(in_channel, out_channel, 3, style_dim, upsample=True,
+                                       blur_kernel=blur_kernel))
+            self.convs.append(conv_cls(out_channel, out_channel, 3, style_dim, blur_kernel=blur_kernel))
+            if per_resolution is not None:
+                per_resolution()
+            # never used by forward(); kept so that reference checkpoints load
+            self.to_rgbs.append(ToRGB(out_channel, style_dim))
+            in_channel = out_channel
+
+    def make_noise(self):
+        device = self.input.input.device
+        noises = [torch.randn(1, 1, 4, 4, device=device)]
+        for i in range(3, self.log_size + 1):
+            noises += [torch.randn(1, 1, 2 ** i, 2 ** i, device=device) for _ in range(2)]
+        return noises
+
+    def mean_latent(self, n_latent):
+        z = torch.randn(n_latent, self.style_dim, device=self.input.input.device)
+        return self.style(z).mean(0, keepdim=True)
+
+    def get_latent(self, input):
+        return self.style(input)
+
+    # -- shared front half of forward(): styles -> per-layer latent [B, n_latent, D] and noises
+    def _latents(self, styles, inject_index, truncation, truncation_latent, input_is_latent, noise,
+                 randomize_noise):
+        if not input_is_latent:
+            styles = [self.style(s) for s in styles]
+        if noise is None:
+            if randomize_noise:
+                noise = [None] * self.num_layers
+            else:
+                noise = [getattr(self.noises, "noise_%d" % i) for i in range(self.num_layers)]
+        if truncation < 1 and truncation_latent is not None:
+            styles = [truncation_latent + truncation * (s - truncation_latent) for s in styles]
+        if len(styles) < 2:
+            inject_index = self.n_latent
+            if styles[0].dim() < 3:
+                latent = styles[0].unsqueeze(1).repeat(1, inject_index, 1)
+            else:
+                latent = styles[0]
+        else:
+            if inject_index is None:
+                inject_index = np.random.choice(self.n_latent - 2) + 1
+            latent = torch.cat([styles[0].unsqueeze(1).repeat(1, inject_index, 1),
+                                styles[1].unsqueeze(1).repeat(1, self.n_latent - inject_index, 1)], 1)
+        return latent, noise
+
+    def forward(self, styles, return_latents=False, inject_index=None, truncation=1,
+                truncation_latent=None, input_is_latent=False, noise=None, randomize_noise=True):
+        latent, noise = self._latents(styles, inject_index, truncation, truncation_latent,
+                                      input_is_latent, noise, randomize_noise)
+        out = self.input(latent)
+        out = self.conv1(out, latent[:, 0], noise=noise[0])
+        skip = self.to_rgb1(out, latent[:, 1])
+        i = 1
+        for conv_up, conv, n_up, n_conv, to_rgb in zip(self.convs[::2], self.convs[1::2],
+                                                       noise[1::2], noise[2::2], self.to_rgbs):
+            out = conv_up(out, latent[:, i], noise=n_up)
+            out = conv(out, latent[:, i + 1], noise=n_conv)
+            skip = to_rgb(out, latent[:, i + 2], skip)
+            i += 2
+        return skip, (latent if return_latents else None)
+
+
+class GeneratorWithMap(Generator):
+    def __init__(self, size, style_dim, n_mlp, n_stylemap=3, channel_multiplier=2,
+                 blur_kernel=[1, 3, 3, 1], lr_mlp=0.01):
+        nn.Module.__init__(self)
+        self._build_trunk(size, style_dim, n_mlp, channel_multiplier, lr_mlp)
+        self.norm_to_style = nn.ModuleList()
+        if n_stylemap != 3:
+            self.norm1 = nn.Sequential(ConvLayer(3, n_stylemap, 3), ResBlock(n_stylemap, 2, downsample=False))
+        else:
+            self.norm1 = ResBlock(n_stylemap, 2, downsample=False)
+
+        def add_map_heads():
+            if n_stylemap != 3:
+                self.norm_to_style.append(ConvLayer(3, n_stylemap, 3))
+            self.norm_to_style.append(ResBlock(n_stylemap, 4, downsample=False))
+
+        self._build_synthesis(StyledMapConv, style_dim, blur_kernel, per_resolution=add_map_heads)
+
+    def forward(self, styles, mesh, return_normals=False, return_latents=False, inject_index=None,
+                truncation=1, truncation_latent=None, input_is_latent=False, noise=None,
+                randomize_noise=True):
+        latent, noise = self._latents(styles, inject_index, truncation, truncation_latent,
+                                      input_is_latent, noise, randomize_noise)
+        vert, attr, tri = mesh[0], mesh[1], mesh[2]
+        out = self.input(latent)
+        norm_maps = [rasterize(vert, attr, tri, int(out.shape[2]), int(out.shape[3])).permute(0, 3, 1, 2)]
+        maps = self.norm1(norm_maps[-1])
+        out = self.conv1(out, latent[:, 0], maps, noise=noise[0])
+        skip = self.to_rgb1(out, latent[:, 1])
+        two_stage = len(self.convs) == len(self.norm_to_style)
+        i = 1
+        for conv_up, conv, n_up, n_conv, to_rgb in zip(self.convs[::2], self.convs[1::2],
+                                                       noise[1::2], noise[2::2], self.to_rgbs):
+            norm_maps.append(rasterize(vert, attr, tri, 2 * int(out.shape[2]),
+                                       2 * int(out.shape[3])).permute(0, 3, 1, 2))
+            if two_stage:
+                maps = self.norm_to_style[i](self.norm_to_style[i - 1](norm_maps[-1]))
+            else:
+                maps = self.norm_to_style[i // 2](norm_maps[-1])
+            out = conv_up(out, latent[:, i], maps[:, :2], noise=n_up)
+            out = conv(out, latent[:, i + 1], maps[:, 2:], noise=n_conv)
+            skip = to_rgb(out, latent[:, i + 2], skip)
+            i += 2
+        return skip, (latent if return_latents else None), (norm_maps if return_normals else None)
+
+
+class Discriminator(nn.Module):
+    def __init__(self, size, channel_multiplier=2, blur_kernel=[1, 3, 3, 1]):
+        super().__init__()
+        channels = channel_table(channel_multiplier)
+        convs = [ConvLayer(3, channels[size], 1)]
+        log_size = int(math.log(size, 2))
+        in_channel = channels[size]
+        for i in range(log_size, 2, -1):
+            out_channel = channels[2 ** (i - 1)]
+            convs.append(ResBlock(in_channel, out_channel, blur_kernel))
+            in_channel = out_channel
+        self.convs = nn.Sequential(*convs)
+        self.stddev_group = 4
+        self.stddev_feat = 1
+        self.final_conv = ConvLayer(in_channel + 1, channels[4], 3)
+        self.final_linear = nn.Sequential(
+            EqualLinear(channels[4] * 4 * 4, channels[4], activation="fused_lrelu"),
+            EqualLinear(channels[4], 1))
+
+    def forward(self, input):
+        out = self.convs(input)
+        batch, channel, height, width = out.shape
+        group = min(batch, self.stddev_group)
+        # minibatch standard deviation over groups of `group` samples
+        stat = out.view(group, -1, self.stddev_feat, channel // self.stddev_feat, height, width)
+        stat = torch.sqrt(stat.var(0, unbiased=False) + 1e-8)
+        stat = stat.mean([2, 3, 4], keepdim=True).squeeze(2).repeat(group, 1, height, width)
+        out = self.final_conv(torch.cat([out, stat], 1))
+        return self.final_linear(out.view(batch, -1))

@@ -1,0 +1,134 @@
+"""CPU: the drop-in model classes against the golden vectors generated from the reference
+(BASELINE config 0: the reference's CPU-runnable plumbing case)."""
+import numpy as np
+import pytest
+import torch
+
+from stylerenderer_amd import model, synth
+from util import rel_err
+
+T = torch.from_numpy
+
+
+def noise_list(g, key):
+    return [T(synth.det_normal((1, 1, 2 ** ((i + 5) // 2), 2 ** ((i + 5) // 2)), key + i))
+            for i in range(g.num_layers)]
+
+
+def test_parameter_counts_and_state_dict_keys():
+    # probed on the reference
+    g256 = model.Generator(256, 512, 8)
+    assert sum(p.numel() for p in g256.parameters()) == 31289268
+    assert len(g256.state_dict()) == 165
+    assert sum(p.numel() for p in model.Generator(64, 512, 8).parameters()) == 28089380
+    assert sum(p.numel() for p in model.GeneratorWithMap(256, 512, 8).parameters()) == 31290709
+    assert sum(p.numel() for p in model.Discriminator(256).parameters()) == 28870017
+    assert sum(p.numel() for p in model.Discriminator(64).parameters()) == 26493953
+    keys = set(g256.state_dict())
+    for k in ("style.1.weight", "input.input", "conv1.conv.weight", "conv1.conv.modulation.bias",
+              "conv1.noise.weight", "conv1.activate.bias", "to_rgb1.bias", "convs.0.conv.blur.kernel",
+              "to_rgbs.0.upsample.kernel", "to_rgbs.11.conv.weight", "noises.noise_12"):
+        assert k in keys, k
+    blur = g256.state_dict()["convs.0.conv.blur.kernel"]
+    assert torch.allclose(blur[0], torch.tensor([.0625, .1875, .1875, .0625]))
+
+
+@pytest.fixture(scope="module")
+def g8():
+    g = model.Generator(8, 64, 2)
+    synth.fill_state_dict(g.state_dict(), salt=41)
+    return g
+
+
+def test_generator_s8_forward_variants(golden, g8):
+    gold = golden("generator_s8")
+    assert int(gold["n_keys"]) == len(g8.state_dict())
+    z = T(synth.det_normal((2, 64), 42))
+    noise = noise_list(g8, 4300)
+    img, lat = g8([z], return_latents=True, noise=noise)
+    assert rel_err(lat.detach().numpy(), gold["latent"]) < 1e-5
+    assert rel_err(img.detach().numpy(), gold["image"]) < 2e-5
+    img2, none = g8([z, T(synth.det_normal((2, 64), 44))], inject_index=1, noise=noise)
+    assert none is None and rel_err(img2.detach().numpy(), gold["image_mix"]) < 2e-5
+    img3, _ = g8([z], randomize_noise=False)
+    assert rel_err(img3.detach().numpy(), gold["image_bufnoise"]) < 2e-5
+    img4, _ = g8([z], truncation=0.7, truncation_latent=T(gold["trunc_latent"]), noise=noise)
+    assert rel_err(img4.detach().numpy(), gold["image_trunc"]) < 2e-5
+    # input_is_latent round trip
+    img5, _ = g8([lat.detach()], input_is_latent=True, noise=noise)
+    assert rel_err(img5.detach().numpy(), gold["image"]) < 2e-5
+
+
+def check_grad_digest(named_grads, names, norms, heads, tol):
+    assert sorted(named_grads) == list(names)
+    for n, want_norm, want_head in zip(names, norms, heads):
+        g = named_grads[n]
+        got_norm = float(g.double().norm())
+        assert abs(got_norm - want_norm) <= tol * max(want_norm, 1e-6), (n, got_norm, want_norm)
+        head = g.reshape(-1)[:8].detach().cpu().numpy()
+        scale = max(float(np.abs(want_head).max()), want_norm / np.sqrt(g.numel()), 1e-8)
+        assert np.abs(head - want_head[:head.size]).max() <= 10 * tol * scale, n
+
+
+def test_generator_s8_gradients_and_unused_tail(golden, g8):
+    gold = golden("generator_s8")
+    z = T(synth.det_normal((2, 64), 42))
+    img, _ = g8([z], noise=noise_list(g8, 4300))
+    proj = T(synth.det_normal(tuple(img.shape), 46))
+    params = dict(g8.named_parameters())
+    grads = torch.autograd.grad((img * proj).sum(), list(params.values()), allow_unused=True)
+    got = {n: g for n, g in zip(params, grads) if g is not None}
+    unused = sorted(n for n, g in zip(params, grads) if g is None)
+    assert unused == list(gold["unused"])                 # the dead half of to_rgbs
+    check_grad_digest(got, gold["grad_names"], gold["grad_norms"], gold["grad_heads"], 1e-4)
+
+
+def test_path_length_regulariser_double_backward(golden, g8):
+    """Double backward through every layer (reference train.py:118-134 semantics)."""
+    gold = golden("generator_s8")
+    z = T(synth.det_normal((2, 64), 42))
+    img, lat = g8([z], return_latents=True, noise=noise_list(g8, 4300))
+    pl_noise = T(synth.det_normal(tuple(img.shape), 47)) / np.sqrt(img.shape[2] * img.shape[3])
+    (gl,) = torch.autograd.grad((img * pl_noise).sum(), lat, create_graph=True)
+    flat = gl.reshape(gl.shape[0], -1)
+    lengths = torch.sqrt((flat * flat).sum(1))
+    assert rel_err(lengths.detach().numpy(), gold["pl_lengths"]) < 1e-4
+    mean = 0.01 * lengths.mean()
+    penalty = (lengths - mean).pow(2).mean()
+    assert abs(float(penalty) - float(gold["pl_penalty"])) < 1e-4 * float(gold["pl_penalty"])
+    g8.zero_grad()
+    penalty.backward()
+    got = {n: p.grad for n, p in g8.named_parameters() if p.grad is not None}
+    check_grad_digest(got, gold["pl_grad_names"], gold["pl_grad_norms"], gold["pl_grad_heads"], 1e-3)
+    g8.zero_grad()
+
+
+def test_generator_s64_plumbing(golden):
+    """BASELINE config 0: 64x64 generator on CPU; image equals the reference's."""
+    gold = golden("generator_s64")
+    g = model.Generator(64, 512, 8)
+    assert sum(p.numel() for p in g.parameters()) == int(gold["n_params"])
+    assert len(g.state_dict()) == int(gold["n_keys"])
+    synth.fill_state_dict(g.state_dict(), salt=41)
+    with torch.no_grad():
+        img, lat = g([T(synth.det_normal((1, 512), 42))], return_latents=True, noise=noise_list(g, 4300))
+    assert rel_err(lat.numpy(), gold["latent"]) < 1e-5
+    assert rel_err(img.numpy(), gold["image"]) < 5e-5
+
+
+def test_discriminator_s16(golden):
+    gold = golden("discriminator_s16")
+    d = model.Discriminator(16)
+    assert sum(p.numel() for p in d.parameters()) == int(gold["n_params"])
+    synth.fill_state_dict(d.state_dict(), salt=61)
+    x = T(gold["x"]).requires_grad_()
+    y = d(x)
+    assert rel_err(y.detach().numpy(), gold["y"]) < 2e-5
+    (gx,) = torch.autograd.grad(y.sum(), x, create_graph=True)
+    assert rel_err(gx.detach().numpy(), gold["gx"]) < 5e-5
+    r1 = (gx * gx).reshape(4, -1).sum(1).mean()
+    assert abs(float(r1) - float(gold["r1"])) < 1e-4 * float(gold["r1"])
+    d.zero_grad()
+    r1.backward()
+    got = {n: p.grad for n, p in d.named_parameters() if p.grad is not None}
+    check_grad_digest(got, gold["r1_grad_names"], gold["r1_grad_norms"], gold["r1_grad_heads"], 1e-3)

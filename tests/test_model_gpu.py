@@ -1,0 +1,158 @@
+"""GPU: the full networks on the HIP path against the golden vectors generated from the reference.
+Tolerance (north_star: "within a stated fp32 tolerance for generator activations"): the modulated
+convolution applies style/demodulation to the operands instead of building per-sample weights, and
+the MFMA accumulates in a different order than oneDNN, so activations agree to fp32 round-off:
+   max |a - b| <= 2e-4 * max |b|      (images, latents, normal maps)
+   gradient digests: norms within 1e-3 relative (first order), 3e-3 (double backward)."""
+import numpy as np
+import pytest
+import torch
+
+from stylerenderer_amd import model, synth
+from test_model_cpu import check_grad_digest, noise_list
+from util import rel_err
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+TOL = 2e-4
+
+
+def T(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+@pytest.fixture(scope="module")
+def g8():
+    g = model.Generator(8, 64, 2)
+    synth.fill_state_dict(g.state_dict(), salt=41)
+    return g.to(DEV)
+
+
+def dev_noise(g, key):
+    return [n.to(DEV) for n in noise_list(g, key)]
+
+
+def test_generator_s8_forward_variants(golden, g8):
+    gold = golden("generator_s8")
+    z = T(synth.det_normal((2, 64), 42))
+    noise = dev_noise(g8, 4300)
+    img, lat = g8([z], return_latents=True, noise=noise)
+    assert rel_err(lat.detach().cpu().numpy(), gold["latent"]) < 1e-5
+    assert rel_err(img.detach().cpu().numpy(), gold["image"]) < TOL
+    img2, _ = g8([z, T(synth.det_normal((2, 64), 44))], inject_index=1, noise=noise)
+    assert rel_err(img2.detach().cpu().numpy(), gold["image_mix"]) < TOL
+    img3, _ = g8([z], randomize_noise=False)
+    assert rel_err(img3.detach().cpu().numpy(), gold["image_bufnoise"]) < TOL
+    img4, _ = g8([z], truncation=0.7, truncation_latent=T(gold["trunc_latent"]), noise=noise)
+    assert rel_err(img4.detach().cpu().numpy(), gold["image_trunc"]) < TOL
+
+
+def test_generator_s8_gradients(golden, g8):
+    gold = golden("generator_s8")
+    z = T(synth.det_normal((2, 64), 42))
+    img, _ = g8([z], noise=dev_noise(g8, 4300))
+    proj = T(synth.det_normal(tuple(img.shape), 46))
+    params = dict(g8.named_parameters())
+    grads = torch.autograd.grad((img * proj).sum(), list(params.values()), allow_unused=True)
+    got = {n: g for n, g in zip(params, grads) if g is not None}
+    assert sorted(n for n, g in zip(params, grads) if g is None) == list(gold["unused"])
+    check_grad_digest(got, gold["grad_names"], gold["grad_norms"], gold["grad_heads"], 1e-3)
+
+
+def test_path_length_regulariser_double_backward(golden, g8):
+    gold = golden("generator_s8")
+    z = T(synth.det_normal((2, 64), 42))
+    img, lat = g8([z], return_latents=True, noise=dev_noise(g8, 4300))
+    pl_noise = T(synth.det_normal(tuple(img.shape), 47)) / np.sqrt(img.shape[2] * img.shape[3])
+    (gl,) = torch.autograd.grad((img * pl_noise).sum(), lat, create_graph=True)
+    flat = gl.reshape(gl.shape[0], -1)
+    lengths = torch.sqrt((flat * flat).sum(1))
+    assert rel_err(lengths.detach().cpu().numpy(), gold["pl_lengths"]) < 1e-3
+    penalty = (lengths - 0.01 * lengths.mean()).pow(2).mean()
+    assert abs(penalty.item() - float(gold["pl_penalty"])) < 2e-3 * float(gold["pl_penalty"])
+    g8.zero_grad()
+    penalty.backward()
+    got = {n: p.grad for n, p in g8.named_parameters() if p.grad is not None}
+    check_grad_digest(got, gold["pl_grad_names"], gold["pl_grad_norms"], gold["pl_grad_heads"], 3e-3)
+    g8.zero_grad()
+
+
+def test_generator_s64_vs_reference_image(golden):
+    gold = golden("generator_s64")
+    g = model.Generator(64, 512, 8)
+    synth.fill_state_dict(g.state_dict(), salt=41)
+    g = g.to(DEV)
+    with torch.no_grad():
+        img, lat = g([T(synth.det_normal((1, 512), 42))], return_latents=True, noise=dev_noise(g, 4300))
+    assert rel_err(img.cpu().numpy(), gold["image"]) < TOL
+
+
+def test_generator_gpu_equals_own_cpu_path_at_64():
+    """Same module, CPU tensors (reference formulation) vs device tensors (HIP kernels), B=4."""
+    g = model.Generator(64, 512, 8)
+    synth.fill_state_dict(g.state_dict(), salt=3)
+    z = torch.from_numpy(synth.det_normal((4, 512), 9))
+    noise = noise_list(g, 77)
+    with torch.no_grad():
+        a, _ = g([z], noise=noise)
+    g = g.to(DEV)
+    with torch.no_grad():
+        b, _ = g([z.to(DEV)], noise=[n.to(DEV) for n in noise])
+    assert rel_err(b.cpu().numpy(), a.numpy()) < TOL
+
+
+def test_generator_with_map_s16(golden):
+    gold = golden("generator_map_s16")
+    g = model.GeneratorWithMap(16, 64, 2)
+    assert sum(p.numel() for p in g.parameters()) == int(gold["n_params"])
+    synth.fill_state_dict(g.state_dict(), salt=51)
+    g = g.to(DEV)
+    mesh = (T(gold["v"]), T(gold["nrm"]), T(gold["tri"].astype(np.int64)))
+    z = T(synth.det_normal((2, 64), 52))
+    img, lat, maps = g([z], mesh, return_normals=True, return_latents=True, noise=dev_noise(g, 5300))
+    assert len(maps) == 3
+    for i, m in enumerate(maps):
+        assert np.abs(m.detach().cpu().numpy() - gold["normmap_%d" % i]).max() <= 2e-7
+    assert rel_err(img.detach().cpu().numpy(), gold["image"]) < TOL
+    # gradients reach the mesh through the rasterizer and the map heads
+    v = mesh[0].clone().requires_grad_()
+    n = mesh[1].clone().requires_grad_()
+    img2, _, _ = g([z], (v, n, mesh[2]), noise=dev_noise(g, 5300))
+    gv, gn = torch.autograd.grad(img2.sum(), [v, n])
+    assert torch.isfinite(gv).all() and torch.isfinite(gn).all() and gn.abs().sum() > 0
+
+
+def test_discriminator_s16(golden):
+    gold = golden("discriminator_s16")
+    d = model.Discriminator(16)
+    synth.fill_state_dict(d.state_dict(), salt=61)
+    d = d.to(DEV)
+    x = T(gold["x"]).requires_grad_()
+    y = d(x)
+    assert rel_err(y.detach().cpu().numpy(), gold["y"]) < TOL
+    (gx,) = torch.autograd.grad(y.sum(), x, create_graph=True)
+    assert rel_err(gx.detach().cpu().numpy(), gold["gx"]) < 5e-4
+    r1 = (gx * gx).reshape(4, -1).sum(1).mean()
+    assert abs(r1.item() - float(gold["r1"])) < 1e-3 * float(gold["r1"])
+    d.zero_grad()
+    r1.backward()
+    got = {n: p.grad for n, p in d.named_parameters() if p.grad is not None}
+    check_grad_digest(got, gold["r1_grad_names"], gold["r1_grad_norms"], gold["r1_grad_heads"], 3e-3)
+
+
+def test_generator_256_full_size_properties():
+    """BASELINE config 1 size (256x256, B=16): fwd+bwd runs on the HIP path; per-sample
+    independence (sample 5 of the batch == the same latent alone) and finite gradients."""
+    g = model.Generator(256, 512, 8).to(DEV)
+    gen = torch.Generator(device=DEV).manual_seed(0)
+    z = torch.randn(16, 512, device=DEV, generator=gen)
+    noise = [n.to(DEV) for n in noise_list(g, 900)]
+    img, _ = g([z], noise=noise)
+    assert img.shape == (16, 3, 256, 256)
+    img.sum().backward()
+    for n, p in g.named_parameters():
+        if p.grad is not None:
+            assert torch.isfinite(p.grad).all(), n
+    with torch.no_grad():
+        one, _ = g([z[5:6]], noise=noise)
+    assert rel_err(one.cpu().numpy(), img[5:6].detach().cpu().numpy()) < TOL
