@@ -133,15 +133,16 @@ int sr_rasterize_grad_f64(int64_t b, int64_t nv, int64_t h, int64_t w, int repea
  *
  *   out[b,n,oy,ox] = oscale[b,n] * sum_{ky,kx,c} wt[ky*k+kx][c][n] * iscale[b,c] * in[b,c,iy,ix] + obias[n]
  *
- *   in  [B, C, IH, IW]   out [B, N, OH, OW]   wt [k*k, C, N]  (N contiguous)
+ *   in  [B, C, IH, IW]   out [B, N, OH, OW]   wt [k*k, C, wt_ld] (row pitch wt_ld >= N, a multiple
+ *   of 4 floats, base 16-byte aligned; columns N..wt_ld-1 are padding and may hold anything)
  *   iscale [B, C] | NULL   oscale [B, N] | NULL   obias [N] | NULL
  *   transposed = 0: correlation, iy = oy*stride + ky - pad   (k in {1,3}, stride in {1,2})
  *   transposed = 1: k = 3, stride = 2, pad = 0: out[2y+ky, 2x+kx] += in[y,x] * wt[ky*3+kx]
  *                   (OH = 2*IH + 1), the stride-2 transposed conv of the upsampling layers. */
 int sr_conv2d_mfma(float* out, const float* in, const float* wt, const float* iscale,
                    const float* oscale, const float* obias, int64_t B, int64_t C, int64_t N,
-                   int64_t IH, int64_t IW, int64_t OH, int64_t OW, int ksize, int stride, int pad,
-                   int transposed, sr_stream_t stream);
+                   int64_t wt_ld, int64_t IH, int64_t IW, int64_t OH, int64_t OW, int ksize, int stride,
+                   int pad, int transposed, sr_stream_t stream);
 
 /* Weight gradient of sr_conv2d_mfma (same geometry arguments):
  *   dwt[ky*k+kx][c][n] = sum_{b, pixels} (xscale[b,c] * x[b,c,window]) * (gscale[b,n] * gy[b,n,pixel])

@@ -7,8 +7,8 @@
 //
 //   out[b, n, oy, ox] = oscale[b, n] * sum_{tap, c} Wt[tap][c][n] * (iscale[b, c] * in[b, c, iy, ix])  (+ obias[n])
 //
-// with ONE shared weight tensor Wt [taps][C][N], the style s[b, c] applied to the activation tile
-// while it is staged into LDS, and the demodulation d[b, n] applied in the epilogue.  The same
+// with ONE shared weight tensor Wt [taps][C][N], the style s[b, c] multiplied onto the MFMA operand
+// right after it is read from LDS, and the demodulation d[b, n] applied in the epilogue.  The same
 // kernel is the data-gradient (swap iscale/oscale, flipped + transposed weights) and serves plain
 // EqualConv2d layers (no scales, optional bias).
 //
@@ -16,12 +16,16 @@
 //   GEMM  D[n][pixel] = sum_k A[n][k] * Bm[k][pixel],  A = weights, Bm = input window; k = (tap, c).
 //   tile  128 output channels x 128 pixels (a PB x PH x PW patch of the output grid), wave = 64 x 64
 //         = 2 x 2 MFMA tiles of 32 x 32 (64 accumulator VGPRs).
-//   K     channel chunks of 8: the input HALO patch of the chunk is staged ONCE in LDS and all
-//         taps read it at shifted addresses (9x less staging than im2col); the chunk's weights
-//         [taps][8][128] sit next to it.  Operand fetch is one conflict-free ds_read_b32 per MFMA
+//   K     channel chunks of KC: the input HALO patch of the chunk is staged ONCE in LDS and every
+//         tap reads it at a shifted address (9x less staging than im2col); the chunk's weights
+//         [taps][KC][128] sit next to it.  Operand fetch is one conflict-free ds_read_b32 per MFMA
 //         operand (lanes 0-31 = 32 consecutive pixels / channels, lanes 32-63 = the next k).
-//   pipe  next chunk's global loads are issued into registers before the MFMA block of the
-//         current chunk and written to LDS after it (async-stage split), 2-3 workgroups per CU.
+//   pipe  LDS is double buffered and filled by LDS-DMA (global_load_lds, 16 B/lane for weights,
+//         4 B/lane for the halo patch whose rows are not 16-byte aligned): no staging VGPRs, no
+//         LDS-write phase, no load result is consumed by VALU, so nothing waits on memory in front of
+//         the MFMA block; chunk i+1 streams in while chunk i is on the matrix cores; ONE barrier
+//         per chunk.  Border / channel-tail elements are sourced from a zero line, the style from a
+//         ones line when absent — every lane always issues its DMA (branch-free).
 //   out   lane (l & 31) owns a pixel, registers own channels: every store instruction writes
 //         32 consecutive pixels of one channel row per half-wave (128 B segments).
 // Variants by template: input stride 1 / 2, tap window (3x3, 2x2, 2x1, 1x2, 1x1) — the stride-2
@@ -32,10 +36,15 @@
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef const void __attribute__((address_space(1)))* gptr_t;
+typedef void __attribute__((address_space(3)))* lptr_t;
 
-// channels per K chunk: 8 (4 for the stride-2 3x3 window, whose halo patch is 4x larger)
 constexpr int BN = 128;    // output channels per workgroup
 constexpr int BM = 128;    // pixels per workgroup
+
+// DMA sources for masked lanes
+__device__ __attribute__((aligned(16))) const float g_zero_line[4] = {0.f, 0.f, 0.f, 0.f};
+__device__ __attribute__((aligned(16))) const float g_ones_line[4] = {1.f, 1.f, 1.f, 1.f};
 
 struct ConvParams {
     const float* in;
@@ -44,7 +53,7 @@ struct ConvParams {
     const float* oscale;
     const float* obias;
     float* out;
-    int B, C, N;
+    int B, C, N, ldw;    // ldw: row pitch of wt in floats (multiple of 4, >= N)
     int IH, IW;          // input extent
     int GH, GW;          // output grid computed by this launch (phase space)
     int OH, OW;          // full output extent
@@ -56,24 +65,28 @@ struct ConvParams {
 
 template <int IS, int TY, int TX, int PW, int PH, int PB>
 struct Geo {
-    static constexpr int KC = (IS == 2 && TY * TX == 9) ? 4 : 8;
+    static constexpr int NT = TY * TX;
+    // channels per K chunk: ~32-36 k-steps of MFMA work per barrier whatever the window
+    static constexpr int KC = NT >= 9 ? 4 : (NT >= 4 ? 8 : 16);
     static constexpr int EH = (PH - 1) * IS + TY;
     static constexpr int EW = (PW - 1) * IS + TX;
     static constexpr int EWP = EW + ((EW % 2 == 0) ? 1 : 0);     // odd row pitch
     static constexpr int PLANE = PB * EH * EWP;                  // one channel of the chunk
-    static constexpr int IN_ELEMS = KC * PB * EH * EW;
-    static constexpr int IN_ITERS = (IN_ELEMS + 255) / 256;
-    static constexpr int NT = TY * TX;
-    static constexpr int LDS_IN = KC * PLANE;
-    static constexpr int LDS_W = NT * KC * BN;
+    static constexpr int W_FLOATS = NT * KC * BN;                // [tap][c][128]
+    static constexpr int W_INSTR = W_FLOATS / 256;               // 1 KiB (2 rows) per wave instruction
+    static constexpr int IN_FLOATS = KC * PLANE + KC * PB;       // halo planes, then the style row(s)
+    static constexpr int IN_INSTR = (IN_FLOATS + 63) / 64;       // 256 B per wave instruction
+    static constexpr int BUF = W_FLOATS + IN_INSTR * 64;         // floats per LDS buffer
+    static constexpr int W_PER_WAVE = (W_INSTR + 3) / 4;
+    static constexpr int IN_PER_WAVE = (IN_INSTR + 3) / 4;
+    static constexpr int LDS_BYTES = 2 * BUF * 4;
 };
 
 template <int IS, int TY, int TX, int PW, int PH, int PB>
-__global__ __launch_bounds__(256, 2) void k_conv_mfma(const ConvParams p) {
+__global__ __launch_bounds__(256) void k_conv_mfma(const ConvParams p) {
     using G = Geo<IS, TY, TX, PW, PH, PB>;
     static_assert(PW * PH * PB == BM, "patch must hold 128 pixels");
-    __shared__ __attribute__((aligned(16))) float s_w[G::LDS_W];
-    __shared__ float s_in[G::LDS_IN];
+    extern __shared__ __attribute__((aligned(16))) float smem[];     // the ONLY LDS object
 
     // ---- tile decode; workgroups that share an input patch (different n tiles) and neighbouring
     // patches are numbered consecutively and kept on one XCD (bid % 8 is the XCD): chunked remap.
@@ -92,82 +105,91 @@ __global__ __launch_bounds__(256, 2) void k_conv_mfma(const ConvParams p) {
     const int n0 = n_t * BN, gy0 = ty_i * PH, gx0 = tx_i * PW, b0 = tb_i * PB;
     const int iy0 = gy0 * IS + p.dy0, ix0 = gx0 * IS + p.dx0;
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = lane >> 5, l31 = lane & 31;
     const int wco = wave & 1, wpx = wave >> 1;
 
-    // ---- per-lane LDS offsets of the MFMA operands
-    int a_off[2], b_off[2];
+    // ---- per-lane LDS offsets of the MFMA operands (inside one buffer)
+    int a_off[2], b_off[2], s_off[2];
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
         a_off[t] = half * BN + wco * 64 + t * 32 + l31;
         const int m = wpx * 64 + t * 32 + l31;
         const int px = m % PW, py = (m / PW) % PH, pb = m / (PW * PH);
-        b_off[t] = half * G::PLANE + (pb * G::EH + py * IS) * G::EWP + px * IS;
+        b_off[t] = G::W_FLOATS + half * G::PLANE + (pb * G::EH + py * IS) * G::EWP + px * IS;
+        s_off[t] = G::W_FLOATS + G::KC * G::PLANE + pb * G::KC + half;   // style of (sample, channel)
     }
 
-    // ---- staging descriptors (what this thread loads every chunk)
-    const int w_c = tid >> 5, w_n4 = (tid & 31) * 4;           // weights: channel of chunk, column
-    const bool w_vec = (p.N % 4 == 0) && (n0 + w_n4 + 3 < p.N);
-    // per staged element only two registers are kept (global offset, LDS offset); the chunk
-    // channel and the sample are re-derived from the element number (constant divisors).
-    int in_goff[G::IN_ITERS];    // offset inside one channel plane, -1 = outside the image / idle
-    int in_lds[G::IN_ITERS];     // LDS offset, -1 = idle slot
+    // ---- DMA descriptors (chunk-invariant part), a few registers per lane
+    // weights: instruction j moves LDS floats [256 j, 256 j + 256) = rows (2j, 2j+1) of [tap*KC + c][128]
+    int w_src[G::W_PER_WAVE];      // element offset into wt for c0 = 0
+    int w_cl[G::W_PER_WAVE];       // chunk-local channel (for the channel-tail mask), -1 = no instr
 #pragma unroll
-    for (int it = 0; it < G::IN_ITERS; ++it) {
-        const int e = tid + it * 256;
-        const int col = e % G::EW, r = (e / G::EW) % G::EH, pb = (e / (G::EW * G::EH)) % PB;
-        const int c = e / (G::EW * G::EH * PB);
-        const int gy = iy0 + r, gx = ix0 + col, b = b0 + pb;
-        const bool live = e < G::IN_ELEMS;
-        const bool inside = live && gy >= 0 && gy < p.IH && gx >= 0 && gx < p.IW && b < p.B;
-        in_goff[it] = inside ? gy * p.IW + gx : -1;
-        in_lds[it] = live ? c * G::PLANE + (pb * G::EH + r) * G::EWP + col : -1;
+    for (int i = 0; i < G::W_PER_WAVE; ++i) {
+        const int j = wave + 4 * i;
+        const int row = 2 * j + half;
+        const int t = row / G::KC, c = row % G::KC;
+        const int col = min(n0 + l31 * 4, p.ldw - 4);
+        w_cl[i] = (j < G::W_INSTR) ? c : -1;
+        int slab = 0;       // p.wmap[t] via selects (a runtime index would spill the kernarg struct)
+#pragma unroll
+        for (int k = 0; k < G::NT; ++k)
+            if (t == k) slab = p.wmap[k];
+        w_src[i] = (slab * p.C + c) * p.ldw + col;
     }
-    const int64_t plane_in = (int64_t)p.IH * p.IW;
-
-    float4 w_reg[G::NT];
-    float in_reg[G::IN_ITERS];
-
-    auto fetch = [&](int c0) {
-        // weights: one float4 per tap per thread (KC channels x 32 float4 columns <= 256 threads)
+    // input: instruction j moves LDS floats [64 j, 64 j + 64) of the halo image, then the style rows
+    int i_src[G::IN_PER_WAVE];     // element offset for (b0, c0) = (0, 0); -1 zero line, -2 style
+    int i_cl[G::IN_PER_WAVE];      // chunk-local channel | sample << 8
 #pragma unroll
-        for (int t = 0; t < G::NT; ++t) {
-            const int c = c0 + w_c;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (w_c < G::KC && c < p.C) {
-                const float* src = p.wt + ((int64_t)p.wmap[t] * p.C + c) * p.N + n0 + w_n4;
-                if (w_vec) {
-                    v = *reinterpret_cast<const float4*>(src);
-                } else {
-                    if (n0 + w_n4 < p.N) v.x = src[0];
-                    if (n0 + w_n4 + 1 < p.N) v.y = src[1];
-                    if (n0 + w_n4 + 2 < p.N) v.z = src[2];
-                    if (n0 + w_n4 + 3 < p.N) v.w = src[3];
-                }
+    for (int i = 0; i < G::IN_PER_WAVE; ++i) {
+        const int j = wave + 4 * i;
+        const int f = j * 64 + lane;
+        int src = -1, c = 0, pb = 0;
+        if (j < G::IN_INSTR && f < G::KC * G::PLANE) {
+            c = f / G::PLANE;
+            const int q = f % G::PLANE;
+            const int colp = q % G::EWP, r = (q / G::EWP) % G::EH;
+            pb = q / (G::EWP * G::EH);
+            const int gy = iy0 + r, gx = ix0 + colp;
+            if (colp < G::EW && gy >= 0 && gy < p.IH && gx >= 0 && gx < p.IW && b0 + pb < p.B)
+                src = (pb * p.C + c) * p.IH * p.IW + gy * p.IW + gx;
+        } else if (j < G::IN_INSTR && f < G::IN_FLOATS) {
+            const int e = f - G::KC * G::PLANE;
+            pb = e / G::KC;
+            c = e % G::KC;
+            src = -2;
+        }
+        i_src[i] = src;
+        i_cl[i] = c | (pb << 8);
+    }
+    const float* in_base = p.in + (int64_t)b0 * p.C * p.IH * p.IW;
+    const int plane_in = p.IH * p.IW;
+
+    auto dma = [&](int c0, int buf) {
+        float* dst = smem + buf * G::BUF;
+#pragma unroll
+        for (int i = 0; i < G::W_PER_WAVE; ++i) {
+            const int j = wave + 4 * i;
+            if (j < G::W_INSTR) {       // wave-uniform
+                const float* src = (c0 + w_cl[i] < p.C) ? p.wt + w_src[i] + (int64_t)c0 * p.ldw : g_zero_line;
+                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(dst + j * 256), 16, 0, 0);
             }
-            w_reg[t] = v;
         }
 #pragma unroll
-        for (int it = 0; it < G::IN_ITERS; ++it) {
-            float v = 0.0f;
-            const int e = tid + it * 256;
-            const int c = c0 + e / (G::EW * G::EH * PB);
-            const int b = b0 + (e / (G::EW * G::EH)) % PB;
-            if (in_goff[it] >= 0 && c < p.C) {
-                v = p.in[((int64_t)b * p.C + c) * plane_in + in_goff[it]];
-                if (p.iscale) v *= p.iscale[(int64_t)b * p.C + c];
+        for (int i = 0; i < G::IN_PER_WAVE; ++i) {
+            const int j = wave + 4 * i;
+            if (j < G::IN_INSTR) {      // wave-uniform
+                const int c = i_cl[i] & 255, pb = i_cl[i] >> 8;
+                const bool c_ok = c0 + c < p.C;
+                const float* src = g_zero_line;
+                if (i_src[i] >= 0 && c_ok) src = in_base + i_src[i] + (int64_t)c0 * plane_in;
+                if (i_src[i] == -2)
+                    src = (p.iscale && c_ok && b0 + pb < p.B) ? p.iscale + (int64_t)(b0 + pb) * p.C + c0 + c
+                                                              : g_ones_line;
+                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(dst + G::W_FLOATS + j * 64), 4, 0, 0);
             }
-            in_reg[it] = v;
         }
-    };
-    auto commit = [&]() {
-#pragma unroll
-        for (int t = 0; t < G::NT; ++t)
-            if (w_c < G::KC) *reinterpret_cast<float4*>(&s_w[(t * G::KC + w_c) * BN + w_n4]) = w_reg[t];
-#pragma unroll
-        for (int it = 0; it < G::IN_ITERS; ++it)
-            if (in_lds[it] >= 0) s_in[in_lds[it]] = in_reg[it];
     };
 
     f32x16 acc[2][2];
@@ -178,30 +200,39 @@ __global__ __launch_bounds__(256, 2) void k_conv_mfma(const ConvParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-    fetch(0);
+    dma(0, 0);
+    int buf = 0;
     for (int c0 = 0; c0 < p.C; c0 += G::KC) {
-        __syncthreads();            // everyone finished reading the previous chunk
-        commit();
+        // (a) this wave's DMA of chunk c0 has landed (the compiler drains vmcnt before the barrier),
+        // (b) every wave is done reading the buffer the next DMA overwrites
         __syncthreads();
-        if (c0 + G::KC < p.C) fetch(c0 + G::KC);     // in flight while the matrix cores run
+        if (c0 + G::KC < p.C) dma(c0 + G::KC, buf ^ 1);
+        const float* sb = smem + buf * G::BUF;
 #pragma unroll
-        for (int ty = 0; ty < TY; ++ty)
+        for (int cp = 0; cp < G::KC / 2; ++cp) {
+            // style of channel (2 cp + half): onto the weight operand when the tile holds one
+            // sample, onto the input operand when it holds several
+            const float sc0 = sb[s_off[0] + 2 * cp];
+            const float sc1 = (PB > 1) ? sb[s_off[1] + 2 * cp] : sc0;
 #pragma unroll
-            for (int tx = 0; tx < TX; ++tx) {
-                const int w_tap = (ty * TX + tx) * G::KC * BN;
-                const int i_tap = ty * G::EWP + tx;
+            for (int ty = 0; ty < TY; ++ty)
 #pragma unroll
-                for (int cp = 0; cp < G::KC / 2; ++cp) {
-                    const float a0 = s_w[w_tap + (2 * cp) * BN + a_off[0]];
-                    const float a1 = s_w[w_tap + (2 * cp) * BN + a_off[1]];
-                    const float x0 = s_in[(2 * cp) * G::PLANE + i_tap + b_off[0]];
-                    const float x1 = s_in[(2 * cp) * G::PLANE + i_tap + b_off[1]];
+                for (int tx = 0; tx < TX; ++tx) {
+                    const int w_tap = ((ty * TX + tx) * G::KC + 2 * cp) * BN;
+                    const int i_tap = (2 * cp) * G::PLANE + ty * G::EWP + tx;
+                    float a0 = sb[w_tap + a_off[0]];
+                    float a1 = sb[w_tap + a_off[1]];
+                    float x0 = sb[i_tap + b_off[0]];
+                    float x1 = sb[i_tap + b_off[1]];
+                    if (PB == 1) { a0 *= sc0; a1 *= sc0; }
+                    else { x0 *= sc0; x1 *= sc1; }
                     acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, x0, acc[0][0], 0, 0, 0);
                     acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, x1, acc[0][1], 0, 0, 0);
                     acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, x0, acc[1][0], 0, 0, 0);
                     acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, x1, acc[1][1], 0, 0, 0);
                 }
-            }
+        }
+        buf ^= 1;
     }
 
     // ---- epilogue: C/D layout of the 32x32 MFMA: column (pixel) = lane & 31,
@@ -229,6 +260,20 @@ __global__ __launch_bounds__(256, 2) void k_conv_mfma(const ConvParams p) {
     }
 }
 
+template <int IS, int TY, int TX, int PW, int PH, int PB>
+int launch_one(const ConvParams& p, dim3 grid, hipStream_t st) {
+    using G = Geo<IS, TY, TX, PW, PH, PB>;
+    auto kern = k_conv_mfma<IS, TY, TX, PW, PH, PB>;
+    static bool configured = false;     // opt in to > 64 KiB of dynamic LDS once per variant
+    if (!configured) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
+        configured = true;
+    }
+    hipLaunchKernelGGL(kern, grid, dim3(256), G::LDS_BYTES, st, p);
+    return sr_launch_status();
+}
+
 template <int IS, int TY, int TX>
 int launch_by_patch(ConvParams& p, hipStream_t st) {
     // patch shape from the grid width: 32x4, 16x8, 8x8x2, 4x4x8
@@ -244,28 +289,31 @@ int launch_by_patch(ConvParams& p, hipStream_t st) {
     const int64_t blocks = (int64_t)p.tiles_x * p.tiles_y * p.tiles_b * p.tiles_n;
     if (blocks <= 0) return SR_OK;
     if (blocks > 0x7FFFFFFFLL) return SR_ERANGE;
-    const dim3 grid((unsigned)blocks), block(256);
-    if (pw == 32) hipLaunchKernelGGL((k_conv_mfma<IS, TY, TX, 32, 4, 1>), grid, block, 0, st, p);
-    else if (pw == 16) hipLaunchKernelGGL((k_conv_mfma<IS, TY, TX, 16, 8, 1>), grid, block, 0, st, p);
-    else if (pw == 8) hipLaunchKernelGGL((k_conv_mfma<IS, TY, TX, 8, 8, 2>), grid, block, 0, st, p);
-    else hipLaunchKernelGGL((k_conv_mfma<IS, TY, TX, 4, 4, 8>), grid, block, 0, st, p);
-    return sr_launch_status();
+    const dim3 grid((unsigned)blocks);
+    if (pw == 32) return launch_one<IS, TY, TX, 32, 4, 1>(p, grid, st);
+    if (pw == 16) return launch_one<IS, TY, TX, 16, 8, 1>(p, grid, st);
+    if (pw == 8) return launch_one<IS, TY, TX, 8, 8, 2>(p, grid, st);
+    return launch_one<IS, TY, TX, 4, 4, 8>(p, grid, st);
 }
 
 }  // namespace
 
 extern "C" int sr_conv2d_mfma(float* out, const float* in, const float* wt, const float* iscale,
                               const float* oscale, const float* obias, int64_t B, int64_t C,
-                              int64_t N, int64_t IH, int64_t IW, int64_t OH, int64_t OW, int ksize,
-                              int stride, int pad, int transposed, sr_stream_t stream) {
+                              int64_t N, int64_t wt_ld, int64_t IH, int64_t IW, int64_t OH, int64_t OW,
+                              int ksize, int stride, int pad, int transposed, sr_stream_t stream) {
     if (B < 0 || C <= 0 || N <= 0 || IH <= 0 || IW <= 0 || OH <= 0 || OW <= 0) return SR_EINVAL;
+    if (wt_ld < N || wt_ld % 4 != 0 || (reinterpret_cast<uintptr_t>(wt) & 15)) return SR_EINVAL;
     if (B == 0) return SR_OK;
     if (!out || !in || !wt) return SR_EINVAL;
-    if (IH * IW >= (1LL << 31) || OH * OW >= (1LL << 31)) return SR_ERANGE;
+    // 32-bit element offsets inside the kernel
+    if (B * C * IH * IW >= (1LL << 31) || B * N * OH * OW >= (1LL << 40) ||
+        (int64_t)ksize * ksize * C * wt_ld >= (1LL << 31))
+        return SR_ERANGE;
     hipStream_t st = sr_stream(stream);
     ConvParams p;
     p.in = in; p.wt = wt; p.iscale = iscale; p.oscale = oscale; p.obias = obias; p.out = out;
-    p.B = (int)B; p.C = (int)C; p.N = (int)N;
+    p.B = (int)B; p.C = (int)C; p.N = (int)N; p.ldw = (int)wt_ld;
     p.IH = (int)IH; p.IW = (int)IW; p.OH = (int)OH; p.OW = (int)OW;
     for (int i = 0; i < 9; ++i) p.wmap[i] = 0;
     if (!transposed) {

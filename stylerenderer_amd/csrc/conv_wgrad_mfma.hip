@@ -9,18 +9,34 @@
 // per-sample weight gradients [B, Cout, Cin, k, k] the reference's grouped convolution would
 // produce are never materialised: the batch is part of the K (pixel) dimension.
 //
-// GEMM per tap:  D[u][v] = sum_k A[u][k] * Bm[k][v],  k = pixel.  A workgroup owns a (UT x VT)
-// tile of channels for ALL taps of the window (each staged U halo patch feeds every tap), a wave
-// owns 32 x 32 x taps = 9 accumulator tiles (144 VGPRs).  K is split over workgroups
+// GEMM per tap:  D[u][v] = sum_k A[u][k] * Bm[k][v],  k = pixel.  A workgroup owns a (UT x VT) tile
+// of channels for ALL taps of the window (each staged U halo patch feeds every tap), a wave owns
+// 32 x 32 x taps = 9 accumulator tiles (144 registers).  K is split over workgroups
 // (grid = channel tiles x K slices ~ 2 x 256 CUs); slices write fp32 partial slabs that a second
 // kernel sums in a fixed order (deterministic; no float atomics) while applying the output layout.
-// LDS: channel-major planes with ODD pitch, so the 32 lanes of an operand fetch (32 channels, same
-// pixel) hit 32 different banks.
+//
+// Data movement: one 64-pixel patch per stage, LDS double buffered.  A staging instruction covers
+// 64 consecutive floats of ONE channel plane (coalesced 256 B), so its per-lane source offset
+// depends only on the lane (computed once per patch) and the channel only adds a wave-uniform
+// stride.  The loads of patch i+1 are software-pipelined INTO the MFMA stream of patch i: a few
+// global loads per pixel pair, written to the other LDS buffer four pixel pairs later (counted
+// vmcnt, ~a dozen staging registers in flight), so the matrix pipe never waits for memory.
+// (4-byte LDS-DMA was measured at ~90 cycles per instruction per CU — 62 TFLOP/s here — and
+// 16-byte DMA needs 16-byte aligned planes, which halo rows are not: profiles/r01_notes.md.)
+// Planes have an ODD pitch: the 32 lanes of an operand fetch (32 channels, same pixel) hit 32
+// different banks.
+// The modulation scales are fetched per patch as two small LDS rows and multiplied onto the
+// operands after the ds_read (never onto freshly loaded registers: no wait on memory in the loop).
 #include "common.h"
 
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef const void __attribute__((address_space(1)))* gptr_t;
+typedef void __attribute__((address_space(3)))* lptr_t;
+
+__device__ __attribute__((aligned(16))) const float g_wzero_line[4] = {0.f, 0.f, 0.f, 0.f};
+__device__ __attribute__((aligned(16))) const float g_wones_line[4] = {1.f, 1.f, 1.f, 1.f};
 
 struct WgradParams {
     const float* U;
@@ -43,86 +59,129 @@ struct WG {
     static constexpr int NT = TY * TX;
     static constexpr int EH = (PH - 1) * IS + TY;
     static constexpr int EW = (PW - 1) * IS + TX;
-    static constexpr int UPL0 = PB * EH * EW;
-    static constexpr int UPL = UPL0 + ((UPL0 % 2 == 0) ? 1 : 0);   // odd plane pitch
-    static constexpr int NPIX = PB * PH * PW;
-    static constexpr int VPL = NPIX + 1;                           // NPIX is even -> odd pitch
-    static constexpr int U_ELEMS = UT * UPL0, V_ELEMS = VT * NPIX;
-    static constexpr int U_ITERS = (U_ELEMS + 255) / 256, V_ITERS = (V_ELEMS + 255) / 256;
+    static constexpr int NU = PB * EH * EW;                 // floats of one U channel plane
+    static constexpr int USLOT = (NU + 63) / 64;            // staging instructions per U plane
+    static constexpr int UPL = USLOT * 64 + 1;              // odd plane pitch
+    static constexpr int NPIX = PB * PH * PW;               // 64
+    static constexpr int VPL = NPIX + 1;
     static constexpr int WU = UT / 32, WV = VT / 32;
+    static constexpr int SC = PB * (UT + VT);               // scale rows: [pb][UT] then [pb][VT]
+    static constexpr int SC_ITEMS = (SC + 255) / 256;       // one float per thread per item
+    static constexpr int OFF_V = UT * UPL;
+    static constexpr int OFF_S = OFF_V + VT * VPL;
+    static constexpr int BUF = ((OFF_S + SC_ITEMS * 256 + 3) / 4) * 4;
+    static constexpr int LDS_BYTES = 2 * BUF * 4;
+    // staging items of ONE wave per stage: its U channels x slots, its V channels, the scale rows
+    static constexpr int U_ITEMS = (UT / 4) * USLOT, V_ITEMS = VT / 4;
+    static constexpr int ITEMS = U_ITEMS + V_ITEMS + SC_ITEMS;
+    static constexpr int KSTEPS = NPIX / 2;                 // pixel pairs per stage
+    static constexpr int LAG = 4;                           // pixel pairs between a load and its LDS write
+    static constexpr int PER_STEP = (ITEMS + (KSTEPS - LAG) - 1) / (KSTEPS - LAG);
+    static_assert(PER_STEP * (KSTEPS - LAG) >= ITEMS, "staging must finish inside the stage");
 };
 
 template <int IS, int TY, int TX, int PW, int PH, int PB, int UT, int VT>
-__global__ __launch_bounds__(256, 1) void k_wgrad_mfma(const WgradParams p) {
+__global__ __launch_bounds__(256) void k_wgrad_mfma(const WgradParams p) {
     using G = WG<IS, TY, TX, PW, PH, PB, UT, VT>;
     static_assert(G::WU * G::WV == 4, "4 waves per workgroup");
+    static_assert(G::NPIX == 64, "one V plane = one staging instruction");
     static_assert(PW % 2 == 0, "pixel pairs run along x");
-    __shared__ float s_u[UT * G::UPL];
-    __shared__ float s_v[VT * G::VPL];
+    extern __shared__ __attribute__((aligned(16))) float smem[];      // the ONLY LDS object
 
     int bid = blockIdx.x;
     const int tile_uv = bid % (p.tiles_u * p.tiles_v);
     const int slice = bid / (p.tiles_u * p.tiles_v);
     const int u0 = (tile_uv / p.tiles_v) * UT, v0 = (tile_uv % p.tiles_v) * VT;
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = lane >> 5, l31 = lane & 31;
     const int wu = wave / G::WV, wv = wave % G::WV;
     const int a_base = (wu * 32 + l31) * G::UPL + half * IS;
-    const int b_base = (wv * 32 + l31) * G::VPL + half;
+    const int b_base = G::OFF_V + (wv * 32 + l31) * G::VPL + half;
 
     const int npatch = p.tiles_x * p.tiles_y * p.tiles_b;
     const int first = slice * p.patches_per_slice;
     int last = first + p.patches_per_slice;
     if (last > npatch) last = npatch;
+    const int plane_u = p.UH * p.UW, plane_v = p.GH * p.GW;
 
-    const int64_t plane_u = (int64_t)p.UH * p.UW, plane_v = (int64_t)p.GH * p.GW;
+    // ---- per-lane, patch-invariant decode of the staging slots
+    int u_r[G::USLOT], u_c[G::USLOT], u_pb[G::USLOT];      // window row / col / sample of slot float
+#pragma unroll
+    for (int s = 0; s < G::USLOT; ++s) {
+        const int f = s * 64 + lane;
+        u_c[s] = f % G::EW;
+        u_r[s] = (f / G::EW) % G::EH;
+        u_pb[s] = (f < G::NU) ? f / (G::EW * G::EH) : -1;
+    }
+    const int v_px = lane % PW, v_py = (lane / PW) % PH, v_pb = lane / (PW * PH);
+    // LDS write bases of this lane (channel `wave`, slot 0); items add immediates
+    const int uw_base = wave * G::UPL + lane;
+    const int vw_base = G::OFF_V + wave * G::VPL + lane;
 
-    float u_reg[G::U_ITERS], v_reg[G::V_ITERS];
-
-    auto fetch = [&](int patch) {
+    // ---- per-patch state, refreshed by prepare(): clamped per-lane offsets + validity
+    int u_off[G::USLOT];
+    bool u_ok[G::USLOT];
+    int v_off;
+    bool v_ok;
+    int pat_b0 = 0;
+    auto prepare = [&](int patch) {
         const int tx_i = patch % p.tiles_x;
         const int ty_i = (patch / p.tiles_x) % p.tiles_y;
         const int tb_i = patch / (p.tiles_x * p.tiles_y);
         const int gy0 = ty_i * PH, gx0 = tx_i * PW, b0 = tb_i * PB;
         const int iy0 = gy0 * IS + p.dy0, ix0 = gx0 * IS + p.dx0;
+        pat_b0 = b0;
 #pragma unroll
-        for (int it = 0; it < G::U_ITERS; ++it) {
-            const int e = tid + it * 256;
-            const int col = e % G::EW, r = (e / G::EW) % G::EH, pb = (e / (G::EW * G::EH)) % PB;
-            const int u = u0 + e / G::UPL0;
-            const int gy = iy0 + r, gx = ix0 + col, b = b0 + pb;
-            float val = 0.0f;
-            if (e < G::U_ELEMS && u < p.CU && b < p.B && gy >= 0 && gy < p.UH && gx >= 0 && gx < p.UW) {
-                val = p.U[((int64_t)b * p.CU + u) * plane_u + (int64_t)gy * p.UW + gx];
-                if (p.uscale) val *= p.uscale[(int64_t)b * p.CU + u];
-            }
-            u_reg[it] = val;
+        for (int s = 0; s < G::USLOT; ++s) {
+            const int gy = iy0 + u_r[s], gx = ix0 + u_c[s], b = b0 + u_pb[s];
+            u_ok[s] = u_pb[s] >= 0 && b < p.B && gy >= 0 && gy < p.UH && gx >= 0 && gx < p.UW;
+            u_off[s] = u_ok[s] ? (b * p.CU) * plane_u + gy * p.UW + gx : 0;
         }
-#pragma unroll
-        for (int it = 0; it < G::V_ITERS; ++it) {
-            const int e = tid + it * 256;
-            const int px = e % PW, py = (e / PW) % PH, pb = (e / (PW * PH)) % PB;
-            const int v = v0 + e / G::NPIX;
-            const int gy = gy0 + py, gx = gx0 + px, b = b0 + pb;
-            float val = 0.0f;
-            if (e < G::V_ELEMS && v < p.CV && b < p.B && gy < p.GH && gx < p.GW) {
-                val = p.V[((int64_t)b * p.CV + v) * plane_v + (int64_t)gy * p.GW + gx];
-                if (p.vscale) val *= p.vscale[(int64_t)b * p.CV + v];
-            }
-            v_reg[it] = val;
-        }
+        const int gy = gy0 + v_py, gx = gx0 + v_px, b = b0 + v_pb;
+        v_ok = b < p.B && gy < p.GH && gx < p.GW;
+        v_off = v_ok ? (b * p.CV) * plane_v + gy * p.GW + gx : 0;
     };
-    auto commit = [&]() {
-#pragma unroll
-        for (int it = 0; it < G::U_ITERS; ++it) {
-            const int e = tid + it * 256;
-            if (e < G::U_ELEMS) s_u[(e / G::UPL0) * G::UPL + e % G::UPL0] = u_reg[it];
+
+    // Staging item k of this wave (k is a compile-time constant wherever these are called):
+    //   k <  U_ITEMS            : U channel wave + 4*(k / USLOT), slot k % USLOT
+    //   k <  U_ITEMS + V_ITEMS  : V channel wave + 4*(k - U_ITEMS)
+    //   else                    : 256 floats of the scale rows (one per thread)
+    // Every load is unconditional: the address is a wave-uniform channel base (SGPR) plus a
+    // clamped per-lane offset; masks are applied when the value is written to LDS.
+    auto item_load = [&](int k) -> float {
+        if (k < G::U_ITEMS) {
+            const int cu = k / G::USLOT, s = k % G::USLOT;
+            const int u = min(u0 + wave + 4 * cu, p.CU - 1);
+            return (p.U + (int64_t)u * plane_u)[u_off[s]];
         }
-#pragma unroll
-        for (int it = 0; it < G::V_ITERS; ++it) {
-            const int e = tid + it * 256;
-            if (e < G::V_ELEMS) s_v[(e / G::NPIX) * G::VPL + e % G::NPIX] = v_reg[it];
+        if (k < G::U_ITEMS + G::V_ITEMS) {
+            const int v = min(v0 + wave + 4 * (k - G::U_ITEMS), p.CV - 1);
+            return (p.V + (int64_t)v * plane_v)[v_off];
+        }
+        const int e = (k - G::U_ITEMS - G::V_ITEMS) * 256 + tid;
+        float val = 1.0f;
+        if (e < PB * UT) {
+            const int pb = e / UT, u = e % UT;
+            if (p.uscale && pat_b0 + pb < p.B && u0 + u < p.CU) val = p.uscale[(int64_t)(pat_b0 + pb) * p.CU + u0 + u];
+        } else if (e < G::SC) {
+            const int pb = (e - PB * UT) / VT, v = (e - PB * UT) % VT;
+            if (p.vscale && pat_b0 + pb < p.B && v0 + v < p.CV) val = p.vscale[(int64_t)(pat_b0 + pb) * p.CV + v0 + v];
+        }
+        return val;
+    };
+    auto item_store = [&](int k, float val, float* dst) {
+        if (k < G::U_ITEMS) {
+            const int cu = k / G::USLOT, s = k % G::USLOT;
+            const bool ok = u_ok[s] && (u0 + wave + 4 * cu < p.CU);
+            dst[uw_base + 4 * cu * G::UPL + s * 64] = ok ? val : 0.0f;
+        } else if (k < G::U_ITEMS + G::V_ITEMS) {
+            const int cv = k - G::U_ITEMS;
+            const bool ok = v_ok && (v0 + wave + 4 * cv < p.CV);
+            dst[vw_base + 4 * cv * G::VPL] = ok ? val : 0.0f;
+        } else {
+            dst[G::OFF_S + (k - G::U_ITEMS - G::V_ITEMS) * 256 + tid] = val;
         }
     };
 
@@ -132,29 +191,70 @@ __global__ __launch_bounds__(256, 1) void k_wgrad_mfma(const WgradParams p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
 
-    if (first < last) fetch(first);
+    if (first < last) {
+        // first patch of the slice: straight load -> write, eight items at a time
+        prepare(first);
+#pragma unroll
+        for (int k0 = 0; k0 < G::ITEMS; k0 += 8) {
+            float t8[8];
+#pragma unroll
+            for (int d = 0; d < 8; ++d)
+                if (k0 + d < G::ITEMS) t8[d] = item_load(k0 + d);
+#pragma unroll
+            for (int d = 0; d < 8; ++d)
+                if (k0 + d < G::ITEMS) item_store(k0 + d, t8[d], smem);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    int buf = 0;
+    float stg[G::ITEMS];         // staged values; live ranges span LAG pixel pairs (~a dozen registers)
     for (int patch = first; patch < last; ++patch) {
-        __syncthreads();
-        commit();
-        __syncthreads();
-        if (patch + 1 < last) fetch(patch + 1);
+        __syncthreads();     // buffer `buf` completely written; the other buffer no longer read
+        const bool more = patch + 1 < last;
+        if (more) prepare(patch + 1);
+        const float* sb = smem + buf * G::BUF;
+        float* so = smem + (buf ^ 1) * G::BUF;
+        float a_sc[PB], b_sc[PB];
+#pragma unroll
+        for (int pb = 0; pb < PB; ++pb) {
+            a_sc[pb] = sb[G::OFF_S + pb * UT + wu * 32 + l31];
+            b_sc[pb] = sb[G::OFF_S + PB * UT + pb * VT + wv * 32 + l31];
+        }
+        int step = 0;
 #pragma unroll
         for (int pb = 0; pb < PB; ++pb)
 #pragma unroll
             for (int py = 0; py < PH; ++py)
 #pragma unroll
-                for (int qx = 0; qx < PW / 2; ++qx) {
-                    const float bv = s_v[b_base + (pb * PH + py) * PW + 2 * qx];
+                for (int qx = 0; qx < PW / 2; ++qx, ++step) {
+                    // next patch: PER_STEP loads per pixel pair, written to the other LDS buffer
+                    // LAG pixel pairs later — all in the MFMA shadow
+#ifndef SR_ABL_W_NODMA
+                    if (more) {
+#pragma unroll
+                        for (int d = 0; d < G::PER_STEP; ++d) {
+                            const int k = step * G::PER_STEP + d;
+                            if (k < G::ITEMS) stg[k] = item_load(k);
+                            const int w = (step - G::LAG) * G::PER_STEP + d;
+                            if (w >= 0 && w < G::ITEMS) item_store(w, stg[w], so);
+                        }
+                    }
+#endif
+                    const float bv = sb[b_base + (pb * PH + py) * PW + 2 * qx] * b_sc[pb];
                     const int ua = a_base + (pb * G::EH + py * IS) * G::EW + 2 * qx * IS;
 #pragma unroll
                     for (int ty = 0; ty < TY; ++ty)
 #pragma unroll
                         for (int tx = 0; tx < TX; ++tx) {
-                            const float av = s_u[ua + ty * G::EW + tx];
+                            const float av = sb[ua + ty * G::EW + tx] * a_sc[pb];
                             acc[ty * TX + tx] =
                                 __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[ty * TX + tx], 0, 0, 0);
                         }
+                    // keep the software pipeline as written (the scheduler would otherwise hoist
+                    // every staging load to the top of the stage)
+                    __builtin_amdgcn_sched_barrier(0);
                 }
+        buf ^= 1;
     }
 
     // partial[slice][tap][u][v]; C/D layout: column (v) = lane & 31, row (u) = (r&3) + 8*(r>>2) + 4*half
@@ -169,8 +269,8 @@ __global__ __launch_bounds__(256, 1) void k_wgrad_mfma(const WgradParams p) {
         }
 }
 
-// out[wslab(t) * CU*CV-sized slab ... ] — sums the K slices in a fixed order and writes the
-// requested layout: element (t, u, v) goes to out[tmap[t] * slab + u * su + v * sv].
+// Sums the K slices in a fixed order and writes the requested layout: element (t, u, v) goes to
+// out[tmap[t] * slab + u * su + v * sv].
 struct ReduceParams {
     const float* partial;
     float* out;
@@ -190,7 +290,11 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(const ReduceParams p) {
         const float* src = p.partial + ((int64_t)t * p.UP + u) * p.VP + v;
         float acc = 0.0f;
         for (int s = 0; s < p.ks; ++s) acc += src[s * stride_s];
-        p.out[p.tmap[t] * p.slab + u * p.su + v * p.sv] = acc;
+        int slab = 0;
+#pragma unroll
+        for (int k = 0; k < 9; ++k)
+            if (t == k) slab = p.tmap[k];
+        p.out[slab * p.slab + u * p.su + v * p.sv] = acc;
     }
 }
 
@@ -201,12 +305,19 @@ struct Plan {
 
 Plan make_plan(int is, int B, int CU, int CV, int GH, int GW) {
     Plan pl;
-    if (GW > 16) { pl.pw = 32; pl.ph = 2; pl.pb = 1; }
-    else if (GW > 8) { pl.pw = 16; pl.ph = 4; pl.pb = 1; }
-    else if (GW > 4) { pl.pw = 8; pl.ph = 8; pl.pb = 1; }
-    else { pl.pw = 4; pl.ph = 4; pl.pb = 4; }
-    if (is == 1) { pl.ut = 64; pl.vt = 64; }
-    else { pl.ut = 32; pl.vt = 128; }
+    if (is == 1) {
+        if (GW > 16) { pl.pw = 32; pl.ph = 2; pl.pb = 1; }
+        else if (GW > 8) { pl.pw = 16; pl.ph = 4; pl.pb = 1; }
+        else if (GW > 4) { pl.pw = 8; pl.ph = 8; pl.pb = 1; }
+        else { pl.pw = 4; pl.ph = 4; pl.pb = 4; }
+        pl.ut = 64; pl.vt = 64;
+    } else {
+        // the stride-2 window patch is 4x larger: narrower U tile, and never more than 5 DMA
+        // slots per plane
+        if (GW > 8) { pl.pw = 16; pl.ph = 4; pl.pb = 1; }
+        else { pl.pw = 8; pl.ph = 8; pl.pb = 1; }
+        pl.ut = 32; pl.vt = 128;
+    }
     pl.tiles_x = (GW + pl.pw - 1) / pl.pw;
     pl.tiles_y = (GH + pl.ph - 1) / pl.ph;
     pl.tiles_b = (B + pl.pb - 1) / pl.pb;
@@ -222,14 +333,34 @@ Plan make_plan(int is, int B, int CU, int CV, int GH, int GW) {
     return pl;
 }
 
-template <int IS, int TY, int TX, int UT, int VT>
-int launch_wgrad(WgradParams& p, const Plan& pl, hipStream_t st) {
-    const dim3 grid((unsigned)(pl.tiles_u * pl.tiles_v * pl.ks)), block(256);
-    if (pl.pw == 32) hipLaunchKernelGGL((k_wgrad_mfma<IS, TY, TX, 32, 2, 1, UT, VT>), grid, block, 0, st, p);
-    else if (pl.pw == 16) hipLaunchKernelGGL((k_wgrad_mfma<IS, TY, TX, 16, 4, 1, UT, VT>), grid, block, 0, st, p);
-    else if (pl.pw == 8) hipLaunchKernelGGL((k_wgrad_mfma<IS, TY, TX, 8, 8, 1, UT, VT>), grid, block, 0, st, p);
-    else hipLaunchKernelGGL((k_wgrad_mfma<IS, TY, TX, 4, 4, 4, UT, VT>), grid, block, 0, st, p);
+template <int IS, int TY, int TX, int PW, int PH, int PB, int UT, int VT>
+int launch_wgrad_one(const WgradParams& p, dim3 grid, hipStream_t st) {
+    using G = WG<IS, TY, TX, PW, PH, PB, UT, VT>;
+    static_assert(G::LDS_BYTES <= 160 * 1024, "LDS budget");
+    auto kern = k_wgrad_mfma<IS, TY, TX, PW, PH, PB, UT, VT>;
+    static bool configured = false;
+    if (!configured) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
+        configured = true;
+    }
+    hipLaunchKernelGGL(kern, grid, dim3(256), G::LDS_BYTES, st, p);
     return sr_launch_status();
+}
+
+template <int TY, int TX>
+int launch_wgrad_s1(const WgradParams& p, const Plan& pl, hipStream_t st) {
+    const dim3 grid((unsigned)(pl.tiles_u * pl.tiles_v * pl.ks));
+    if (pl.pw == 32) return launch_wgrad_one<1, TY, TX, 32, 2, 1, 64, 64>(p, grid, st);
+    if (pl.pw == 16) return launch_wgrad_one<1, TY, TX, 16, 4, 1, 64, 64>(p, grid, st);
+    if (pl.pw == 8) return launch_wgrad_one<1, TY, TX, 8, 8, 1, 64, 64>(p, grid, st);
+    return launch_wgrad_one<1, TY, TX, 4, 4, 4, 64, 64>(p, grid, st);
+}
+template <int TY, int TX>
+int launch_wgrad_s2(const WgradParams& p, const Plan& pl, hipStream_t st) {
+    const dim3 grid((unsigned)(pl.tiles_u * pl.tiles_v * pl.ks));
+    if (pl.pw == 16) return launch_wgrad_one<2, TY, TX, 16, 4, 1, 32, 128>(p, grid, st);
+    return launch_wgrad_one<2, TY, TX, 8, 8, 1, 32, 128>(p, grid, st);
 }
 
 bool geometry(int64_t B, int64_t C, int64_t N, int64_t IH, int64_t IW, int64_t OH, int64_t OW,
@@ -268,6 +399,7 @@ extern "C" int sr_conv2d_wgrad_mfma(float* dwt, const float* x, const float* gy,
     if (!geometry(B, C, N, IH, IW, OH, OW, ksize, stride, pad, transposed, is, GH, GW, UH, UW, CUc, CVc, d0))
         return SR_EINVAL;
     if (!dwt || !x || !gy || !scratch) return SR_EINVAL;
+    if (B * C * IH * IW >= (1LL << 31) || B * N * OH * OW >= (1LL << 31)) return SR_ERANGE;
     hipStream_t st = sr_stream(stream);
     const Plan pl = make_plan(is, (int)B, CUc, CVc, GH, GW);
     WgradParams p;
@@ -283,10 +415,10 @@ extern "C" int sr_conv2d_wgrad_mfma(float* dwt, const float* x, const float* gy,
     p.UP = pl.tiles_u * pl.ut; p.VP = pl.tiles_v * pl.vt;
     int rc = SR_OK;
     if (B > 0) {
-        if (ksize == 3 && is == 1) rc = launch_wgrad<1, 3, 3, 64, 64>(p, pl, st);
-        else if (ksize == 3 && is == 2) rc = launch_wgrad<2, 3, 3, 32, 128>(p, pl, st);
-        else if (ksize == 1 && is == 1) rc = launch_wgrad<1, 1, 1, 64, 64>(p, pl, st);
-        else rc = launch_wgrad<2, 1, 1, 32, 128>(p, pl, st);
+        if (ksize == 3 && is == 1) rc = launch_wgrad_s1<3, 3>(p, pl, st);
+        else if (ksize == 3 && is == 2) rc = launch_wgrad_s2<3, 3>(p, pl, st);
+        else if (ksize == 1 && is == 1) rc = launch_wgrad_s1<1, 1>(p, pl, st);
+        else rc = launch_wgrad_s2<1, 1>(p, pl, st);
         if (rc != SR_OK) return rc;
     }
     ReduceParams r;

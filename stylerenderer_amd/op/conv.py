@@ -41,9 +41,11 @@ def conv2d_mfma(x, wt, iscale=None, oscale=None, obias=None, ksize=3, stride=1, 
     require_f32(x, "conv2d_mfma")
     require_f32(wt, "conv2d_mfma weight")
     x = x.contiguous()
-    wt = wt.contiguous()
     b, c, ih, iw = x.shape
     taps, cw, n = wt.shape
+    ldw = (n + 3) // 4 * 4
+    # the kernel reads weight rows as 16-byte vectors: pad the row pitch to a multiple of 4 floats
+    wt = torch.nn.functional.pad(wt, (0, ldw - n)) if ldw != n else wt.contiguous()
     if taps != ksize * ksize or cw != c:
         raise RuntimeError("conv2d_mfma: weight must be [k*k, C, N]; got %s for C=%d k=%d"
                            % (tuple(wt.shape), c, ksize))
@@ -60,7 +62,7 @@ def conv2d_mfma(x, wt, iscale=None, oscale=None, obias=None, ksize=3, stride=1, 
         rc = _timed("conv", (ksize, stride, int(bool(transposed)), b, c, n, gh, gw), flops,
                     lambda: _lib.lib().sr_conv2d_mfma(
                         _lib.ptr(out), _lib.ptr(x), _lib.ptr(wt), _lib.ptr(iscale), _lib.ptr(oscale),
-                        _lib.ptr(obias), b, c, n, ih, iw, oh, ow, ksize, stride, pad,
+                        _lib.ptr(obias), b, c, n, ldw, ih, iw, oh, ow, ksize, stride, pad,
                         int(bool(transposed)), stream_of(x)))
     _lib.check(rc, "sr_conv2d_mfma")
     return out
