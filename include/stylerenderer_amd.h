@@ -60,6 +60,30 @@ int sr_fused_act_bwd(float* gx, float* gb, const float* gy, const float* out, fl
                      float scale, int64_t n, int64_t c, int64_t inner, float* partial,
                      sr_stream_t stream);
 
+/* Fused StyledConv tail (reference model.py:26-32: NoiseInjection layers.py:328-332 followed by
+ * FusedLeakyReLU op/fused_act.py:52-62) in one pass.  x, y [n, c, inner]; noise [n or 1, 1, inner]
+ * with batch stride noise_bstride (0 = shared); noise_w a 1-element DEVICE tensor; bias [c].
+ *   t = x + noise_w[0]*noise[b, i] + bias[ch] ;  y = (cond > 0 ? t : alpha*t) * scale
+ * cond = t, or ref[...] when ref != NULL (the double-backward form).  noise / bias may be NULL.
+ * Requires inner % 4 == 0 and 16-byte aligned pointers (SR_EINVAL otherwise: the caller then uses
+ * sr_fused_bias_act). */
+int sr_noise_bias_act(float* y, const float* x, const float* noise, const float* noise_w,
+                      const float* bias, const float* ref, float alpha, float scale, int64_t n,
+                      int64_t c, int64_t inner, int64_t noise_bstride, sr_stream_t stream);
+/* Its backward in one pass: gx = (out > 0 ? gy : alpha*gy)*scale, gbias[ch] = sum gx,
+ * gnoise_w[0] = sum gx*noise (deterministic two-stage reductions; gbias / gnoise_w may be NULL). */
+int64_t sr_noise_bias_act_bwd_scratch_floats(int64_t n, int64_t c, int64_t inner);
+int sr_noise_bias_act_bwd(float* gx, float* gbias, float* gnoise_w, const float* gy, const float* out,
+                          const float* noise, float alpha, float scale, int64_t n, int64_t c,
+                          int64_t inner, int64_t noise_bstride, float* scratch, sr_stream_t stream);
+/* Row-wise dot products of two [rows, inner] tensors, optionally with a scaled copy in the same
+ * sweep: dots[r] = sum_i a[r,i]*b[r,i] ; out_scaled[r,i] = b[r,i]*scale[r] (out_scaled may be NULL).
+ * These are the style / demodulation gradients of the modulated convolution (sum_p x*dx', sum_p g*y)
+ * that autograd would otherwise compute as a multiply pass plus a reduction pass. */
+int64_t sr_rowdot_scratch_floats(int64_t rows, int64_t inner);
+int sr_rowdot(float* dots, float* out_scaled, const float* a, const float* b, const float* scale,
+              int64_t rows, int64_t inner, float* scratch, sr_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------
  * upfirdn2d: zero-insert upsample -> pad/crop -> 2-D FIR (correlation with the flipped kernel)
  * -> decimate.  Replaces  bool upfirdn2d_op(float* out, const float* x, const float* k,

@@ -22,6 +22,11 @@ SIGNATURES = {
     "sr_fused_bias_act": (_i, [_p, _p, _p, _p, _i, _i, _f, _f, _l, _l, _l, _i, _i, _p]),
     "sr_fused_act_bwd_scratch_floats": (_l, [_l, _l, _l]),
     "sr_fused_act_bwd": (_i, [_p, _p, _p, _p, _f, _f, _l, _l, _l, _p, _p]),
+    "sr_noise_bias_act": (_i, [_p] * 6 + [_f, _f] + [_l] * 4 + [_p]),
+    "sr_noise_bias_act_bwd_scratch_floats": (_l, [_l, _l, _l]),
+    "sr_noise_bias_act_bwd": (_i, [_p] * 6 + [_f, _f] + [_l] * 4 + [_p, _p]),
+    "sr_rowdot_scratch_floats": (_l, [_l, _l]),
+    "sr_rowdot": (_i, [_p] * 5 + [_l, _l, _p, _p]),
     "sr_upfirdn2d": (_i, [_p, _p, _p, _l] + [_i] * 14 + [_p]),
     "sr_rasterize_scratch_bytes": (_l, [_l, _l, _l, _i]),
     "sr_rasterize_forward_f32": (_i, [_l] * 5 + [_i] * 3 + [_p] * 5 + [_f, _p, _l, _p, _p, _p]),

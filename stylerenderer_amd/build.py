@@ -25,6 +25,7 @@ SOURCES = [
     ("fused_bias_act.hip", EXACT),
     ("upfirdn2d.hip", EXACT),
     ("rasterize.hip", EXACT),
+    ("fused_elem.hip", EXACT),
     ("conv_mfma.hip", []),
     ("conv_wgrad_mfma.hip", []),
 ]

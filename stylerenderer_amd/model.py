@@ -18,6 +18,7 @@ from torch import nn
 from .layers import (Blur, ConstantInput, ConvLayer, EqualLinear, ModulatedConv2d, NoiseInjection,  # noqa: F401
                      PixelNorm, ResBlock, Upsample)
 from .op import FusedLeakyReLU, rasterize
+from .op.fused_elem import noise_bias_act
 
 CHANNEL_BASE = {4: 512, 8: 512, 16: 512, 32: 512, 64: 256, 128: 128, 256: 64, 512: 32, 1024: 16}
 
@@ -40,6 +41,12 @@ class StyledConv(nn.Module):
 
     def forward(self, input, style, noise=None):
         out = self.conv(input, style)
+        if out.device.type == "cuda":
+            # noise injection + bias + LeakyReLU in one pass over the activation
+            if noise is None:
+                noise = out.new_empty(out.shape[0], 1, out.shape[2], out.shape[3]).normal_()
+            return noise_bias_act(out, noise, self.noise.weight, self.activate.bias,
+                                  self.activate.negative_slope, self.activate.scale)
         out = self.noise(out, noise=noise)
         return self.activate(out)
 
@@ -60,6 +67,11 @@ class StyledMapConv(nn.Module):
     def forward(self, input, style, stylemap, noise=None):
         out = self.conv(input, style)
         out = out * stylemap[:, :1] + stylemap[:, 1:2]
+        if out.device.type == "cuda":
+            if noise is None:
+                noise = out.new_empty(out.shape[0], 1, out.shape[2], out.shape[3]).normal_()
+            return noise_bias_act(out, noise, self.noise.weight, self.activate.bias,
+                                  self.activate.negative_slope, self.activate.scale)
         out = self.noise(out, noise=noise)
         return self.activate(out)
 

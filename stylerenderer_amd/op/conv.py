@@ -12,6 +12,7 @@ import torch
 
 from .. import _lib
 from ._dispatch import on_device_of, require_f32, stream_of
+from .fused_elem import rowdot
 
 
 # Optional per-launch timing used by bench.py's roofline leg: when PROFILE is a list, every MFMA
@@ -150,15 +151,19 @@ class ConvFn(torch.autograd.Function):
                 dxu[:, :, ::2, ::2] = inner
             else:
                 dxu = ConvFn.apply(g, adjoint_weight(wt, geom), oscale, None, None, _ADJOINT[geom])
-            if need_is:
-                gis = (x * dxu).sum((2, 3))
-            if need_x:
-                gx = dxu * _bc(iscale) if iscale is not None else dxu
+            # style gradient sum_p x*dxu and dx = s*dxu in one sweep (csrc/fused_elem.hip)
+            if need_is and need_x and iscale is not None:
+                gis, gx = rowdot(x, dxu, iscale)
+            else:
+                if need_is:
+                    gis = rowdot(x, dxu)
+                if need_x:
+                    gx = dxu * _bc(iscale) if iscale is not None else dxu
         if need_w:
             gw = WgradFn.apply(x, g, iscale, oscale, geom)
         if need_os:
             y0 = out - bias[None, :, None, None] if bias is not None else out
-            gos = (g * y0).sum((2, 3)) / oscale
+            gos = rowdot(g, y0) / oscale
         if need_b:
             gb = g.sum((0, 2, 3))
         return gx, gw, gis, gos, gb, None
@@ -188,13 +193,13 @@ class WgradFn(torch.autograd.Function):
             else:
                 dxu = ConvFn.apply(g, adjoint_weight(gg, geom), oscale, None, None, _ADJOINT[geom])
             if need_is:
-                gis = (x * dxu).sum((2, 3))
+                gis = rowdot(x, dxu)
             if need_x:
                 gx = dxu * _bc(iscale) if iscale is not None else dxu
         if need_g or need_os:
             dgu = ConvFn.apply(x, gg, iscale, None, None, geom)
             if need_os:
-                gos = (g * dgu).sum((2, 3))
+                gos = rowdot(g, dgu)
             if need_g:
                 g_g = dgu * _bc(oscale) if oscale is not None else dgu
         return gx, g_g, gis, gos, None

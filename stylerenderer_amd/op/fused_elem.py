@@ -1,0 +1,149 @@
+"""Fused element-wise passes — host side of csrc/fused_elem.hip.
+
+  noise_bias_act(x, noise, noise_weight, bias, negative_slope, scale)
+      = fused_leaky_relu(x + noise_weight * noise, bias)   (reference model.py:26-32) in ONE pass,
+      twice differentiable like the reference's pair of autograd Functions.
+  rowdot(a, b [, scale])  row-wise dot products (+ scaled copy) used by the modulated-conv backward.
+"""
+import torch
+from torch.autograd import Function
+
+from .. import _lib
+from ._dispatch import on_device_of, stream_of
+from .fused_act import fused_leaky_relu
+
+
+def _geometry(x):
+    n = x.size(0)
+    c = x.size(1)
+    inner = 1
+    for i in range(2, x.dim()):
+        inner *= x.size(i)
+    return n, c, inner
+
+
+def _fusable(x, noise):
+    if x.device.type != "cuda" or x.dtype != torch.float32 or x.dim() < 3:
+        return False
+    n, c, inner = _geometry(x)
+    if inner % 4 != 0 or n * c > 65535 or x.data_ptr() % 16:
+        return False
+    if noise is not None:
+        if noise.dtype != torch.float32 or noise.numel() not in (inner, n * inner) or noise.data_ptr() % 16:
+            return False
+    return True
+
+
+def _launch_fwd(x, noise, noise_w, bias, ref, slope, scale):
+    n, c, inner = _geometry(x)
+    y = torch.empty_like(x)
+    bstride = 0 if noise is None or noise.numel() == inner else inner
+    with on_device_of(x):
+        rc = _lib.lib().sr_noise_bias_act(_lib.ptr(y), _lib.ptr(x), _lib.ptr(noise), _lib.ptr(noise_w),
+                                          _lib.ptr(bias), _lib.ptr(ref), float(slope), float(scale), n, c,
+                                          inner, bstride, stream_of(x))
+    _lib.check(rc, "sr_noise_bias_act")
+    return y
+
+
+class _NBABackward(Function):
+    @staticmethod
+    def forward(ctx, gy, out, noise, slope, scale):
+        n, c, inner = _geometry(out)
+        gy = gy.contiguous()
+        gx = torch.empty_like(out)
+        gb = torch.empty(c, dtype=out.dtype, device=out.device)
+        gnw = torch.zeros(1, dtype=out.dtype, device=out.device)
+        L = _lib.lib()
+        scratch = torch.empty(L.sr_noise_bias_act_bwd_scratch_floats(n, c, inner), dtype=out.dtype,
+                              device=out.device)
+        bstride = 0 if noise is None or noise.numel() == inner else inner
+        with on_device_of(out):
+            rc = L.sr_noise_bias_act_bwd(_lib.ptr(gx), _lib.ptr(gb), _lib.ptr(gnw), _lib.ptr(gy),
+                                         _lib.ptr(out), _lib.ptr(noise), float(slope), float(scale), n, c,
+                                         inner, bstride, _lib.ptr(scratch), stream_of(out))
+        _lib.check(rc, "sr_noise_bias_act_bwd")
+        ctx.save_for_backward(out, noise)
+        ctx.slope, ctx.scale = slope, scale
+        return gx, gb, gnw
+
+    @staticmethod
+    def backward(ctx, ggx, ggb, ggnw):
+        out, noise = ctx.saved_tensors
+        gg = _launch_fwd(ggx.contiguous(), noise, ggnw.contiguous() if noise is not None else None,
+                         ggb.contiguous(), out, ctx.slope, ctx.scale)
+        return gg, None, None, None, None
+
+
+class _NBA(Function):
+    @staticmethod
+    def forward(ctx, x, noise, noise_w, bias, slope, scale):
+        y = _launch_fwd(x, noise, noise_w, bias, None, slope, scale)
+        ctx.save_for_backward(y, noise)
+        ctx.slope, ctx.scale = slope, scale
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        y, noise = ctx.saved_tensors
+        gx, gb, gnw = _NBABackward.apply(gy, y, noise, ctx.slope, ctx.scale)
+        return gx, None, (gnw if noise is not None else None), gb, None, None
+
+
+def noise_bias_act(x, noise, noise_weight, bias, negative_slope=0.2, scale=2 ** 0.5):
+    """lrelu(x + noise_weight*noise + bias) * scale; `noise` [B or 1, 1, H, W] or None."""
+    if noise is not None:
+        noise = noise.contiguous()
+    if _fusable(x, noise) and x.is_contiguous():
+        return _NBA.apply(x, noise, noise_weight if noise is not None else None, bias, negative_slope, scale)
+    if noise is not None:
+        x = x + noise_weight * noise
+    return fused_leaky_relu(x, bias, negative_slope, scale)
+
+
+def _rowdot_launch(a, b, scale):
+    rows = a.size(0) * a.size(1)
+    inner = a.numel() // max(rows, 1)
+    dots = torch.empty(a.shape[:2], dtype=a.dtype, device=a.device)
+    out = torch.empty_like(b) if scale is not None else None
+    L = _lib.lib()
+    scratch = torch.empty(L.sr_rowdot_scratch_floats(rows, inner), dtype=a.dtype, device=a.device)
+    with on_device_of(a):
+        rc = L.sr_rowdot(_lib.ptr(dots), _lib.ptr(out), _lib.ptr(a), _lib.ptr(b), _lib.ptr(scale), rows,
+                         inner, _lib.ptr(scratch), stream_of(a))
+    _lib.check(rc, "sr_rowdot")
+    return dots, out
+
+
+class _RowDot(Function):
+    """(a, b, scale) -> (dots [B,C], b*scale[:, :, None, None]).  Differentiable (torch ops)."""
+
+    @staticmethod
+    def forward(ctx, a, b, scale):
+        ctx.save_for_backward(a, b, scale)
+        dots, out = _rowdot_launch(a, b, scale)
+        if out is None:
+            return dots
+        return dots, out
+
+    @staticmethod
+    def backward(ctx, gd, go=None):
+        a, b, scale = ctx.saved_tensors
+        ga = gd[:, :, None, None] * b
+        gb = gd[:, :, None, None] * a
+        gs = None
+        if scale is not None and go is not None:
+            gb = gb + go * scale[:, :, None, None]
+            gs = (go * b).sum((2, 3))
+        return ga, gb, gs
+
+
+def rowdot(a, b, scale=None):
+    """dots[b,c] = sum_hw a*b (and, with `scale` [B,C], also b*scale broadcast over hw)."""
+    ok = (a.device.type == "cuda" and a.dtype == torch.float32 and a.dim() == 4 and a.shape == b.shape
+          and (a.size(2) * a.size(3)) % 4 == 0 and a.size(0) * a.size(1) <= 65535
+          and a.is_contiguous() and b.is_contiguous() and a.data_ptr() % 16 == 0 and b.data_ptr() % 16 == 0)
+    if not ok:
+        dots = (a * b).sum((2, 3))
+        return dots if scale is None else (dots, b * scale[:, :, None, None])
+    return _RowDot.apply(a, b, scale.contiguous() if scale is not None else None)

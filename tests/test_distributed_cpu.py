@@ -1,0 +1,129 @@
+"""CPU, world_size = 2 over gloo: the N > 1 data-parallel path —
+gradient averaging equals the single-process full-batch gradient, packed scalar reduction, and the
+full training step (D, R1, G, path-length regulariser, EMA) keeps replicas bit-identical."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from stylerenderer_amd import distributed as sr_dist
+from stylerenderer_amd import model, synth, train
+
+SIZE, LATENT, NMLP = 8, 32, 2
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def fixed_inputs():
+    z = torch.from_numpy(synth.det_normal((8, LATENT), 5))
+    noise = [torch.from_numpy(synth.det_normal((1, 1, 2 ** ((i + 5) // 2), 2 ** ((i + 5) // 2)), 60 + i))
+             for i in range(3)]
+    return z, noise
+
+
+def build_models():
+    g = model.Generator(SIZE, LATENT, NMLP)
+    d = model.Discriminator(SIZE)
+    synth.fill_state_dict(g.state_dict(), salt=7)
+    synth.fill_state_dict(d.state_dict(), salt=8)
+    sr_dist.freeze_unused_tail(g)
+    return g, d
+
+
+def g_loss_grads(g_net, d_net, z, noise):
+    for p in d_net.parameters():
+        p.requires_grad_(False)
+    img, _ = g_net([z], noise=noise)
+    loss = train.g_nonsaturating_loss(d_net(img))
+    loss.backward()
+    return loss.detach()
+
+
+def worker(rank, world, port, outdir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    torch.set_num_threads(2)
+    r, _, w, device = sr_dist.initialize(backend="gloo")
+    assert (r, w) == (rank, world) and sr_dist.get_world_size() == world
+    # --- (1) DDP gradient == full-batch gradient
+    g, d = build_models()
+    g_ddp = sr_dist.construct_ddp(g, device)
+    z, noise = fixed_inputs()
+    # minibatch-stddev groups of a batch of 8 are {0,2,4,6} and {1,3,5,7} (reference model.py:325-332):
+    # shard accordingly so the two replicas see exactly the single-process groups
+    loss = g_loss_grads(g_ddp, d, z[rank::2], noise)
+    grads = {n: p.grad.clone() for n, p in g.named_parameters() if p.grad is not None}
+    # --- (2) packed scalar reduction
+    red = sr_dist.reduce_scalars({"a": torch.tensor(float(rank + 1)), "b": 2.0 * rank, "loss": loss})
+    # --- (3) two full training iterations (i = 0 runs R1 and the path-length regulariser)
+    tr = train.Trainer(size=SIZE, latent=LATENT, n_mlp=NMLP, device="cpu", seed=3)
+    data = train.SyntheticImages(16, SIZE, "cpu")
+    logs = [tr.step(data.batch(4)) for _ in range(2)]
+    checksum = torch.stack([p.detach().double().sum() for p in tr.generator.parameters()]
+                           + [p.detach().double().sum() for p in tr.discriminator.parameters()])
+    torch.save({"grads": grads, "red": red, "logs": logs, "checksum": checksum, "loss": loss},
+               os.path.join(outdir, "rank%d.pt" % rank))
+    sr_dist.synchronize()
+    torch.distributed.destroy_process_group()
+
+
+@pytest.fixture(scope="module")
+def two_rank_run(tmp_path_factory):
+    outdir = str(tmp_path_factory.mktemp("ddp"))
+    mp.spawn(worker, args=(2, free_port(), outdir), nprocs=2, join=True)
+    return [torch.load(os.path.join(outdir, "rank%d.pt" % r), weights_only=False) for r in range(2)]
+
+
+def test_ddp_gradients_equal_full_batch(two_rank_run):
+    r0, r1 = two_rank_run
+    g, d = build_models()
+    z, noise = fixed_inputs()
+    g_loss_grads(g, d, z, noise)                       # single process, batch 8
+    for n, p in g.named_parameters():
+        if p.grad is None:
+            assert n not in r0["grads"]
+            continue
+        ref = p.grad
+        scale = float(ref.abs().max()) + 1e-12
+        assert float((r0["grads"][n] - ref).abs().max()) <= 2e-5 * scale, n
+        assert torch.equal(r0["grads"][n], r1["grads"][n]), n      # replicas hold the same gradient
+
+
+def test_packed_scalar_reduction(two_rank_run):
+    r0, r1 = two_rank_run
+    assert r0["red"] == r1["red"]
+    assert abs(r0["red"]["a"] - 1.5) < 1e-6 and abs(r0["red"]["b"] - 1.0) < 1e-6
+    assert abs(r0["red"]["loss"] - 0.5 * (float(r0["loss"]) + float(r1["loss"]))) < 1e-6
+
+
+def test_training_step_keeps_replicas_identical(two_rank_run):
+    r0, r1 = two_rank_run
+    assert torch.equal(r0["checksum"], r1["checksum"])
+    for log in r0["logs"]:
+        assert set(log) >= {"d", "g", "real_score", "fake_score"}
+        assert all(np.isfinite(v) for v in log.values())
+    assert {"r1", "path", "path_length"} <= set(r0["logs"][0])     # lazy regularisers fire at i = 0
+    assert "r1" not in r0["logs"][1]
+
+
+def test_single_process_training_step_updates_parameters():
+    tr = train.Trainer(size=SIZE, latent=LATENT, n_mlp=NMLP, device="cpu", seed=1)
+    before = {n: p.detach().clone() for n, p in tr.generator.named_parameters()}
+    ema_before = {n: p.detach().clone() for n, p in tr.g_ema.named_parameters()}
+    data = train.SyntheticImages(8, SIZE, "cpu")
+    log = tr.step(data.batch(4))
+    assert np.isfinite(log["d"]) and np.isfinite(log["g"]) and log["path_length"] > 0
+    changed = [n for n, p in tr.generator.named_parameters() if not torch.equal(p, before[n])]
+    assert "conv1.conv.weight" in changed and "style.1.weight" in changed
+    frozen = [n for n in before if n.startswith("to_rgbs.1.")]
+    assert frozen and all(torch.equal(dict(tr.generator.named_parameters())[n], before[n]) for n in frozen)
+    assert any(not torch.equal(p, ema_before[n]) for n, p in tr.g_ema.named_parameters())

@@ -280,3 +280,58 @@ def test_rasterize_rejects_bad_inputs():
     # empty triangle list: all background
     idx, coeff = R.forward(v, torch.zeros(0, 3, dtype=torch.int64, device=DEV), 4, 4)
     assert not idx.any() and not coeff.any()
+
+
+# ------------------------------------------------------------------------------- fused element-wise
+@pytest.mark.parametrize("shape,shared", [((2, 6, 8, 8), True), ((3, 5, 16, 12), False), ((2, 4, 4, 4), True),
+                                          ((2, 3, 64, 68), False)])
+def test_noise_bias_act_matches_two_step_path(shape, shared):
+    """One fused pass == NoiseInjection followed by fused_leaky_relu, bit for bit, incl. all
+    gradients and the double backward."""
+    import stylerenderer_amd.op as op
+    from stylerenderer_amd import synth
+    from stylerenderer_amd.op.fused_elem import noise_bias_act
+
+    b, c, h, w = shape
+    x = T(synth.det_normal(shape, 81))
+    noise = T(synth.det_normal((1 if shared else b, 1, h, w), 82))
+    nw = T(synth.det_normal((1,), 83))
+    bias = T(synth.det_normal((c,), 84))
+    gy = T(synth.det_normal(shape, 85))
+
+    def run(fused):
+        xs, nws, bs = (t.clone().requires_grad_() for t in (x, nw, bias))
+        if fused:
+            y = noise_bias_act(xs, noise, nws, bs)
+        else:
+            y = op.fused_leaky_relu(xs + nws * noise, bs)
+        g = gy.clone().requires_grad_()
+        gx, gnw, gb = torch.autograd.grad(y, [xs, nws, bs], g, create_graph=True)
+        probe = (gx * x).sum() + (gb * bias).sum() + (gnw * nw).sum()
+        (gg,) = torch.autograd.grad(probe, g)
+        return y, gx, gnw, gb, gg
+
+    a, r = run(True), run(False)
+    assert torch.equal(a[0], r[0]) and torch.equal(a[1], r[1])
+    for i in (2, 3):
+        assert torch.allclose(a[i], r[i], rtol=2e-5, atol=1e-5)
+    assert torch.allclose(a[4], r[4], rtol=1e-5, atol=1e-6)
+
+
+def test_rowdot_matches_torch():
+    from stylerenderer_amd import synth
+    from stylerenderer_amd.op.fused_elem import rowdot
+
+    a = T(synth.det_normal((3, 7, 20, 24), 91)).requires_grad_()
+    b = T(synth.det_normal((3, 7, 20, 24), 92)).requires_grad_()
+    s = T(synth.det_normal((3, 7), 93)).requires_grad_()
+    dots, out = rowdot(a, b, s)
+    want = (a.double() * b.double()).sum((2, 3))
+    assert torch.allclose(dots.double(), want, rtol=1e-5, atol=1e-5)
+    assert torch.equal(out, b * s[:, :, None, None])
+    d2 = rowdot(a, b)
+    assert torch.equal(d2, dots)
+    ga, gb, gs = torch.autograd.grad(dots.sum() + (out * a).sum(), [a, b, s])
+    ra, rb, rs = torch.autograd.grad((a * b).sum() + (b * s[:, :, None, None] * a).sum(), [a, b, s])
+    assert torch.allclose(ga, ra, rtol=1e-5, atol=1e-6) and torch.allclose(gb, rb, rtol=1e-5, atol=1e-6)
+    assert torch.allclose(gs, rs, rtol=1e-4, atol=1e-4)
