@@ -44,10 +44,52 @@ def parse():
     ap.add_argument("--batch", type=int, default=16, help="images per GPU")
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-raster", action="store_true", help="skip the rasterizer (BASELINE config[3]) leg")
     ap.add_argument("--cpu-batch", type=int, default=2)
     ap.add_argument("--cpu-iters", type=int, default=1)
     ap.add_argument("--cpu-threads", type=int, default=32)
     return ap.parse_args()
+
+
+def raster_leg(dev, batch=64, res=256, iters=5):
+    """Second half of the metric: rasterizer Mtri/s on BASELINE config[3] (BFM-size-class mesh,
+    ~50k triangles, 256x256, batch 64, int64 ids as the API demands), forward and forward+backward
+    (fused attribute interpolation + fused gradient scatter).  Algorithmic HBM bytes per image
+    24*nf + 12*nv + 36*h*w."""
+    import stylerenderer_amd.op as op
+    from stylerenderer_amd import synth
+
+    v0, tri = synth.face_sized_mesh()
+    v = torch.from_numpy(synth.random_poses(v0, batch, seed=1234)).to(dev)
+    nrm = torch.from_numpy(synth.vertex_normals(v.cpu().numpy(), tri)).to(dev)
+    t = torch.from_numpy(tri).to(dev)
+    nf, nv = tri.shape[0], v0.shape[0]
+
+    def timed(fn):
+        fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / iters
+
+    ms_f = timed(lambda: op.rasterize(v, nrm, t, res))
+    vg, ng = v.clone().requires_grad_(), nrm.clone().requires_grad_()
+
+    def fb():
+        vg.grad = ng.grad = None
+        op.rasterize(vg, ng, t, res).sum().backward()
+
+    ms_fb = timed(fb)
+    bytes_img = 24 * nf + 12 * nv + 36 * res * res
+    return {"workload": "BASELINE config[3]: nv=%d nf=%d, %dx%d, batch %d" % (nv, nf, res, res, batch),
+            "fwd_mtri_s": round(batch * nf / ms_f / 1e3, 1), "fwd_ms": round(ms_f, 3),
+            "fwd_bwd_mtri_s": round(batch * nf / ms_fb / 1e3, 1), "fwd_bwd_ms": round(ms_fb, 3),
+            "fwd_algorithmic_GBps": round(batch * bytes_img / ms_f / 1e6, 1),
+            "bit_exact_vs_cpu_oracle": "tests/test_ops_gpu.py"}
 
 
 def main():
@@ -136,6 +178,7 @@ def main():
         breakdown = {k: {"ms_per_step": round(v[1] / args.steps, 3),
                          "tflops": round(v[0] / (v[1] * 1e-3) / 1e12, 1) if v[1] > 0 else None,
                          "launches_per_step": v[2] // max(args.steps, 1)} for k, v in sorted(by_kind.items())}
+        raster = raster_leg(dev) if not args.no_raster else None
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             import model_oracle
@@ -161,7 +204,7 @@ def main():
                        "parallelism": "dp%d" % world,
                        "step": "zero_grad + forward + backward" + (" + DDP all-reduce (RCCL)" if world > 1 else "")},
             "model_flop_frac_of_mfma_peak": round(value / world * FLOP_PER_IMAGE_FWD_BWD / (FP32_MFMA_PEAK_TFLOPS * 1e12), 4),
-            "roofline": roof, "cpu_baseline": cpu, "kernel_breakdown": breakdown,
+            "roofline": roof, "cpu_baseline": cpu, "kernel_breakdown": breakdown, "rasterizer": raster,
         }
     if world > 1:
         dist.barrier()
