@@ -75,7 +75,10 @@ struct WG {
     static constexpr int U_ITEMS = (UT / 4) * USLOT, V_ITEMS = VT / 4;
     static constexpr int ITEMS = U_ITEMS + V_ITEMS + SC_ITEMS;
     static constexpr int KSTEPS = NPIX / 2;                 // pixel pairs per stage
-    static constexpr int LAG = 4;                           // pixel pairs between a load and its LDS write
+#ifndef SR_WGRAD_LAG
+#define SR_WGRAD_LAG 4
+#endif
+    static constexpr int LAG = SR_WGRAD_LAG;                // pixel pairs between a load and its LDS write
     static constexpr int PER_STEP = (ITEMS + (KSTEPS - LAG) - 1) / (KSTEPS - LAG);
     static_assert(PER_STEP * (KSTEPS - LAG) >= ITEMS, "staging must finish inside the stage");
 };
@@ -210,8 +213,10 @@ __global__ __launch_bounds__(256) void k_wgrad_mfma(const WgradParams p) {
     float stg[G::ITEMS];         // staged values; live ranges span LAG pixel pairs (~a dozen registers)
     for (int patch = first; patch < last; ++patch) {
         __syncthreads();     // buffer `buf` completely written; the other buffer no longer read
-        const bool more = patch + 1 < last;
-        if (more) prepare(patch + 1);
+        // the staging stream is branch-free (a per-step branch makes the compiler's vmcnt
+        // bookkeeping conservative and collapses the pipeline): after the last patch it simply
+        // re-stages that patch into the idle buffer
+        prepare(patch + 1 < last ? patch + 1 : patch);
         const float* sb = smem + buf * G::BUF;
         float* so = smem + (buf ^ 1) * G::BUF;
         float a_sc[PB], b_sc[PB];
@@ -220,40 +225,47 @@ __global__ __launch_bounds__(256) void k_wgrad_mfma(const WgradParams p) {
             a_sc[pb] = sb[G::OFF_S + pb * UT + wu * 32 + l31];
             b_sc[pb] = sb[G::OFF_S + PB * UT + pb * VT + wv * 32 + l31];
         }
-        int step = 0;
+        // MFMA operands are register double-buffered: the ds_reads of pixel pair s+1 are issued
+        // BEFORE the MFMA block of pair s (one wave per SIMD: nobody else would hide the LDS
+        // latency), and multiplied by the modulation scales at the top of the next iteration.
+        float a_raw[G::NT], b_raw;
+        auto fetch_operands = [&](int step) {
+            const int qx = step % (PW / 2), py = (step / (PW / 2)) % PH, pb = step / ((PW / 2) * PH);
+            b_raw = sb[b_base + (pb * PH + py) * PW + 2 * qx];
+            const int ua = a_base + (pb * G::EH + py * IS) * G::EW + 2 * qx * IS;
 #pragma unroll
-        for (int pb = 0; pb < PB; ++pb)
+            for (int ty = 0; ty < TY; ++ty)
 #pragma unroll
-            for (int py = 0; py < PH; ++py)
+                for (int tx = 0; tx < TX; ++tx) a_raw[ty * TX + tx] = sb[ua + ty * G::EW + tx];
+        };
+        fetch_operands(0);
 #pragma unroll
-                for (int qx = 0; qx < PW / 2; ++qx, ++step) {
-                    // next patch: PER_STEP loads per pixel pair, written to the other LDS buffer
-                    // LAG pixel pairs later — all in the MFMA shadow
+        for (int step = 0; step < G::KSTEPS; ++step) {
+            // next patch: PER_STEP loads per pixel pair, written to the other LDS buffer LAG pixel
+            // pairs later — all in the MFMA shadow
 #ifndef SR_ABL_W_NODMA
-                    if (more) {
 #pragma unroll
-                        for (int d = 0; d < G::PER_STEP; ++d) {
-                            const int k = step * G::PER_STEP + d;
-                            if (k < G::ITEMS) stg[k] = item_load(k);
-                            const int w = (step - G::LAG) * G::PER_STEP + d;
-                            if (w >= 0 && w < G::ITEMS) item_store(w, stg[w], so);
-                        }
-                    }
+            for (int d = 0; d < G::PER_STEP; ++d) {
+                const int k = step * G::PER_STEP + d;
+                if (k < G::ITEMS) stg[k] = item_load(k);
+                const int w = (step - G::LAG) * G::PER_STEP + d;
+                if (w >= 0 && w < G::ITEMS) item_store(w, stg[w], so);
+            }
 #endif
-                    const float bv = sb[b_base + (pb * PH + py) * PW + 2 * qx] * b_sc[pb];
-                    const int ua = a_base + (pb * G::EH + py * IS) * G::EW + 2 * qx * IS;
+            const int pb = step / ((PW / 2) * PH);
+            const float bv = b_raw * b_sc[pb];
+            float av[G::NT];
 #pragma unroll
-                    for (int ty = 0; ty < TY; ++ty)
+            for (int t = 0; t < G::NT; ++t) av[t] = a_raw[t] * a_sc[pb];
+            if (step + 1 < G::KSTEPS) fetch_operands(step + 1);
+            __builtin_amdgcn_sched_barrier(0);      // the reads go out BEFORE the MFMA block
 #pragma unroll
-                        for (int tx = 0; tx < TX; ++tx) {
-                            const float av = sb[ua + ty * G::EW + tx] * a_sc[pb];
-                            acc[ty * TX + tx] =
-                                __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[ty * TX + tx], 0, 0, 0);
-                        }
-                    // keep the software pipeline as written (the scheduler would otherwise hoist
-                    // every staging load to the top of the stage)
-                    __builtin_amdgcn_sched_barrier(0);
-                }
+            for (int t = 0; t < G::NT; ++t)
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], bv, acc[t], 0, 0, 0);
+            // keep the software pipeline as written (the scheduler would otherwise hoist every
+            // staging load to the top of the stage)
+            __builtin_amdgcn_sched_barrier(0);
+        }
         buf ^= 1;
     }
 
