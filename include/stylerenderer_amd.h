@@ -162,11 +162,15 @@ int sr_rasterize_grad_f64(int64_t b, int64_t nv, int64_t h, int64_t w, int repea
  *   iscale [B, C] | NULL   oscale [B, N] | NULL   obias [N] | NULL
  *   transposed = 0: correlation, iy = oy*stride + ky - pad   (k in {1,3}, stride in {1,2})
  *   transposed = 1: k = 3, stride = 2, pad = 0: out[2y+ky, 2x+kx] += in[y,x] * wt[ky*3+kx]
- *                   (OH = 2*IH + 1), the stride-2 transposed conv of the upsampling layers. */
+ *                   (OH = 2*IH + 1), the stride-2 transposed conv of the upsampling layers.
+ *   scratch: sr_conv2d_scratch_floats(...) floats (0 for large maps) for the split-K partial sums
+ *   of small feature maps, reduced in fixed order (deterministic); NULL disables the split. */
+int64_t sr_conv2d_scratch_floats(int64_t B, int64_t C, int64_t N, int64_t IH, int64_t IW, int64_t OH,
+                                 int64_t OW, int ksize, int stride, int pad, int transposed);
 int sr_conv2d_mfma(float* out, const float* in, const float* wt, const float* iscale,
                    const float* oscale, const float* obias, int64_t B, int64_t C, int64_t N,
                    int64_t wt_ld, int64_t IH, int64_t IW, int64_t OH, int64_t OW, int ksize, int stride,
-                   int pad, int transposed, sr_stream_t stream);
+                   int pad, int transposed, float* scratch, sr_stream_t stream);
 
 /* Weight gradient of sr_conv2d_mfma (same geometry arguments):
  *   dwt[ky*k+kx][c][n] = sum_{b, pixels} (xscale[b,c] * x[b,c,window]) * (gscale[b,n] * gy[b,n,pixel])

@@ -34,6 +34,11 @@ static void run(const char* tag, int B, int C, int N, int IH, int k, int stride,
     float* os = dev_random((size_t)B * N, 4);
     float* y = dev_random((size_t)B * N * OH * OH, 5);
     float* scratch = nullptr;
+    float* cscratch = nullptr;
+    if (!wgrad) {
+        const long long nf = sr_conv2d_scratch_floats(B, C, N, IH, IH, OH, OH, k, stride, pad, tr);
+        if (nf > 0) hipMalloc(&cscratch, nf * sizeof(float));
+    }
     if (wgrad) {
         const long long nf = sr_conv2d_wgrad_scratch_floats(B, C, N, IH, IH, OH, OH, k, stride, pad, tr);
         hipMalloc(&scratch, nf * sizeof(float));
@@ -46,7 +51,8 @@ static void run(const char* tag, int B, int C, int N, int IH, int k, int stride,
     for (int it = 0; it < iters + 2; ++it) {
         hipEventRecord(e0, 0);
         int rc = wgrad ? sr_conv2d_wgrad_mfma(w, x, y, is, os, B, C, N, IH, IH, OH, OH, k, stride, pad, tr, scratch, 0)
-                       : sr_conv2d_mfma(y, x, w, is, os, nullptr, B, C, N, N, IH, IH, OH, OH, k, stride, pad, tr, 0);
+                       : sr_conv2d_mfma(y, x, w, is, os, nullptr, B, C, N, N, IH, IH, OH, OH, k, stride, pad, tr,
+                                        cscratch, 0);
         hipEventRecord(e1, 0);
         hipEventSynchronize(e1);
         if (rc != 0) { printf("%s: rc=%d\n", tag, rc); break; }
@@ -68,6 +74,15 @@ int main(int argc, char** argv) {
         run("conv256 128->128", 16, 128, 128, 256, 3, 1, 1, 0, 0);
         run("conv128 256->256", 16, 256, 256, 128, 3, 1, 1, 0, 0);
         run("conv64 512->512", 16, 512, 512, 64, 3, 1, 1, 0, 0);
+    }
+    if (which & 8) {
+        run("conv32 512->512", 16, 512, 512, 32, 3, 1, 1, 0, 0);
+        run("conv16 512->512", 16, 512, 512, 16, 3, 1, 1, 0, 0);
+        run("conv8 512->512", 16, 512, 512, 8, 3, 1, 1, 0, 0);
+        run("conv4 512->512", 16, 512, 512, 4, 3, 1, 1, 0, 0);
+        run("up8 512->512 (convT)", 16, 512, 512, 4, 3, 2, 0, 1, 0);
+        run("up32 512->512 (convT)", 16, 512, 512, 16, 3, 2, 0, 1, 0);
+        run("dgrad-up16 s2", 16, 512, 512, 17, 3, 2, 0, 0, 0);
     }
     if (which & 2) {
         run("up256 256->128 (convT)", 16, 256, 128, 128, 3, 2, 0, 1, 0);

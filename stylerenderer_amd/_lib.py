@@ -36,7 +36,8 @@ SIGNATURES = {
     "sr_rasterize_grad_f32": (_i, [_l] * 4 + [_i] * 2 + [_p, _p, _l] + [_p] * 5 + [_f, _p]),
     "sr_conv2d_wgrad_scratch_floats": (_l, [_l] * 7 + [_i] * 4),
     "sr_conv2d_wgrad_mfma": (_i, [_p] * 5 + [_l] * 7 + [_i] * 4 + [_p, _p]),
-    "sr_conv2d_mfma": (_i, [_p] * 6 + [_l] * 8 + [_i] * 4 + [_p]),
+    "sr_conv2d_scratch_floats": (_l, [_l] * 7 + [_i] * 4),
+    "sr_conv2d_mfma": (_i, [_p] * 6 + [_l] * 8 + [_i] * 4 + [_p, _p]),
     "sr_rasterize_grad_f64": (_i, [_l] * 4 + [_i] * 2 + [_p, _p, _l] + [_p] * 5 + [_d, _p]),
 }
 

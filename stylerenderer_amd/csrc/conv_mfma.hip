@@ -61,6 +61,11 @@ struct ConvParams {
     int dy0, dx0;        // input coordinate = grid * IS + d0 + tap
     int wmap[9];         // weight slab of window position (ty, tx)
     int tiles_x, tiles_y, tiles_b, tiles_n;
+    // split-K for small feature maps (few tiles, long serial K loop): slice s handles channels
+    // [s * c_per_slice, (s+1) * c_per_slice) and writes raw sums to partial[s] (layout of `out`);
+    // k_conv_reduce adds the slices in order and applies oscale / bias.  ks == 1: direct epilogue.
+    float* partial;
+    int ks, c_per_slice;
 };
 
 template <int IS, int TY, int TX, int PW, int PH, int PB>
@@ -101,7 +106,11 @@ __global__ __launch_bounds__(256) void k_conv_mfma(const ConvParams p) {
     const int tx_i = bid % p.tiles_x;
     bid /= p.tiles_x;
     const int ty_i = bid % p.tiles_y;
-    const int tb_i = bid / p.tiles_y;
+    bid /= p.tiles_y;
+    const int tb_i = bid % p.tiles_b;
+    const int slice = bid / p.tiles_b;
+    const int c_beg = slice * p.c_per_slice;
+    const int c_end = min(p.C, c_beg + p.c_per_slice);
     const int n0 = n_t * BN, gy0 = ty_i * PH, gx0 = tx_i * PW, b0 = tb_i * PB;
     const int iy0 = gy0 * IS + p.dy0, ix0 = gx0 * IS + p.dx0;
 
@@ -200,13 +209,13 @@ __global__ __launch_bounds__(256) void k_conv_mfma(const ConvParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-    dma(0, 0);
+    dma(c_beg, 0);
     int buf = 0;
-    for (int c0 = 0; c0 < p.C; c0 += G::KC) {
+    for (int c0 = c_beg; c0 < c_end; c0 += G::KC) {
         // (a) this wave's DMA of chunk c0 has landed (the compiler drains vmcnt before the barrier),
         // (b) every wave is done reading the buffer the next DMA overwrites
         __syncthreads();
-        if (c0 + G::KC < p.C) dma(c0 + G::KC, buf ^ 1);
+        if (c0 + G::KC < c_end) dma(c0 + G::KC, buf ^ 1);
         const float* sb = smem + buf * G::BUF;
 #pragma unroll
         for (int cp = 0; cp < G::KC / 2; ++cp) {
@@ -252,9 +261,13 @@ __global__ __launch_bounds__(256) void k_conv_mfma(const ConvParams p) {
                 const int n = n0 + wco * 64 + ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
                 if (n < p.N) {
                     float v = acc[ct][pt][r];
-                    if (p.oscale) v *= p.oscale[(int64_t)b * p.N + n];
-                    if (p.obias) v += p.obias[n];
-                    p.out[((int64_t)b * p.N + n) * plane_out + pix] = v;
+                    if (p.ks > 1) {
+                        p.partial[((int64_t)slice * p.B * p.N + (int64_t)b * p.N + n) * plane_out + pix] = v;
+                    } else {
+                        if (p.oscale) v *= p.oscale[(int64_t)b * p.N + n];
+                        if (p.obias) v += p.obias[n];
+                        p.out[((int64_t)b * p.N + n) * plane_out + pix] = v;
+                    }
                 }
             }
     }
@@ -274,19 +287,58 @@ int launch_one(const ConvParams& p, dim3 grid, hipStream_t st) {
     return sr_launch_status();
 }
 
+void patch_shape(int GW, int& pw, int& ph, int& pb) {
+    // patch shape from the grid width: 32x4, 16x8, 8x8x2, 4x4x8
+    if (GW > 16) { pw = 32; ph = 4; pb = 1; }
+    else if (GW > 8) { pw = 16; ph = 8; pb = 1; }
+    else if (GW > 4) { pw = 8; ph = 8; pb = 2; }
+    else { pw = 4; ph = 4; pb = 8; }
+}
+
+// Number of K slices for an output grid: 1 when the grid alone fills the chip, otherwise enough
+// slices for ~2 workgroups per CU while keeping >= 32 channels (a multiple of 16) per slice.
+void choose_split(int GH, int GW, int B, int N, int C, int& ks, int& c_per_slice) {
+    int pw, ph, pb;
+    patch_shape(GW, pw, ph, pb);
+    const int64_t blocks = (int64_t)((GW + pw - 1) / pw) * ((GH + ph - 1) / ph) * ((B + pb - 1) / pb) *
+                           ((N + BN - 1) / BN);
+    ks = 1;
+    c_per_slice = (C + 15) / 16 * 16;
+    if (blocks >= SR_NUM_CU || C < 64) return;
+    int want = (int)((2 * SR_NUM_CU + blocks - 1) / blocks);
+    if (want > 16) want = 16;
+    int per = (C + want - 1) / want;
+    per = (per + 15) / 16 * 16;
+    if (per < 32) per = 32;
+    c_per_slice = per;
+    ks = (C + per - 1) / per;
+}
+
+__global__ __launch_bounds__(256) void k_conv_reduce(float* __restrict__ out,
+                                                     const float* __restrict__ partial,
+                                                     const float* __restrict__ oscale,
+                                                     const float* __restrict__ obias, int ks, int N,
+                                                     int64_t plane, int64_t total) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        float acc = 0.0f;
+        for (int s = 0; s < ks; ++s) acc += partial[s * total + i];      // fixed order: deterministic
+        const int64_t row = i / plane;                                   // b * N + n
+        if (oscale) acc *= oscale[row];
+        if (obias) acc += obias[row % N];
+        out[i] = acc;
+    }
+}
+
 template <int IS, int TY, int TX>
 int launch_by_patch(ConvParams& p, hipStream_t st) {
-    // patch shape from the grid width: 32x4, 16x8, 8x8x2, 4x4x8
     int pw, ph, pb;
-    if (p.GW > 16) { pw = 32; ph = 4; pb = 1; }
-    else if (p.GW > 8) { pw = 16; ph = 8; pb = 1; }
-    else if (p.GW > 4) { pw = 8; ph = 8; pb = 2; }
-    else { pw = 4; ph = 4; pb = 8; }
+    patch_shape(p.GW, pw, ph, pb);
     p.tiles_x = (p.GW + pw - 1) / pw;
     p.tiles_y = (p.GH + ph - 1) / ph;
     p.tiles_b = (p.B + pb - 1) / pb;
     p.tiles_n = (p.N + BN - 1) / BN;
-    const int64_t blocks = (int64_t)p.tiles_x * p.tiles_y * p.tiles_b * p.tiles_n;
+    const int64_t blocks = (int64_t)p.tiles_x * p.tiles_y * p.tiles_b * p.tiles_n * p.ks;
     if (blocks <= 0) return SR_OK;
     if (blocks > 0x7FFFFFFFLL) return SR_ERANGE;
     const dim3 grid((unsigned)blocks);
@@ -296,12 +348,32 @@ int launch_by_patch(ConvParams& p, hipStream_t st) {
     return launch_one<IS, TY, TX, 4, 4, 8>(p, grid, st);
 }
 
+int finish_split(const ConvParams& p, hipStream_t st) {
+    if (p.ks <= 1) return SR_OK;
+    const int64_t plane = (int64_t)p.OH * p.OW, total = (int64_t)p.B * p.N * plane;
+    hipLaunchKernelGGL(k_conv_reduce, dim3(sr_stream_grid(total, 256)), dim3(256), 0, st, p.out, p.partial,
+                       p.oscale, p.obias, p.ks, p.N, plane, total);
+    return sr_launch_status();
+}
+
 }  // namespace
+
+extern "C" int64_t sr_conv2d_scratch_floats(int64_t B, int64_t C, int64_t N, int64_t IH, int64_t IW,
+                                            int64_t OH, int64_t OW, int ksize, int stride, int pad,
+                                            int transposed) {
+    (void)ksize; (void)stride; (void)pad;
+    if (B <= 0 || C <= 0 || N <= 0 || OH <= 0 || OW <= 0) return 0;
+    int ks, per;
+    if (transposed) choose_split((int)IH + 1, (int)IW + 1, (int)B, (int)N, (int)C, ks, per);
+    else choose_split((int)OH, (int)OW, (int)B, (int)N, (int)C, ks, per);
+    return ks > 1 ? (int64_t)ks * B * N * OH * OW : 0;
+}
 
 extern "C" int sr_conv2d_mfma(float* out, const float* in, const float* wt, const float* iscale,
                               const float* oscale, const float* obias, int64_t B, int64_t C,
                               int64_t N, int64_t wt_ld, int64_t IH, int64_t IW, int64_t OH, int64_t OW,
-                              int ksize, int stride, int pad, int transposed, sr_stream_t stream) {
+                              int ksize, int stride, int pad, int transposed, float* scratch,
+                              sr_stream_t stream) {
     if (B < 0 || C <= 0 || N <= 0 || IH <= 0 || IW <= 0 || OH <= 0 || OW <= 0) return SR_EINVAL;
     if (wt_ld < N || wt_ld % 4 != 0 || (reinterpret_cast<uintptr_t>(wt) & 15)) return SR_EINVAL;
     if (B == 0) return SR_OK;
@@ -315,7 +387,11 @@ extern "C" int sr_conv2d_mfma(float* out, const float* in, const float* wt, cons
     p.in = in; p.wt = wt; p.iscale = iscale; p.oscale = oscale; p.obias = obias; p.out = out;
     p.B = (int)B; p.C = (int)C; p.N = (int)N; p.ldw = (int)wt_ld;
     p.IH = (int)IH; p.IW = (int)IW; p.OH = (int)OH; p.OW = (int)OW;
+    p.partial = scratch;
     for (int i = 0; i < 9; ++i) p.wmap[i] = 0;
+    if (transposed) choose_split(p.IH + 1, p.IW + 1, p.B, p.N, p.C, p.ks, p.c_per_slice);
+    else choose_split(p.OH, p.OW, p.B, p.N, p.C, p.ks, p.c_per_slice);
+    if (!scratch) { p.ks = 1; p.c_per_slice = (p.C + 15) / 16 * 16; }
     if (!transposed) {
         if (OH != (IH + 2 * pad - ksize) / stride + 1 || OW != (IW + 2 * pad - ksize) / stride + 1)
             return SR_EINVAL;
@@ -323,11 +399,13 @@ extern "C" int sr_conv2d_mfma(float* out, const float* in, const float* wt, cons
         p.osy = p.osx = 1; p.ooy = p.oox = 0;
         p.dy0 = p.dx0 = -pad;
         for (int i = 0; i < ksize * ksize; ++i) p.wmap[i] = i;
-        if (ksize == 3 && stride == 1) return launch_by_patch<1, 3, 3>(p, st);
-        if (ksize == 3 && stride == 2) return launch_by_patch<2, 3, 3>(p, st);
-        if (ksize == 1 && stride == 1) return launch_by_patch<1, 1, 1>(p, st);
-        if (ksize == 1 && stride == 2) return launch_by_patch<2, 1, 1>(p, st);
-        return SR_EINVAL;
+        int rc;
+        if (ksize == 3 && stride == 1) rc = launch_by_patch<1, 3, 3>(p, st);
+        else if (ksize == 3 && stride == 2) rc = launch_by_patch<2, 3, 3>(p, st);
+        else if (ksize == 1 && stride == 1) rc = launch_by_patch<1, 1, 1>(p, st);
+        else if (ksize == 1 && stride == 2) rc = launch_by_patch<2, 1, 1>(p, st);
+        else return SR_EINVAL;
+        return rc != SR_OK ? rc : finish_split(p, st);
     }
     // transposed 3x3 stride 2, no padding: out[2y + ky, 2x + kx] += in[y, x] * W[ky][kx].
     // Output phase (py, px) of grid point (j, i) = output (2j + py, 2i + px); window position ty
@@ -352,5 +430,5 @@ extern "C" int sr_conv2d_mfma(float* out, const float* in, const float* wt, cons
             else rc = launch_by_patch<1, 1, 1>(p, st);
             if (rc != SR_OK) return rc;
         }
-    return SR_OK;
+    return finish_split(p, st);
 }

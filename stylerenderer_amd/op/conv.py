@@ -59,12 +59,15 @@ def conv2d_mfma(x, wt, iscale=None, oscale=None, obias=None, ksize=3, stride=1, 
     out = torch.empty((b, n, oh, ow), dtype=x.dtype, device=x.device)
     gh, gw = (ih, iw) if transposed else (oh, ow)
     flops = 2.0 * b * gh * gw * c * n * ksize * ksize
+    L = _lib.lib()
+    nscr = L.sr_conv2d_scratch_floats(b, c, n, ih, iw, oh, ow, ksize, stride, pad, int(bool(transposed)))
+    scratch = torch.empty(nscr, dtype=x.dtype, device=x.device) if nscr > 0 else None   # split-K (small maps)
     with on_device_of(x):
         rc = _timed("conv", (ksize, stride, int(bool(transposed)), b, c, n, gh, gw), flops,
-                    lambda: _lib.lib().sr_conv2d_mfma(
+                    lambda: L.sr_conv2d_mfma(
                         _lib.ptr(out), _lib.ptr(x), _lib.ptr(wt), _lib.ptr(iscale), _lib.ptr(oscale),
                         _lib.ptr(obias), b, c, n, ldw, ih, iw, oh, ow, ksize, stride, pad,
-                        int(bool(transposed)), stream_of(x)))
+                        int(bool(transposed)), _lib.ptr(scratch), stream_of(x)))
     _lib.check(rc, "sr_conv2d_mfma")
     return out
 
