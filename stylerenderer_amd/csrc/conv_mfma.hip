@@ -55,7 +55,8 @@ struct ConvParams {
     float* out;
     int B, C, N, ldw;    // ldw: row pitch of wt in floats (multiple of 4, >= N)
     int IH, IW;          // input extent
-    int GH, GW;          // output grid computed by this launch (phase space)
+    int GH, GW;          // output grid (phase space): rows [gy_base, GH), columns [gx_base, GW)
+    int gy_base, gx_base;
     int OH, OW;          // full output extent
     int osy, osx, ooy, oox;   // output coordinate = grid * os + oo
     int dy0, dx0;        // input coordinate = grid * IS + d0 + tap
@@ -111,7 +112,7 @@ __global__ __launch_bounds__(256) void k_conv_mfma(const ConvParams p) {
     const int slice = bid / p.tiles_b;
     const int c_beg = slice * p.c_per_slice;
     const int c_end = min(p.C, c_beg + p.c_per_slice);
-    const int n0 = n_t * BN, gy0 = ty_i * PH, gx0 = tx_i * PW, b0 = tb_i * PB;
+    const int n0 = n_t * BN, gy0 = p.gy_base + ty_i * PH, gx0 = p.gx_base + tx_i * PW, b0 = tb_i * PB;
     const int iy0 = gy0 * IS + p.dy0, ix0 = gx0 * IS + p.dx0;
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -333,9 +334,11 @@ __global__ __launch_bounds__(256) void k_conv_reduce(float* __restrict__ out,
 template <int IS, int TY, int TX>
 int launch_by_patch(ConvParams& p, hipStream_t st) {
     int pw, ph, pb;
-    patch_shape(p.GW, pw, ph, pb);
-    p.tiles_x = (p.GW + pw - 1) / pw;
-    p.tiles_y = (p.GH + ph - 1) / ph;
+    const int ext_w = p.GW - p.gx_base, ext_h = p.GH - p.gy_base;
+    if (ext_w <= 0 || ext_h <= 0) return SR_OK;
+    patch_shape(ext_w, pw, ph, pb);
+    p.tiles_x = (ext_w + pw - 1) / pw;
+    p.tiles_y = (ext_h + ph - 1) / ph;
     p.tiles_b = (p.B + pb - 1) / pb;
     p.tiles_n = (p.N + BN - 1) / BN;
     const int64_t blocks = (int64_t)p.tiles_x * p.tiles_y * p.tiles_b * p.tiles_n * p.ks;
@@ -364,7 +367,7 @@ extern "C" int64_t sr_conv2d_scratch_floats(int64_t B, int64_t C, int64_t N, int
     (void)ksize; (void)stride; (void)pad;
     if (B <= 0 || C <= 0 || N <= 0 || OH <= 0 || OW <= 0) return 0;
     int ks, per;
-    if (transposed) choose_split((int)IH + 1, (int)IW + 1, (int)B, (int)N, (int)C, ks, per);
+    if (transposed) choose_split((int)IH, (int)IW, (int)B, (int)N, (int)C, ks, per);
     else choose_split((int)OH, (int)OW, (int)B, (int)N, (int)C, ks, per);
     return ks > 1 ? (int64_t)ks * B * N * OH * OW : 0;
 }
@@ -389,13 +392,14 @@ extern "C" int sr_conv2d_mfma(float* out, const float* in, const float* wt, cons
     p.IH = (int)IH; p.IW = (int)IW; p.OH = (int)OH; p.OW = (int)OW;
     p.partial = scratch;
     for (int i = 0; i < 9; ++i) p.wmap[i] = 0;
-    if (transposed) choose_split(p.IH + 1, p.IW + 1, p.B, p.N, p.C, p.ks, p.c_per_slice);
+    if (transposed) choose_split(p.IH, p.IW, p.B, p.N, p.C, p.ks, p.c_per_slice);
     else choose_split(p.OH, p.OW, p.B, p.N, p.C, p.ks, p.c_per_slice);
     if (!scratch) { p.ks = 1; p.c_per_slice = (p.C + 15) / 16 * 16; }
     if (!transposed) {
         if (OH != (IH + 2 * pad - ksize) / stride + 1 || OW != (IW + 2 * pad - ksize) / stride + 1)
             return SR_EINVAL;
         p.GH = p.OH; p.GW = p.OW;
+        p.gy_base = p.gx_base = 0;
         p.osy = p.osx = 1; p.ooy = p.oox = 0;
         p.dy0 = p.dx0 = -pad;
         for (int i = 0; i < ksize * ksize; ++i) p.wmap[i] = i;
@@ -411,11 +415,12 @@ extern "C" int sr_conv2d_mfma(float* out, const float* in, const float* wt, cons
     // Output phase (py, px) of grid point (j, i) = output (2j + py, 2i + px); window position ty
     // reads input row j + ty - (TY - 1) and pairs with ky = py + 2 * (TY - 1 - ty).
     if (ksize != 3 || stride != 2 || pad != 0 || OH != 2 * IH + 1 || OW != 2 * IW + 1) return SR_EINVAL;
+    // The phase grids have 2^k + 1 points per side: the 2^k x 2^k interior tiles the 32-wide
+    // patches exactly, the last grid row / column (output row 2*IH, column 2*IW: even phases only)
+    // runs as thin strip launches instead of padding every tile row by up to 50 %.
     for (int py = 0; py < 2; ++py)
         for (int px = 0; px < 2; ++px) {
             const int TYp = py == 0 ? 2 : 1, TXp = px == 0 ? 2 : 1;
-            p.GH = py == 0 ? p.IH + 1 : p.IH;
-            p.GW = px == 0 ? p.IW + 1 : p.IW;
             p.osy = p.osx = 2; p.ooy = py; p.oox = px;
             p.dy0 = -(TYp - 1); p.dx0 = -(TXp - 1);
             for (int ty = 0; ty < TYp; ++ty)
@@ -423,12 +428,29 @@ extern "C" int sr_conv2d_mfma(float* out, const float* in, const float* wt, cons
                     const int ky = py + 2 * (TYp - 1 - ty), kx = px + 2 * (TXp - 1 - tx);
                     p.wmap[ty * TXp + tx] = ky * 3 + kx;
                 }
-            int rc;
-            if (py == 0 && px == 0) rc = launch_by_patch<1, 2, 2>(p, st);
-            else if (py == 0) rc = launch_by_patch<1, 2, 1>(p, st);
-            else if (px == 0) rc = launch_by_patch<1, 1, 2>(p, st);
-            else rc = launch_by_patch<1, 1, 1>(p, st);
-            if (rc != SR_OK) return rc;
+            const int gh_full = py == 0 ? p.IH + 1 : p.IH, gw_full = px == 0 ? p.IW + 1 : p.IW;
+            // sub-grids: {rows, cols} ranges as [y0, y1) x [x0, x1)
+            int regions[3][4] = {{0, p.IH, 0, p.IW},                       // interior
+                                 {p.IH, gh_full, 0, gw_full},              // last row (py == 0)
+                                 {0, p.IH, p.IW, gw_full}};                // last column (px == 0)
+            // measured: the split pays for 16..64-wide inputs (padding waste 35-50 %); larger maps
+            // lose more to the extra launches than the 20 % padding costs, tiny maps are launch bound
+            const bool split_border = p.IW >= 16 && p.IW <= 64;
+            if (!split_border) {
+                regions[0][1] = gh_full;
+                regions[0][3] = gw_full;
+            }
+            for (int rg = 0; rg < (split_border ? 3 : 1); ++rg) {
+                p.gy_base = regions[rg][0]; p.GH = regions[rg][1];
+                p.gx_base = regions[rg][2]; p.GW = regions[rg][3];
+                if (p.GH <= p.gy_base || p.GW <= p.gx_base) continue;
+                int rc;
+                if (py == 0 && px == 0) rc = launch_by_patch<1, 2, 2>(p, st);
+                else if (py == 0) rc = launch_by_patch<1, 2, 1>(p, st);
+                else if (px == 0) rc = launch_by_patch<1, 1, 2>(p, st);
+                else rc = launch_by_patch<1, 1, 1>(p, st);
+                if (rc != SR_OK) return rc;
+            }
         }
     return finish_split(p, st);
 }

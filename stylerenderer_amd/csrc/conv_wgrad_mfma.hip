@@ -54,8 +54,15 @@ struct WgradParams {
     int UP, VP;           // padded channel extents (tiles_u * UT, tiles_v * VT)
 };
 
-template <int IS, int TY, int TX, int PW, int PH, int PB, int UT, int VT>
+// NG = number of 4-wave groups per workgroup.  With NG = 2 (512 threads) the two groups share
+// the staged patch and split its pixel pairs (rows), each with its own accumulators and its own
+// partial slab: two waves per SIMD cover each other's LDS / barrier stalls while the 133 KB
+// double buffer still fits one workgroup per CU.
+template <int IS, int TY, int TX, int PW, int PH, int PB, int UT, int VT, int NG>
 struct WG {
+    static constexpr int NWAVE = 4 * NG, THREADS = 256 * NG;
+    static constexpr int PHG = PH / NG;                     // patch rows per group
+    static_assert(NG == 1 || (PB == 1 && PH % NG == 0), "row split needs a single-sample patch");
     static constexpr int NT = TY * TX;
     static constexpr int EH = (PH - 1) * IS + TY;
     static constexpr int EW = (PW - 1) * IS + TX;
@@ -66,15 +73,15 @@ struct WG {
     static constexpr int VPL = NPIX + 1;
     static constexpr int WU = UT / 32, WV = VT / 32;
     static constexpr int SC = PB * (UT + VT);               // scale rows: [pb][UT] then [pb][VT]
-    static constexpr int SC_ITEMS = (SC + 255) / 256;       // one float per thread per item
+    static constexpr int SC_ITEMS = (SC + THREADS - 1) / THREADS;   // one float per thread per item
     static constexpr int OFF_V = UT * UPL;
     static constexpr int OFF_S = OFF_V + VT * VPL;
-    static constexpr int BUF = ((OFF_S + SC_ITEMS * 256 + 3) / 4) * 4;
+    static constexpr int BUF = ((OFF_S + SC_ITEMS * THREADS + 3) / 4) * 4;
     static constexpr int LDS_BYTES = 2 * BUF * 4;
     // staging items of ONE wave per stage: its U channels x slots, its V channels, the scale rows
-    static constexpr int U_ITEMS = (UT / 4) * USLOT, V_ITEMS = VT / 4;
+    static constexpr int U_ITEMS = (UT / NWAVE) * USLOT, V_ITEMS = VT / NWAVE;
     static constexpr int ITEMS = U_ITEMS + V_ITEMS + SC_ITEMS;
-    static constexpr int KSTEPS = NPIX / 2;                 // pixel pairs per stage
+    static constexpr int KSTEPS = NPIX / 2 / NG;            // pixel pairs per stage and group
 #ifndef SR_WGRAD_LAG
 #define SR_WGRAD_LAG 4
 #endif
@@ -83,9 +90,9 @@ struct WG {
     static_assert(PER_STEP * (KSTEPS - LAG) >= ITEMS, "staging must finish inside the stage");
 };
 
-template <int IS, int TY, int TX, int PW, int PH, int PB, int UT, int VT>
-__global__ __launch_bounds__(256) void k_wgrad_mfma(const WgradParams p) {
-    using G = WG<IS, TY, TX, PW, PH, PB, UT, VT>;
+template <int IS, int TY, int TX, int PW, int PH, int PB, int UT, int VT, int NG>
+__global__ __launch_bounds__(256 * NG) void k_wgrad_mfma(const WgradParams p) {
+    using G = WG<IS, TY, TX, PW, PH, PB, UT, VT, NG>;
     static_assert(G::WU * G::WV == 4, "4 waves per workgroup");
     static_assert(G::NPIX == 64, "one V plane = one staging instruction");
     static_assert(PW % 2 == 0, "pixel pairs run along x");
@@ -99,9 +106,10 @@ __global__ __launch_bounds__(256) void k_wgrad_mfma(const WgradParams p) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = lane >> 5, l31 = lane & 31;
-    const int wu = wave / G::WV, wv = wave % G::WV;
-    const int a_base = (wu * 32 + l31) * G::UPL + half * IS;
-    const int b_base = G::OFF_V + (wv * 32 + l31) * G::VPL + half;
+    const int grp = wave >> 2, w4 = wave & 3;            // group = which rows of the patch
+    const int wu = w4 / G::WV, wv = w4 % G::WV;
+    const int a_base = (wu * 32 + l31) * G::UPL + half * IS + grp * G::PHG * IS * G::EW;
+    const int b_base = G::OFF_V + (wv * 32 + l31) * G::VPL + half + grp * G::PHG * PW;
 
     const int npatch = p.tiles_x * p.tiles_y * p.tiles_b;
     const int first = slice * p.patches_per_slice;
@@ -156,14 +164,14 @@ __global__ __launch_bounds__(256) void k_wgrad_mfma(const WgradParams p) {
     auto item_load = [&](int k) -> float {
         if (k < G::U_ITEMS) {
             const int cu = k / G::USLOT, s = k % G::USLOT;
-            const int u = min(u0 + wave + 4 * cu, p.CU - 1);
+            const int u = min(u0 + wave + G::NWAVE * cu, p.CU - 1);
             return (p.U + (int64_t)u * plane_u)[u_off[s]];
         }
         if (k < G::U_ITEMS + G::V_ITEMS) {
-            const int v = min(v0 + wave + 4 * (k - G::U_ITEMS), p.CV - 1);
+            const int v = min(v0 + wave + G::NWAVE * (k - G::U_ITEMS), p.CV - 1);
             return (p.V + (int64_t)v * plane_v)[v_off];
         }
-        const int e = (k - G::U_ITEMS - G::V_ITEMS) * 256 + tid;
+        const int e = (k - G::U_ITEMS - G::V_ITEMS) * G::THREADS + tid;
         float val = 1.0f;
         if (e < PB * UT) {
             const int pb = e / UT, u = e % UT;
@@ -177,14 +185,14 @@ __global__ __launch_bounds__(256) void k_wgrad_mfma(const WgradParams p) {
     auto item_store = [&](int k, float val, float* dst) {
         if (k < G::U_ITEMS) {
             const int cu = k / G::USLOT, s = k % G::USLOT;
-            const bool ok = u_ok[s] && (u0 + wave + 4 * cu < p.CU);
-            dst[uw_base + 4 * cu * G::UPL + s * 64] = ok ? val : 0.0f;
+            const bool ok = u_ok[s] && (u0 + wave + G::NWAVE * cu < p.CU);
+            dst[uw_base + G::NWAVE * cu * G::UPL + s * 64] = ok ? val : 0.0f;
         } else if (k < G::U_ITEMS + G::V_ITEMS) {
             const int cv = k - G::U_ITEMS;
-            const bool ok = v_ok && (v0 + wave + 4 * cv < p.CV);
-            dst[vw_base + 4 * cv * G::VPL] = ok ? val : 0.0f;
+            const bool ok = v_ok && (v0 + wave + G::NWAVE * cv < p.CV);
+            dst[vw_base + G::NWAVE * cv * G::VPL] = ok ? val : 0.0f;
         } else {
-            dst[G::OFF_S + (k - G::U_ITEMS - G::V_ITEMS) * 256 + tid] = val;
+            dst[G::OFF_S + (k - G::U_ITEMS - G::V_ITEMS) * G::THREADS + tid] = val;
         }
     };
 
@@ -230,7 +238,7 @@ __global__ __launch_bounds__(256) void k_wgrad_mfma(const WgradParams p) {
         // latency), and multiplied by the modulation scales at the top of the next iteration.
         float a_raw[G::NT], b_raw;
         auto fetch_operands = [&](int step) {
-            const int qx = step % (PW / 2), py = (step / (PW / 2)) % PH, pb = step / ((PW / 2) * PH);
+            const int qx = step % (PW / 2), py = (step / (PW / 2)) % G::PHG, pb = step / ((PW / 2) * G::PHG);
             b_raw = sb[b_base + (pb * PH + py) * PW + 2 * qx];
             const int ua = a_base + (pb * G::EH + py * IS) * G::EW + 2 * qx * IS;
 #pragma unroll
@@ -252,7 +260,7 @@ __global__ __launch_bounds__(256) void k_wgrad_mfma(const WgradParams p) {
                 if (w >= 0 && w < G::ITEMS) item_store(w, stg[w], so);
             }
 #endif
-            const int pb = step / ((PW / 2) * PH);
+            const int pb = step / ((PW / 2) * G::PHG);
             const float bv = b_raw * b_sc[pb];
             float av[G::NT];
 #pragma unroll
@@ -270,7 +278,7 @@ __global__ __launch_bounds__(256) void k_wgrad_mfma(const WgradParams p) {
     }
 
     // partial[slice][tap][u][v]; C/D layout: column (v) = lane & 31, row (u) = (r&3) + 8*(r>>2) + 4*half
-    float* dst = p.partial + (int64_t)slice * G::NT * p.UP * p.VP;
+    float* dst = p.partial + ((int64_t)slice * NG + grp) * G::NT * p.UP * p.VP;
 #pragma unroll
     for (int t = 0; t < G::NT; ++t)
 #pragma unroll
@@ -337,7 +345,9 @@ Plan make_plan(int is, int B, int CU, int CV, int GH, int GW) {
     pl.tiles_v = (CV + pl.vt - 1) / pl.vt;
     const int npatch = pl.tiles_x * pl.tiles_y * pl.tiles_b;
     const int tiles_uv = pl.tiles_u * pl.tiles_v;
-    int ks = (2 * SR_NUM_CU + tiles_uv - 1) / tiles_uv;
+    // one 512-thread workgroup per CU (two 256-thread ones for the multi-sample patch type)
+    const int target = (pl.pb == 1 ? 1 : 2) * SR_NUM_CU;
+    int ks = (target + tiles_uv - 1) / tiles_uv;
     if (ks > npatch) ks = npatch;
     if (ks < 1) ks = 1;
     pl.pps = (npatch + ks - 1) / ks;
@@ -345,18 +355,21 @@ Plan make_plan(int is, int B, int CU, int CV, int GH, int GW) {
     return pl;
 }
 
+constexpr int NG_OF(int pb) { return pb == 1 ? 2 : 1; }     // groups per workgroup by patch type
+
 template <int IS, int TY, int TX, int PW, int PH, int PB, int UT, int VT>
 int launch_wgrad_one(const WgradParams& p, dim3 grid, hipStream_t st) {
-    using G = WG<IS, TY, TX, PW, PH, PB, UT, VT>;
+    constexpr int NG = NG_OF(PB);
+    using G = WG<IS, TY, TX, PW, PH, PB, UT, VT, NG>;
     static_assert(G::LDS_BYTES <= 160 * 1024, "LDS budget");
-    auto kern = k_wgrad_mfma<IS, TY, TX, PW, PH, PB, UT, VT>;
+    auto kern = k_wgrad_mfma<IS, TY, TX, PW, PH, PB, UT, VT, NG>;
     static bool configured = false;
     if (!configured) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
         configured = true;
     }
-    hipLaunchKernelGGL(kern, grid, dim3(256), G::LDS_BYTES, st, p);
+    hipLaunchKernelGGL(kern, grid, dim3(G::THREADS), G::LDS_BYTES, st, p);
     return sr_launch_status();
 }
 
@@ -400,7 +413,7 @@ extern "C" int64_t sr_conv2d_wgrad_scratch_floats(int64_t B, int64_t C, int64_t 
     if (!geometry(B, C, N, IH, IW, OH, OW, ksize, stride, pad, transposed, is, GH, GW, UH, UW, CUc, CVc, d0))
         return -1;
     const Plan pl = make_plan(is, (int)B, CUc, CVc, GH, GW);
-    return (int64_t)pl.ks * ksize * ksize * (pl.tiles_u * pl.ut) * (int64_t)(pl.tiles_v * pl.vt) + 4;
+    return (int64_t)pl.ks * NG_OF(pl.pb) * ksize * ksize * (pl.tiles_u * pl.ut) * (int64_t)(pl.tiles_v * pl.vt) + 4;
 }
 
 extern "C" int sr_conv2d_wgrad_mfma(float* dwt, const float* x, const float* gy, const float* xscale,
@@ -435,7 +448,7 @@ extern "C" int sr_conv2d_wgrad_mfma(float* dwt, const float* x, const float* gy,
     }
     ReduceParams r;
     r.partial = scratch; r.out = dwt;
-    r.ks = B > 0 ? pl.ks : 0; r.nt = ksize * ksize; r.UP = p.UP; r.VP = p.VP; r.CU = CUc; r.CV = CVc;
+    r.ks = B > 0 ? pl.ks * NG_OF(pl.pb) : 0; r.nt = ksize * ksize; r.UP = p.UP; r.VP = p.VP; r.CU = CUc; r.CV = CVc;
     r.slab = C * N;
     // dwt is [k*k][C][N]: regular conv has (u, v) = (c, n); transposed has (u, v) = (n, c)
     r.su = transposed ? 1 : N;
