@@ -66,31 +66,41 @@ struct ConvParams {
     // [s * c_per_slice, (s+1) * c_per_slice) and writes raw sums to partial[s] (layout of `out`);
     // k_conv_reduce adds the slices in order and applies oscale / bias.  ks == 1: direct epilogue.
     float* partial;
+    int64_t partial_floats;
     int ks, c_per_slice;
 };
 
-template <int IS, int TY, int TX, int PW, int PH, int PB>
+// V4: the halo window starts at a 16-byte aligned column (LEAD extra columns on the left), rows
+// are padded to a multiple of 4 floats, and the whole image moves with 16-byte DMAs (a 4-byte DMA
+// costs the same issue slot for a quarter of the data: measured ~3x fewer DMA instructions per
+// chunk).  Needs IW % 4 == 0, a 16-byte aligned input and stride 1; otherwise the 4-byte form.
+template <int IS, int TY, int TX, int PW, int PH, int PB, bool V4>
 struct Geo {
     static constexpr int NT = TY * TX;
     // channels per K chunk: ~32-36 k-steps of MFMA work per barrier whatever the window
     static constexpr int KC = NT >= 9 ? 4 : (NT >= 4 ? 8 : 16);
     static constexpr int EH = (PH - 1) * IS + TY;
     static constexpr int EW = (PW - 1) * IS + TX;
-    static constexpr int EWP = EW + ((EW % 2 == 0) ? 1 : 0);     // odd row pitch
+    static constexpr int LEAD = V4 ? (TX > 1 ? 3 : 0) : 0;
+    static constexpr int EWP = V4 ? (LEAD + EW + 3) / 4 * 4 : EW + ((EW % 2 == 0) ? 1 : 0);
     static constexpr int PLANE = PB * EH * EWP;                  // one channel of the chunk
     static constexpr int W_FLOATS = NT * KC * BN;                // [tap][c][128]
     static constexpr int W_INSTR = W_FLOATS / 256;               // 1 KiB (2 rows) per wave instruction
+    // image instructions, then style instructions (V4) / one mixed 4-byte stream (!V4)
+    static constexpr int IMG_INSTR = V4 ? (KC * PLANE + 255) / 256 : 0;
+    static constexpr int ST_INSTR = V4 ? (KC * PB + 63) / 64 : 0;
     static constexpr int IN_FLOATS = KC * PLANE + KC * PB;       // halo planes, then the style row(s)
-    static constexpr int IN_INSTR = (IN_FLOATS + 63) / 64;       // 256 B per wave instruction
-    static constexpr int BUF = W_FLOATS + IN_INSTR * 64;         // floats per LDS buffer
+    static constexpr int IN_INSTR = V4 ? IMG_INSTR + ST_INSTR : (IN_FLOATS + 63) / 64;
+    static constexpr int S_BASE = V4 ? W_FLOATS + IMG_INSTR * 256 : W_FLOATS + KC * PLANE;
+    static constexpr int BUF = V4 ? S_BASE + ST_INSTR * 64 : W_FLOATS + IN_INSTR * 64;
     static constexpr int W_PER_WAVE = (W_INSTR + 3) / 4;
     static constexpr int IN_PER_WAVE = (IN_INSTR + 3) / 4;
     static constexpr int LDS_BYTES = 2 * BUF * 4;
 };
 
-template <int IS, int TY, int TX, int PW, int PH, int PB>
+template <int IS, int TY, int TX, int PW, int PH, int PB, bool V4>
 __global__ __launch_bounds__(256) void k_conv_mfma(const ConvParams p) {
-    using G = Geo<IS, TY, TX, PW, PH, PB>;
+    using G = Geo<IS, TY, TX, PW, PH, PB, V4>;
     static_assert(PW * PH * PB == BM, "patch must hold 128 pixels");
     extern __shared__ __attribute__((aligned(16))) float smem[];     // the ONLY LDS object
 
@@ -127,8 +137,8 @@ __global__ __launch_bounds__(256) void k_conv_mfma(const ConvParams p) {
         a_off[t] = half * BN + wco * 64 + t * 32 + l31;
         const int m = wpx * 64 + t * 32 + l31;
         const int px = m % PW, py = (m / PW) % PH, pb = m / (PW * PH);
-        b_off[t] = G::W_FLOATS + half * G::PLANE + (pb * G::EH + py * IS) * G::EWP + px * IS;
-        s_off[t] = G::W_FLOATS + G::KC * G::PLANE + pb * G::KC + half;   // style of (sample, channel)
+        b_off[t] = G::W_FLOATS + half * G::PLANE + (pb * G::EH + py * IS) * G::EWP + px * IS + G::LEAD;
+        s_off[t] = G::S_BASE + pb * G::KC + half;                        // style of (sample, channel)
     }
 
     // ---- DMA descriptors (chunk-invariant part), a few registers per lane
@@ -148,27 +158,49 @@ __global__ __launch_bounds__(256) void k_conv_mfma(const ConvParams p) {
             if (t == k) slab = p.wmap[k];
         w_src[i] = (slab * p.C + c) * p.ldw + col;
     }
-    // input: instruction j moves LDS floats [64 j, 64 j + 64) of the halo image, then the style rows
+    // input: !V4: instruction j moves LDS floats [64 j, 64 j + 64) of the halo image, then the
+    // style rows;  V4: instruction j < IMG_INSTR moves floats [256 j, 256 j + 256) (4 per lane, never
+    // straddling a row or the image border), the remaining ones move the style rows.
     int i_src[G::IN_PER_WAVE];     // element offset for (b0, c0) = (0, 0); -1 zero line, -2 style
     int i_cl[G::IN_PER_WAVE];      // chunk-local channel | sample << 8
 #pragma unroll
     for (int i = 0; i < G::IN_PER_WAVE; ++i) {
         const int j = wave + 4 * i;
-        const int f = j * 64 + lane;
         int src = -1, c = 0, pb = 0;
-        if (j < G::IN_INSTR && f < G::KC * G::PLANE) {
-            c = f / G::PLANE;
-            const int q = f % G::PLANE;
-            const int colp = q % G::EWP, r = (q / G::EWP) % G::EH;
-            pb = q / (G::EWP * G::EH);
-            const int gy = iy0 + r, gx = ix0 + colp;
-            if (colp < G::EW && gy >= 0 && gy < p.IH && gx >= 0 && gx < p.IW && b0 + pb < p.B)
-                src = (pb * p.C + c) * p.IH * p.IW + gy * p.IW + gx;
-        } else if (j < G::IN_INSTR && f < G::IN_FLOATS) {
-            const int e = f - G::KC * G::PLANE;
-            pb = e / G::KC;
-            c = e % G::KC;
-            src = -2;
+        if (V4) {
+            const int f = (j * 64 + lane) * 4;
+            if (j < G::IMG_INSTR && f < G::KC * G::PLANE) {
+                c = f / G::PLANE;
+                const int q = f % G::PLANE;
+                const int cola = q % G::EWP, r = (q / G::EWP) % G::EH;
+                pb = q / (G::EWP * G::EH);
+                const int gy = iy0 + r, gx = ix0 - G::LEAD + cola;
+                if (gy >= 0 && gy < p.IH && gx >= 0 && gx + 3 < p.IW && b0 + pb < p.B)
+                    src = (pb * p.C + c) * p.IH * p.IW + gy * p.IW + gx;
+            } else if (j >= G::IMG_INSTR && j < G::IN_INSTR) {
+                const int e = (j - G::IMG_INSTR) * 64 + lane;
+                if (e < G::KC * PB) {
+                    pb = e / G::KC;
+                    c = e % G::KC;
+                    src = -2;
+                }
+            }
+        } else {
+            const int f = j * 64 + lane;
+            if (j < G::IN_INSTR && f < G::KC * G::PLANE) {
+                c = f / G::PLANE;
+                const int q = f % G::PLANE;
+                const int colp = q % G::EWP, r = (q / G::EWP) % G::EH;
+                pb = q / (G::EWP * G::EH);
+                const int gy = iy0 + r, gx = ix0 + colp;
+                if (colp < G::EW && gy >= 0 && gy < p.IH && gx >= 0 && gx < p.IW && b0 + pb < p.B)
+                    src = (pb * p.C + c) * p.IH * p.IW + gy * p.IW + gx;
+            } else if (j < G::IN_INSTR && f < G::IN_FLOATS) {
+                const int e = f - G::KC * G::PLANE;
+                pb = e / G::KC;
+                c = e % G::KC;
+                src = -2;
+            }
         }
         i_src[i] = src;
         i_cl[i] = c | (pb << 8);
@@ -197,7 +229,13 @@ __global__ __launch_bounds__(256) void k_conv_mfma(const ConvParams p) {
                 if (i_src[i] == -2)
                     src = (p.iscale && c_ok && b0 + pb < p.B) ? p.iscale + (int64_t)(b0 + pb) * p.C + c0 + c
                                                               : g_ones_line;
-                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(dst + G::W_FLOATS + j * 64), 4, 0, 0);
+                if (V4 && j < G::IMG_INSTR)
+                    __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(dst + G::W_FLOATS + j * 256), 16, 0, 0);
+                else if (V4)
+                    __builtin_amdgcn_global_load_lds((gptr_t)src,
+                                                     (lptr_t)(dst + G::S_BASE + (j - G::IMG_INSTR) * 64), 4, 0, 0);
+                else
+                    __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(dst + G::W_FLOATS + j * 64), 4, 0, 0);
             }
         }
     };
@@ -263,7 +301,10 @@ __global__ __launch_bounds__(256) void k_conv_mfma(const ConvParams p) {
                 if (n < p.N) {
                     float v = acc[ct][pt][r];
                     if (p.ks > 1) {
-                        p.partial[((int64_t)slice * p.B * p.N + (int64_t)b * p.N + n) * plane_out + pix] = v;
+                        // compact slab of THIS launch's region: [slice][b][n][row][col]
+                        const int rw = p.GW - p.gx_base, rh = p.GH - p.gy_base;
+                        p.partial[(((int64_t)slice * p.B + b) * p.N + n) * (rh * rw) +
+                                  (gy - p.gy_base) * rw + (gx - p.gx_base)] = v;
                     } else {
                         if (p.oscale) v *= p.oscale[(int64_t)b * p.N + n];
                         if (p.obias) v += p.obias[n];
@@ -274,10 +315,10 @@ __global__ __launch_bounds__(256) void k_conv_mfma(const ConvParams p) {
     }
 }
 
-template <int IS, int TY, int TX, int PW, int PH, int PB>
+template <int IS, int TY, int TX, int PW, int PH, int PB, bool V4>
 int launch_one(const ConvParams& p, dim3 grid, hipStream_t st) {
-    using G = Geo<IS, TY, TX, PW, PH, PB>;
-    auto kern = k_conv_mfma<IS, TY, TX, PW, PH, PB>;
+    using G = Geo<IS, TY, TX, PW, PH, PB, V4>;
+    auto kern = k_conv_mfma<IS, TY, TX, PW, PH, PB, V4>;
     static bool configured = false;     // opt in to > 64 KiB of dynamic LDS once per variant
     if (!configured) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -315,19 +356,21 @@ void choose_split(int GH, int GW, int B, int N, int C, int& ks, int& c_per_slice
     ks = (C + per - 1) / per;
 }
 
-__global__ __launch_bounds__(256) void k_conv_reduce(float* __restrict__ out,
-                                                     const float* __restrict__ partial,
-                                                     const float* __restrict__ oscale,
-                                                     const float* __restrict__ obias, int ks, int N,
-                                                     int64_t plane, int64_t total) {
+// Sums the K slices of one launch's region in a fixed order (deterministic) and writes the
+// region's outputs with oscale / bias applied.
+__global__ __launch_bounds__(256) void k_conv_reduce(const ConvParams p, int rh, int rw) {
+    const int64_t region = (int64_t)rh * rw, total = (int64_t)p.B * p.N * region;
+    const int64_t plane_out = (int64_t)p.OH * p.OW;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
          i += (int64_t)gridDim.x * blockDim.x) {
         float acc = 0.0f;
-        for (int s = 0; s < ks; ++s) acc += partial[s * total + i];      // fixed order: deterministic
-        const int64_t row = i / plane;                                   // b * N + n
-        if (oscale) acc *= oscale[row];
-        if (obias) acc += obias[row % N];
-        out[i] = acc;
+        for (int s = 0; s < p.ks; ++s) acc += p.partial[s * total + i];
+        const int64_t row = i / region;                                  // b * N + n
+        const int q = (int)(i - row * region);
+        const int gy = p.gy_base + q / rw, gx = p.gx_base + q % rw;
+        if (p.oscale) acc *= p.oscale[row];
+        if (p.obias) acc += p.obias[row % p.N];
+        p.out[row * plane_out + (int64_t)(gy * p.osy + p.ooy) * p.OW + (gx * p.osx + p.oox)] = acc;
     }
 }
 
@@ -336,6 +379,13 @@ int launch_by_patch(ConvParams& p, hipStream_t st) {
     int pw, ph, pb;
     const int ext_w = p.GW - p.gx_base, ext_h = p.GH - p.gy_base;
     if (ext_w <= 0 || ext_h <= 0) return SR_OK;
+    // split-K is decided per launch (thin border strips of the transposed conv need it even when
+    // the interior does not); each launch reduces its own compact slab
+    choose_split(ext_h, ext_w, p.B, p.N, p.C, p.ks, p.c_per_slice);
+    if (!p.partial || (int64_t)p.ks * p.B * p.N * ext_h * ext_w > p.partial_floats) {
+        p.ks = 1;
+        p.c_per_slice = (p.C + 15) / 16 * 16;
+    }
     patch_shape(ext_w, pw, ph, pb);
     p.tiles_x = (ext_w + pw - 1) / pw;
     p.tiles_y = (ext_h + ph - 1) / ph;
@@ -345,17 +395,20 @@ int launch_by_patch(ConvParams& p, hipStream_t st) {
     if (blocks <= 0) return SR_OK;
     if (blocks > 0x7FFFFFFFLL) return SR_ERANGE;
     const dim3 grid((unsigned)blocks);
-    if (pw == 32) return launch_one<IS, TY, TX, 32, 4, 1>(p, grid, st);
-    if (pw == 16) return launch_one<IS, TY, TX, 16, 8, 1>(p, grid, st);
-    if (pw == 8) return launch_one<IS, TY, TX, 8, 8, 2>(p, grid, st);
-    return launch_one<IS, TY, TX, 4, 4, 8>(p, grid, st);
-}
-
-int finish_split(const ConvParams& p, hipStream_t st) {
-    if (p.ks <= 1) return SR_OK;
-    const int64_t plane = (int64_t)p.OH * p.OW, total = (int64_t)p.B * p.N * plane;
-    hipLaunchKernelGGL(k_conv_reduce, dim3(sr_stream_grid(total, 256)), dim3(256), 0, st, p.out, p.partial,
-                       p.oscale, p.obias, p.ks, p.N, plane, total);
+    // 16-byte halo DMAs: stride 1, one sample per tile, aligned rows, window origin dx0 = -(TX > 1)
+    const bool v4 = IS == 1 && pb == 1 && p.IW % 4 == 0 && (reinterpret_cast<uintptr_t>(p.in) & 15) == 0 &&
+                    p.gx_base % 4 == 0 && p.dx0 == (TX > 1 ? -1 : 0);
+    int rc;
+    if (IS == 1 && v4) {
+        if (pw == 32) rc = launch_one<1, TY, TX, 32, 4, 1, true>(p, grid, st);
+        else rc = launch_one<1, TY, TX, 16, 8, 1, true>(p, grid, st);
+    } else if (pw == 32) rc = launch_one<IS, TY, TX, 32, 4, 1, false>(p, grid, st);
+    else if (pw == 16) rc = launch_one<IS, TY, TX, 16, 8, 1, false>(p, grid, st);
+    else if (pw == 8) rc = launch_one<IS, TY, TX, 8, 8, 2, false>(p, grid, st);
+    else rc = launch_one<IS, TY, TX, 4, 4, 8, false>(p, grid, st);
+    if (rc != SR_OK || p.ks <= 1) return rc;
+    const int64_t total = (int64_t)p.B * p.N * ext_h * ext_w;
+    hipLaunchKernelGGL(k_conv_reduce, dim3(sr_stream_grid(total, 256)), dim3(256), 0, st, p, ext_h, ext_w);
     return sr_launch_status();
 }
 
@@ -366,10 +419,24 @@ extern "C" int64_t sr_conv2d_scratch_floats(int64_t B, int64_t C, int64_t N, int
                                             int transposed) {
     (void)ksize; (void)stride; (void)pad;
     if (B <= 0 || C <= 0 || N <= 0 || OH <= 0 || OW <= 0) return 0;
+    // regions a launch may split: the whole output grid (small maps) or, for the transposed conv,
+    // its border strips.  Upper bound: ks * B * N * region for the largest split region.
     int ks, per;
-    if (transposed) choose_split((int)IH, (int)IW, (int)B, (int)N, (int)C, ks, per);
-    else choose_split((int)OH, (int)OW, (int)B, (int)N, (int)C, ks, per);
-    return ks > 1 ? (int64_t)ks * B * N * OH * OW : 0;
+    int64_t need = 0;
+    auto consider = [&](int64_t gh, int64_t gw) {
+        if (gh <= 0 || gw <= 0) return;
+        choose_split((int)gh, (int)gw, (int)B, (int)N, (int)C, ks, per);
+        if (ks > 1) need = need > ks * B * N * gh * gw ? need : ks * B * N * gh * gw;
+    };
+    if (!transposed) {
+        consider(OH, OW);
+    } else {
+        consider(IH + 1, IW + 1);
+        consider(IH, IW);
+        consider(1, IW + 1);
+        consider(IH, 1);
+    }
+    return need;
 }
 
 extern "C" int sr_conv2d_mfma(float* out, const float* in, const float* wt, const float* iscale,
@@ -391,10 +458,9 @@ extern "C" int sr_conv2d_mfma(float* out, const float* in, const float* wt, cons
     p.B = (int)B; p.C = (int)C; p.N = (int)N; p.ldw = (int)wt_ld;
     p.IH = (int)IH; p.IW = (int)IW; p.OH = (int)OH; p.OW = (int)OW;
     p.partial = scratch;
+    p.partial_floats = scratch ? sr_conv2d_scratch_floats(B, C, N, IH, IW, OH, OW, ksize, stride, pad, transposed) : 0;
     for (int i = 0; i < 9; ++i) p.wmap[i] = 0;
-    if (transposed) choose_split(p.IH, p.IW, p.B, p.N, p.C, p.ks, p.c_per_slice);
-    else choose_split(p.OH, p.OW, p.B, p.N, p.C, p.ks, p.c_per_slice);
-    if (!scratch) { p.ks = 1; p.c_per_slice = (p.C + 15) / 16 * 16; }
+    p.ks = 1; p.c_per_slice = (p.C + 15) / 16 * 16;
     if (!transposed) {
         if (OH != (IH + 2 * pad - ksize) / stride + 1 || OW != (IW + 2 * pad - ksize) / stride + 1)
             return SR_EINVAL;
@@ -409,7 +475,7 @@ extern "C" int sr_conv2d_mfma(float* out, const float* in, const float* wt, cons
         else if (ksize == 1 && stride == 1) rc = launch_by_patch<1, 1, 1>(p, st);
         else if (ksize == 1 && stride == 2) rc = launch_by_patch<2, 1, 1>(p, st);
         else return SR_EINVAL;
-        return rc != SR_OK ? rc : finish_split(p, st);
+        return rc;
     }
     // transposed 3x3 stride 2, no padding: out[2y + ky, 2x + kx] += in[y, x] * W[ky][kx].
     // Output phase (py, px) of grid point (j, i) = output (2j + py, 2i + px); window position ty
@@ -433,9 +499,8 @@ extern "C" int sr_conv2d_mfma(float* out, const float* in, const float* wt, cons
             int regions[3][4] = {{0, p.IH, 0, p.IW},                       // interior
                                  {p.IH, gh_full, 0, gw_full},              // last row (py == 0)
                                  {0, p.IH, p.IW, gw_full}};                // last column (px == 0)
-            // measured: the split pays for 16..64-wide inputs (padding waste 35-50 %); larger maps
-            // lose more to the extra launches than the 20 % padding costs, tiny maps are launch bound
-            const bool split_border = p.IW >= 16 && p.IW <= 64;
+            // (tiny maps are launch bound: one launch per phase there)
+            const bool split_border = p.IW >= 16;
             if (!split_border) {
                 regions[0][1] = gh_full;
                 regions[0][3] = gw_full;
@@ -452,5 +517,5 @@ extern "C" int sr_conv2d_mfma(float* out, const float* in, const float* wt, cons
                 if (rc != SR_OK) return rc;
             }
         }
-    return finish_split(p, st);
+    return SR_OK;
 }
