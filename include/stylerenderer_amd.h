@@ -84,6 +84,19 @@ int64_t sr_rowdot_scratch_floats(int64_t rows, int64_t inner);
 int sr_rowdot(float* dots, float* out_scaled, const float* a, const float* b, const float* scale,
               int64_t rows, int64_t inner, float* scratch, sr_stream_t stream);
 
+/* 1x1 modulated convolution with N <= 4 output channels (ToRGB: reference model.py:56-69 via
+ * layers.py:293-323 with kernel_size 1, demodulate off), as streaming passes instead of MFMA tiles.
+ * ws [B, N, C] = W[j,c] * style[b,c]; x [B, C, hw]; out / g [B, N, hw]; hw % 4 == 0.
+ *   fwd: out[b,j,p] = sum_c ws[b,j,c]*x[b,c,p] + bias[j]      dx: dx[b,c,p] = sum_j ws[b,j,c]*g[b,j,p]
+ *   dw:  dws[b,j,c] = sum_p g[b,j,p]*x[b,c,p]  (deterministic two-stage reduction) */
+int sr_smallconv_fwd(float* out, const float* x, const float* ws, const float* bias, int64_t B, int64_t C,
+                     int64_t N, int64_t hw, sr_stream_t stream);
+int sr_smallconv_dx(float* dx, const float* g, const float* ws, int64_t B, int64_t C, int64_t N, int64_t hw,
+                    sr_stream_t stream);
+int64_t sr_smallconv_dw_scratch_floats(int64_t B, int64_t C, int64_t N, int64_t hw);
+int sr_smallconv_dw(float* dws, const float* g, const float* x, int64_t B, int64_t C, int64_t N, int64_t hw,
+                    float* scratch, sr_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------
  * upfirdn2d: zero-insert upsample -> pad/crop -> 2-D FIR (correlation with the flipped kernel)
  * -> decimate.  Replaces  bool upfirdn2d_op(float* out, const float* x, const float* k,

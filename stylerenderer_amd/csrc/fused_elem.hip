@@ -110,27 +110,34 @@ __global__ __launch_bounds__(EB) void k_nba_bwd(float* __restrict__ gx, float* _
     }
 }
 
-// one wave per channel (+ one extra workgroup for the scalar noise gradient)
-__global__ __launch_bounds__(64) void k_nba_finish(float* __restrict__ gb, float* __restrict__ gnw,
+// one wave per channel: both sums of the channel (bias gradient, and the channel's share of the
+// noise-strength gradient into chan_nw[ch]); k_nba_finish2 then adds the c shares in order.
+__global__ __launch_bounds__(64) void k_nba_finish(float* __restrict__ gb, float* __restrict__ chan_nw,
                                                    const float* __restrict__ partial, int64_t n, int c,
                                                    int chunks) {
-    if ((int)blockIdx.x < c) {
-        const int ch = blockIdx.x;
-        float acc = 0.0f;
-        const int64_t total = n * chunks;
-        for (int64_t i = threadIdx.x; i < total; i += 64) {
-            const int64_t s = i / chunks, k = i % chunks;
-            acc += partial[((s * c + ch) * chunks + k) * 2];
-        }
-        acc = sr_wave_sum(acc);
-        if (threadIdx.x == 0 && gb) gb[ch] = acc;
-    } else if (gnw) {
-        float acc = 0.0f;
-        const int64_t total = n * (int64_t)c * chunks;
-        for (int64_t i = threadIdx.x; i < total; i += 64) acc += partial[i * 2 + 1];
-        acc = sr_wave_sum(acc);
-        if (threadIdx.x == 0) gnw[0] = acc;
+    const int ch = blockIdx.x;
+    float acc = 0.0f, accn = 0.0f;
+    const int64_t total = n * chunks;
+    for (int64_t i = threadIdx.x; i < total; i += 64) {
+        const int64_t s = i / chunks, k = i % chunks;
+        const float2 v = reinterpret_cast<const float2*>(partial)[(s * c + ch) * chunks + k];
+        acc += v.x;
+        accn += v.y;
     }
+    acc = sr_wave_sum(acc);
+    accn = sr_wave_sum(accn);
+    if (threadIdx.x == 0) {
+        if (gb) gb[ch] = acc;
+        chan_nw[ch] = accn;
+    }
+}
+
+__global__ __launch_bounds__(64) void k_nba_finish2(float* __restrict__ gnw,
+                                                    const float* __restrict__ chan_nw, int c) {
+    float acc = 0.0f;
+    for (int i = threadIdx.x; i < c; i += 64) acc += chan_nw[i];
+    acc = sr_wave_sum(acc);
+    if (threadIdx.x == 0) gnw[0] = acc;
 }
 
 // grid = (chunks, rows): partial dot products of two [rows, inner] tensors, optional scaled copy
@@ -195,7 +202,7 @@ extern "C" int sr_noise_bias_act(float* y, const float* x, const float* noise, c
 
 extern "C" int64_t sr_noise_bias_act_bwd_scratch_floats(int64_t n, int64_t c, int64_t inner) {
     if (n <= 0 || c <= 0 || inner <= 0) return 2;
-    return 2 * n * c * sr_ceil_div(inner, ECHUNK) + 2;
+    return 2 * n * c * sr_ceil_div(inner, ECHUNK) + c + 2;      // partial pairs + per-channel shares
 }
 
 extern "C" int sr_noise_bias_act_bwd(float* gx, float* gbias, float* gnoise_w, const float* gy,
@@ -210,8 +217,11 @@ extern "C" int sr_noise_bias_act_bwd(float* gx, float* gbias, float* gnoise_w, c
     hipStream_t st = sr_stream(stream);
     hipLaunchKernelGGL(k_nba_bwd, dim3(chunks, (unsigned)(n * c)), dim3(EB), 0, st, gx, scratch, gy, out,
                        noise, alpha, scale, (int)c, inner, noise_bstride, chunks);
-    hipLaunchKernelGGL(k_nba_finish, dim3((unsigned)c + 1), dim3(64), 0, st, gbias,
-                       noise ? gnoise_w : nullptr, scratch, n, (int)c, chunks);
+    float* chan_nw = scratch + 2 * n * c * (int64_t)chunks;
+    hipLaunchKernelGGL(k_nba_finish, dim3((unsigned)c), dim3(64), 0, st, gbias, chan_nw, scratch, n, (int)c,
+                       chunks);
+    if (noise && gnoise_w)
+        hipLaunchKernelGGL(k_nba_finish2, dim3(1), dim3(64), 0, st, gnoise_w, chan_nw, (int)c);
     return sr_launch_status();
 }
 
@@ -236,5 +246,177 @@ extern "C" int sr_rowdot(float* dots, float* out_scaled, const float* a, const f
         hipLaunchKernelGGL(k_rowdot<false>, dim3(chunks, (unsigned)rows), dim3(EB), 0, st, scratch, out_scaled,
                            a, b, scale, inner, chunks);
     hipLaunchKernelGGL(k_rowdot_finish, dim3((unsigned)rows), dim3(64), 0, st, dots, scratch, chunks);
+    return sr_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------
+// 1x1 modulated convolution with <= 4 output channels (ToRGB, reference model.py:56-69).  A 128-wide
+// MFMA tile would be 97 % idle here; the layer is one streaming pass over the activation:
+//   fwd  out[b,j,p]  = sum_c ws[b,j,c] * x[b,c,p] (+ bias[j])        ws = W[j,c] * style[b,c]
+//   dx   dx[b,c,p]   = sum_j ws[b,j,c] * g[b,j,p]
+//   dw   dws[b,j,c]  = sum_p g[b,j,p] * x[b,c,p]
+// The three maps are each other's derivatives (bilinear), so gradients of any order stay on them.
+namespace {
+
+constexpr int SC_MAXN = 4;
+
+template <int N>
+__global__ __launch_bounds__(256) void k_smallconv_fwd(float* __restrict__ out, const float* __restrict__ x,
+                                                       const float* __restrict__ ws,
+                                                       const float* __restrict__ bias, int C, int64_t hw4) {
+    extern __shared__ float s_ws[];                  // [N][C] of this sample
+    const int b = blockIdx.y;
+    for (int i = threadIdx.x; i < N * C; i += 256) s_ws[i] = ws[(int64_t)b * N * C + i];
+    __syncthreads();
+    const int64_t p4 = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (p4 >= hw4) return;
+    const float4* xs = reinterpret_cast<const float4*>(x) + (int64_t)b * C * hw4 + p4;
+    float4 acc[N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        const float bb = bias ? bias[j] : 0.0f;
+        acc[j] = make_float4(bb, bb, bb, bb);
+    }
+#pragma unroll 8
+    for (int c = 0; c < C; ++c) {
+        const float4 v = xs[(int64_t)c * hw4];
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            const float w = s_ws[j * C + c];
+            acc[j].x += w * v.x; acc[j].y += w * v.y; acc[j].z += w * v.z; acc[j].w += w * v.w;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < N; ++j)
+        reinterpret_cast<float4*>(out)[((int64_t)b * N + j) * hw4 + p4] = acc[j];
+}
+
+template <int N>
+__global__ __launch_bounds__(256) void k_smallconv_dx(float* __restrict__ dx, const float* __restrict__ g,
+                                                      const float* __restrict__ ws, int C, int64_t hw4) {
+    extern __shared__ float s_ws[];
+    const int b = blockIdx.y;
+    for (int i = threadIdx.x; i < N * C; i += 256) s_ws[i] = ws[(int64_t)b * N * C + i];
+    __syncthreads();
+    const int64_t p4 = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (p4 >= hw4) return;
+    float4 gv[N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) gv[j] = reinterpret_cast<const float4*>(g)[((int64_t)b * N + j) * hw4 + p4];
+    float4* dst = reinterpret_cast<float4*>(dx) + (int64_t)b * C * hw4 + p4;
+#pragma unroll 4
+    for (int c = 0; c < C; ++c) {
+        float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            const float w = s_ws[j * C + c];
+            r.x += w * gv[j].x; r.y += w * gv[j].y; r.z += w * gv[j].z; r.w += w * gv[j].w;
+        }
+        dst[(int64_t)c * hw4] = r;
+    }
+}
+
+// grid = (chunks, B*C): N partial dot products of one x row chunk with the N gradient rows
+template <int N>
+__global__ __launch_bounds__(256) void k_smallconv_dw(float* __restrict__ partial, const float* __restrict__ g,
+                                                      const float* __restrict__ x, int C, int64_t hw,
+                                                      int chunks) {
+    __shared__ float lds[4 * SC_MAXN];
+    const int64_t row = blockIdx.y;                  // b * C + c
+    const int64_t b = row / C;
+    const int64_t off = (int64_t)blockIdx.x * ECHUNK;
+    const int64_t remain = hw - off;
+    const int n4 = (int)((remain < ECHUNK ? remain : ECHUNK) / 4);
+    const float4* xs = reinterpret_cast<const float4*>(x + row * hw + off);
+    float acc[N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) acc[j] = 0.0f;
+    for (int i = threadIdx.x; i < n4; i += 256) {
+        const float4 v = xs[i];
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            const float4 gg = reinterpret_cast<const float4*>(g + (b * N + j) * hw + off)[i];
+            acc[j] += (v.x * gg.x + v.y * gg.y) + (v.z * gg.z + v.w * gg.w);
+        }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        acc[j] = sr_wave_sum(acc[j]);
+        if (lane == 0) lds[j * 4 + wave] = acc[j];
+    }
+    __syncthreads();
+    if (threadIdx.x < N) {
+        const int j = threadIdx.x;
+        partial[(row * chunks + blockIdx.x) * N + j] = (lds[j * 4] + lds[j * 4 + 1]) + (lds[j * 4 + 2] + lds[j * 4 + 3]);
+    }
+}
+
+// dws[b][j][c] = sum over chunks of partial[(b*C + c)][chunk][j]
+__global__ __launch_bounds__(64) void k_smallconv_dw_finish(float* __restrict__ dws,
+                                                            const float* __restrict__ partial, int C, int N,
+                                                            int chunks, int64_t rows) {
+    const int64_t row = blockIdx.x;
+    if (row >= rows) return;
+    const int64_t b = row / C, c = row % C;
+    for (int j = 0; j < N; ++j) {
+        float acc = 0.0f;
+        for (int i = threadIdx.x; i < chunks; i += 64) acc += partial[(row * chunks + i) * N + j];
+        acc = sr_wave_sum(acc);
+        if (threadIdx.x == 0) dws[(b * N + j) * C + c] = acc;
+    }
+}
+
+inline bool smallconv_ok(int64_t B, int64_t C, int64_t N, int64_t hw, const void* a, const void* b2) {
+    return B > 0 && B <= 65535 && C > 0 && C <= 4096 && N >= 1 && N <= SC_MAXN && hw % 4 == 0 &&
+           (((uintptr_t)a | (uintptr_t)b2) & 15) == 0;
+}
+
+}  // namespace
+
+#define SR_SMALLCONV_DISPATCH(KERNEL, ...)                                   \
+    switch (N) {                                                             \
+        case 1: hipLaunchKernelGGL(KERNEL<1>, __VA_ARGS__); break;           \
+        case 2: hipLaunchKernelGGL(KERNEL<2>, __VA_ARGS__); break;           \
+        case 3: hipLaunchKernelGGL(KERNEL<3>, __VA_ARGS__); break;           \
+        default: hipLaunchKernelGGL(KERNEL<4>, __VA_ARGS__); break;          \
+    }
+
+extern "C" int sr_smallconv_fwd(float* out, const float* x, const float* ws, const float* bias, int64_t B,
+                                int64_t C, int64_t N, int64_t hw, sr_stream_t stream) {
+    if (!out || !x || !ws || !smallconv_ok(B, C, N, hw, out, x)) return SR_EINVAL;
+    const int64_t hw4 = hw / 4;
+    const dim3 grid((unsigned)sr_ceil_div(hw4, 256), (unsigned)B);
+    const size_t lds = (size_t)N * C * sizeof(float);
+    hipStream_t st = sr_stream(stream);
+    SR_SMALLCONV_DISPATCH(k_smallconv_fwd, grid, dim3(256), lds, st, out, x, ws, bias, (int)C, hw4);
+    return sr_launch_status();
+}
+
+extern "C" int sr_smallconv_dx(float* dx, const float* g, const float* ws, int64_t B, int64_t C, int64_t N,
+                               int64_t hw, sr_stream_t stream) {
+    if (!dx || !g || !ws || !smallconv_ok(B, C, N, hw, dx, g)) return SR_EINVAL;
+    const int64_t hw4 = hw / 4;
+    const dim3 grid((unsigned)sr_ceil_div(hw4, 256), (unsigned)B);
+    const size_t lds = (size_t)N * C * sizeof(float);
+    hipStream_t st = sr_stream(stream);
+    SR_SMALLCONV_DISPATCH(k_smallconv_dx, grid, dim3(256), lds, st, dx, g, ws, (int)C, hw4);
+    return sr_launch_status();
+}
+
+extern "C" int64_t sr_smallconv_dw_scratch_floats(int64_t B, int64_t C, int64_t N, int64_t hw) {
+    if (B <= 0 || C <= 0 || N <= 0 || hw <= 0) return 1;
+    return B * C * sr_ceil_div(hw, ECHUNK) * N + 1;
+}
+
+extern "C" int sr_smallconv_dw(float* dws, const float* g, const float* x, int64_t B, int64_t C, int64_t N,
+                               int64_t hw, float* scratch, sr_stream_t stream) {
+    if (!dws || !g || !x || !scratch || !smallconv_ok(B, C, N, hw, g, x) || B * C > 65535) return SR_EINVAL;
+    const int chunks = (int)sr_ceil_div(hw, ECHUNK);
+    const dim3 grid((unsigned)chunks, (unsigned)(B * C));
+    hipStream_t st = sr_stream(stream);
+    SR_SMALLCONV_DISPATCH(k_smallconv_dw, grid, dim3(256), 0, st, scratch, g, x, (int)C, hw, chunks);
+    hipLaunchKernelGGL(k_smallconv_dw_finish, dim3((unsigned)(B * C)), dim3(64), 0, st, dws, scratch, (int)C,
+                       (int)N, chunks, B * C);
     return sr_launch_status();
 }

@@ -21,6 +21,7 @@ from torch.nn import functional as F
 
 from .op import FusedLeakyReLU, fused_leaky_relu, upfirdn2d
 from .op import conv as _conv
+from .op import smallconv as _smallconv
 
 
 def make_kernel(k):
@@ -183,6 +184,10 @@ class ModulatedConv2d(nn.Module):
     def _forward_mfma(self, input, style):
         w = self.weight[0] * self.scale                                  # [Co, Ci, k, k]
         s = self.modulation(style)                                       # [B, Ci]
+        if (self.kernel_size == 1 and not self.demodulate and not self.upsample and not self.downsample
+                and _smallconv.supported(input, self.out_channel)):
+            # ToRGB: <= 4 output channels -> streaming kernels instead of 128-wide MFMA tiles
+            return _smallconv.modulated_conv1x1_small(input, w[:, :, 0, 0], s)
         d = None
         if self.demodulate:
             w2 = w.pow(2).sum((2, 3)).t()                                # [Ci, Co]

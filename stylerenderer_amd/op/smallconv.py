@@ -1,0 +1,103 @@
+"""1x1 modulated convolution with <= 4 output channels (ToRGB) — host side of the sr_smallconv_*
+kernels in csrc/fused_elem.hip.  Three bilinear maps that are each other's derivatives, each an
+autograd Function, so gradients of any order (path-length regulariser) stay on the HIP kernels:
+
+    fwd(x, ws)  out[b,j,p] = sum_c ws[b,j,c] x[b,c,p]        d/dx -> dx(g, ws)    d/dws -> dw(g, x)
+    dx(g, ws)   dx[b,c,p]  = sum_j ws[b,j,c] g[b,j,p]        d/dg -> fwd(gg, ws)  d/dws -> dw(g, gg)
+    dw(g, x)    dws[b,j,c] = sum_p g[b,j,p] x[b,c,p]         d/dg -> fwd(x, gw)   d/dx  -> dx(g, gw)
+"""
+import torch
+from torch.autograd import Function
+
+from .. import _lib
+from ._dispatch import on_device_of, stream_of
+
+
+def supported(x, n_out):
+    return (x.device.type == "cuda" and x.dtype == torch.float32 and x.dim() == 4 and 1 <= n_out <= 4
+            and (x.size(2) * x.size(3)) % 4 == 0 and x.size(0) * x.size(1) <= 65535 and x.size(1) <= 4096)
+
+
+def _fwd(x, ws):
+    x, ws = x.contiguous(), ws.contiguous()
+    b, c, h, w = x.shape
+    n = ws.size(1)
+    out = torch.empty((b, n, h, w), dtype=x.dtype, device=x.device)
+    with on_device_of(x):
+        rc = _lib.lib().sr_smallconv_fwd(_lib.ptr(out), _lib.ptr(x), _lib.ptr(ws), None, b, c, n, h * w,
+                                         stream_of(x))
+    _lib.check(rc, "sr_smallconv_fwd")
+    return out
+
+
+def _dx(g, ws):
+    g, ws = g.contiguous(), ws.contiguous()
+    b, n, h, w = g.shape
+    c = ws.size(2)
+    dx = torch.empty((b, c, h, w), dtype=g.dtype, device=g.device)
+    with on_device_of(g):
+        rc = _lib.lib().sr_smallconv_dx(_lib.ptr(dx), _lib.ptr(g), _lib.ptr(ws), b, c, n, h * w, stream_of(g))
+    _lib.check(rc, "sr_smallconv_dx")
+    return dx
+
+
+def _dw(g, x):
+    g, x = g.contiguous(), x.contiguous()
+    b, n, h, w = g.shape
+    c = x.size(1)
+    L = _lib.lib()
+    dws = torch.empty((b, n, c), dtype=g.dtype, device=g.device)
+    scratch = torch.empty(L.sr_smallconv_dw_scratch_floats(b, c, n, h * w), dtype=g.dtype, device=g.device)
+    with on_device_of(g):
+        rc = L.sr_smallconv_dw(_lib.ptr(dws), _lib.ptr(g), _lib.ptr(x), b, c, n, h * w, _lib.ptr(scratch),
+                               stream_of(g))
+    _lib.check(rc, "sr_smallconv_dw")
+    return dws
+
+
+class SmallConvFwd(Function):
+    @staticmethod
+    def forward(ctx, x, ws):
+        ctx.save_for_backward(x, ws)
+        return _fwd(x, ws)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, ws = ctx.saved_tensors
+        gx = SmallConvDx.apply(g, ws) if ctx.needs_input_grad[0] else None
+        gw = SmallConvDw.apply(g, x) if ctx.needs_input_grad[1] else None
+        return gx, gw
+
+
+class SmallConvDx(Function):
+    @staticmethod
+    def forward(ctx, g, ws):
+        ctx.save_for_backward(g, ws)
+        return _dx(g, ws)
+
+    @staticmethod
+    def backward(ctx, gg):
+        g, ws = ctx.saved_tensors
+        d_g = SmallConvFwd.apply(gg, ws) if ctx.needs_input_grad[0] else None
+        d_ws = SmallConvDw.apply(g, gg) if ctx.needs_input_grad[1] else None
+        return d_g, d_ws
+
+
+class SmallConvDw(Function):
+    @staticmethod
+    def forward(ctx, g, x):
+        ctx.save_for_backward(g, x)
+        return _dw(g, x)
+
+    @staticmethod
+    def backward(ctx, gw):
+        g, x = ctx.saved_tensors
+        d_g = SmallConvFwd.apply(x, gw) if ctx.needs_input_grad[0] else None
+        d_x = SmallConvDx.apply(g, gw) if ctx.needs_input_grad[1] else None
+        return d_g, d_x
+
+
+def modulated_conv1x1_small(x, weight_jc, style):
+    """weight_jc [N, C] (already scaled), style [B, C] -> [B, N, H, W]."""
+    ws = weight_jc[None, :, :] * style[:, None, :]
+    return SmallConvFwd.apply(x, ws)

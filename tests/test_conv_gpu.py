@@ -140,3 +140,37 @@ def test_wgrad_deterministic_and_large():
     want = torch.nn.grad.conv2d_weight(xd, (128, 128, 3, 3), gd, padding=1)
     want = want.permute(2, 3, 1, 0).reshape(9, 128, 128)
     assert float((a.cpu().double() - want).abs().max()) < 1e-4 * float(want.abs().max())
+
+
+@pytest.mark.parametrize("shape", [(2, 8, 3, 8, 8), (3, 20, 3, 16, 12), (2, 16, 4, 4, 4), (1, 128, 3, 64, 64),
+                                   (2, 6, 1, 8, 8)])
+def test_smallconv_primitives_and_double_backward(shape):
+    """ToRGB-sized 1x1 modulated conv: value, first-order gradients and a double backward, against
+    float64 einsum on the CPU."""
+    from stylerenderer_amd.op.smallconv import modulated_conv1x1_small
+
+    b, c, n, h, w = shape
+    g = torch.Generator().manual_seed(c * 7 + n)
+    x = torch.randn(b, c, h, w, generator=g)
+    wgt = torch.randn(n, c, generator=g)
+    s = torch.randn(b, c, generator=g)
+    gy = torch.randn(b, n, h, w, generator=g)
+    probe = torch.randn(b, c, h, w, generator=g)
+
+    def run(dev, dt):
+        xs, ws, ss = (t.to(dev, dt).requires_grad_() for t in (x, wgt, s))
+        if dev == "cpu":
+            y = torch.einsum("bjc,bchw->bjhw", ws[None] * ss[:, None, :], xs)
+        else:
+            y = modulated_conv1x1_small(xs, ws, ss)
+        gyd = gy.to(dev, dt).requires_grad_()
+        gx, gw, gs = torch.autograd.grad(y, [xs, ws, ss], gyd, create_graph=True)
+        q = (gx * probe.to(dev, dt)).sum() + (gw * ws.detach()).sum() + (gs * ss.detach()).sum()
+        ggy, gss = torch.autograd.grad(q, [gyd, ss])
+        return [t.detach().cpu().double() for t in (y, gx, gw, gs, ggy, gss)]
+
+    want = run("cpu", torch.float64)
+    got = run(DEV, torch.float32)
+    for a, r in zip(got, want):
+        assert a.shape == r.shape
+        assert float((a - r).abs().max()) <= 3e-5 * (float(r.abs().max()) + 1e-6) * max(1.0, np.sqrt(h * w) / 8)
