@@ -264,31 +264,50 @@ template <int N>
 __global__ __launch_bounds__(256) void k_smallconv_fwd(float* __restrict__ out, const float* __restrict__ x,
                                                        const float* __restrict__ ws,
                                                        const float* __restrict__ bias, int C, int64_t hw4) {
-    extern __shared__ float s_ws[];                  // [N][C] of this sample
+    // A workgroup covers 64 float4 (256 pixels) of one sample; its four waves split the channel
+    // loop (short serial chains and enough workgroups even for 64x64 maps) and are summed through
+    // LDS in a fixed order.  Weights are wave-uniform -> scalar loads.
+    __shared__ float4 s_part[3][64][N];
     const int b = blockIdx.y;
-    for (int i = threadIdx.x; i < N * C; i += 256) s_ws[i] = ws[(int64_t)b * N * C + i];
-    __syncthreads();
-    const int64_t p4 = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (p4 >= hw4) return;
-    const float4* xs = reinterpret_cast<const float4*>(x) + (int64_t)b * C * hw4 + p4;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float* __restrict__ wsb = ws + (int64_t)b * N * C;
+    const int64_t p4 = (int64_t)blockIdx.x * 64 + lane;
+    const bool ok = p4 < hw4;
+    const float4* xs = reinterpret_cast<const float4*>(x) + (int64_t)b * C * hw4 + (ok ? p4 : 0);
     float4 acc[N];
 #pragma unroll
-    for (int j = 0; j < N; ++j) {
-        const float bb = bias ? bias[j] : 0.0f;
-        acc[j] = make_float4(bb, bb, bb, bb);
-    }
+    for (int j = 0; j < N; ++j) acc[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int c_per = (C + 3) / 4;
+    const int c_lo = __builtin_amdgcn_readfirstlane(wave * c_per);
+    const int c_hi = min(C, c_lo + c_per);
 #pragma unroll 8
-    for (int c = 0; c < C; ++c) {
+    for (int c = c_lo; c < c_hi; ++c) {
         const float4 v = xs[(int64_t)c * hw4];
 #pragma unroll
         for (int j = 0; j < N; ++j) {
-            const float w = s_ws[j * C + c];
+            const float w = wsb[j * C + c];
             acc[j].x += w * v.x; acc[j].y += w * v.y; acc[j].z += w * v.z; acc[j].w += w * v.w;
         }
     }
+    if (wave > 0) {
 #pragma unroll
-    for (int j = 0; j < N; ++j)
-        reinterpret_cast<float4*>(out)[((int64_t)b * N + j) * hw4 + p4] = acc[j];
+        for (int j = 0; j < N; ++j) s_part[wave - 1][lane][j] = acc[j];
+    }
+    __syncthreads();
+    if (wave == 0 && ok) {
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            float4 r = acc[j];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const float4 t = s_part[k][lane][j];
+                r.x += t.x; r.y += t.y; r.z += t.z; r.w += t.w;
+            }
+            const float bb = bias ? bias[j] : 0.0f;
+            r.x += bb; r.y += bb; r.z += bb; r.w += bb;
+            reinterpret_cast<float4*>(out)[((int64_t)b * N + j) * hw4 + p4] = r;
+        }
+    }
 }
 
 template <int N>
@@ -386,10 +405,9 @@ extern "C" int sr_smallconv_fwd(float* out, const float* x, const float* ws, con
                                 int64_t C, int64_t N, int64_t hw, sr_stream_t stream) {
     if (!out || !x || !ws || !smallconv_ok(B, C, N, hw, out, x)) return SR_EINVAL;
     const int64_t hw4 = hw / 4;
-    const dim3 grid((unsigned)sr_ceil_div(hw4, 256), (unsigned)B);
-    const size_t lds = (size_t)N * C * sizeof(float);
+    const dim3 grid((unsigned)sr_ceil_div(hw4, 64), (unsigned)B);
     hipStream_t st = sr_stream(stream);
-    SR_SMALLCONV_DISPATCH(k_smallconv_fwd, grid, dim3(256), lds, st, out, x, ws, bias, (int)C, hw4);
+    SR_SMALLCONV_DISPATCH(k_smallconv_fwd, grid, dim3(256), 0, st, out, x, ws, bias, (int)C, hw4);
     return sr_launch_status();
 }
 
