@@ -92,6 +92,27 @@ def raster_leg(dev, batch=64, res=256, iters=5):
             "bit_exact_vs_cpu_oracle": "tests/test_ops_gpu.py"}
 
 
+def pmc_traffic(kernel_row):
+    """HBM bytes per launch of `kernel_row` from the newest committed PMC summary (profiles/r*_pmc.csv,
+    written by scripts/profile_round.sh + scripts/pmc_summary.py from separate rocprofv3 --pmc
+    FETCH_SIZE / WRITE_SIZE passes of this same command).  Units are KB; gfx950's FETCH_SIZE reports
+    half of a 16 B/lane streaming read (MI355X_MICROARCH.md, HBM section; confirmed here on k_nba_bwd
+    and k_rowdot, whose read:write byte ratios are known), hence 2*FETCH + WRITE."""
+    import csv
+    import glob
+
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.csv")))
+    if not files:
+        return {}
+    with open(files[-1]) as f:
+        for r in csv.DictReader(l for l in f if not l.startswith("#")):
+            if r["kernel"] == kernel_row and r.get("FETCH_SIZE") and r.get("WRITE_SIZE"):
+                b = (2.0 * float(r["FETCH_SIZE"]) + float(r["WRITE_SIZE"])) * 1024.0
+                return {"traffic": round(b), "traffic_unit": "bytes/launch",
+                        "traffic_source": "profiles/%s (2*FETCH_SIZE+WRITE_SIZE)" % os.path.basename(files[-1])}
+    return {}
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -175,6 +196,7 @@ def main():
                     "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4),
                     "traffic": None, "launches": len(dom), "avg_launch_ms": round(ms, 4),
                     "flop_per_launch": fl}
+            roof.update(pmc_traffic("k_conv_mfma<1; 3; 3; 32; 4; 1; true>"))
         breakdown = {k: {"ms_per_step": round(v[1] / args.steps, 3),
                          "tflops": round(v[0] / (v[1] * 1e-3) / 1e12, 1) if v[1] > 0 else None,
                          "launches_per_step": v[2] // max(args.steps, 1)} for k, v in sorted(by_kind.items())}
