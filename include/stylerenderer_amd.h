@@ -97,6 +97,21 @@ int64_t sr_smallconv_dw_scratch_floats(int64_t B, int64_t C, int64_t N, int64_t 
 int sr_smallconv_dw(float* dws, const float* g, const float* x, int64_t B, int64_t C, int64_t N, int64_t hw,
                     float* scratch, sr_stream_t stream);
 
+/* Weight preparation for sr_conv2d_mfma (replaces the per-layer ATen passes of reference
+ * layers.py:293-300 / 213-216: scale * weight, pow, sum, views).  w [Co, Ci, k, k], k in {1, 3}.
+ *   sr_weight_prep:     wt [k*k, Ci, ld] = scale*w  (ld % 4 == 0, ld >= Co, pad columns zeroed);
+ *                       wsq [Ci, Co] = sum_taps (scale*w)^2, or NULL.
+ *   sr_weight_prep_bwd: gw [Co,Ci,k,k] = scale*gwt^T + 2*scale^2*w*gwsq  (gwt [k*k,Ci,ldg] or NULL,
+ *                       gwsq [Ci,Co] or NULL, not both NULL).
+ *   sr_weight_adjoint:  out [taps, N, ldc] = in [taps', C, ldn] transposed in (C, N), taps reversed
+ *                       when flip != 0 — the weights of the data-gradient convolution. */
+int sr_weight_prep(float* wt, float* wsq, const float* w, float scale, int64_t Co, int64_t Ci, int ksize,
+                   int64_t ld, sr_stream_t stream);
+int sr_weight_prep_bwd(float* gw, const float* gwt, const float* gwsq, const float* w, float scale,
+                       int64_t Co, int64_t Ci, int ksize, int64_t ldg, sr_stream_t stream);
+int sr_weight_adjoint(float* out, const float* in, int64_t taps, int64_t C, int64_t N, int64_t ldn,
+                      int64_t ldc, int flip, sr_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------
  * upfirdn2d: zero-insert upsample -> pad/crop -> 2-D FIR (correlation with the flipped kernel)
  * -> decimate.  Replaces  bool upfirdn2d_op(float* out, const float* x, const float* k,

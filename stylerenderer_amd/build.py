@@ -26,6 +26,7 @@ SOURCES = [
     ("upfirdn2d.hip", EXACT),
     ("rasterize.hip", EXACT),
     ("fused_elem.hip", EXACT),
+    ("weight_prep.hip", EXACT),
     ("conv_mfma.hip", []),
     ("conv_wgrad_mfma.hip", []),
 ]

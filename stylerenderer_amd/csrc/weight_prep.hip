@@ -1,0 +1,125 @@
+// Weight preparation for the MFMA convolutions (C ABI: sr_weight_prep, sr_weight_prep_bwd,
+// sr_weight_adjoint).
+//
+// The reference scales and modulates a [B, Co, Ci, k, k] weight tensor with half a dozen ATen
+// passes per layer (layers.py:293-300: scale * weight * style, pow, sum, rsqrt, views).  Here the
+// shared weight is touched once per step:
+//   k_wprep      W[Co,Ci,kk] -> Wt[kk,Ci,ld] = scale*W (tap-major, Cout contiguous, 16-byte row
+//                pitch: the layout k_conv_mfma streams) and Wsq[Ci,Co] = sum_taps (scale*W)^2 (the
+//                demodulation matrix: rsqrt(style^2 @ Wsq + eps) is the per-sample output scale)
+//   k_wprep_bwd  dW = scale*dWt^T + 2*scale^2 * W * dWsq   (one pass, both cotangents)
+//   k_wadjoint   Wt[kk,C,ldn] -> WtA[kk',N,ldc]: channel transpose (+ tap reversal for the
+//                stride-1 correlation) = the weights of the data-gradient convolution
+// All three are small (<= 9.4 MB at 512x512x3x3) HBM passes; the point is launch count.
+#include "common.h"
+
+namespace {
+
+template <int KK>
+__global__ __launch_bounds__(256) void k_wprep(float* __restrict__ wt, float* __restrict__ wsq,
+                                               const float* __restrict__ w, float scale, int Co, int Ci,
+                                               int ld) {
+    const int co = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int ci = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (ci >= Ci || co >= ld) return;
+    float v[KK];
+    float sq = 0.0f;
+    if (co < Co) {
+        const float* src = w + ((int64_t)co * Ci + ci) * KK;
+#pragma unroll
+        for (int t = 0; t < KK; ++t) {
+            v[t] = src[t] * scale;
+            sq += v[t] * v[t];
+        }
+    } else {
+#pragma unroll
+        for (int t = 0; t < KK; ++t) v[t] = 0.0f;
+    }
+#pragma unroll
+    for (int t = 0; t < KK; ++t) wt[((int64_t)t * Ci + ci) * ld + co] = v[t];
+    if (wsq && co < Co) wsq[(int64_t)ci * Co + co] = sq;
+}
+
+template <int KK>
+__global__ __launch_bounds__(256) void k_wprep_bwd(float* __restrict__ gw, const float* __restrict__ gwt,
+                                                   const float* __restrict__ gwsq,
+                                                   const float* __restrict__ w, float scale, int Co,
+                                                   int Ci, int ldg) {
+    const int co = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int ci = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (ci >= Ci || co >= Co) return;
+    const int64_t base = ((int64_t)co * Ci + ci) * KK;
+    const float q = gwsq ? 2.0f * scale * scale * gwsq[(int64_t)ci * Co + co] : 0.0f;
+#pragma unroll
+    for (int t = 0; t < KK; ++t) {
+        float g = gwt ? scale * gwt[((int64_t)t * Ci + ci) * ldg + co] : 0.0f;
+        if (gwsq) g += q * w[base + t];
+        gw[base + t] = g;
+    }
+}
+
+// out[tA][n][c] = in[t][c][n]; 32x32 tiles through LDS so both sides are coalesced
+__global__ __launch_bounds__(256) void k_wadjoint(float* __restrict__ out, const float* __restrict__ in,
+                                                  int C, int N, int ldn, int ldc, int KK, int flip) {
+    __shared__ float tile[32][33];
+    const int t = blockIdx.z;
+    const int tA = flip ? KK - 1 - t : t;
+    const int c0 = blockIdx.x * 32, n0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;       // 32 x 8
+#pragma unroll
+    for (int r = ty; r < 32; r += 8) {
+        const int c = c0 + r, n = n0 + tx;
+        tile[r][tx] = (c < C && n < N) ? in[((int64_t)t * C + c) * ldn + n] : 0.0f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = ty; r < 32; r += 8) {
+        const int n = n0 + r, c = c0 + tx;
+        if (n < N && c < ldc) out[((int64_t)tA * N + n) * ldc + c] = tile[tx][r];
+    }
+}
+
+}  // namespace
+
+extern "C" int sr_weight_prep(float* wt, float* wsq, const float* w, float scale, int64_t Co, int64_t Ci,
+                              int ksize, int64_t ld, sr_stream_t stream) {
+    if (Co <= 0 || Ci <= 0 || !wt || !w || ld < Co || (ld & 3)) return SR_EINVAL;
+    if (Co > (1 << 20) || Ci > (1 << 20)) return SR_ERANGE;
+    const dim3 grid((unsigned)sr_ceil_div(ld, 64), (unsigned)sr_ceil_div(Ci, 4));
+    hipStream_t st = sr_stream(stream);
+    if (ksize == 3)
+        hipLaunchKernelGGL(k_wprep<9>, grid, dim3(256), 0, st, wt, wsq, w, scale, (int)Co, (int)Ci, (int)ld);
+    else if (ksize == 1)
+        hipLaunchKernelGGL(k_wprep<1>, grid, dim3(256), 0, st, wt, wsq, w, scale, (int)Co, (int)Ci, (int)ld);
+    else
+        return SR_EINVAL;
+    return sr_launch_status();
+}
+
+extern "C" int sr_weight_prep_bwd(float* gw, const float* gwt, const float* gwsq, const float* w,
+                                  float scale, int64_t Co, int64_t Ci, int ksize, int64_t ldg,
+                                  sr_stream_t stream) {
+    if (Co <= 0 || Ci <= 0 || !gw || (!gwt && !gwsq) || (gwsq && !w) || (gwt && ldg < Co)) return SR_EINVAL;
+    if (Co > (1 << 20) || Ci > (1 << 20)) return SR_ERANGE;
+    const dim3 grid((unsigned)sr_ceil_div(Co, 64), (unsigned)sr_ceil_div(Ci, 4));
+    hipStream_t st = sr_stream(stream);
+    if (ksize == 3)
+        hipLaunchKernelGGL(k_wprep_bwd<9>, grid, dim3(256), 0, st, gw, gwt, gwsq, w, scale, (int)Co, (int)Ci,
+                           (int)ldg);
+    else if (ksize == 1)
+        hipLaunchKernelGGL(k_wprep_bwd<1>, grid, dim3(256), 0, st, gw, gwt, gwsq, w, scale, (int)Co, (int)Ci,
+                           (int)ldg);
+    else
+        return SR_EINVAL;
+    return sr_launch_status();
+}
+
+extern "C" int sr_weight_adjoint(float* out, const float* in, int64_t taps, int64_t C, int64_t N, int64_t ldn,
+                                 int64_t ldc, int flip, sr_stream_t stream) {
+    if (taps <= 0 || C <= 0 || N <= 0 || !out || !in || ldn < N || ldc < C) return SR_EINVAL;
+    if (taps > 65535 || sr_ceil_div(N, 32) > 65535) return SR_ERANGE;
+    const dim3 grid((unsigned)sr_ceil_div(ldc, 32), (unsigned)sr_ceil_div(N, 32), (unsigned)taps);
+    hipLaunchKernelGGL(k_wadjoint, grid, dim3(256), 0, sr_stream(stream), out, in, (int)C, (int)N, (int)ldn,
+                       (int)ldc, (int)taps, flip);
+    return sr_launch_status();
+}

@@ -22,6 +22,7 @@ from torch.nn import functional as F
 from .op import FusedLeakyReLU, fused_leaky_relu, upfirdn2d
 from .op import conv as _conv
 from .op import smallconv as _smallconv
+from .op.weight_prep import weight_prep as _weight_prep
 
 
 def make_kernel(k):
@@ -102,7 +103,8 @@ class EqualConv2d(nn.Module):
     def forward(self, input):
         geom = self._geom()
         if input.device.type == "cuda" and geom is not None:
-            return _conv.conv2d(input, _taps(self.weight * self.scale), None, None, self.bias, geom)
+            wt, _ = _weight_prep(self.weight, self.scale)
+            return _conv.conv2d(input, wt, None, None, self.bias, geom)
         return F.conv2d(input, self.weight * self.scale, bias=self.bias, stride=self.stride,
                         padding=self.padding)
 
@@ -182,17 +184,16 @@ class ModulatedConv2d(nn.Module):
 
     # ---- device tensors: shared weights + operand scaling on the MFMA kernels
     def _forward_mfma(self, input, style):
-        w = self.weight[0] * self.scale                                  # [Co, Ci, k, k]
         s = self.modulation(style)                                       # [B, Ci]
         if (self.kernel_size == 1 and not self.demodulate and not self.upsample and not self.downsample
                 and _smallconv.supported(input, self.out_channel)):
             # ToRGB: <= 4 output channels -> streaming kernels instead of 128-wide MFMA tiles
-            return _smallconv.modulated_conv1x1_small(input, w[:, :, 0, 0], s)
+            return _smallconv.modulated_conv1x1_small(input, self.weight[0, :, :, 0, 0] * self.scale, s)
+        # one launch: tap-major scaled weights + the demodulation matrix sum_taps (scale*W)^2 [Ci, Co]
+        wt, wsq = _weight_prep(self.weight, self.scale, self.demodulate)
         d = None
         if self.demodulate:
-            w2 = w.pow(2).sum((2, 3)).t()                                # [Ci, Co]
-            d = torch.rsqrt(torch.matmul(s * s, w2) + self.eps)          # [B, Co]
-        wt = _taps(w)
+            d = torch.rsqrt(torch.matmul(s * s, wsq) + self.eps)         # [B, Co]
         k = self.kernel_size
         if self.upsample:
             if k != 3:

@@ -12,6 +12,7 @@ import torch
 
 from .. import _lib
 from ._dispatch import on_device_of, require_f32, stream_of
+from . import weight_prep as _wp
 from .fused_elem import rowdot
 
 
@@ -44,9 +45,14 @@ def conv2d_mfma(x, wt, iscale=None, oscale=None, obias=None, ksize=3, stride=1, 
     x = x.contiguous()
     b, c, ih, iw = x.shape
     taps, cw, n = wt.shape
-    ldw = (n + 3) // 4 * 4
-    # the kernel reads weight rows as 16-byte vectors: pad the row pitch to a multiple of 4 floats
-    wt = torch.nn.functional.pad(wt, (0, ldw - n)) if ldw != n else wt.contiguous()
+    # the kernel reads weight rows as 16-byte vectors: row pitch a multiple of 4 floats (views of the
+    # padded buffers of op.weight_prep pass through untouched)
+    if (wt.stride(2) == 1 and wt.stride(1) % 4 == 0 and wt.stride(1) >= n and wt.stride(0) == cw * wt.stride(1)
+            and wt.data_ptr() % 16 == 0):
+        ldw = wt.stride(1)
+    else:
+        ldw = (n + 3) // 4 * 4
+        wt = torch.nn.functional.pad(wt, (0, ldw - n)) if ldw != n else wt.contiguous()
     if taps != ksize * ksize or cw != c:
         raise RuntimeError("conv2d_mfma: weight must be [k*k, C, N]; got %s for C=%d k=%d"
                            % (tuple(wt.shape), c, ksize))
@@ -120,10 +126,7 @@ _GEOM = {  # name -> (ksize, stride, pad, transposed)
 def adjoint_weight(wt, geom):
     """Weights of the data-gradient convolution: channels swapped; taps reversed for the
     stride-1 3x3 correlation (the strided pair c3s2 <-> t3s2 keeps tap order)."""
-    w = wt.transpose(1, 2)
-    if geom == "c3":
-        w = w.flip(0)
-    return w.contiguous()
+    return _wp.adjoint(wt, geom == "c3")
 
 
 def _bc(s):

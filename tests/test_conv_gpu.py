@@ -174,3 +174,65 @@ def test_smallconv_primitives_and_double_backward(shape):
     for a, r in zip(got, want):
         assert a.shape == r.shape
         assert float((a - r).abs().max()) <= 3e-5 * (float(r.abs().max()) + 1e-6) * max(1.0, np.sqrt(h * w) / 8)
+
+
+# ---- weight preparation (csrc/weight_prep.hip): one-launch replacements of ATen view/scale passes
+def _wprep_reference(w, scale, want_sq):
+    ws = w.reshape(w.shape[-4:]) * scale
+    co, ci, k, _ = ws.shape
+    wt = ws.permute(2, 3, 1, 0).reshape(k * k, ci, co)
+    return wt, (ws.pow(2).sum((2, 3)).t() if want_sq else None)
+
+
+@pytest.mark.parametrize("shape", [(1, 24, 16, 3, 3), (6, 10, 3, 3), (3, 16, 1, 1), (1, 64, 130, 1, 1)])
+def test_weight_prep_forward_backward_and_second_order(shape):
+    from stylerenderer_amd.op.weight_prep import weight_prep
+
+    g = torch.Generator().manual_seed(sum(shape))
+    w0 = torch.randn(shape, generator=g)
+    scale = 0.37
+    for want_sq in (True, False):
+        w = w0.clone().to(DEV).requires_grad_(True)
+        wr = w0.clone().double().requires_grad_(True)
+        wt, wsq = weight_prep(w, scale, want_sq)
+        wt_r, wsq_r = _wprep_reference(wr, scale, want_sq)
+        assert torch.equal(wt.detach().cpu(), _wprep_reference(w0, scale, False)[0])   # one fp32 product
+        a = torch.randn(wt_r.shape, generator=g)
+        loss, loss_r = (wt * a.to(DEV)).sum(), (wt_r * a.double()).sum()
+        if want_sq:
+            np.testing.assert_allclose(wsq.detach().cpu().numpy(), wsq_r.detach().numpy(), rtol=2e-6)
+            b = torch.randn(wsq_r.shape, generator=g)
+            loss, loss_r = loss + (wsq * wsq * b.to(DEV)).sum(), loss_r + (wsq_r * wsq_r * b.double()).sum()
+        (gw,) = torch.autograd.grad(loss, w, create_graph=True)
+        (gw_r,) = torch.autograd.grad(loss_r, wr, create_graph=True)
+        np.testing.assert_allclose(gw.detach().cpu().numpy(), gw_r.detach().numpy(), rtol=1e-5, atol=1e-6)
+        if not want_sq:
+            assert not gw_r.requires_grad                                   # linear in w: constant gradient
+            continue
+        c = torch.randn(shape, generator=g)
+        (g2,) = torch.autograd.grad((gw * c.to(DEV)).sum(), w)
+        (g2_r,) = torch.autograd.grad((gw_r * c.double()).sum(), wr)
+        np.testing.assert_allclose(g2.cpu().numpy(), g2_r.numpy(), rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("taps,c,n,flip", [(9, 40, 24, True), (9, 3, 128, False), (1, 130, 6, False)])
+def test_weight_adjoint(taps, c, n, flip):
+    from stylerenderer_amd.op.weight_prep import adjoint
+
+    g = torch.Generator().manual_seed(taps + c + n)
+    wt = torch.randn(taps, c, n, generator=g)
+    want = wt.transpose(1, 2)
+    if flip:
+        want = want.flip(0)
+    x = wt.to(DEV).requires_grad_(True)
+    got = adjoint(x, flip)
+    assert torch.equal(got.cpu(), want)
+    assert got.stride(1) % 4 == 0                                          # padded pitch for the kernel
+    a = torch.randn(want.shape, generator=g)
+    (gx,) = torch.autograd.grad((got * a.to(DEV)).sum(), x)
+    want_g = a.flip(0).transpose(1, 2) if flip else a.transpose(1, 2)
+    assert torch.equal(gx.cpu(), want_g)
+    # padded-pitch input view
+    padded = torch.zeros(taps, c, (n + 3) // 4 * 4 + 4, device=DEV)
+    padded[:, :, :n] = wt.to(DEV)
+    assert torch.equal(adjoint(padded[:, :, :n], flip).cpu(), want)
