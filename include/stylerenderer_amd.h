@@ -97,6 +97,31 @@ int64_t sr_smallconv_dw_scratch_floats(int64_t B, int64_t C, int64_t N, int64_t 
 int sr_smallconv_dw(float* dws, const float* g, const float* x, int64_t B, int64_t C, int64_t N, int64_t hw,
                     float* scratch, sr_stream_t stream);
 
+/* Skinny linear algebra of the style path, B = per-GPU batch rows (csrc/style_linear.hip).
+ * EqualLinear (reference layers.py:222-248), optionally with the fused leaky-ReLU of the mapping
+ * network (act != 0: op/fused_act.py:86-97 semantics, bias inside the activation):
+ *   sr_linear_fwd:   y[b,n] = act(wscale * sum_k x[b,k]*w[n,k] + bscale*bias[n])      (bias may be NULL)
+ *   sr_linear_bwd_x: gx[b,k] = wscale * sum_n g'[b,n]*w[n,k],  g' = act'(y) * gy  (y = saved output)
+ *   sr_linear_bwd_w: gw[n,k] = wscale * sum_b g'[b,n]*x[b,k];  gbias[n] = bscale * sum_b g'[b,n] (or NULL)
+ * Demodulation scale of ModulatedConv2d (layers.py:298-300 as rsqrt(s^2 @ wsq + eps), wsq from
+ * sr_weight_prep):
+ *   sr_demod_fwd: d[b,co] = rsqrt(sum_ci s[b,ci]^2 * wsq[ci,co] + eps)
+ *   sr_demod_bwd: gq = -gd*d^3/2;  gs[b,ci] = gs_add[b,ci] + 2*s[b,ci]*sum_co gq[b,co]*wsq[ci,co]
+ *                 (gs_add may be NULL);  gwsq[ci,co] = sum_b s[b,ci]^2 * gq[b,co]   (gs or gwsq may be NULL)
+ * x rows have pitch ldx floats (a [B, n_latent, K] latent slice is read in place); everything else is
+ * dense.  K, ldx (resp. Co) must be multiples of 4 and the matrices 16-byte aligned (SR_EINVAL otherwise). */
+int sr_linear_fwd(float* y, const float* x, const float* w, const float* bias, int64_t B, int64_t K, int64_t N,
+                  int64_t ldx, float wscale, float bscale, int act, float alpha, float gain, sr_stream_t stream);
+int sr_linear_bwd_x(float* gx, const float* gy, const float* y, const float* w, int64_t B, int64_t K, int64_t N,
+                    float wscale, int act, float alpha, float gain, sr_stream_t stream);
+int sr_linear_bwd_w(float* gw, float* gbias, const float* gy, const float* y, const float* x, int64_t B,
+                    int64_t K, int64_t N, int64_t ldx, float wscale, float bscale, int act, float alpha,
+                    float gain, sr_stream_t stream);
+int sr_demod_fwd(float* d, const float* s, const float* wsq, int64_t B, int64_t Ci, int64_t Co, float eps,
+                 sr_stream_t stream);
+int sr_demod_bwd(float* gs, float* gwsq, const float* gd, const float* gs_add, const float* s, const float* d,
+                 const float* wsq, int64_t B, int64_t Ci, int64_t Co, sr_stream_t stream);
+
 /* Weight preparation for sr_conv2d_mfma (replaces the per-layer ATen passes of reference
  * layers.py:293-300 / 213-216: scale * weight, pow, sum, views).  w [Co, Ci, k, k], k in {1, 3}.
  *   sr_weight_prep:     wt [k*k, Ci, ld] = scale*w  (ld % 4 == 0, ld >= Co, pad columns zeroed);

@@ -31,6 +31,11 @@ SIGNATURES = {
     "sr_smallconv_dx": (_i, [_p] * 3 + [_l] * 4 + [_p]),
     "sr_smallconv_dw_scratch_floats": (_l, [_l] * 4),
     "sr_smallconv_dw": (_i, [_p] * 3 + [_l] * 4 + [_p, _p]),
+    "sr_linear_fwd": (_i, [_p] * 4 + [_l] * 4 + [_f, _f, _i, _f, _f, _p]),
+    "sr_linear_bwd_x": (_i, [_p] * 4 + [_l] * 3 + [_f, _i, _f, _f, _p]),
+    "sr_linear_bwd_w": (_i, [_p] * 5 + [_l] * 4 + [_f, _f, _i, _f, _f, _p]),
+    "sr_demod_fwd": (_i, [_p] * 3 + [_l] * 3 + [_f, _p]),
+    "sr_demod_bwd": (_i, [_p] * 7 + [_l] * 3 + [_p]),
     "sr_weight_prep": (_i, [_p, _p, _p, _f, _l, _l, _i, _l, _p]),
     "sr_weight_prep_bwd": (_i, [_p, _p, _p, _p, _f, _l, _l, _i, _l, _p]),
     "sr_weight_adjoint": (_i, [_p, _p, _l, _l, _l, _l, _l, _i, _p]),

@@ -27,6 +27,7 @@ SOURCES = [
     ("rasterize.hip", EXACT),
     ("fused_elem.hip", EXACT),
     ("weight_prep.hip", EXACT),
+    ("style_linear.hip", EXACT),
     ("conv_mfma.hip", []),
     ("conv_wgrad_mfma.hip", []),
 ]

@@ -22,6 +22,7 @@ from torch.nn import functional as F
 from .op import FusedLeakyReLU, fused_leaky_relu, upfirdn2d
 from .op import conv as _conv
 from .op import smallconv as _smallconv
+from .op import style as _style
 from .op.weight_prep import weight_prep as _weight_prep
 
 
@@ -124,6 +125,10 @@ class EqualLinear(nn.Module):
         self.lr_mul = lr_mul
 
     def forward(self, input):
+        if self.activation in (None, "fused_lrelu") and _style.linear_supported(input, self.weight):
+            # device tensors: one launch (scale, bias and the mapping network's leaky-ReLU fused)
+            return _style.equal_linear(input, self.weight, self.bias, self.scale, self.lr_mul,
+                                       self.activation == "fused_lrelu")
         if self.activation == "fused_lrelu":
             out = F.linear(input, self.weight * self.scale)
             return fused_leaky_relu(out, self.bias * self.lr_mul)
@@ -193,7 +198,10 @@ class ModulatedConv2d(nn.Module):
         wt, wsq = _weight_prep(self.weight, self.scale, self.demodulate)
         d = None
         if self.demodulate:
-            d = torch.rsqrt(torch.matmul(s * s, wsq) + self.eps)         # [B, Co]
+            if _style.demod_supported(s, wsq):
+                d = _style.demod_scale(s, wsq, self.eps)                 # [B, Co]
+            else:
+                d = torch.rsqrt(torch.matmul(s * s, wsq) + self.eps)
         k = self.kernel_size
         if self.upsample:
             if k != 3:

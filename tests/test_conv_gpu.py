@@ -236,3 +236,70 @@ def test_weight_adjoint(taps, c, n, flip):
     padded = torch.zeros(taps, c, (n + 3) // 4 * 4 + 4, device=DEV)
     padded[:, :, :n] = wt.to(DEV)
     assert torch.equal(adjoint(padded[:, :, :n], flip).cpu(), want)
+
+
+# ---- style path (csrc/style_linear.hip) against its defining tensor algebra in float64
+@pytest.mark.parametrize("b,k,n,act,bias,strided", [(16, 512, 512, True, True, False), (5, 64, 24, False, True, True),
+                                                    (3, 16, 130, False, False, False), (1, 512, 128, True, True, True)])
+def test_equal_linear_forward_backward(b, k, n, act, bias, strided):
+    from stylerenderer_amd.op import style
+
+    g = torch.Generator().manual_seed(b * 1000 + n)
+    xfull = torch.randn(b, 3, k, generator=g)
+    w0 = torch.randn(n, k, generator=g)
+    b0 = torch.randn(n, generator=g) if bias else None
+    wscale, bscale = 1.0 / np.sqrt(k), 0.7
+    xd = xfull.to(DEV).requires_grad_(True)
+    xr = xfull.double().requires_grad_(True)
+    x_in = xd[:, 1] if strided else xd[:, 1].contiguous()
+    assert style.linear_supported(x_in, w0.to(DEV))
+    wd, wr = w0.to(DEV).requires_grad_(True), w0.double().requires_grad_(True)
+    bd = b0.to(DEV).requires_grad_(True) if bias else None
+    br = b0.double().requires_grad_(True) if bias else None
+    y = style.equal_linear(x_in, wd, bd, wscale, bscale, act)
+    yr = style._linear_composite(xr[:, 1], wr, br, wscale, bscale, act)
+    np.testing.assert_allclose(y.detach().cpu().numpy(), yr.detach().numpy(), rtol=2e-5, atol=2e-6)
+    gy = torch.randn(b, n, generator=g)
+    ins_d = [t for t in (xd, wd, bd) if t is not None]
+    ins_r = [t for t in (xr, wr, br) if t is not None]
+    got = torch.autograd.grad(y, ins_d, gy.to(DEV))
+    want = torch.autograd.grad(yr, ins_r, gy.double())
+    for a, r in zip(got, want):
+        np.testing.assert_allclose(a.cpu().numpy(), r.numpy(), rtol=3e-5, atol=3e-6)
+    # second order (composite route): d/dw of <grad_x, c>
+    y2 = style.equal_linear(x_in, wd, bd, wscale, bscale, act)
+    (gx,) = torch.autograd.grad(y2, xd, gy.to(DEV), create_graph=True)
+    yr2 = style._linear_composite(xr[:, 1], wr, br, wscale, bscale, act)
+    (gxr,) = torch.autograd.grad(yr2, xr, gy.double(), create_graph=True)
+    c = torch.randn(xfull.shape, generator=g)
+    (g2,) = torch.autograd.grad((gx * c.to(DEV)).sum(), wd)
+    (g2r,) = torch.autograd.grad((gxr * c.double()).sum(), wr)
+    np.testing.assert_allclose(g2.cpu().numpy(), g2r.numpy(), rtol=3e-5, atol=3e-6)
+
+
+@pytest.mark.parametrize("b,ci,co", [(16, 512, 512), (3, 24, 8), (1, 130, 64)])
+def test_demod_scale_forward_backward(b, ci, co):
+    from stylerenderer_amd.op import style
+
+    g = torch.Generator().manual_seed(b + ci + co)
+    s0 = torch.randn(b, ci, generator=g)
+    w0 = torch.rand(ci, co, generator=g) / ci
+    eps = 1e-8
+    sd, wd = s0.to(DEV).requires_grad_(True), w0.to(DEV).requires_grad_(True)
+    sr, wr = s0.double().requires_grad_(True), w0.double().requires_grad_(True)
+    d = style.demod_scale(sd, wd, eps)
+    dr = style._demod_composite(sr, wr, eps)
+    np.testing.assert_allclose(d.detach().cpu().numpy(), dr.detach().numpy(), rtol=1e-5)
+    gd = torch.randn(b, co, generator=g)
+    got = torch.autograd.grad(d, (sd, wd), gd.to(DEV), create_graph=True)
+    want = torch.autograd.grad(dr, (sr, wr), gd.double(), create_graph=True)
+    for a, r in zip(got, want):
+        np.testing.assert_allclose(a.detach().cpu().numpy(), r.detach().numpy(), rtol=5e-5, atol=1e-5)
+    (g2,) = torch.autograd.grad((got[0] * got[0]).sum(), wd)
+    (g2r,) = torch.autograd.grad((want[0] * want[0]).sum(), wr)
+    np.testing.assert_allclose(g2.cpu().numpy(), g2r.numpy(), rtol=2e-4, atol=1e-4 * float(g2r.abs().max()))
+    # first-order fused kernels (no graph recording)
+    d2 = style.demod_scale(sd, wd, eps)
+    fused = torch.autograd.grad(d2, (sd, wd), gd.to(DEV))
+    for a, r in zip(fused, want):
+        np.testing.assert_allclose(a.cpu().numpy(), r.detach().numpy(), rtol=5e-5, atol=1e-5)
