@@ -79,7 +79,8 @@ int sr_noise_bias_act_bwd(float* gx, float* gbias, float* gnoise_w, const float*
 /* Row-wise dot products of two [rows, inner] tensors, optionally with a scaled copy in the same
  * sweep: dots[r] = sum_i a[r,i]*b[r,i] ; out_scaled[r,i] = b[r,i]*scale[r] (out_scaled may be NULL).
  * These are the style / demodulation gradients of the modulated convolution (sum_p x*dx', sum_p g*y)
- * that autograd would otherwise compute as a multiply pass plus a reduction pass. */
+ * that autograd would otherwise compute as a multiply pass plus a reduction pass.  Rows of any length
+ * (16-byte vector accesses when inner % 4 == 0 and the pointers are aligned, dword accesses otherwise). */
 int64_t sr_rowdot_scratch_floats(int64_t rows, int64_t inner);
 int sr_rowdot(float* dots, float* out_scaled, const float* a, const float* b, const float* scale,
               int64_t rows, int64_t inner, float* scratch, sr_stream_t stream);

@@ -141,7 +141,7 @@ __global__ __launch_bounds__(64) void k_nba_finish2(float* __restrict__ gnw,
 }
 
 // grid = (chunks, rows): partial dot products of two [rows, inner] tensors, optional scaled copy
-template <bool SCALE_OUT>
+template <bool SCALE_OUT, bool VEC>
 __global__ __launch_bounds__(EB) void k_rowdot(float* __restrict__ partial, float* __restrict__ out,
                                                const float* __restrict__ a, const float* __restrict__ b,
                                                const float* __restrict__ s, int64_t inner, int chunks) {
@@ -149,16 +149,30 @@ __global__ __launch_bounds__(EB) void k_rowdot(float* __restrict__ partial, floa
     const int64_t row = blockIdx.y;
     const int64_t off = (int64_t)blockIdx.x * ECHUNK;
     const int64_t remain = inner - off;
-    const int n4 = (int)((remain < ECHUNK ? remain : ECHUNK) / 4);
-    const float4* as = reinterpret_cast<const float4*>(a + row * inner + off);
-    const float4* bs = reinterpret_cast<const float4*>(b + row * inner + off);
-    float4* os = SCALE_OUT ? reinterpret_cast<float4*>(out + row * inner + off) : nullptr;
+    const int n = (int)(remain < ECHUNK ? remain : ECHUNK);
     const float sc = SCALE_OUT ? s[row] : 1.0f;
     float acc = 0.0f, dummy = 0.0f;
-    for (int i = threadIdx.x; i < n4; i += EB) {
-        const float4 x = as[i], y = bs[i];
-        acc += (x.x * y.x + x.y * y.y) + (x.z * y.z + x.w * y.w);
-        if (SCALE_OUT) os[i] = make_float4(y.x * sc, y.y * sc, y.z * sc, y.w * sc);
+    if (VEC) {
+        const float4* as = reinterpret_cast<const float4*>(a + row * inner + off);
+        const float4* bs = reinterpret_cast<const float4*>(b + row * inner + off);
+        float4* os = SCALE_OUT ? reinterpret_cast<float4*>(out + row * inner + off) : nullptr;
+        for (int i = threadIdx.x; i < n / 4; i += EB) {
+            const float4 x = as[i], y = bs[i];
+            acc += (x.x * y.x + x.y * y.y) + (x.z * y.z + x.w * y.w);
+            if (SCALE_OUT) os[i] = make_float4(y.x * sc, y.y * sc, y.z * sc, y.w * sc);
+        }
+    } else {
+        // rows whose length is not a multiple of 4 (the (2^k+1)^2 maps around the stride-2 transposed
+        // convolution) start at unaligned addresses: dword accesses, still fully coalesced
+        const float* as = a + row * inner + off;
+        const float* bs = b + row * inner + off;
+        float* os = SCALE_OUT ? out + row * inner + off : nullptr;
+#pragma unroll 4
+        for (int i = threadIdx.x; i < n; i += EB) {
+            const float x = as[i], y = bs[i];
+            acc += x * y;
+            if (SCALE_OUT) os[i] = y * sc;
+        }
     }
     block_sum2(acc, dummy, lds8);
     if (threadIdx.x == 0) partial[row * chunks + blockIdx.x] = acc;
@@ -236,15 +250,17 @@ extern "C" int sr_rowdot(float* dots, float* out_scaled, const float* a, const f
     if (rows < 0 || inner < 0) return SR_EINVAL;
     if (rows == 0) return SR_OK;
     if (!dots || !a || !b || !scratch || rows > 65535 || (out_scaled && !scale)) return SR_EINVAL;
-    if (!vec_ok(inner, a, b, out_scaled, nullptr)) return SR_EINVAL;
+    const bool vec = vec_ok(inner, a, b, out_scaled, nullptr);
     hipStream_t st = sr_stream(stream);
     const int chunks = (int)sr_ceil_div(inner > 0 ? inner : 1, ECHUNK);
-    if (out_scaled)
-        hipLaunchKernelGGL(k_rowdot<true>, dim3(chunks, (unsigned)rows), dim3(EB), 0, st, scratch, out_scaled,
-                           a, b, scale, inner, chunks);
-    else
-        hipLaunchKernelGGL(k_rowdot<false>, dim3(chunks, (unsigned)rows), dim3(EB), 0, st, scratch, out_scaled,
-                           a, b, scale, inner, chunks);
+    const dim3 grid(chunks, (unsigned)rows);
+    if (out_scaled) {
+        if (vec) hipLaunchKernelGGL((k_rowdot<true, true>), grid, dim3(EB), 0, st, scratch, out_scaled, a, b, scale, inner, chunks);
+        else hipLaunchKernelGGL((k_rowdot<true, false>), grid, dim3(EB), 0, st, scratch, out_scaled, a, b, scale, inner, chunks);
+    } else {
+        if (vec) hipLaunchKernelGGL((k_rowdot<false, true>), grid, dim3(EB), 0, st, scratch, out_scaled, a, b, scale, inner, chunks);
+        else hipLaunchKernelGGL((k_rowdot<false, false>), grid, dim3(EB), 0, st, scratch, out_scaled, a, b, scale, inner, chunks);
+    }
     hipLaunchKernelGGL(k_rowdot_finish, dim3((unsigned)rows), dim3(64), 0, st, dots, scratch, chunks);
     return sr_launch_status();
 }

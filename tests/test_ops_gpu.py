@@ -318,12 +318,13 @@ def test_noise_bias_act_matches_two_step_path(shape, shared):
     assert torch.allclose(a[4], r[4], rtol=1e-5, atol=1e-6)
 
 
-def test_rowdot_matches_torch():
+@pytest.mark.parametrize("hw", [(20, 24), (17, 17), (65, 65)])      # aligned rows / (2^k+1)^2 unaligned rows
+def test_rowdot_matches_torch(hw):
     from stylerenderer_amd import synth
     from stylerenderer_amd.op.fused_elem import rowdot
 
-    a = T(synth.det_normal((3, 7, 20, 24), 91)).requires_grad_()
-    b = T(synth.det_normal((3, 7, 20, 24), 92)).requires_grad_()
+    a = T(synth.det_normal((3, 7) + hw, 91)).requires_grad_()
+    b = T(synth.det_normal((3, 7) + hw, 92)).requires_grad_()
     s = T(synth.det_normal((3, 7), 93)).requires_grad_()
     dots, out = rowdot(a, b, s)
     want = (a.double() * b.double()).sum((2, 3))
