@@ -29,6 +29,7 @@ SOURCES = [
     ("weight_prep.hip", EXACT),
     ("style_linear.hip", EXACT),
     ("conv_mfma.hip", []),
+    ("conv_wino.hip", []),
     ("conv_wgrad_mfma.hip", []),
 ]
 

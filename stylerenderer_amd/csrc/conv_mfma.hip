@@ -32,6 +32,9 @@
 // transposed convolution of the upsampling layers is run as its four output phases — and the patch
 // shape for 4x4 ... 256x256 feature maps.
 #include "common.h"
+#include "conv_wino.h"
+
+#include <cstdlib>
 
 namespace {
 
@@ -374,6 +377,13 @@ __global__ __launch_bounds__(256) void k_conv_reduce(const ConvParams p, int rh,
     }
 }
 
+// Winograd F(2x2,3x3) for the stride-1 3x3 convolution (csrc/conv_wino.hip); SR_WINOGRAD=0 keeps the
+// direct implicit GEMM (A/B measurements, exact-fma-chain numerics).
+bool wino_enabled() {
+    const char* e = std::getenv("SR_WINOGRAD");      // read per call: tests flip it at run time
+    return !(e && e[0] == '0');
+}
+
 template <int IS, int TY, int TX>
 int launch_by_patch(ConvParams& p, hipStream_t st) {
     int pw, ph, pb;
@@ -430,6 +440,11 @@ extern "C" int64_t sr_conv2d_scratch_floats(int64_t B, int64_t C, int64_t N, int
     };
     if (!transposed) {
         consider(OH, OW);
+        if (ksize == 3 && stride == 1 && pad == 1 && wino_enabled() &&
+            sr_wino_eligible(B, C, N, IH, IW, nullptr, nullptr)) {
+            const int64_t w = sr_wino_scratch_floats(C, N);
+            need = need > w ? need : w;
+        }
     } else {
         consider(IH + 1, IW + 1);
         consider(IH, IW);
@@ -470,6 +485,9 @@ extern "C" int sr_conv2d_mfma(float* out, const float* in, const float* wt, cons
         p.dy0 = p.dx0 = -pad;
         for (int i = 0; i < ksize * ksize; ++i) p.wmap[i] = i;
         int rc;
+        if (ksize == 3 && stride == 1 && pad == 1 && scratch && wino_enabled() &&
+            sr_wino_eligible(B, C, N, IH, IW, in, out))
+            return sr_wino_conv3x3(out, in, wt, wt_ld, iscale, oscale, obias, B, C, N, IH, IW, scratch, st);
         if (ksize == 3 && stride == 1) rc = launch_by_patch<1, 3, 3>(p, st);
         else if (ksize == 3 && stride == 2) rc = launch_by_patch<2, 3, 3>(p, st);
         else if (ksize == 1 && stride == 1) rc = launch_by_patch<1, 1, 1>(p, st);

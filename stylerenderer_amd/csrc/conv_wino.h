@@ -1,0 +1,22 @@
+// Internal interface of the Winograd F(2x2,3x3) path (csrc/conv_wino.hip), used by sr_conv2d_mfma.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+struct WinoParams {
+    const float* in;
+    const float* u;        // transformed weights, chunk-ordered (k_wino_weights)
+    const float* iscale;
+    const float* oscale;
+    const float* obias;
+    float* out;
+    int B, C, N, H, W;
+    int tiles_x, tiles_y, tiles_n;
+};
+
+// stride-1 3x3 pad-1 convolution with H % 8 == 0, W % 32 == 0, C % 8 == 0, N % 64 == 0
+bool sr_wino_eligible(int64_t B, int64_t C, int64_t N, int64_t H, int64_t W, const void* in, const void* out);
+int64_t sr_wino_scratch_floats(int64_t C, int64_t N);
+int sr_wino_conv3x3(float* out, const float* in, const float* wt, int64_t ldw, const float* iscale,
+                    const float* oscale, const float* obias, int64_t B, int64_t C, int64_t N, int64_t H, int64_t W,
+                    float* u_scratch, hipStream_t st);

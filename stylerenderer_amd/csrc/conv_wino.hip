@@ -1,0 +1,351 @@
+// Winograd F(2x2, 3x3) convolution on the gfx950 matrix cores (fp32, v_mfma_f32_32x32x2_f32).
+//
+// The stride-1 3x3 modulated convolution (forward and data-gradient: 43 % of the generator step as a
+// direct implicit GEMM, csrc/conv_mfma.hip) does 36 multiply-adds per 2x2 output tile, input channel
+// and output channel.  The minimal-filtering form needs 16:
+//
+//     Y = A^T [ sum_c (G g_c G^T) (.) (B^T d_c B) ] A          d: 4x4 input tile, g: 3x3 filter
+//
+// i.e. 16 independent GEMMs  M[pos][n][tile] = sum_c U[pos][c][n] * V[pos][c][tile]  — 2.25x less
+// matrix-core work for the same result up to fp32 round-off (the same algorithm MIOpen / cuDNN pick
+// for fp32 3x3 convolutions, i.e. what the reference's F.conv2d runs on a GPU).
+//
+// One 256-thread workgroup = 64 tiles (16 x 4 -> 32 x 8 output pixels) x 64 output channels:
+//   * wave (i, j) owns tile block i (32 tiles) and channel block j (32 channels) for ALL 16 positions:
+//     16 accumulator tiles of 32x32 = 256 registers, so the output transform A^T M A is register-local
+//     (the 16 positions of a (tile, channel) pair sit in the same lane).
+//   * K loop over chunks of KC input channels.  Per chunk: the halo patch d (10 x 40 floats per
+//     channel, 16-byte aligned rows) and the pre-transformed weights U (a contiguous 32 KB block, see
+//     k_wino_weights) arrive by LDS-DMA; the input transform B^T d B (32 add/sub per tile-channel, the
+//     style s[b,c] multiplied in) runs on the VALU between the MFMAs of the PREVIOUS chunk and writes V
+//     in the operand layout; operands are fetched with one conflict-free ds_read_b64 per two k-steps.
+//   * pipeline (one barrier per chunk):  iteration k:  DMA d[k+2], U[k+1]  |  transform d[k+1] -> V[k+1]
+//     |  MFMA over V[k], U[k].
+//   * epilogue: output transform in registers, demodulation scale / bias, float2 stores (16 lanes =
+//     128 contiguous bytes of an output row).
+// LDS: 2 x (U 32 KB + V 32 KB + d 13 KB) + style = 156 KB of the CU's 160 KB; one workgroup per CU
+// (the 256 accumulators allow one wave per SIMD anyway).
+#include "common.h"
+#include "conv_wino.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef const void __attribute__((address_space(1)))* gptr_t;
+typedef void __attribute__((address_space(3)))* lptr_t;
+
+__device__ __attribute__((aligned(16))) const float g_wino_zero[4] = {0.f, 0.f, 0.f, 0.f};
+
+constexpr int TW = 16, TH = 4;            // tiles per workgroup: 32 x 8 output pixels
+constexpr int NB = 64;                    // output channels per workgroup
+constexpr int EH = 2 * TH + 2;            // halo rows
+constexpr int LEAD = 3;                   // halo columns start at x0 - 4 (16-byte aligned); x0 - 1 is column 3
+constexpr int EWP = 40;                   // LEAD + 2*TW + 2 = 37 -> row pitch 40 floats
+constexpr int PLANE = EH * EWP;           // 400 floats per channel
+
+template <int KC>
+struct WG {
+    static constexpr int CQ = KC / 4;                       // channel quads per chunk
+    static constexpr int PS = CQ * 256;                     // position stride in a U / V buffer
+    static constexpr int UV = 16 * PS;                      // floats per U (or V) chunk: [pos][cq][h][64][2]
+    static constexpr int U_INSTR = UV / 256;                // 16-byte DMA wave-instructions per U chunk
+    static constexpr int D_FLOATS = KC * PLANE;
+    static constexpr int D_INSTR = (D_FLOATS / 4 + 63) / 64;
+    static constexpr int D_BUF = D_INSTR * 256;
+    static constexpr int D_PER_WAVE = (D_INSTR + 3) / 4;
+    static constexpr int STY = 4 * UV + 2 * D_BUF;          // style row offset
+};
+
+template <int KC>
+__global__ __launch_bounds__(256) void k_conv_wino(const WinoParams p) {
+    using G = WG<KC>;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* const ubuf = smem;
+    float* const vbuf = smem + 2 * G::UV;
+    float* const dbuf = smem + 4 * G::UV;
+    float* const sty = smem + G::STY;
+
+    // ---- tile decode (XCD-chunked: consecutive ids = same input patch / neighbouring patches on one L2)
+    const int nwg = gridDim.x;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg / SR_NUM_XCD, r = nwg % SR_NUM_XCD, xcd = bid % SR_NUM_XCD;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + bid / SR_NUM_XCD;
+    }
+    const int n_t = bid % p.tiles_n;
+    bid /= p.tiles_n;
+    const int tx_i = bid % p.tiles_x;
+    bid /= p.tiles_x;
+    const int ty_i = bid % p.tiles_y;
+    const int b = bid / p.tiles_y;
+    const int oy0 = ty_i * (2 * TH), ox0 = tx_i * (2 * TW), n0 = n_t * NB;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = lane >> 5, l31 = lane & 31;
+    const int wn = wave & 1, wt = wave >> 1;
+    const int nchunks = p.C / KC;
+
+    // style row of this sample (ones when absent), consumed by the input transform
+    for (int c = tid; c < p.C; c += 256) sty[c] = p.iscale ? p.iscale[(int64_t)b * p.C + c] : 1.0f;
+
+    // ---- DMA descriptors of the halo patch (chunk 0); -1 = zero line (outside the image)
+    int d_src[G::D_PER_WAVE];
+#pragma unroll
+    for (int i = 0; i < G::D_PER_WAVE; ++i) {
+        const int j = wave + 4 * i;
+        const int f = (j * 64 + lane) * 4;
+        int src = -1;
+        if (j < G::D_INSTR && f < G::D_FLOATS) {
+            const int c = f / PLANE, q = f % PLANE;
+            const int r = q / EWP, cola = q % EWP;
+            const int gy = oy0 - 1 + r, gx = ox0 - 4 + cola;
+            if (gy >= 0 && gy < p.H && gx >= 0 && gx + 3 < p.W) src = (c * p.H + gy) * p.W + gx;
+        }
+        d_src[i] = src;
+    }
+    const float* in_b = p.in + (int64_t)b * p.C * p.H * p.W;
+    const int chunk_in = KC * p.H * p.W;
+    const float* u_n = p.u + (int64_t)n_t * nchunks * G::UV + lane * 4;
+
+    auto dma_d = [&](int k, int buf) {
+        float* dst = dbuf + buf * G::D_BUF;
+#pragma unroll
+        for (int i = 0; i < G::D_PER_WAVE; ++i) {
+            const int j = wave + 4 * i;
+            if (j < G::D_INSTR) {
+                const float* src = d_src[i] >= 0 ? in_b + (int64_t)k * chunk_in + d_src[i] : g_wino_zero;
+                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(dst + j * 256), 16, 0, 0);
+            }
+        }
+    };
+    auto dma_u = [&](int k, int buf) {
+        float* dst = ubuf + buf * G::UV;
+        const float* src = u_n + (int64_t)k * G::UV;
+#pragma unroll
+        for (int i = 0; i < G::U_INSTR / 4; ++i) {
+            const int j = wave + 4 * i;
+            __builtin_amdgcn_global_load_lds((gptr_t)(src + j * 256), (lptr_t)(dst + j * 256), 16, 0, 0);
+        }
+    };
+
+    // ---- input transform item of this thread: tile = lane, channels (ca, ca + 2) of the chunk
+    const int t_cq = (G::CQ > 1) ? (wave & 1) : 0;
+    const int t_h = (G::CQ > 1) ? (wave >> 1) : (wave & 1);
+    const bool t_on = (G::CQ > 1) || wave < 2;
+    const int t_ca = 4 * t_cq + t_h;
+    const int t_rd = t_ca * PLANE + (2 * (lane >> 4)) * EWP + LEAD + 2 * (lane & 15);
+    const int t_wr = t_cq * 256 + t_h * 128 + lane * 2;
+
+    // B^T d B of one channel, row q of the 4x4 result (12 VALU ops), style multiplied in
+    auto bt_row = [](const float (&d)[16], float (&o)[16], int q, float s) {
+        float t[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            t[j] = q == 0 ? d[j] - d[8 + j] : q == 1 ? d[4 + j] + d[8 + j] : q == 2 ? d[8 + j] - d[4 + j]
+                                                                          : d[4 + j] - d[12 + j];
+        o[4 * q + 0] = (t[0] - t[2]) * s;
+        o[4 * q + 1] = (t[1] + t[2]) * s;
+        o[4 * q + 2] = (t[2] - t[1]) * s;
+        o[4 * q + 3] = (t[1] - t[3]) * s;
+    };
+    // whole transform of chunk k (prologue only; inside the loop it is sliced between the MFMAs)
+    auto transform = [&](int k, int dsel, int vsel) {
+        if (!t_on) return;
+        const float* d0 = dbuf + dsel * G::D_BUF + t_rd;
+        float* v = vbuf + vsel * G::UV + t_wr;
+        const float sa = sty[k * KC + t_ca], sb = sty[k * KC + t_ca + 2];
+        float da[16], db[16], va[16], vb[16];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                da[4 * r + j] = d0[r * EWP + j];
+                db[4 * r + j] = d0[2 * PLANE + r * EWP + j];
+            }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            bt_row(da, va, q, sa);
+            bt_row(db, vb, q, sb);
+        }
+#pragma unroll
+        for (int pos = 0; pos < 16; ++pos) {
+            v[pos * G::PS] = va[pos];
+            v[pos * G::PS + 1] = vb[pos];
+        }
+    };
+
+    f32x16 acc[16];
+#pragma unroll
+    for (int pos = 0; pos < 16; ++pos)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[pos][r] = 0.0f;
+
+    const int a_off = (half * 64 + wn * 32 + l31) * 2;
+    const int b_off = (half * 64 + wt * 32 + l31) * 2;
+
+    // ---- prologue: d[0], U[0], d[1] in flight; V[0] from d[0]
+    dma_d(0, 0);
+    dma_u(0, 0);
+    if (nchunks > 1) dma_d(1, 1);
+    __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): this wave's DMAs have landed
+    __syncthreads();
+    transform(0, 0, 0);
+
+    static_assert(KC == 8, "the slot schedule below is written for two channel quads per chunk");
+    for (int k = 0; k < nchunks; ++k) {
+        // V[k] complete, d[k+1] / U[k] landed (every wave drained its own DMAs), iteration k-1's buffers free
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+        __syncthreads();
+        if (k + 2 < nchunks) dma_d(k + 2, k & 1);
+        if (k + 1 < nchunks) dma_u(k + 1, (k + 1) & 1);
+        const float* ub = ubuf + (k & 1) * G::UV + a_off;
+        const float* vb_ = vbuf + (k & 1) * G::UV + b_off;
+        // transform of chunk k+1 (garbage in, unused out on the last iteration: no branch in this block)
+        const int kn = (k + 1 < nchunks) ? k + 1 : k;
+        const float* d0 = dbuf + ((k + 1) & 1) * G::D_BUF + t_rd;
+        float* vout = vbuf + ((k + 1) & 1) * G::UV + t_wr;
+        const float sa = sty[kn * KC + t_ca], sb = sty[kn * KC + t_ca + 2];
+        float da[16], db[16], va[16], vb[16];
+        float ax[2][16], ay[2][16], xx[2][16], xy[2][16];       // operand sets of the two channel quads
+        auto load_ops = [&](int cq, int pos) {
+            ax[cq][pos] = ub[pos * G::PS + cq * 256];
+            ay[cq][pos] = ub[pos * G::PS + cq * 256 + 1];
+            xx[cq][pos] = vb_[pos * G::PS + cq * 256];
+            xy[cq][pos] = vb_[pos * G::PS + cq * 256 + 1];
+        };
+#pragma unroll
+        for (int pos = 0; pos < 16; ++pos) load_ops(0, pos);
+        // 16 slots of 4 MFMAs; the VALU / LDS work of the next chunk's input transform and the operand
+        // fetch of the second quad are pinned between them (sched_barrier: nothing crosses a slot edge)
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const int cq = s >> 3, j = s & 7;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int m = 4 * j + u, pos = m & 15;
+                if (m < 16) acc[pos] = __builtin_amdgcn_mfma_f32_32x32x2f32(ax[cq][pos], xx[cq][pos], acc[pos], 0, 0, 0);
+                else acc[pos] = __builtin_amdgcn_mfma_f32_32x32x2f32(ay[cq][pos], xy[cq][pos], acc[pos], 0, 0, 0);
+            }
+            if (s < 4) {                         // halo reads: 8 floats per slot
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int idx = 8 * (s & 1) + e, r = idx >> 2, jj = idx & 3;
+                    if (s < 2) da[idx] = d0[r * EWP + jj];
+                    else db[idx] = d0[2 * PLANE + r * EWP + jj];
+                }
+            }
+            if (s >= 2 && s < 6) {               // operands of the second quad: 4 positions per slot
+#pragma unroll
+                for (int e = 0; e < 4; ++e) load_ops(1, 4 * (s - 2) + e);
+            }
+            if (s >= 4 && s < 8) bt_row(da, va, s - 4, sa);
+            if (s >= 8 && s < 12) bt_row(db, vb, s - 8, sb);
+            if (s >= 12) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int pos = 4 * (s - 12) + e;
+                    vout[pos * G::PS] = va[pos];
+                    vout[pos * G::PS + 1] = vb[pos];
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+
+    // ---- epilogue: Y = A^T M A per (tile, channel); C/D layout: column (tile) = lane & 31,
+    // row (channel) = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+    const int tile = wt * 32 + l31;
+    const int oy = oy0 + 2 * (tile >> 4), ox = ox0 + 2 * (tile & 15);
+    const int64_t plane = (int64_t)p.H * p.W;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int n = n0 + wn * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        float s[2][4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float m0 = acc[j][r], m1 = acc[4 + j][r], m2 = acc[8 + j][r], m3 = acc[12 + j][r];
+            s[0][j] = (m0 + m1) + m2;
+            s[1][j] = (m1 - m2) - m3;
+        }
+        const float os = p.oscale ? p.oscale[(int64_t)b * p.N + n] : 1.0f;
+        const float ob = p.obias ? p.obias[n] : 0.0f;
+        float* o = p.out + ((int64_t)b * p.N + n) * plane + (int64_t)oy * p.W + ox;
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            const float y0 = (s[a][0] + s[a][1]) + s[a][2];
+            const float y1 = (s[a][1] - s[a][2]) - s[a][3];
+            *reinterpret_cast<float2*>(o + a * p.W) = make_float2(y0 * os + ob, y1 * os + ob);
+        }
+    }
+}
+
+// U[pos][c][n] = (G g G^T)[pos], written in the chunk order the kernel DMAs:
+//   [n / 64][c / KC][pos][cq][h][n % 64][e],  chunk-local channel = 4 cq + 2 e + h
+template <int KC>
+__global__ __launch_bounds__(64) void k_wino_weights(float* __restrict__ u, const float* __restrict__ wt, int C,
+                                                     int N, int ldw) {
+    using G = WG<KC>;
+    const int n = blockIdx.x * 64 + threadIdx.x, c = blockIdx.y;
+    float g[3][3];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) g[t / 3][t % 3] = wt[((int64_t)t * C + c) * ldw + n];
+    float h[4][3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        h[0][j] = g[0][j];
+        h[1][j] = 0.5f * ((g[0][j] + g[2][j]) + g[1][j]);
+        h[2][j] = 0.5f * ((g[0][j] + g[2][j]) - g[1][j]);
+        h[3][j] = g[2][j];
+    }
+    const int cl = c % KC, cq = cl / 4, e = (cl % 4) / 2, hh = cl % 2;
+    float* dst = u + ((int64_t)blockIdx.x * (C / KC) + c / KC) * G::UV + cq * 256 + hh * 128 + threadIdx.x * 2 + e;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        dst[(4 * i + 0) * G::PS] = h[i][0];
+        dst[(4 * i + 1) * G::PS] = 0.5f * ((h[i][0] + h[i][2]) + h[i][1]);
+        dst[(4 * i + 2) * G::PS] = 0.5f * ((h[i][0] + h[i][2]) - h[i][1]);
+        dst[(4 * i + 3) * G::PS] = h[i][2];
+    }
+}
+
+template <int KC>
+int launch(const WinoParams& p, float* u, const float* wt, int ldw, hipStream_t st) {
+    using G = WG<KC>;
+    const int lds = (G::STY + p.C) * 4;
+    auto kern = k_conv_wino<KC>;
+    static bool configured = false;
+    if (!configured) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                160 * 1024) != hipSuccess) {
+            (void)hipGetLastError();
+            return SR_EINVAL;
+        }
+        configured = true;
+    }
+    hipLaunchKernelGGL(k_wino_weights<KC>, dim3(p.N / 64, p.C), dim3(64), 0, st, u, wt, p.C, p.N, ldw);
+    const int64_t blocks = (int64_t)p.tiles_n * p.tiles_x * p.tiles_y * p.B;
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, st, p);
+    return sr_launch_status();
+}
+
+}  // namespace
+
+bool sr_wino_eligible(int64_t B, int64_t C, int64_t N, int64_t H, int64_t W, const void* in, const void* out) {
+    if (B <= 0 || C % 8 != 0 || N % 64 != 0 || H % 8 != 0 || W % 32 != 0) return false;
+    if (C > 1024 || B * ((W / 32) * (H / 8)) * (N / 64) > 0x7FFFFFFFLL) return false;
+    if (C * H * W >= (1LL << 31)) return false;
+    return ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out)) & 15) == 0;
+}
+
+int64_t sr_wino_scratch_floats(int64_t C, int64_t N) { return 16 * C * N; }
+
+int sr_wino_conv3x3(float* out, const float* in, const float* wt, int64_t ldw, const float* iscale,
+                    const float* oscale, const float* obias, int64_t B, int64_t C, int64_t N, int64_t H, int64_t W,
+                    float* u_scratch, hipStream_t st) {
+    WinoParams p;
+    p.in = in; p.u = u_scratch; p.iscale = iscale; p.oscale = oscale; p.obias = obias; p.out = out;
+    p.B = (int)B; p.C = (int)C; p.N = (int)N; p.H = (int)H; p.W = (int)W;
+    p.tiles_x = (int)(W / (2 * TW)); p.tiles_y = (int)(H / (2 * TH)); p.tiles_n = (int)(N / NB);
+    return launch<8>(p, u_scratch, wt, (int)ldw, st);
+}
