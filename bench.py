@@ -176,8 +176,9 @@ def main():
     if rank == 0:
         images = args.batch * world * args.steps
         value = images / elapsed
-        # ---- roofline of the dominant kernel: k_conv_mfma<IS=1,3x3,patch 32x4> (forward and
-        # data-gradient launches of the 64^2..256^2 layers), timed inside the steps above
+        # ---- roofline of the dominant kernel: the stride-1 3x3 convolution (forward and data-gradient
+        # launches of the 64^2..256^2 layers; k_conv_wino, or k_conv_mfma with SR_WINOGRAD=0), timed
+        # inside the steps above
         dom = [(fl, e0.elapsed_time(e1)) for (kind, geom, fl, e0, e1) in prof
                if kind == "conv" and geom[0] == 3 and geom[1] == 1 and geom[2] == 0 and geom[7] > 16]
         roof = None
@@ -192,11 +193,19 @@ def main():
             fl = sum(d[0] for d in dom) / len(dom)
             ms = sum(d[1] for d in dom) / len(dom)
             ach = fl / (ms * 1e-3) / 1e12
-            roof = {"bound": "mfma", "kernel": "k_conv_mfma<1,3,3,32,4,1>", "achieved": round(ach, 2),
-                    "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4),
-                    "traffic": None, "launches": len(dom), "avg_launch_ms": round(ms, 4),
-                    "flop_per_launch": fl}
-            roof.update(pmc_traffic("k_conv_mfma<1; 3; 3; 32; 4; 1; true>"))
+            wino = os.environ.get("SR_WINOGRAD", "1") != "0"
+            roof = {"bound": "mfma", "kernel": "k_conv_wino<8>" if wino else "k_conv_mfma<1,3,3,32,4,1>",
+                    "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None, "launches": len(dom),
+                    "avg_launch_ms": round(ms, 4), "flop_per_launch": fl}
+            if wino:
+                # `achieved` counts the ALGORITHMIC (direct-convolution) FLOPs of SURVEY.md 8(d); the
+                # Winograd F(2x2,3x3) kernel issues 16/36 of them on the matrix cores
+                roof["executed_tflops"] = round(ach * 16.0 / 36.0, 2)
+                roof["executed_frac"] = round(ach * 16.0 / 36.0 / FP32_MFMA_PEAK_TFLOPS, 4)
+                roof["note"] = ("Winograd F(2x2,3x3): achieved = direct-conv FLOPs / time, so frac can exceed 1; "
+                                "executed_* = MFMA FLOPs actually issued (x16/36)")
+            roof.update(pmc_traffic("k_conv_wino<8>" if wino else "k_conv_mfma<1; 3; 3; 32; 4; 1; true>"))
         breakdown = {k: {"ms_per_step": round(v[1] / args.steps, 3),
                          "tflops": round(v[0] / (v[1] * 1e-3) / 1e12, 1) if v[1] > 0 else None,
                          "launches_per_step": v[2] // max(args.steps, 1)} for k, v in sorted(by_kind.items())}

@@ -303,3 +303,31 @@ def test_demod_scale_forward_backward(b, ci, co):
     fused = torch.autograd.grad(d2, (sd, wd), gd.to(DEV))
     for a, r in zip(fused, want):
         np.testing.assert_allclose(a.cpu().numpy(), r.detach().numpy(), rtol=5e-5, atol=1e-5)
+
+
+# ---- Winograd F(2x2,3x3) path (csrc/conv_wino.hip) vs float64 and vs the direct implicit GEMM.
+# Stated tolerance: |err| <= 4e-6 * sum|a*b| (the transforms add a few fp32 roundings on sums of up to
+# 4 inputs / 3 weights; measured 5e-7), against 2e-6 for the exact-fma-chain direct kernel.
+@pytest.mark.parametrize("b,c,n,h,w,scales", [(2, 24, 64, 16, 32, True), (1, 8, 128, 8, 64, False),
+                                               (3, 40, 64, 24, 32, True)])
+def test_winograd_conv_vs_float64_and_direct(b, c, n, h, w, scales, monkeypatch):
+    from stylerenderer_amd.op.conv import conv2d_mfma
+
+    g = torch.Generator().manual_seed(b * 100 + c)
+    x = torch.randn(b, c, h, w, generator=g)
+    wgt = torch.randn(n, c, 3, 3, generator=g) / (3 * c ** 0.5)
+    isc = torch.randn(b, c, generator=g) if scales else None
+    osc = torch.randn(b, n, generator=g) if scales else None
+    bias = torch.randn(n, generator=g) if scales else None
+    ref = ref_conv(x, wgt, isc, osc, bias, 1, 1, False)
+    mag = ref_conv(x.abs(), wgt.abs(), isc.abs() if scales else None, osc.abs() if scales else None, None, 1, 1,
+                   False) + (bias.abs().double()[None, :, None, None] if scales else 0.0)
+    args = [t.to(DEV) if t is not None else None for t in (x, to_taps(wgt, False), isc, osc, bias)]
+    monkeypatch.setenv("SR_WINOGRAD", "1")
+    wino = conv2d_mfma(*args, 3, 1, 1).cpu().double()
+    monkeypatch.setenv("SR_WINOGRAD", "0")
+    direct = conv2d_mfma(*args, 3, 1, 1).cpu().double()
+    assert float(((wino - ref).abs() / mag).max()) < 4e-6
+    assert float(((direct - ref).abs() / mag).max()) < 2e-6
+    assert float(((wino - direct).abs() / mag).max()) < 4e-6
+    assert not torch.equal(wino, direct)                 # the two paths really are different kernels
