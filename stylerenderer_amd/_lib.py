@@ -7,7 +7,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libstylerenderer_hip.so")
+# STYLERENDERER_AMD_LIB: development override (ablation builds of scripts/build_variant.sh)
+LIB_PATH = os.environ.get("STYLERENDERER_AMD_LIB") or os.path.join(_HERE, "libstylerenderer_hip.so")
 
 _i = ctypes.c_int
 _l = ctypes.c_int64

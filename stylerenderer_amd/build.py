@@ -30,6 +30,7 @@ SOURCES = [
     ("style_linear.hip", EXACT),
     ("conv_mfma.hip", []),
     ("conv_wino.hip", []),
+    ("conv_wgrad_wino.hip", []),
     ("conv_wgrad_mfma.hip", []),
 ]
 

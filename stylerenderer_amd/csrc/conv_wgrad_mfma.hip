@@ -28,6 +28,9 @@
 // The modulation scales are fetched per patch as two small LDS rows and multiplied onto the
 // operands after the ds_read (never onto freshly loaded registers: no wait on memory in the loop).
 #include "common.h"
+#include "conv_wino.h"
+
+#include <cstdlib>
 
 namespace {
 
@@ -406,6 +409,11 @@ bool geometry(int64_t B, int64_t C, int64_t N, int64_t IH, int64_t IW, int64_t O
 
 }  // namespace
 
+static bool wgrad_wino_enabled() {
+    const char* e = std::getenv("SR_WINOGRAD");          // "0" keeps the direct correlation kernel
+    return !(e && e[0] == '0');
+}
+
 extern "C" int64_t sr_conv2d_wgrad_scratch_floats(int64_t B, int64_t C, int64_t N, int64_t IH,
                                                   int64_t IW, int64_t OH, int64_t OW, int ksize,
                                                   int stride, int pad, int transposed) {
@@ -413,7 +421,13 @@ extern "C" int64_t sr_conv2d_wgrad_scratch_floats(int64_t B, int64_t C, int64_t 
     if (!geometry(B, C, N, IH, IW, OH, OW, ksize, stride, pad, transposed, is, GH, GW, UH, UW, CUc, CVc, d0))
         return -1;
     const Plan pl = make_plan(is, (int)B, CUc, CVc, GH, GW);
-    return (int64_t)pl.ks * NG_OF(pl.pb) * ksize * ksize * (pl.tiles_u * pl.ut) * (int64_t)(pl.tiles_v * pl.vt) + 4;
+    int64_t need = (int64_t)pl.ks * NG_OF(pl.pb) * ksize * ksize * (pl.tiles_u * pl.ut) * (int64_t)(pl.tiles_v * pl.vt) + 4;
+    if (!transposed && ksize == 3 && stride == 1 && pad == 1 && wgrad_wino_enabled() &&
+        sr_wgrad_wino_eligible(B, C, N, IH, IW, nullptr, nullptr)) {
+        const int64_t w = sr_wgrad_wino_scratch_floats(B, C, N, IH, IW);
+        need = need > w ? need : w;
+    }
+    return need;
 }
 
 extern "C" int sr_conv2d_wgrad_mfma(float* dwt, const float* x, const float* gy, const float* xscale,
@@ -426,6 +440,9 @@ extern "C" int sr_conv2d_wgrad_mfma(float* dwt, const float* x, const float* gy,
     if (!dwt || !x || !gy || !scratch) return SR_EINVAL;
     if (B * C * IH * IW >= (1LL << 31) || B * N * OH * OW >= (1LL << 31)) return SR_ERANGE;
     hipStream_t st = sr_stream(stream);
+    if (!transposed && ksize == 3 && stride == 1 && pad == 1 && wgrad_wino_enabled() &&
+        sr_wgrad_wino_eligible(B, C, N, IH, IW, x, gy))
+        return sr_wgrad_wino_3x3(dwt, x, gy, xscale, gscale, B, C, N, IH, IW, scratch, st);
     const Plan pl = make_plan(is, (int)B, CUc, CVc, GH, GW);
     WgradParams p;
     p.U = transposed ? gy : x;

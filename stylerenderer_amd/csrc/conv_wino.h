@@ -20,3 +20,10 @@ int64_t sr_wino_scratch_floats(int64_t C, int64_t N);
 int sr_wino_conv3x3(float* out, const float* in, const float* wt, int64_t ldw, const float* iscale,
                     const float* oscale, const float* obias, int64_t B, int64_t C, int64_t N, int64_t H, int64_t W,
                     float* u_scratch, hipStream_t st);
+
+// Winograd weight gradient of the same convolution (csrc/conv_wgrad_wino.hip): H % 2 == 0, W % 16 == 0,
+// C % 64 == 0, N % 64 == 0, B <= 32
+bool sr_wgrad_wino_eligible(int64_t B, int64_t C, int64_t N, int64_t H, int64_t W, const void* x, const void* gy);
+int64_t sr_wgrad_wino_scratch_floats(int64_t B, int64_t C, int64_t N, int64_t H, int64_t W);
+int sr_wgrad_wino_3x3(float* dwt, const float* x, const float* gy, const float* xscale, const float* gscale,
+                      int64_t B, int64_t C, int64_t N, int64_t H, int64_t W, float* scratch, hipStream_t st);
