@@ -331,3 +331,37 @@ def test_winograd_conv_vs_float64_and_direct(b, c, n, h, w, scales, monkeypatch)
     assert float(((direct - ref).abs() / mag).max()) < 2e-6
     assert float(((wino - direct).abs() / mag).max()) < 4e-6
     assert not torch.equal(wino, direct)                 # the two paths really are different kernels
+
+
+# Winograd F(3x3,2x2) weight gradient (csrc/conv_wgrad_wino.hip) vs float64 and vs the direct kernel.
+# Stated tolerance 4e-6 * sum|a*b| (measured 3e-7), direct kernel 2e-6.
+@pytest.mark.parametrize("b,c,n,h,w,scales", [(3, 64, 128, 8, 32, True), (2, 128, 64, 16, 16, False),
+                                               (5, 64, 64, 6, 48, True)])
+def test_winograd_wgrad_vs_float64_and_direct(b, c, n, h, w, scales, monkeypatch):
+    from stylerenderer_amd.op.conv import conv2d_wgrad_mfma
+
+    g = torch.Generator().manual_seed(b * 10 + h)
+    x = torch.randn(b, c, h, w, generator=g)
+    gy = torch.randn(b, n, h, w, generator=g)
+    xs = torch.randn(b, c, generator=g) if scales else None
+    gs = torch.randn(b, n, generator=g) if scales else None
+
+    def ref(xv, gv, xsv, gsv):
+        wref = torch.zeros(n, c, 3, 3, dtype=torch.float64, requires_grad=True)
+        xin = xv.double() * (xsv.double()[:, :, None, None] if xsv is not None else 1.0)
+        gin = gv.double() * (gsv.double()[:, :, None, None] if gsv is not None else 1.0)
+        (gw,) = torch.autograd.grad(F.conv2d(xin, wref, padding=1), wref, gin)
+        return gw.permute(2, 3, 1, 0).reshape(9, c, n)
+
+    want = ref(x, gy, xs, gs)
+    mag = ref(x.abs(), gy.abs(), xs.abs() if scales else None, gs.abs() if scales else None)
+    args = [t.to(DEV) if t is not None else None for t in (x, gy, xs, gs)]
+    monkeypatch.setenv("SR_WINOGRAD", "1")
+    wino = conv2d_wgrad_mfma(*args, 3, 1, 1).cpu().double()
+    again = conv2d_wgrad_mfma(*args, 3, 1, 1).cpu().double()
+    monkeypatch.setenv("SR_WINOGRAD", "0")
+    direct = conv2d_wgrad_mfma(*args, 3, 1, 1).cpu().double()
+    assert torch.equal(wino, again)                      # fixed-order split-K: run-to-run identical
+    assert float(((wino - want).abs() / mag).max()) < 4e-6
+    assert float(((direct - want).abs() / mag).max()) < 2e-6
+    assert not torch.equal(wino, direct)
