@@ -53,7 +53,8 @@ struct WG {
     static constexpr int D_INSTR = (D_FLOATS / 4 + 63) / 64;
     static constexpr int D_BUF = D_INSTR * 256;
     static constexpr int D_PER_WAVE = (D_INSTR + 3) / 4;
-    static constexpr int STY = 4 * UV + 2 * D_BUF;          // style row offset
+    static constexpr int PAD = 4 * UV + 2 * D_BUF;          // landing zone of surplus DMA instructions (3 x 1 KB)
+    static constexpr int STY = PAD + 3 * 256;               // style row offset
 };
 
 template <int KC>
@@ -108,25 +109,25 @@ __global__ __launch_bounds__(256) void k_conv_wino(const WinoParams p) {
     const int chunk_in = KC * p.H * p.W;
     const float* u_n = p.u + (int64_t)n_t * nchunks * G::UV + lane * 4;
 
+    // one DMA instruction each (all waves issue the same number; surplus ones land in the pad zone)
+    auto dma_d1 = [&](int k, int buf, int i) {
+        const int j = wave + 4 * i;
+        float* dst = j < G::D_INSTR ? dbuf + buf * G::D_BUF + j * 256 : smem + G::PAD + (wave - 1) * 256;
+        const float* src = d_src[i] >= 0 ? in_b + (int64_t)k * chunk_in + d_src[i] : g_wino_zero;
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)dst, 16, 0, 0);
+    };
+    auto dma_u1 = [&](int k, int buf, int i) {
+        const int j = wave + 4 * i;
+        __builtin_amdgcn_global_load_lds((gptr_t)(u_n + (int64_t)k * G::UV + j * 256),
+                                         (lptr_t)(ubuf + buf * G::UV + j * 256), 16, 0, 0);
+    };
     auto dma_d = [&](int k, int buf) {
-        float* dst = dbuf + buf * G::D_BUF;
 #pragma unroll
-        for (int i = 0; i < G::D_PER_WAVE; ++i) {
-            const int j = wave + 4 * i;
-            if (j < G::D_INSTR) {
-                const float* src = d_src[i] >= 0 ? in_b + (int64_t)k * chunk_in + d_src[i] : g_wino_zero;
-                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(dst + j * 256), 16, 0, 0);
-            }
-        }
+        for (int i = 0; i < G::D_PER_WAVE; ++i) dma_d1(k, buf, i);
     };
     auto dma_u = [&](int k, int buf) {
-        float* dst = ubuf + buf * G::UV;
-        const float* src = u_n + (int64_t)k * G::UV;
 #pragma unroll
-        for (int i = 0; i < G::U_INSTR / 4; ++i) {
-            const int j = wave + 4 * i;
-            __builtin_amdgcn_global_load_lds((gptr_t)(src + j * 256), (lptr_t)(dst + j * 256), 16, 0, 0);
-        }
+        for (int i = 0; i < G::U_INSTR / 4; ++i) dma_u1(k, buf, i);
     };
 
     // ---- input transform item of this thread: tile = lane, channels (ca, ca + 2) of the chunk
@@ -137,6 +138,19 @@ __global__ __launch_bounds__(256) void k_conv_wino(const WinoParams p) {
     const int t_rd = t_ca * PLANE + (2 * (lane >> 4)) * EWP + LEAD + 2 * (lane & 15);
     const int t_wr = t_cq * 256 + t_h * 128 + lane * 2;
 
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    // the same on (channel a, channel b) pairs: v_pk_add_f32 / v_pk_mul_f32, half the VALU issue slots
+    auto bt_row2 = [](const f2 (&d)[16], f2 (&o)[16], int q, f2 s) {
+        f2 t[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            t[j] = q == 0 ? d[j] - d[8 + j] : q == 1 ? d[4 + j] + d[8 + j] : q == 2 ? d[8 + j] - d[4 + j]
+                                                                          : d[4 + j] - d[12 + j];
+        o[4 * q + 0] = (t[0] - t[2]) * s;
+        o[4 * q + 1] = (t[1] + t[2]) * s;
+        o[4 * q + 2] = (t[2] - t[1]) * s;
+        o[4 * q + 3] = (t[1] - t[3]) * s;
+    };
     // B^T d B of one channel, row q of the 4x4 result (12 VALU ops), style multiplied in
     auto bt_row = [](const float (&d)[16], float (&o)[16], int q, float s) {
         float t[4];
@@ -197,16 +211,19 @@ __global__ __launch_bounds__(256) void k_conv_wino(const WinoParams p) {
         // V[k] complete, d[k+1] / U[k] landed (every wave drained its own DMAs), iteration k-1's buffers free
         __builtin_amdgcn_s_waitcnt(0x0F70);
         __syncthreads();
-        if (k + 2 < nchunks) dma_d(k + 2, k & 1);
-        if (k + 1 < nchunks) dma_u(k + 1, (k + 1) & 1);
+        // chunks fetched during this iteration (clamped at the end: a redundant fetch into a free buffer
+        // keeps the loop body branch-free): d[k+2] -> dbuf[k & 1], U[k+1] -> ubuf[(k+1) & 1]
+        const int kd = min(k + 2, nchunks - 1), ku = min(k + 1, nchunks - 1);
         const float* ub = ubuf + (k & 1) * G::UV + a_off;
         const float* vb_ = vbuf + (k & 1) * G::UV + b_off;
         // transform of chunk k+1 (garbage in, unused out on the last iteration: no branch in this block)
         const int kn = (k + 1 < nchunks) ? k + 1 : k;
         const float* d0 = dbuf + ((k + 1) & 1) * G::D_BUF + t_rd;
         float* vout = vbuf + ((k + 1) & 1) * G::UV + t_wr;
-        const float sa = sty[kn * KC + t_ca], sb = sty[kn * KC + t_ca + 2];
-        float da[16], db[16], va[16], vb[16];
+        f2 sab;
+        sab.x = sty[kn * KC + t_ca];
+        sab.y = sty[kn * KC + t_ca + 2];
+        f2 dd[16], vv[16];                                       // (channel a, channel b) pairs: packed VALU ops
         float ax[2][16], ay[2][16], xx[2][16], xy[2][16];       // operand sets of the two channel quads
         auto load_ops = [&](int cq, int pos) {
             ax[cq][pos] = ub[pos * G::PS + cq * 256];
@@ -227,28 +244,36 @@ __global__ __launch_bounds__(256) void k_conv_wino(const WinoParams p) {
                 if (m < 16) acc[pos] = __builtin_amdgcn_mfma_f32_32x32x2f32(ax[cq][pos], xx[cq][pos], acc[pos], 0, 0, 0);
                 else acc[pos] = __builtin_amdgcn_mfma_f32_32x32x2f32(ay[cq][pos], xy[cq][pos], acc[pos], 0, 0, 0);
             }
-            if (s < 4) {                         // halo reads: 8 floats per slot
+#ifndef WINO_NO_DMA
+            // one DMA instruction per slot, under the MFMAs (4 halo + 8 weight instructions per wave)
+            if (s < 4) dma_d1(kd, k & 1, s);
+            else if (s < 12) dma_u1(ku, (k + 1) & 1, s - 4);
+#endif
+#ifndef WINO_NO_XFORM
+            if (s < 4) {                         // halo reads: 4 positions of both channels per slot
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const int idx = 8 * (s & 1) + e, r = idx >> 2, jj = idx & 3;
-                    if (s < 2) da[idx] = d0[r * EWP + jj];
-                    else db[idx] = d0[2 * PLANE + r * EWP + jj];
+                for (int e = 0; e < 4; ++e) {
+                    const int idx = 4 * s + e, r = idx >> 2, jj = idx & 3;
+                    dd[idx].x = d0[r * EWP + jj];
+                    dd[idx].y = d0[2 * PLANE + r * EWP + jj];
                 }
             }
+#endif
             if (s >= 2 && s < 6) {               // operands of the second quad: 4 positions per slot
 #pragma unroll
                 for (int e = 0; e < 4; ++e) load_ops(1, 4 * (s - 2) + e);
             }
-            if (s >= 4 && s < 8) bt_row(da, va, s - 4, sa);
-            if (s >= 8 && s < 12) bt_row(db, vb, s - 8, sb);
+#ifndef WINO_NO_XFORM
+            if (s >= 6 && s < 10) bt_row2(dd, vv, s - 6, sab);
             if (s >= 12) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int pos = 4 * (s - 12) + e;
-                    vout[pos * G::PS] = va[pos];
-                    vout[pos * G::PS + 1] = vb[pos];
+                    vout[pos * G::PS] = vv[pos].x;
+                    vout[pos * G::PS + 1] = vv[pos].y;
                 }
             }
+#endif
             __builtin_amdgcn_sched_barrier(0);
         }
     }
