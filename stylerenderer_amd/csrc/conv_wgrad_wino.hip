@@ -125,30 +125,41 @@ __global__ __launch_bounds__(256) void k_wgrad_wino(const WgWinoParams p) {
     }
     const int64_t plane = (int64_t)p.H * p.W;
 
-    // strip coordinates of the chunk the NEXT dma() call fetches (advanced incrementally)
+    // strip coordinates of the chunk the next fetch brings in (advanced incrementally, clamped at the last
+    // chunk of the tensor so that a surplus fetch at the end of a slice stays in bounds)
     int d_txc = k_beg % p.ctx, d_ty = (k_beg / p.ctx) % p.cty, d_b = k_beg / (p.ctx * p.cty);
-    auto dma_next = [&](int buf) {
+    const float* d_xo;
+    const float* d_go;
+    int d_edge;
+    float* d_dst;
+    auto dma_begin = [&](int buf) {          // uniform part of one chunk fetch
         const int y0 = 2 * d_ty, x0 = 16 * d_txc;
-        const float* xo = p.x + ((int64_t)d_b * p.C + c0) * plane + (int64_t)y0 * p.W + x0;
-        const float* go = p.gy + ((int64_t)d_b * p.N + n0) * plane + (int64_t)y0 * p.W + x0;
-        const int edge = (d_ty == 0 ? 1 : 0) | (d_ty == p.cty - 1 ? 2 : 0) | (d_txc == 0 ? 4 : 0) |
-                         (d_txc == p.ctx - 1 ? 8 : 0);
-        float* dst = smem + buf * BUF;
-#pragma unroll
-        for (int i = 0; i < X_PER_WAVE; ++i) {
-            const float* src = (xd_flag[i] & edge) ? g_wgw_zero : xo + xd_off[i];
-            __builtin_amdgcn_global_load_lds(
-                (gptr_t)src, (lptr_t)(wave + 4 * i < X_INSTR ? dst + (wave + 4 * i) * 256 : pad + wave * 256), 16, 0, 0);
-        }
-#pragma unroll
-        for (int i = 0; i < G_PER_WAVE; ++i)
-            __builtin_amdgcn_global_load_lds(
-                (gptr_t)(go + gd_off[i]),
-                (lptr_t)(wave + 4 * i < G_INSTR ? dst + X_FLOATS + (wave + 4 * i) * 256 : pad + wave * 256), 16, 0, 0);
-        if (++d_txc == p.ctx) {
+        d_xo = p.x + ((int64_t)d_b * p.C + c0) * plane + (int64_t)y0 * p.W + x0;
+        d_go = p.gy + ((int64_t)d_b * p.N + n0) * plane + (int64_t)y0 * p.W + x0;
+        d_edge = (d_ty == 0 ? 1 : 0) | (d_ty == p.cty - 1 ? 2 : 0) | (d_txc == 0 ? 4 : 0) | (d_txc == p.ctx - 1 ? 8 : 0);
+        d_dst = smem + buf * BUF;
+        const bool last = d_txc == p.ctx - 1 && d_ty == p.cty - 1 && d_b == p.B - 1;
+        if (!last && ++d_txc == p.ctx) {
             d_txc = 0;
             if (++d_ty == p.cty) { d_ty = 0; ++d_b; }
         }
+    };
+    auto dma_x1 = [&](int i) {
+        const float* src = (xd_flag[i] & d_edge) ? g_wgw_zero : d_xo + xd_off[i];
+        __builtin_amdgcn_global_load_lds(
+            (gptr_t)src, (lptr_t)(wave + 4 * i < X_INSTR ? d_dst + (wave + 4 * i) * 256 : pad + wave * 256), 16, 0, 0);
+    };
+    auto dma_g1 = [&](int i) {
+        __builtin_amdgcn_global_load_lds(
+            (gptr_t)(d_go + gd_off[i]),
+            (lptr_t)(wave + 4 * i < G_INSTR ? d_dst + X_FLOATS + (wave + 4 * i) * 256 : pad + wave * 256), 16, 0, 0);
+    };
+    auto dma_next = [&](int buf) {
+        dma_begin(buf);
+#pragma unroll
+        for (int i = 0; i < X_PER_WAVE; ++i) dma_x1(i);
+#pragma unroll
+        for (int i = 0; i < G_PER_WAVE; ++i) dma_g1(i);
     };
 
     f32x16 acc[16];
@@ -226,11 +237,10 @@ __global__ __launch_bounds__(256) void k_wgrad_wino(const WgWinoParams p) {
     float V[2][16], Z[2][16];
     Raw R;
     float sx, sg;
-    if (k_beg < k_end) dma_next(0);
-    if (k_beg + 1 < k_end) dma_next(1);
-    if (k_beg + 2 < k_end) dma_next(2);
-    if (k_beg + 2 < k_end) asm volatile("s_waitcnt vmcnt(20) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    dma_next(0);
+    dma_next(1);
+    dma_next(2);
+    asm volatile("s_waitcnt vmcnt(20) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     scales_next(sx, sg);
 #ifdef WGW_NO_XFORM
 #pragma unroll
@@ -242,11 +252,10 @@ __global__ __launch_bounds__(256) void k_wgrad_wino(const WgWinoParams p) {
 #endif
     int cur = 0;
     for (int kk = k_beg; kk < k_end; ++kk) {
-        if (kk + 2 < k_end) asm volatile("s_waitcnt vmcnt(10) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-#ifndef WGW_NO_DMA
-        if (kk + 3 < k_end) dma_next((cur + 3) & 3);
-#endif
+        asm volatile("s_waitcnt vmcnt(10) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        // chunk kk+3 (a surplus fetch past the slice lands in a free buffer): its 10 DMA instructions are
+        // spread over the four k-steps below, under the MFMAs; no branch in the loop body
+        dma_begin((cur + 3) & 3);
         const unsigned xaddr = lds0 + (unsigned)(cur * BUF + xb) * 4u, gaddr = lds0 + (unsigned)(cur * BUF + gb) * 4u;
         const int nxt = (cur + 1) & 3;
         const unsigned xaddr_n = lds0 + (unsigned)(nxt * BUF + xb) * 4u, gaddr_n = lds0 + (unsigned)(nxt * BUF + gb) * 4u;
@@ -271,13 +280,20 @@ __global__ __launch_bounds__(256) void k_wgrad_wino(const WgWinoParams p) {
 #pragma unroll
             for (int pos = 2; pos < 16; ++pos)
                 acc[pos] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[ks & 1][pos], Z[ks & 1][pos], acc[pos], 0, 0, 0);
+#ifndef WGW_NO_DMA
+            if (ks == 0) { dma_x1(0); dma_x1(1); dma_x1(2); }
+            if (ks == 1) { dma_x1(3); dma_x1(4); dma_x1(5); }
+            if (ks == 2) { dma_x1(6); dma_g1(0); dma_g1(1); }
+            if (ks == 3) dma_g1(2);
+#endif
 #ifndef WGW_NO_XFORM
             if (ks + 1 < 4) transform(R, ks + 1, sx, sg, V[(ks + 1) & 1], Z[(ks + 1) & 1]);
             else transform(R, 0, sxn, sgn, V[0], Z[0]);
 #pragma unroll
             for (int i = 0; i < 14; ++i) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
+                if (i % 4 == 1) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
             }
 #endif
             __builtin_amdgcn_sched_barrier(0);
@@ -286,6 +302,8 @@ __global__ __launch_bounds__(256) void k_wgrad_wino(const WgWinoParams p) {
         sg = sgn;
         cur = nxt;
     }
+    // surplus fetches are still landing in this workgroup's LDS: drain them before the wave can retire
+    __builtin_amdgcn_s_waitcnt(0x0F70);
 
     // ---- partial dU slab of this slice: rows = channels (r & 3) + 8 (r >> 2) + 4 half, cols = l31
     float* out = p.partial + (int64_t)slice * 16 * p.C * p.N;

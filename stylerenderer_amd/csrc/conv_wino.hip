@@ -278,6 +278,10 @@ __global__ __launch_bounds__(256) void k_conv_wino(const WinoParams p) {
         }
     }
 
+    // the clamped fetches of the last iteration are still landing in this workgroup's LDS: drain them
+    // before the wave can retire
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+
     // ---- epilogue: Y = A^T M A per (tile, channel); C/D layout: column (tile) = lane & 31,
     // row (channel) = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
     const int tile = wt * 32 + l31;
