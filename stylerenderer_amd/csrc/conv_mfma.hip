@@ -20,8 +20,9 @@
 //         tap reads it at a shifted address (9x less staging than im2col); the chunk's weights
 //         [taps][KC][128] sit next to it.  Operand fetch is one conflict-free ds_read_b32 per MFMA
 //         operand (lanes 0-31 = 32 consecutive pixels / channels, lanes 32-63 = the next k).
-//   pipe  LDS is double buffered and filled by LDS-DMA (global_load_lds, 16 B/lane for weights,
-//         4 B/lane for the halo patch whose rows are not 16-byte aligned): no staging VGPRs, no
+//   pipe  LDS is double buffered and filled by LDS-DMA (global_load_lds, 16 B/lane for weights and,
+//         when the map is >= 32 wide and 16-byte aligned, for the halo patch too (Geo<.., V4>: aligned
+//         window with LEAD extra columns); 4 B/lane otherwise): no staging VGPRs, no
 //         LDS-write phase, no load result is consumed by VALU, so nothing waits on memory in front of
 //         the MFMA block; chunk i+1 streams in while chunk i is on the matrix cores; ONE barrier
 //         per chunk.  Border / channel-tail elements are sourced from a zero line, the style from a
@@ -29,8 +30,10 @@
 //   out   lane (l & 31) owns a pixel, registers own channels: every store instruction writes
 //         32 consecutive pixels of one channel row per half-wave (128 B segments).
 // Variants by template: input stride 1 / 2, tap window (3x3, 2x2, 2x1, 1x2, 1x1) — the stride-2
-// transposed convolution of the upsampling layers is run as its four output phases — and the patch
-// shape for 4x4 ... 256x256 feature maps.
+// transposed convolution of the upsampling layers is run as its four output phases (interior +
+// border strips) — and the patch shape for 4x4 ... 256x256 feature maps; small maps split K.
+// The stride-1 3x3 case of maps >= 32 wide is normally taken by the Winograd kernel (conv_wino.hip);
+// this file then serves the strided / transposed / 1x1 / small-map launches and SR_WINOGRAD=0.
 #include "common.h"
 #include "conv_wino.h"
 
