@@ -98,6 +98,15 @@ int64_t sr_smallconv_dw_scratch_floats(int64_t B, int64_t C, int64_t N, int64_t 
 int sr_smallconv_dw(float* dws, const float* g, const float* x, int64_t B, int64_t C, int64_t N, int64_t hw,
                     float* scratch, sr_stream_t stream);
 
+/* Vertex normals of a posed mesh (replaces reference utils_3d.py:379-404 mesh_point_normal: three
+ * sparse.mm scatters + layers.py:13-34 Normalize).  v [B, nv, 3]; tri [nf, 3] int64 with ids in
+ * [0, nv); (adj_off [nv + 1], adj [3 nf]) = CSR list of the corner-major incidences k*nf + f of every
+ * vertex, ascending (the caller builds it once per topology).  vn [B, nv, 3] = sum of incident face
+ * normals (b-a)x(c-a), divided by max(|.|, eps); norm_out [B, nv] (may be NULL) = the clamped length.
+ * Gather in a fixed order: deterministic, no atomics. */
+int sr_vertex_normals_f32(float* vn, float* norm_out, const float* v, const int64_t* tri, const int32_t* adj_off,
+                          const int32_t* adj, int64_t B, int64_t nv, int64_t nf, float eps, sr_stream_t stream);
+
 /* Skinny linear algebra of the style path, B = per-GPU batch rows (csrc/style_linear.hip).
  * EqualLinear (reference layers.py:222-248), optionally with the fused leaky-ReLU of the mapping
  * network (act != 0: op/fused_act.py:86-97 semantics, bias inside the activation):

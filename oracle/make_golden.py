@@ -350,14 +350,51 @@ def gold_raster(ns):
          coeff_bf=c_bf, covered_bf=np.array(int((idx_bf != 0).any(-1).sum())))
 
 
+
+# ------------------------------------------------------------------------------- mesh front-end
+def gold_mesh(ns):
+    """reference utils_3d.py: euler_mat, mesh_point_normal (+ gradient), pose application with given
+    transforms; face_model.LinearMorphableModel with given bases."""
+    sys.path.insert(0, ref_shim.REF)                            # reference modules (layers already shimmed)
+    try:
+        import utils_3d as ref3d
+        import face_model as ref_fm
+    finally:
+        sys.path.remove(ref_shim.REF)
+
+    v0, tri = synth.uv_ellipsoid(12, 10)
+    v = synth.random_poses(v0, 3, seed=7)
+    vt = T(v).requires_grad_(True)
+    trit = T(tri.astype(np.int64))
+    n = ref3d.mesh_point_normal(vt, trit)
+    proj = T(dn(tuple(n.shape), 71))
+    (gv,) = torch.autograd.grad((n * proj).sum(), vt)
+    ang = T(dn((4, 3), 72))
+    R = ref3d.euler_mat(ang, "yxz")
+    R2 = ref3d.euler_mat(ang[0], "zyx")
+    nrm = ref3d.normalize(T(dn((5, 3), 73)) * T(np.array([[1.0], [1e-9], [2.0], [0.0], [3.0]], np.float32)))
+    # LMM with explicit data (constructor paths for mean / bases / sigmas)
+    nv, ds, de = 7, 3, 2
+    mean = dn((nv, 3), 74)
+    wsh = dn((ds, nv * 3), 75)
+    wex = dn((nv * 3, de), 76)                                  # transposed layout on purpose
+    m = ref_fm.LinearMorphableModel(nv, ds, de, mean, wsh, wex, sigma_shape=[1.5, 2.0], sigma_expression=.25)
+    x = T(dn((4, ds + de), 77))
+    save("mesh_frontend", v=v, tri=tri.astype(np.int32), normals=n.detach().numpy(), grad_v=gv.numpy(),
+         euler_in=ang.numpy(), euler_yxz=R.numpy(), euler_zyx_single=R2.numpy(), normalize_out=nrm.numpy(),
+         lmm_mean=mean, lmm_wsh=wsh, lmm_wex=wex, lmm_x=x.numpy(), lmm_out=m(x).detach().numpy(),
+         lmm_sigma=m.sigma.detach().numpy(), lmm_reg=np.array(m.regulation(x).item()),
+         lmm_keys=np.array(sorted(m.state_dict().keys())))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     ns = ref_shim.load()
     torch.manual_seed(0)
-    which = sys.argv[1:] or ["fused", "ufd", "modconv", "gen", "gwm", "disc", "raster"]
+    which = sys.argv[1:] or ["fused", "ufd", "modconv", "gen", "gwm", "disc", "raster", "mesh"]
     table = {"fused": gold_fused_act, "ufd": gold_upfirdn2d, "modconv": gold_modconv,
              "gen": gold_generator, "gwm": gold_generator_with_map, "disc": gold_discriminator,
-             "raster": gold_raster}
+             "raster": gold_raster, "mesh": gold_mesh}
     with torch.no_grad():
         pass
     for k in which:

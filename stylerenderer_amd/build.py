@@ -28,6 +28,7 @@ SOURCES = [
     ("fused_elem.hip", EXACT),
     ("weight_prep.hip", EXACT),
     ("style_linear.hip", EXACT),
+    ("mesh.hip", EXACT),
     ("conv_mfma.hip", []),
     ("conv_wino.hip", []),
     ("conv_wgrad_wino.hip", []),

@@ -220,6 +220,36 @@ def synthetic_mesh(batch, device, seed=0, face_sized=True):
     return (torch.from_numpy(v).to(device), torch.from_numpy(nrm).to(device), torch.from_numpy(tri).to(device))
 
 
+class SyntheticFaceSource:
+    """Per-iteration mesh sampling of the reference's training loop (train.py:246-251: coefficients ->
+    3DMM vertices -> random pose -> vertex normals), with a synthetic 3DMM: the face-sized UV mesh as the
+    mean (BFM itself is licensed and absent) and small random shape / expression bases.  Everything runs
+    on the device: one GEMM, one small matmul, one gather kernel (utils_3d.mesh_point_normal)."""
+
+    def __init__(self, device, shape_dim=80, expression_dim=64, seed=0, face_sized=True):
+        from . import face_model, utils_3d
+
+        v0, tri = synth.face_sized_mesh() if face_sized else synth.uv_ellipsoid(16, 14)
+        nv = v0.shape[0]
+        state = np.random.get_state()
+        np.random.seed(seed)
+        try:
+            wsh = synth.det_normal((shape_dim, nv * 3), 901) * 0.01
+            wex = synth.det_normal((expression_dim, nv * 3), 902) * 0.5
+            self.model = face_model.LinearMorphableModel(nv, shape_dim, expression_dim, v0, wsh, wex).to(device)
+        finally:
+            np.random.set_state(state)
+        self.tri = torch.from_numpy(tri.astype(np.int64)).to(device)
+        self.device = device
+        self._u = utils_3d
+
+    @torch.no_grad()
+    def sample(self, batch):
+        coeff = self.model.random_input(batch).to(self.device)
+        vert = self._u.random_apply_pose3D(v=self.model(coeff))
+        return vert, self._u.mesh_point_normal(vert, self.tri), self.tri
+
+
 def main():
     ap = argparse.ArgumentParser(description="StyleRenderer training step on synthetic data")
     ap.add_argument("--iter", type=int, default=16)
@@ -243,14 +273,14 @@ def main():
                  args.path_regularize, args.path_batch_shrink, args.d_reg_every, args.g_reg_every,
                  args.mixing, args.mesh, device, args.seed)
     data = SyntheticImages(max(64, args.batch * 4), args.size, device)
-    mesh = synthetic_mesh(args.batch, device, seed=rank) if args.mesh else None
+    faces = SyntheticFaceSource(device, seed=args.seed) if args.mesh else None
     t0 = None
     for it in range(args.iter):
         if it == 1:
             if device.type == "cuda":
                 torch.cuda.synchronize()
             t0 = time.perf_counter()
-        out = tr.step(data.batch(args.batch), mesh)
+        out = tr.step(data.batch(args.batch), faces.sample(args.batch) if faces else None)
         if rank == 0:
             print("iter %d  " % it + "  ".join("%s %.4f" % kv for kv in sorted(out.items())), flush=True)
     if device.type == "cuda":

@@ -1,0 +1,149 @@
+"""Mesh front-end of the rasterizer: the three helpers the reference's training loop calls between the
+3DMM and GeneratorWithMap (reference train.py:229-230, 250-251, 305-306) — same names and argument
+meaning as reference utils_3d.py / layers.py:
+
+    normalize(vec, axis=-1, _type='L2', eps=1e-8)          layers.py:13-53 (Normalize)
+    euler_mat(angle, _type='yxz')                          utils_3d.py:43-80
+    random_apply_pose3D(p=[...], v=None)                   utils_3d.py:360-378
+    mesh_point_normal(v, tri)                              utils_3d.py:379-404
+
+`mesh_point_normal` on device tensors runs ONE gather kernel (csrc/mesh.hip, C ABI
+sr_vertex_normals_f32) over a per-topology incidence list built once and cached, instead of three
+sparse.mm scatters over index tensors rebuilt in Python on every call; it is deterministic and
+differentiable (first and higher order through the defining tensor algebra).
+"""
+import torch
+from torch.autograd import Function
+
+from . import _lib
+from .op._dispatch import on_device_of, stream_of
+
+
+def normalize(vec, axis=-1, _type="L2", eps=1e-8):
+    eps = abs(eps)
+    kind = _type.upper()
+    if "L2" in kind:
+        norm = torch.sqrt(torch.sum(vec * vec, axis, keepdim=True))
+    elif "L1" in kind:
+        norm = torch.sum(vec, axis, keepdim=True)              # (sic) the reference sums signed entries
+    elif "LINF" in kind:
+        norm = torch.max(torch.abs(vec), axis, keepdim=True)[0]
+    else:
+        raise ValueError("normalize: unknown type %r" % (_type,))
+    # the reference's hand-written backward treats the clamp as pass-through: same here
+    norm = norm + (torch.clamp(norm, min=eps) - norm).detach()
+    return vec / norm
+
+
+def euler_mat(angle, _type="yxz"):
+    """Rotation matrices from Euler angles; axis i of `_type` uses angle[:, i]; later axes multiply
+    from the left (T = R_i @ T)."""
+    single = angle.dim() == 1
+    a = angle.view(1, -1) if single else angle
+    c, s = torch.cos(a), torch.sin(a)
+    one = torch.ones(len(c), 1, dtype=c.dtype, device=c.device)
+    zero = torch.zeros(len(c), 1, dtype=c.dtype, device=c.device)
+    T = None
+    for i in range(3):
+        ci, si = c[:, i:i + 1], s[:, i:i + 1]
+        ax = _type[i].lower()
+        if ax == "x":
+            rows = (one, zero, zero, zero, ci, -si, zero, si, ci)
+        elif ax == "y":
+            rows = (ci, zero, si, zero, one, zero, -si, zero, ci)
+        elif ax == "z":
+            rows = (ci, -si, zero, si, ci, zero, zero, zero, one)
+        else:
+            continue
+        R = torch.cat(rows, -1).view(-1, 3, 3)
+        T = R if T is None else torch.matmul(R, T)
+    return T.view(3, 3) if single else T
+
+
+def random_apply_pose3D(p=[.5, .1, .05, .1, .1, .1, .15], v=None):
+    """p = sigmas of [yaw, pitch, roll, tx, ty, tz, log-scale]; returns the posed vertices
+    v @ (scale * R) + t (row-vector convention of the reference), or one 3x4 transform when v is None."""
+    batch = len(v) if v is not None and v.dim() >= 3 else 1
+    if not isinstance(p, torch.Tensor):
+        p = torch.Tensor(p)
+    p = torch.abs(p.reshape(-1)[:7])
+    if len(p) < 7:
+        p = torch.cat((p, torch.zeros(7 - len(p), dtype=p.dtype, device=p.device)))
+    z = torch.normal(mean=0, std=p.unsqueeze(0).expand(batch, -1))
+    T = torch.cat((torch.exp(z[:, -1]).view(-1, 1, 1) * euler_mat(z[:, :3], "yxz"), z[:, 3:6].view(-1, 3, 1)), -1)
+    if v is None:
+        return T[0]
+    T = T.to(v.device)
+    return torch.matmul(v[..., :3].reshape(batch, -1, 3), T[:, :3, :3]) + T[:, :3, 3:].view(-1, 1, 3)
+
+
+# ---- vertex normals -------------------------------------------------------------------------------
+_ADJ_CACHE = {}
+
+
+def incidence_lists(tri, nv):
+    """CSR incidence of a [nf, 3] triangle list: (adj_off [nv+1] int32, adj [3 nf] int32) with the entries
+    of vertex i = ascending corner-major indices k*nf + f such that tri[f, k] == i.  Cached per tensor."""
+    key = (tri.data_ptr(), tuple(tri.shape), tri._version, str(tri.device), int(nv))
+    hit = _ADJ_CACHE.get(key)
+    if hit is not None:
+        return hit
+    flat = tri.t().reshape(-1)                                   # corner-major: index = k*nf + f
+    if flat.numel() and (int(flat.min()) < 0 or int(flat.max()) >= nv):
+        raise RuntimeError("mesh_point_normal: triangle index out of range [0, %d)" % nv)
+    order = torch.sort(flat, stable=True)[1].to(torch.int32)
+    counts = torch.bincount(flat, minlength=nv)
+    off = torch.zeros(nv + 1, dtype=torch.int32, device=tri.device)
+    off[1:] = torch.cumsum(counts, 0).to(torch.int32)
+    if len(_ADJ_CACHE) > 16:
+        _ADJ_CACHE.clear()
+    _ADJ_CACHE[key] = (off, order.contiguous(), tri)             # keep `tri` alive: the key holds its address
+    return _ADJ_CACHE[key]
+
+
+def _normals_composite(v, tri):
+    """The defining tensor algebra (reference utils_3d.py:380-404 with index_add in place of sparse.mm)."""
+    va, vb, vc = v[:, tri[:, 0]], v[:, tri[:, 1]], v[:, tri[:, 2]]
+    fn = torch.cross(vb - va, vc - va, dim=2)
+    vn = torch.zeros_like(v[:, :, :3])
+    for j in range(3):
+        vn = vn + torch.zeros_like(vn).index_add_(1, tri[:, j], fn)
+    return normalize(vn)
+
+
+class _VertexNormals(Function):
+    @staticmethod
+    def forward(ctx, v, tri):
+        vc = v.contiguous()
+        b, nv, _ = vc.shape
+        off, adj, _ = incidence_lists(tri, nv)
+        tric = tri.contiguous()
+        out = torch.empty_like(vc)
+        with on_device_of(vc):
+            rc = _lib.lib().sr_vertex_normals_f32(_lib.ptr(out), None, _lib.ptr(vc), _lib.ptr(tric), _lib.ptr(off),
+                                                  _lib.ptr(adj), b, nv, tric.size(0), 1e-8, stream_of(vc))
+        _lib.check(rc, "sr_vertex_normals_f32")
+        ctx.save_for_backward(v, tri)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        v, tri = ctx.saved_tensors
+        higher = torch.is_grad_enabled()                         # create_graph=True upstream
+        with torch.enable_grad():
+            vv = v if (higher and v.requires_grad) else v.detach().requires_grad_(True)
+            out = _normals_composite(vv, tri)
+            (gv,) = torch.autograd.grad(out, vv, g, create_graph=higher)
+        return gv, None
+
+
+def mesh_point_normal(v, tri):
+    """Area-weighted, normalised vertex normals [B, nv, 3] of vertices v [B, nv, >=3] and triangles
+    tri [nf, 3] (int64)."""
+    if v.dim() != 3 or tri.dim() != 2 or tri.size(1) != 3:
+        raise ValueError("mesh_point_normal: expected v [B, nv, 3+] and tri [nf, 3]")
+    if v.dtype not in (torch.float32, torch.float64):
+        raise ValueError("Not supported type")
+    if v.device.type == "cuda" and v.dtype == torch.float32:
+        return _VertexNormals.apply(v[:, :, :3], tri)
+    return _normals_composite(v[:, :, :3], tri)

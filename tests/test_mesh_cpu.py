@@ -1,0 +1,72 @@
+"""CPU: mesh front-end (utils_3d / face_model mirrors of the reference) against golden vectors the
+reference produced (oracle/make_golden.py gold_mesh; reference utils_3d.py:43-80, 360-404,
+face_model.py:4-74, layers.py:13-53)."""
+import numpy as np
+import torch
+
+from stylerenderer_amd import face_model, utils_3d
+from util import rel_err
+
+T = torch.from_numpy
+
+
+def test_euler_and_normalize_match_reference(golden):
+    g = golden("mesh_frontend")
+    ang = T(g["euler_in"])
+    assert rel_err(utils_3d.euler_mat(ang, "yxz").numpy(), g["euler_yxz"]) < 1e-6
+    assert rel_err(utils_3d.euler_mat(ang[0], "zyx").numpy(), g["euler_zyx_single"]) < 1e-6
+    from stylerenderer_amd import synth
+
+    x = T(synth.det_normal((5, 3), 73)) * T(np.array([[1.0], [1e-9], [2.0], [0.0], [3.0]], np.float32))
+    assert np.allclose(utils_3d.normalize(x).numpy(), g["normalize_out"], rtol=1e-6, atol=1e-7)
+
+
+def test_mesh_point_normal_cpu_matches_reference(golden):
+    g = golden("mesh_frontend")
+    v = T(g["v"]).requires_grad_(True)
+    tri = T(g["tri"].astype(np.int64))
+    n = utils_3d.mesh_point_normal(v, tri)
+    assert rel_err(n.detach().numpy(), g["normals"]) < 2e-6
+    from stylerenderer_amd import synth
+
+    proj = T(synth.det_normal(tuple(n.shape), 71))
+    (gv,) = torch.autograd.grad((n * proj).sum(), v)
+    assert rel_err(gv.numpy(), g["grad_v"]) < 1e-5
+
+
+def test_incidence_lists_order():
+    tri = torch.tensor([[0, 1, 2], [2, 1, 3], [0, 2, 3]], dtype=torch.int64)
+    off, adj, _ = utils_3d.incidence_lists(tri, 5)
+    assert off.tolist() == [0, 2, 4, 7, 9, 9]
+    nf = 3
+    # vertex 2: corner 0 of face 1 (idx 1), corner 1 of face 2 (idx nf+2), corner 2 of face 0 (idx 2nf+0)
+    assert adj[off[2]:off[3]].tolist() == [1, nf + 2, 2 * nf + 0]
+    try:
+        utils_3d.incidence_lists(torch.tensor([[0, 1, 9]]), 5)
+    except RuntimeError as e:
+        assert "out of range" in str(e)
+    else:
+        raise AssertionError("expected a range error")
+
+
+def test_pose_application_semantics():
+    torch.manual_seed(3)
+    v = torch.randn(2, 11, 3)
+    out = utils_3d.random_apply_pose3D(p=[0, 0, 0, 0, 0, 0, 0], v=v)          # zero sigmas: identity
+    assert torch.allclose(out, v, atol=1e-6)
+    Tm = utils_3d.random_apply_pose3D()
+    assert tuple(Tm.shape) == (3, 4)
+    out = utils_3d.random_apply_pose3D(v=v)
+    assert tuple(out.shape) == (2, 11, 3) and torch.isfinite(out).all()
+
+
+def test_linear_morphable_model_matches_reference(golden):
+    g = golden("mesh_frontend")
+    m = face_model.LinearMorphableModel(7, 3, 2, g["lmm_mean"], g["lmm_wsh"], g["lmm_wex"], sigma_shape=[1.5, 2.0],
+                                        sigma_expression=.25)
+    assert sorted(m.state_dict().keys()) == list(g["lmm_keys"])
+    assert np.allclose(m.sigma.numpy(), g["lmm_sigma"])
+    x = T(g["lmm_x"])
+    assert rel_err(m(x).detach().numpy(), g["lmm_out"]) < 1e-6
+    assert abs(m.regulation(x).item() - float(g["lmm_reg"])) < 1e-4 * abs(float(g["lmm_reg"]))
+    assert not m.fc.weight.requires_grad and tuple(m.random_input(5).shape) == (5, 5)
