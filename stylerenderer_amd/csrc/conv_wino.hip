@@ -245,9 +245,10 @@ __global__ __launch_bounds__(256) void k_conv_wino(const WinoParams p) {
                 else acc[pos] = __builtin_amdgcn_mfma_f32_32x32x2f32(ay[cq][pos], xy[cq][pos], acc[pos], 0, 0, 0);
             }
 #ifndef WINO_NO_DMA
-            // one DMA instruction per slot, under the MFMAs (4 halo + 8 weight instructions per wave)
-            if (s < 4) dma_d1(kd, k & 1, s);
-            else if (s < 12) dma_u1(ku, (k + 1) & 1, s - 4);
+            // two DMA instructions per slot in the first six slots, under the MFMAs (8 weight + 4 halo
+            // instructions per wave): everything is in flight ~10 slots (~1.1 us) before the next barrier
+            if (s < 4) { dma_u1(ku, (k + 1) & 1, 2 * s); dma_u1(ku, (k + 1) & 1, 2 * s + 1); }
+            else if (s < 6) { dma_d1(kd, k & 1, 2 * (s - 4)); dma_d1(kd, k & 1, 2 * (s - 4) + 1); }
 #endif
 #ifndef WINO_NO_XFORM
             if (s < 4) {                         // halo reads: 4 positions of both channels per slot

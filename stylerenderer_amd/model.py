@@ -181,14 +181,17 @@ class Generator(nn.Module):
         latent, noise = self._latents(styles, inject_index, truncation, truncation_latent,
                                       input_is_latent, noise, randomize_noise)
         out = self.input(latent)
-        out = self.conv1(out, latent[:, 0], noise=noise[0])
-        skip = self.to_rgb1(out, latent[:, 1])
+        # one unbind (its backward is one stack) instead of a select per layer, whose backward would
+        # materialise and add a zero-filled [B, n_latent, D] tensor 2 * n_latent times
+        w = latent.unbind(1)
+        out = self.conv1(out, w[0], noise=noise[0])
+        skip = self.to_rgb1(out, w[1])
         i = 1
         for conv_up, conv, n_up, n_conv, to_rgb in zip(self.convs[::2], self.convs[1::2],
                                                        noise[1::2], noise[2::2], self.to_rgbs):
-            out = conv_up(out, latent[:, i], noise=n_up)
-            out = conv(out, latent[:, i + 1], noise=n_conv)
-            skip = to_rgb(out, latent[:, i + 2], skip)
+            out = conv_up(out, w[i], noise=n_up)
+            out = conv(out, w[i + 1], noise=n_conv)
+            skip = to_rgb(out, w[i + 2], skip)
             i += 2
         return skip, (latent if return_latents else None)
 
@@ -220,8 +223,9 @@ class GeneratorWithMap(Generator):
         out = self.input(latent)
         norm_maps = [rasterize(vert, attr, tri, int(out.shape[2]), int(out.shape[3])).permute(0, 3, 1, 2)]
         maps = self.norm1(norm_maps[-1])
-        out = self.conv1(out, latent[:, 0], maps, noise=noise[0])
-        skip = self.to_rgb1(out, latent[:, 1])
+        w = latent.unbind(1)
+        out = self.conv1(out, w[0], maps, noise=noise[0])
+        skip = self.to_rgb1(out, w[1])
         two_stage = len(self.convs) == len(self.norm_to_style)
         i = 1
         for conv_up, conv, n_up, n_conv, to_rgb in zip(self.convs[::2], self.convs[1::2],
@@ -232,9 +236,9 @@ class GeneratorWithMap(Generator):
                 maps = self.norm_to_style[i](self.norm_to_style[i - 1](norm_maps[-1]))
             else:
                 maps = self.norm_to_style[i // 2](norm_maps[-1])
-            out = conv_up(out, latent[:, i], maps[:, :2], noise=n_up)
-            out = conv(out, latent[:, i + 1], maps[:, 2:], noise=n_conv)
-            skip = to_rgb(out, latent[:, i + 2], skip)
+            out = conv_up(out, w[i], maps[:, :2], noise=n_up)
+            out = conv(out, w[i + 1], maps[:, 2:], noise=n_conv)
+            skip = to_rgb(out, w[i + 2], skip)
             i += 2
         return skip, (latent if return_latents else None), (norm_maps if return_normals else None)
 
