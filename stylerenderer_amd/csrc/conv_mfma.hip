@@ -335,6 +335,224 @@ int launch_one(const ConvParams& p, dim3 grid, hipStream_t st) {
     return sr_launch_status();
 }
 
+// ------------------------------------------------------------------------------------------------
+// Stride-2 transposed 3x3 convolution, all four output phases in ONE workgroup (interior of the map).
+//
+// out[2j + py, 2i + px] = sum over the taps (ky, kx) with ky = py (mod 2), kx = px (mod 2) of
+// in[j - (ky >> 1), i - (kx >> 1)] * W[ky][kx]: nine (tap -> phase, input shift) pairs over only four
+// distinct input shifts.  Run as four launches (above) every phase re-stages the same halo patch and
+// the 1- and 2-tap phases are operand-fetch bound (80 TFLOP/s).  Here a wave keeps the 2x2 MFMA tiles
+// of ALL four phases (16 accumulator tiles = 256 registers, one wave per SIMD), so per k-step the 36
+// MFMAs share 8 input operands and 18 weight operands, and the halo patch is staged once.
+// Workgroup = 32x4 input positions (-> 64x8 output pixels) x 128 output channels, K chunks of 4 input
+// channels, double-buffered LDS-DMA as in k_conv_mfma.  The last output row / column (grid row H,
+// column W) are left to the strip launches of the per-phase kernel.
+struct TFused {
+    static constexpr int KC = 8;
+    static constexpr int PW = 32, PH = 4;
+    static constexpr int LEAD = 3;                          // halo columns start at i0 - 4 (aligned); i0 - 1 is column 3
+    static constexpr int EWP = 36;                          // LEAD + 33 columns
+    static constexpr int EH = PH + 1;
+    static constexpr int PLANE = EH * EWP;                  // 180
+    static constexpr int W_FLOATS = 9 * KC * BN;            // [tap][c][128] = 9216
+    static constexpr int W_INSTR = W_FLOATS / 256;          // 36 = 9 per wave
+    static constexpr int I_INSTR = (KC * PLANE / 4 + 63) / 64;   // 6
+    static constexpr int I_FLOATS = I_INSTR * 256;          // 1536
+    static constexpr int BUF = W_FLOATS + I_FLOATS;         // 10752 floats = 42 KB
+    static constexpr int W_PER_WAVE = 9, I_PER_WAVE = 2;    // 36 / 8 instruction slots (surplus -> pad zone)
+    static constexpr int PAD = 2 * BUF;
+    static constexpr int STY = PAD + 4 * 256;
+};
+
+__global__ __launch_bounds__(256) void k_convt_fused(const ConvParams p) {
+    using G = TFused;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* const sty = smem + G::STY;
+
+    const int nwg = gridDim.x;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg / SR_NUM_XCD, r = nwg % SR_NUM_XCD, xcd = bid % SR_NUM_XCD;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + bid / SR_NUM_XCD;
+    }
+    const int n_t = bid % p.tiles_n;
+    bid /= p.tiles_n;
+    const int tx_i = bid % p.tiles_x;
+    bid /= p.tiles_x;
+    const int ty_i = bid % p.tiles_y;
+    const int b = bid / p.tiles_y;
+    const int n0 = n_t * BN, j0 = ty_i * G::PH, i0 = tx_i * G::PW;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = lane >> 5, l31 = lane & 31;
+    const int wco = wave & 1, wpx = wave >> 1;
+
+    for (int c = tid; c < p.C; c += 256) sty[c] = p.iscale ? p.iscale[(int64_t)b * p.C + c] : 1.0f;
+
+    // ---- DMA descriptors (chunk 0)
+    int w_src[G::W_PER_WAVE];
+#pragma unroll
+    for (int i = 0; i < G::W_PER_WAVE; ++i) {
+        const int j = wave + 4 * i;
+        const int row = 2 * j + half;                       // [tap * KC + c]
+        const int t = row / G::KC, c = row % G::KC;
+        const int col = min(n0 + l31 * 4, p.ldw - 4);
+        w_src[i] = j < G::W_INSTR ? (t * p.C + c) * p.ldw + col : 0;
+    }
+    int i_src[G::I_PER_WAVE];                               // -1: outside the image (zero line)
+#pragma unroll
+    for (int i = 0; i < G::I_PER_WAVE; ++i) {
+        const int j = wave + 4 * i;
+        const int f = (j * 64 + lane) * 4;
+        int src = j < G::I_INSTR ? -1 : 0;                  // surplus instruction: any valid address
+        if (j < G::I_INSTR && f < G::KC * G::PLANE) {
+            const int c = f / G::PLANE, q = f % G::PLANE;
+            const int r = q / G::EWP, cola = q % G::EWP;
+            const int gy = j0 - 1 + r, gx = i0 - 4 + cola;
+            if (gy >= 0 && gy < p.IH && gx >= 0 && gx + 3 < p.IW) src = (c * p.IH + gy) * p.IW + gx;
+        }
+        i_src[i] = src;
+    }
+    const float* in_b = p.in + (int64_t)b * p.C * p.IH * p.IW;
+    const int plane_in = p.IH * p.IW;
+
+    auto dma = [&](int c0, int buf) {
+        float* dst = smem + buf * G::BUF;
+#pragma unroll
+        for (int i = 0; i < G::W_PER_WAVE; ++i) {
+            const int j = wave + 4 * i;
+            __builtin_amdgcn_global_load_lds((gptr_t)(p.wt + w_src[i] + (int64_t)c0 * p.ldw),
+                                             (lptr_t)(j < G::W_INSTR ? dst + j * 256 : smem + G::PAD + wave * 256), 16,
+                                             0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < G::I_PER_WAVE; ++i) {
+            const int j = wave + 4 * i;
+            const float* src = i_src[i] >= 0 ? in_b + i_src[i] + (int64_t)c0 * plane_in : g_zero_line;
+            __builtin_amdgcn_global_load_lds(
+                (gptr_t)src, (lptr_t)(j < G::I_INSTR ? dst + G::W_FLOATS + j * 256 : smem + G::PAD + wave * 256), 16, 0, 0);
+        }
+    };
+
+    // accumulators: [phase py*2+px][channel tile][pixel tile]
+    f32x16 acc[4][2][2];
+#pragma unroll
+    for (int ph = 0; ph < 4; ++ph)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[ph][i][j][r] = 0.0f;
+
+    int a_off[2], b_off[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        a_off[t] = half * BN + wco * 64 + t * 32 + l31;
+        const int py = wpx * 2 + t;                          // pixel tile t = input row py of the patch
+        b_off[t] = G::W_FLOATS + half * G::PLANE + (py + 1) * G::EWP + l31 + G::LEAD + 1;
+    }
+
+    dma(0, 0);
+    int buf = 0;
+    for (int c0 = 0; c0 < p.C; c0 += G::KC) {
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+        __syncthreads();
+        if (c0 + G::KC < p.C) dma(c0 + G::KC, buf ^ 1);
+        const float* sb = smem + buf * G::BUF;
+        // One wave per SIMD: nobody else hides LDS latency, so the 26 operands of k-step s+1 are fetched
+        // (and style-scaled) under the 36 MFMAs of k-step s; only the first k-step of a chunk waits.
+        float A[2][9][2], X[2][4][2];                        // [set][tap][channel tile], [set][dy*2+dx][pixel tile]
+        auto load_set = [&](int cp, int set) {
+#pragma unroll
+            for (int sh = 0; sh < 4; ++sh)
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+                    X[set][sh][t] = sb[(2 * cp) * G::PLANE + b_off[t] - (sh >> 1) * G::EWP - (sh & 1)];
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+                for (int t = 0; t < 2; ++t) A[set][tap][t] = sb[(tap * G::KC + 2 * cp) * BN + a_off[t]];
+        };
+        auto scale_set = [&](int cp, int set) {              // style onto the 8 input operands (not the 18 weights)
+            const float sc = sty[c0 + 2 * cp + half];
+#pragma unroll
+            for (int sh = 0; sh < 4; ++sh) { X[set][sh][0] *= sc; X[set][sh][1] *= sc; }
+        };
+        load_set(0, 0);
+        scale_set(0, 0);
+#pragma unroll
+        for (int cp = 0; cp < G::KC / 2; ++cp) {
+            const int cur = cp & 1;
+            if (cp + 1 < G::KC / 2) load_set(cp + 1, cur ^ 1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const int tap = ky * 3 + kx, ph = (ky & 1) * 2 + (kx & 1), sh = (ky >> 1) * 2 + (kx >> 1);
+                    acc[ph][0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[cur][tap][0], X[cur][sh][0], acc[ph][0][0], 0, 0, 0);
+                    acc[ph][0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[cur][tap][0], X[cur][sh][1], acc[ph][0][1], 0, 0, 0);
+                    acc[ph][1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[cur][tap][1], X[cur][sh][0], acc[ph][1][0], 0, 0, 0);
+                    acc[ph][1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[cur][tap][1], X[cur][sh][1], acc[ph][1][1], 0, 0, 0);
+                }
+            if (cp + 1 < G::KC / 2) {
+                scale_set(cp + 1, cur ^ 1);
+                // four MFMAs cover the LDS latency, then one scale multiply per four MFMAs
+                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        buf ^= 1;
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+
+    // ---- epilogue: lane = input column i, registers = channels; phases (py, 0) and (py, 1) are the
+    // neighbouring output columns 2i, 2i + 1 of output row 2j + py
+    const int64_t plane_out = (int64_t)p.OH * p.OW;
+#pragma unroll
+    for (int pt = 0; pt < 2; ++pt) {
+        const int j = j0 + wpx * 2 + pt, i = i0 + l31;
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int n = n0 + wco * 64 + ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (n < p.N) {
+                    const float os = p.oscale ? p.oscale[(int64_t)b * p.N + n] : 1.0f;
+                    const float ob = p.obias ? p.obias[n] : 0.0f;
+                    float* o = p.out + ((int64_t)b * p.N + n) * plane_out + (int64_t)(2 * j) * p.OW + 2 * i;
+                    o[0] = acc[0][ct][pt][r] * os + ob;
+                    o[1] = acc[1][ct][pt][r] * os + ob;
+                    o[p.OW] = acc[2][ct][pt][r] * os + ob;
+                    o[p.OW + 1] = acc[3][ct][pt][r] * os + ob;
+                }
+            }
+    }
+}
+
+bool convt_fused_eligible(const ConvParams& p) {
+    return p.IH % TFused::PH == 0 && p.IW % TFused::PW == 0 && p.C % TFused::KC == 0 && p.C <= 2048 &&
+           (reinterpret_cast<uintptr_t>(p.in) & 15) == 0;
+}
+
+int launch_convt_fused(ConvParams p, hipStream_t st) {
+    p.tiles_x = p.IW / TFused::PW;
+    p.tiles_y = p.IH / TFused::PH;
+    p.tiles_n = (p.N + BN - 1) / BN;
+    const int64_t blocks = (int64_t)p.tiles_x * p.tiles_y * p.tiles_n * p.B;
+    if (blocks > 0x7FFFFFFFLL) return SR_ERANGE;
+    const int lds = (TFused::STY + p.C) * 4;
+    hipLaunchKernelGGL(k_convt_fused, dim3((unsigned)blocks), dim3(256), lds, st, p);
+    return sr_launch_status();
+}
+
 void patch_shape(int GW, int& pw, int& ph, int& pb) {
     // patch shape from the grid width: 32x4, 16x8, 8x8x2, 4x4x8
     if (GW > 16) { pw = 32; ph = 4; pb = 1; }
@@ -505,6 +723,18 @@ extern "C" int sr_conv2d_mfma(float* out, const float* in, const float* wt, cons
     // The phase grids have 2^k + 1 points per side: the 2^k x 2^k interior tiles the 32-wide
     // patches exactly, the last grid row / column (output row 2*IH, column 2*IW: even phases only)
     // runs as thin strip launches instead of padding every tile row by up to 50 %.
+    // interior of the map: all four phases in one workgroup (k_convt_fused); SR_CONVT_FUSED=0 keeps the
+    // per-phase launches
+    bool fused_ok = false;
+    {
+        const char* e = std::getenv("SR_CONVT_FUSED");
+        if (!(e && e[0] == '0') && p.IW >= 16 && convt_fused_eligible(p)) {
+            for (int i = 0; i < 9; ++i) p.wmap[i] = i;
+            const int rc = launch_convt_fused(p, st);
+            if (rc != SR_OK) return rc;
+            fused_ok = true;
+        }
+    }
     for (int py = 0; py < 2; ++py)
         for (int px = 0; px < 2; ++px) {
             const int TYp = py == 0 ? 2 : 1, TXp = px == 0 ? 2 : 1;
@@ -526,7 +756,8 @@ extern "C" int sr_conv2d_mfma(float* out, const float* in, const float* wt, cons
                 regions[0][1] = gh_full;
                 regions[0][3] = gw_full;
             }
-            for (int rg = 0; rg < (split_border ? 3 : 1); ++rg) {
+            const bool fused = split_border && fused_ok;
+            for (int rg = fused ? 1 : 0; rg < (split_border ? 3 : 1); ++rg) {
                 p.gy_base = regions[rg][0]; p.GH = regions[rg][1];
                 p.gx_base = regions[rg][2]; p.GW = regions[rg][3];
                 if (p.GH <= p.gy_base || p.GW <= p.gx_base) continue;

@@ -51,6 +51,8 @@ CASES = [
     (2, 8, 6, 8, 8, 3, 2, 0, True),
     (1, 11, 9, 16, 16, 3, 2, 0, True),
     (1, 6, 130, 32, 32, 3, 2, 0, True),
+    (2, 8, 130, 32, 32, 3, 2, 0, True),          # fused four-phase kernel (interior) + border strips
+    (1, 12, 64, 8, 64, 3, 2, 0, True),
     (2, 8, 3, 8, 8, 1, 1, 0, False),
     (2, 16, 5, 32, 32, 1, 1, 0, False),
     (2, 6, 4, 9, 9, 1, 2, 0, False),
