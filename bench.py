@@ -46,7 +46,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-raster", action="store_true", help="skip the rasterizer (BASELINE config[3]) leg")
     ap.add_argument("--cpu-batch", type=int, default=2)
-    ap.add_argument("--cpu-iters", type=int, default=1)
+    ap.add_argument("--cpu-iters", type=int, default=6)
     ap.add_argument("--cpu-threads", type=int, default=32)
     return ap.parse_args()
 
