@@ -140,16 +140,25 @@ __global__ __launch_bounds__(256) void k_conv_wino(const WinoParams p) {
 
     typedef float f2 __attribute__((ext_vector_type(2)));
     // the same on (channel a, channel b) pairs: v_pk_add_f32 / v_pk_mul_f32, half the VALU issue slots
-    auto bt_row2 = [](const f2 (&d)[16], f2 (&o)[16], int q, f2 s) {
+    // (explicit v_pk_*_f32: the compiler scalarises ext_vector arithmetic here; a non-MFMA instruction costs the
+    // matrix pipe an issue slot)
+    auto pk_add = [](f2 a, f2 b) { f2 r; asm("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; };
+    auto pk_sub = [](f2 a, f2 b) {
+        f2 r;
+        asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+        return r;
+    };
+    auto pk_mul = [](f2 a, f2 b) { f2 r; asm("v_pk_mul_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; };
+    auto bt_row2 = [&](const f2 (&d)[16], f2 (&o)[16], int q, f2 s) {
         f2 t[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-            t[j] = q == 0 ? d[j] - d[8 + j] : q == 1 ? d[4 + j] + d[8 + j] : q == 2 ? d[8 + j] - d[4 + j]
-                                                                          : d[4 + j] - d[12 + j];
-        o[4 * q + 0] = (t[0] - t[2]) * s;
-        o[4 * q + 1] = (t[1] + t[2]) * s;
-        o[4 * q + 2] = (t[2] - t[1]) * s;
-        o[4 * q + 3] = (t[1] - t[3]) * s;
+            t[j] = q == 0 ? pk_sub(d[j], d[8 + j]) : q == 1 ? pk_add(d[4 + j], d[8 + j]) : q == 2 ? pk_sub(d[8 + j], d[4 + j])
+                                                                                    : pk_sub(d[4 + j], d[12 + j]);
+        o[4 * q + 0] = pk_mul(pk_sub(t[0], t[2]), s);
+        o[4 * q + 1] = pk_mul(pk_add(t[1], t[2]), s);
+        o[4 * q + 2] = pk_mul(pk_sub(t[2], t[1]), s);
+        o[4 * q + 3] = pk_mul(pk_sub(t[1], t[3]), s);
     };
     // B^T d B of one channel, row q of the 4x4 result (12 VALU ops), style multiplied in
     auto bt_row = [](const float (&d)[16], float (&o)[16], int q, float s) {
