@@ -42,24 +42,59 @@ __global__ __launch_bounds__(256) void k_nt(float* __restrict__ out, const float
     if (n >= N) return;
     const float4* Mr = reinterpret_cast<const float4*>(M + (int64_t)n * K);
     const int k4n = K >> 2;
-    for (int b0 = 0; b0 < B; b0 += 4) {
-        float acc[4] = {0.f, 0.f, 0.f, 0.f};
-        for (int k4 = lane; k4 < k4n; k4 += 64) {
-            const float4 m = Mr[k4];
+    // these kernels are latency bound (a few KB per wave): keep the row of M in registers when it fits
+    // (K <= 1024) and put the loads of 8 rows of A in flight at once — two dependent memory round trips
+    // per 8 rows instead of one per row group
+    constexpr int RB = 8;
+    float4 mreg[4];
+    const bool mfit = k4n <= 256;
+    if (mfit) {
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int b = min(b0 + u, B - 1);
-                float4 a = reinterpret_cast<const float4*>(A + (int64_t)b * lda)[k4];
-                if (MODE == 1) {
-                    const float4 d = reinterpret_cast<const float4*>(A2 + (int64_t)b * K)[k4];
-                    a.x = demod_gq(a.x, d.x); a.y = demod_gq(a.y, d.y);
-                    a.z = demod_gq(a.z, d.z); a.w = demod_gq(a.w, d.w);
+        for (int q = 0; q < 4; ++q) {
+            const int k4 = lane + 64 * q;
+            mreg[q] = k4 < k4n ? Mr[k4] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    for (int b0 = 0; b0 < B; b0 += RB) {
+        float acc[RB];
+#pragma unroll
+        for (int u = 0; u < RB; ++u) acc[u] = 0.0f;
+        if (mfit) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int k4 = lane + 64 * q;
+                if (k4 < k4n) {
+#pragma unroll
+                    for (int u = 0; u < RB; ++u) {
+                        const int b = min(b0 + u, B - 1);
+                        float4 a = reinterpret_cast<const float4*>(A + (int64_t)b * lda)[k4];
+                        if (MODE == 1) {
+                            const float4 d = reinterpret_cast<const float4*>(A2 + (int64_t)b * K)[k4];
+                            a.x = demod_gq(a.x, d.x); a.y = demod_gq(a.y, d.y);
+                            a.z = demod_gq(a.z, d.z); a.w = demod_gq(a.w, d.w);
+                        }
+                        acc[u] += dot4(a, mreg[q]);
+                    }
                 }
-                acc[u] += dot4(a, m);
+            }
+        } else {
+            for (int k4 = lane; k4 < k4n; k4 += 64) {
+                const float4 m = Mr[k4];
+#pragma unroll
+                for (int u = 0; u < RB; ++u) {
+                    const int b = min(b0 + u, B - 1);
+                    float4 a = reinterpret_cast<const float4*>(A + (int64_t)b * lda)[k4];
+                    if (MODE == 1) {
+                        const float4 d = reinterpret_cast<const float4*>(A2 + (int64_t)b * K)[k4];
+                        a.x = demod_gq(a.x, d.x); a.y = demod_gq(a.y, d.y);
+                        a.z = demod_gq(a.z, d.z); a.w = demod_gq(a.w, d.w);
+                    }
+                    acc[u] += dot4(a, m);
+                }
             }
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < RB; ++u) {
             const float r = sr_wave_sum(acc[u]);
             const int b = b0 + u;
             if (lane == 0 && b < B) {
@@ -94,7 +129,7 @@ __global__ __launch_bounds__(256) void k_nn(float* __restrict__ out, const float
     const float* A2r = A2 ? A2 + (int64_t)b * I : nullptr;
     const float4* Mc = reinterpret_cast<const float4*>(M) + (ok ? j4 : 0);
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll 8
+#pragma unroll 32
     for (int i = i_lo; i < i_hi; ++i) {
         float a = Ar[i];
         if (MODE == 0) a = act_bwd(a, A2r ? A2r[i] : 1.0f, ap);

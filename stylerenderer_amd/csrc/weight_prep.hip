@@ -40,21 +40,43 @@ __global__ __launch_bounds__(256) void k_wprep(float* __restrict__ wt, float* __
     if (wsq && co < Co) wsq[(int64_t)ci * Co + co] = sq;
 }
 
+// One workgroup = 16 output channels x 16 input channels.  gwt / gwsq are read with co fastest (64-byte
+// runs), w and gw are [co][ci][KK] with ci*KK fastest (16 * KK contiguous floats per co): both sides go
+// through an LDS tile so that neither is a 36-byte-strided access.
 template <int KK>
 __global__ __launch_bounds__(256) void k_wprep_bwd(float* __restrict__ gw, const float* __restrict__ gwt,
                                                    const float* __restrict__ gwsq,
                                                    const float* __restrict__ w, float scale, int Co,
                                                    int Ci, int ldg) {
-    const int co = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int ci = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (ci >= Ci || co >= Co) return;
-    const int64_t base = ((int64_t)co * Ci + ci) * KK;
-    const float q = gwsq ? 2.0f * scale * scale * gwsq[(int64_t)ci * Co + co] : 0.0f;
+    __shared__ float tile[16][16 * KK + 1];              // [co][ci * KK + t]
+    const int co0 = blockIdx.x * 16, ci0 = blockIdx.y * 16;
+    const int row_floats = 16 * KK;
+    // (1) w tile -> LDS, row-contiguous
+    if (gwsq) {
+        for (int e = threadIdx.x; e < 16 * row_floats; e += 256) {
+            const int r = e / row_floats, q = e % row_floats;
+            const int co = co0 + r, ci = ci0 + q / KK;
+            tile[r][q] = (co < Co && ci < Ci) ? w[((int64_t)co * Ci + ci0) * KK + q] : 0.0f;
+        }
+        __syncthreads();
+    }
+    // (2) thread (co fastest, ci): combine the two cotangents, result back into the tile
+    const int lco = threadIdx.x & 15, lci = threadIdx.x >> 4;
+    const int co = co0 + lco, ci = ci0 + lci;
+    const bool ok = co < Co && ci < Ci;
+    const float q2 = (gwsq && ok) ? 2.0f * scale * scale * gwsq[(int64_t)ci * Co + co] : 0.0f;
 #pragma unroll
     for (int t = 0; t < KK; ++t) {
-        float g = gwt ? scale * gwt[((int64_t)t * Ci + ci) * ldg + co] : 0.0f;
-        if (gwsq) g += q * w[base + t];
-        gw[base + t] = g;
+        float g = (gwt && ok) ? scale * gwt[((int64_t)t * Ci + ci) * ldg + co] : 0.0f;
+        if (gwsq) g += q2 * tile[lco][lci * KK + t];
+        tile[lco][lci * KK + t] = g;
+    }
+    __syncthreads();
+    // (3) tile -> gw, row-contiguous
+    for (int e = threadIdx.x; e < 16 * row_floats; e += 256) {
+        const int r = e / row_floats, q = e % row_floats;
+        const int oco = co0 + r, oci = ci0 + q / KK;
+        if (oco < Co && oci < Ci) gw[((int64_t)oco * Ci + ci0) * KK + q] = tile[r][q];
     }
 }
 
@@ -101,7 +123,7 @@ extern "C" int sr_weight_prep_bwd(float* gw, const float* gwt, const float* gwsq
                                   sr_stream_t stream) {
     if (Co <= 0 || Ci <= 0 || !gw || (!gwt && !gwsq) || (gwsq && !w) || (gwt && ldg < Co)) return SR_EINVAL;
     if (Co > (1 << 20) || Ci > (1 << 20)) return SR_ERANGE;
-    const dim3 grid((unsigned)sr_ceil_div(Co, 64), (unsigned)sr_ceil_div(Ci, 4));
+    const dim3 grid((unsigned)sr_ceil_div(Co, 16), (unsigned)sr_ceil_div(Ci, 16));
     hipStream_t st = sr_stream(stream);
     if (ksize == 3)
         hipLaunchKernelGGL(k_wprep_bwd<9>, grid, dim3(256), 0, st, gw, gwt, gwsq, w, scale, (int)Co, (int)Ci,
