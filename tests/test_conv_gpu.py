@@ -310,7 +310,7 @@ def test_demod_scale_forward_backward(b, ci, co):
 # ---- Winograd F(2x2,3x3) path (csrc/conv_wino.hip) vs float64 and vs the direct implicit GEMM.
 # Stated tolerance: |err| <= 4e-6 * sum|a*b| (the transforms add a few fp32 roundings on sums of up to
 # 4 inputs / 3 weights; measured 5e-7), against 2e-6 for the exact-fma-chain direct kernel.
-@pytest.mark.parametrize("b,c,n,h,w,scales", [(2, 24, 64, 16, 32, True), (1, 8, 128, 8, 64, False),
+@pytest.mark.parametrize("b,c,n,h,w,scales", [(2, 24, 64, 16, 32, True), (1, 16, 128, 8, 64, False),
                                                (3, 40, 64, 24, 32, True)])
 def test_winograd_conv_vs_float64_and_direct(b, c, n, h, w, scales, monkeypatch):
     from stylerenderer_amd.op.conv import conv2d_mfma
