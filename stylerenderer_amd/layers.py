@@ -33,12 +33,6 @@ def make_kernel(k):
     return k / k.sum()
 
 
-def _taps(w):
-    """[Cout, Cin, k, k] -> [k*k, Cin, Cout] (the layout of the MFMA kernels)."""
-    co, ci, kh, kw = w.shape
-    return w.permute(2, 3, 1, 0).reshape(kh * kw, ci, co).contiguous()
-
-
 class PixelNorm(nn.Module):
     def __init__(self, eps=1e-8):
         super().__init__()
