@@ -372,7 +372,8 @@ int launch(const WinoParams& p, float* u, const float* wt, int ldw, hipStream_t 
 
 bool sr_wino_eligible(int64_t B, int64_t C, int64_t N, int64_t H, int64_t W, const void* in, const void* out) {
     if (B <= 0 || C % 8 != 0 || N % 64 != 0 || H % 8 != 0 || W % 32 != 0) return false;
-    if (C > 1024 || B * ((W / 32) * (H / 8)) * (N / 64) > 0x7FFFFFFFLL) return false;
+    // LDS: 157 KB of buffers + the style row (C floats) must fit the 160 KB of a CU
+    if (C > 512 || B * ((W / 32) * (H / 8)) * (N / 64) > 0x7FFFFFFFLL) return false;
     if (C * H * W >= (1LL << 31)) return false;
     return ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out)) & 15) == 0;
 }
