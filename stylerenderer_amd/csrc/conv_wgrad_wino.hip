@@ -197,24 +197,105 @@ __global__ __launch_bounds__(256) void k_wgrad_wino(const WgWinoParams p) {
                      : "+v"(R.a[0]), "+v"(R.a[1]), "+v"(R.a[2]), "+v"(R.a[3]), "+v"(R.b[0]), "+v"(R.b[1]), "+v"(R.b[2]),
                        "+v"(R.b[3]), "+v"(R.g0), "+v"(R.g1));
     };
-    auto transform = [&](const Raw& R, int ks, float sx, float sg, float (&V)[16], float (&Z)[16]) {
-        float d[16];
+    // Transforms with packed fp32 ops where the data allows (a non-MFMA instruction costs the matrix pipe an
+    // issue slot).  B^T d B, row q: t0..t3 scalar (the two operands of each come from
+    // different 16-byte loads), then with P = (t1, t2), Q = (t0, t3):
+    //   (o1, o2) = (P.lo + P.hi, P.hi - P.lo)        (o0, -o3) = (Q.lo - P.hi, Q.hi - P.lo)
+    // one v_pk_add_f32 each (op_sel / neg modifiers), one v_pk_mul_f32 each for the style (the second with
+    // neg_hi to undo the sign).  A dY A^T: both stages packed on the (p, q) / (r, s) pairs as loaded.
+    auto pk_mul = [](f2 a, f2 b) { f2 r; asm("v_pk_mul_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; };
+    auto pk_mul_pn = [](f2 a, f2 b) {            // (a.lo * b.lo, -(a.hi * b.hi))
+        f2 r;
+        asm("v_pk_mul_f32 %0, %1, %2 neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+        return r;
+    };
+    auto pk_add = [](f2 a, f2 b) { f2 r; asm("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; };
+    auto pk_sub = [](f2 a, f2 b) {
+        f2 r;
+        asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+        return r;
+    };
+    auto pk_sum_diff = [](f2 w) {                // (w.lo + w.hi, w.lo - w.hi)
+        f2 r;
+        asm("v_pk_add_f32 %0, %1, %1 op_sel:[0,1] op_sel_hi:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(w));
+        return r;
+    };
+    auto pk_nsum_ndiff = [](f2 w) {              // (-w.lo - w.hi, -w.lo + w.hi)
+        f2 r;
+        asm("v_pk_add_f32 %0, %1, %1 op_sel:[0,1] op_sel_hi:[0,1] neg_lo:[1,1] neg_hi:[1,0]" : "=v"(r) : "v"(w));
+        return r;
+    };
+    auto pk_o12 = [](f2 P) {                     // (P.lo + P.hi, P.hi - P.lo)
+        f2 r;
+        asm("v_pk_add_f32 %0, %1, %1 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(P));
+        return r;
+    };
+    auto pk_o03 = [](f2 Q, f2 P) {               // (Q.lo - P.hi, Q.hi - P.lo)
+        f2 r;
+        asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(Q), "v"(P));
+        return r;
+    };
+    struct ZTmp { f2 w0, w1, w2, w3; };
+    auto unpack_d = [](const Raw& R, int ks, float (&d)[16]) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             if ((ks & 1) == 0) { d[4 * r] = R.a[r].w; d[4 * r + 1] = R.b[r].x; d[4 * r + 2] = R.b[r].y; d[4 * r + 3] = R.b[r].z; }
             else { d[4 * r] = R.a[r].y; d[4 * r + 1] = R.a[r].z; d[4 * r + 2] = R.a[r].w; d[4 * r + 3] = R.b[r].x; }
         }
+    };
+    auto v_row = [&](const float (&d)[16], int q, f2 s2, float (&V)[16]) {
+        float t[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) bt_row4(d, V, q, sx);
-        const float pp = R.g0.x * sg, qq = R.g0.y * sg, rr = R.g1.x * sg, ss = R.g1.y * sg;
-        const float w[4][2] = {{pp, qq}, {pp + rr, qq + ss}, {pp - rr, qq - ss}, {-rr, -ss}};
+        for (int j = 0; j < 4; ++j)
+            t[j] = q == 0 ? d[j] - d[8 + j] : q == 1 ? d[4 + j] + d[8 + j] : q == 2 ? d[8 + j] - d[4 + j]
+                                                                          : d[4 + j] - d[12 + j];
+        f2 P, Q;
+        P.x = t[1]; P.y = t[2];
+        Q.x = t[0]; Q.y = t[3];
+        const f2 a = pk_mul(pk_o12(P), s2);          // (o1, o2) * s
+        const f2 b = pk_mul_pn(pk_o03(Q, P), s2);    // (o0, o3) * s
+        V[4 * q + 0] = b.x;
+        V[4 * q + 1] = a.x;
+        V[4 * q + 2] = a.y;
+        V[4 * q + 3] = b.y;
+    };
+    auto z_begin = [&](const Raw& R, f2 g2, ZTmp& T) {
+        T.w0 = pk_mul(R.g0, g2);                     // (p, q) * sg
+        T.w3 = pk_mul(R.g1, g2);                     // (r, s) * sg   (row 3 is its negative)
+        T.w1 = pk_add(T.w0, T.w3);
+        T.w2 = pk_sub(T.w0, T.w3);
+    };
+    auto z_row = [&](f2 w, int i, float (&Z)[16]) {  // rows 0..2: (a, a + b, a - b, -b)
+        const f2 sd = pk_sum_diff(w);
+        Z[4 * i + 0] = w.x;
+        Z[4 * i + 1] = sd.x;
+        Z[4 * i + 2] = sd.y;
+        Z[4 * i + 3] = -w.y;
+    };
+    auto z_row3 = [&](f2 w, float (&Z)[16]) {        // row 3 from (r, s): (-r, -r - s, -r + s, s)
+        const f2 nd = pk_nsum_ndiff(w);
+        Z[12] = -w.x;
+        Z[13] = nd.x;
+        Z[14] = nd.y;
+        Z[15] = w.y;
+    };
+    // piece i (0..3) of the transforms of one k-step: pinned into the four MFMA slots of the previous one
+    auto transform_piece = [&](const float (&d)[16], const Raw& R, ZTmp& T, int i, f2 s2, f2 g2, float (&V)[16],
+                               float (&Z)[16]) {
+        v_row(d, i, s2, V);
+        if (i == 0) z_begin(R, g2, T);
+        if (i == 1) { z_row(T.w0, 0, Z); z_row(T.w1, 1, Z); }
+        if (i == 2) { z_row(T.w2, 2, Z); z_row3(T.w3, Z); }
+    };
+    auto transform = [&](const Raw& R, int ks, float sx, float sg, float (&V)[16], float (&Z)[16]) {
+        float d[16];
+        unpack_d(R, ks, d);
+        f2 s2, g2;
+        s2.x = s2.y = sx;
+        g2.x = g2.y = sg;
+        ZTmp T;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            Z[4 * i + 0] = w[i][0];
-            Z[4 * i + 1] = w[i][0] + w[i][1];
-            Z[4 * i + 2] = w[i][0] - w[i][1];
-            Z[4 * i + 3] = -w[i][1];
-        }
+        for (int i = 0; i < 4; ++i) transform_piece(d, R, T, i, s2, g2, V, Z);
     };
 
     // ---- pipeline.  Four chunk buffers; at the top of iteration kk chunks kk and kk+1 are complete in
@@ -269,34 +350,39 @@ __global__ __launch_bounds__(256) void k_wgrad_wino(const WgWinoParams p) {
             else load_raw(xaddr_n, gaddr_n, 0, R);
 #endif
             __builtin_amdgcn_sched_barrier(0);
-            // two MFMAs cover the LDS latency of the reads above, then the wait, then MFMA : VALU = 1 : 5
+            // two MFMAs cover the LDS latency of the reads above, then the wait; after that four slots of
+            // MFMAs, each with one piece of the next k-step's transforms (and its share of the DMA issue)
+            // pinned into it
 #pragma unroll
             for (int pos = 0; pos < 2; ++pos)
                 acc[pos] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[ks & 1][pos], Z[ks & 1][pos], acc[pos], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
 #ifndef WGW_NO_XFORM
             lds_wait(R);
+            float dn[16];
+            unpack_d(R, ks + 1 < 4 ? ks + 1 : 0, dn);
+            f2 s2, g2;
+            s2.x = s2.y = (ks + 1 < 4) ? sx : sxn;
+            g2.x = g2.y = (ks + 1 < 4) ? sg : sgn;
+            ZTmp T;
 #endif
 #pragma unroll
-            for (int pos = 2; pos < 16; ++pos)
-                acc[pos] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[ks & 1][pos], Z[ks & 1][pos], acc[pos], 0, 0, 0);
-#ifndef WGW_NO_DMA
-            if (ks == 0) { dma_x1(0); dma_x1(1); dma_x1(2); }
-            if (ks == 1) { dma_x1(3); dma_x1(4); dma_x1(5); }
-            if (ks == 2) { dma_x1(6); dma_g1(0); dma_g1(1); }
-            if (ks == 3) dma_g1(2);
-#endif
+            for (int slot = 0; slot < 4; ++slot) {
+#pragma unroll
+                for (int pos = (slot == 0 ? 2 : 4 * slot); pos < 4 * slot + 4; ++pos)
+                    acc[pos] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[ks & 1][pos], Z[ks & 1][pos], acc[pos], 0, 0, 0);
 #ifndef WGW_NO_XFORM
-            if (ks + 1 < 4) transform(R, ks + 1, sx, sg, V[(ks + 1) & 1], Z[(ks + 1) & 1]);
-            else transform(R, 0, sxn, sgn, V[0], Z[0]);
-#pragma unroll
-            for (int i = 0; i < 14; ++i) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
-                if (i % 4 == 1) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-            }
+                transform_piece(dn, R, T, slot, s2, g2, V[(ks + 1) & 1], Z[(ks + 1) & 1]);
 #endif
-            __builtin_amdgcn_sched_barrier(0);
+#ifndef WGW_NO_DMA
+                if (slot > 0) {
+                    const int i = 3 * ks + slot - 1;             // 10 DMA instructions over ks 0..3, slots 1..3
+                    if (i < X_PER_WAVE) dma_x1(i);
+                    else if (i < X_PER_WAVE + G_PER_WAVE) dma_g1(i - X_PER_WAVE);
+                }
+#endif
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
         sx = sxn;
         sg = sgn;
