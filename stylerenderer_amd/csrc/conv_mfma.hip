@@ -104,7 +104,12 @@ struct Geo {
     static constexpr int LDS_BYTES = 2 * BUF * 4;
 };
 
-template <int IS, int TY, int TX, int PW, int PH, int PB, bool V4>
+// FAST: C is a multiple of the chunk size (no channel tail): every DMA source is then
+//   pointer(chunk 0) + chunk_channel * stride   with a chunk-invariant per-lane pointer and stride
+// (image lanes: one plane; style lanes: one float; border / absent-style lanes: 0 from the zero / ones
+// line), i.e. one v_mad_u64_u32 per DMA instruction instead of a dozen selects and scalar branches.  Every
+// instruction issued on the SIMD costs the matrix pipe a slot.
+template <int IS, int TY, int TX, int PW, int PH, int PB, bool V4, bool FAST>
 __global__ __launch_bounds__(256) void k_conv_mfma(const ConvParams p) {
     using G = Geo<IS, TY, TX, PW, PH, PB, V4>;
     static_assert(PW * PH * PB == BM, "patch must hold 128 pixels");
@@ -214,8 +219,58 @@ __global__ __launch_bounds__(256) void k_conv_mfma(const ConvParams p) {
     const float* in_base = p.in + (int64_t)b0 * p.C * p.IH * p.IW;
     const int plane_in = p.IH * p.IW;
 
+    const char* f_wp[G::W_PER_WAVE];
+    const char* f_ip[G::IN_PER_WAVE];
+    unsigned f_is[G::IN_PER_WAVE];
+    if (FAST) {
+#pragma unroll
+        for (int i = 0; i < G::W_PER_WAVE; ++i) f_wp[i] = reinterpret_cast<const char*>(p.wt + w_src[i]);
+#pragma unroll
+        for (int i = 0; i < G::IN_PER_WAVE; ++i) {
+            const int c = i_cl[i] & 255, pb = i_cl[i] >> 8;
+            const char* ptr = reinterpret_cast<const char*>(g_zero_line);
+            unsigned str = 0;
+            if (i_src[i] >= 0) {
+                ptr = reinterpret_cast<const char*>(in_base + i_src[i]);
+                str = (unsigned)plane_in * 4u;
+            } else if (i_src[i] == -2) {
+                const bool ok = p.iscale && b0 + pb < p.B;
+                ptr = ok ? reinterpret_cast<const char*>(p.iscale + (int64_t)(b0 + pb) * p.C + c)
+                         : reinterpret_cast<const char*>(g_ones_line);
+                str = ok ? 4u : 0u;
+            }
+            f_ip[i] = ptr;
+            f_is[i] = str;
+        }
+    }
+    const unsigned w_chunk_stride = (unsigned)p.ldw * 4u;
+
     auto dma = [&](int c0, int buf) {
         float* dst = smem + buf * G::BUF;
+        if (FAST) {
+#pragma unroll
+            for (int i = 0; i < G::W_PER_WAVE; ++i) {
+                const int j = wave + 4 * i;
+                if (j < G::W_INSTR)
+                    __builtin_amdgcn_global_load_lds((gptr_t)(f_wp[i] + (uint64_t)(unsigned)c0 * w_chunk_stride),
+                                                     (lptr_t)(dst + j * 256), 16, 0, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < G::IN_PER_WAVE; ++i) {
+                const int j = wave + 4 * i;
+                if (j < G::IN_INSTR) {
+                    const char* src = f_ip[i] + (uint64_t)(unsigned)c0 * f_is[i];
+                    if (V4 && j < G::IMG_INSTR)
+                        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(dst + G::W_FLOATS + j * 256), 16, 0, 0);
+                    else if (V4)
+                        __builtin_amdgcn_global_load_lds((gptr_t)src,
+                                                         (lptr_t)(dst + G::S_BASE + (j - G::IMG_INSTR) * 64), 4, 0, 0);
+                    else
+                        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(dst + G::W_FLOATS + j * 64), 4, 0, 0);
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < G::W_PER_WAVE; ++i) {
             const int j = wave + 4 * i;
@@ -321,10 +376,10 @@ __global__ __launch_bounds__(256) void k_conv_mfma(const ConvParams p) {
     }
 }
 
-template <int IS, int TY, int TX, int PW, int PH, int PB, bool V4>
-int launch_one(const ConvParams& p, dim3 grid, hipStream_t st) {
+template <int IS, int TY, int TX, int PW, int PH, int PB, bool V4, bool FAST>
+int launch_fast(const ConvParams& p, dim3 grid, hipStream_t st) {
     using G = Geo<IS, TY, TX, PW, PH, PB, V4>;
-    auto kern = k_conv_mfma<IS, TY, TX, PW, PH, PB, V4>;
+    auto kern = k_conv_mfma<IS, TY, TX, PW, PH, PB, V4, FAST>;
     static bool configured = false;     // opt in to > 64 KiB of dynamic LDS once per variant
     if (!configured) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -333,6 +388,14 @@ int launch_one(const ConvParams& p, dim3 grid, hipStream_t st) {
     }
     hipLaunchKernelGGL(kern, grid, dim3(256), G::LDS_BYTES, st, p);
     return sr_launch_status();
+}
+
+template <int IS, int TY, int TX, int PW, int PH, int PB, bool V4>
+int launch_one(const ConvParams& p, dim3 grid, hipStream_t st) {
+    using G = Geo<IS, TY, TX, PW, PH, PB, V4>;
+    // no channel tail in any K slice -> chunk-invariant DMA descriptors
+    if (p.C % G::KC == 0 && p.c_per_slice % G::KC == 0) return launch_fast<IS, TY, TX, PW, PH, PB, V4, true>(p, grid, st);
+    return launch_fast<IS, TY, TX, PW, PH, PB, V4, false>(p, grid, st);
 }
 
 // ------------------------------------------------------------------------------------------------
