@@ -14,14 +14,14 @@
 //
 // K loop in chunks of 8 tiles (a 16x2 pixel strip):
 //   * the strip's x halo (64 channels x 4 rows x 24 columns, 16-byte aligned window) and gy pixels
-//     (64 channels x 2 rows x 16 columns) arrive by LDS-DMA, three chunks deep; every channel occupies
+//     (64 channels x 2 rows x 16 columns) arrive by LDS-DMA, four chunks deep; every channel occupies
 //     25 (resp. 9) float4 slots = 24 (8) payload + 1 hole, so that the 32 lanes of a half-wave, which
 //     own 32 different channels, hit different bank groups with ds_read_b128 / ds_read_b64;
 //   * BOTH transforms run in registers, directly into the MFMA operands: lane (channel = l & 31,
-//     k = l >> 5) computes B^T d B of its own (channel, tile) — 8 ds_read_b128 + 48 VALU ops per
-//     k-step — and A dY A^T of its own (output channel, tile) — 2 ds_read_b64 + 16 VALU ops.  No
-//     transformed operand ever touches LDS.  The transforms of k-step s+1 are issued between the 16
-//     MFMAs of k-step s.
+//     k = l >> 5) computes B^T d B of its own (channel, tile) — 8 ds_read_b128 + 32 VALU ops per
+//     k-step (packed fp32 where the data allows) — and A dY A^T of its own (output channel, tile) —
+//     2 ds_read_b64 + 12 VALU ops.  No transformed operand ever touches LDS.  The transforms of k-step
+//     s+1 (and the chunk's 10 DMA instructions) are pinned into the four 4-MFMA slots of k-step s.
 //   * k-step s pairs tiles (t, t + 2) on the two k-lanes so both halves read with the same
 //     compile-time element pattern (tile columns 3 + 2t .. 6 + 2t of the aligned window).
 #include "common.h"
