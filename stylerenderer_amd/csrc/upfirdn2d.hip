@@ -92,13 +92,24 @@ __global__ __launch_bounds__(256) void k_fir4_tile(float* __restrict__ out,
         const int ky = threadIdx.x >> 2, kx = threadIdx.x & 3;
         s_k[threadIdx.x] = k[(3 - ky) * 4 + (3 - kx)];
     }
-    // stage the halo tile: consecutive lanes read consecutive columns of one row (coalesced)
-    for (int i = threadIdx.x; i < T_IH * T_LD; i += 256) {
+    // stage the halo tile: consecutive lanes read consecutive columns of one row (coalesced).  All ten
+    // loads of a lane are issued before the first LDS write (unconditional loads from clamped addresses,
+    // masked afterwards): one memory round trip per tile instead of ten dependent ones.
+    constexpr int T_STAGE = (T_IH * T_LD + 255) / 256;
+    float stage[T_STAGE];
+#pragma unroll
+    for (int k = 0; k < T_STAGE; ++k) {
+        const int i = threadIdx.x + 256 * k;
         const int r = i / T_LD, c = i - r * T_LD;
         const int gy = iy0 + r, gx = ix0 + c;
-        float v = 0.0f;
-        if (c < T_IW && gy >= 0 && gy < in_h && gx >= 0 && gx < in_w) v = src[(int64_t)gy * in_w + gx];
-        s_in[i] = v;
+        const bool ok = i < T_IH * T_LD && c < T_IW && gy >= 0 && gy < in_h && gx >= 0 && gx < in_w;
+        const float v = src[ok ? (int64_t)gy * in_w + gx : 0];
+        stage[k] = ok ? v : 0.0f;
+    }
+#pragma unroll
+    for (int k = 0; k < T_STAGE; ++k) {
+        const int i = threadIdx.x + 256 * k;
+        if (i < T_IH * T_LD) s_in[i] = stage[k];
     }
     __syncthreads();
 
