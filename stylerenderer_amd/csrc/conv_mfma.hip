@@ -651,7 +651,8 @@ __global__ __launch_bounds__(256) void k_conv_reduce(const ConvParams p, int rh,
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
          i += (int64_t)gridDim.x * blockDim.x) {
         float acc = 0.0f;
-        for (int s = 0; s < p.ks; ++s) acc += p.partial[s * total + i];
+#pragma unroll 8
+        for (int s = 0; s < p.ks; ++s) acc += p.partial[s * total + i];    // loads in flight, fixed order
         const int64_t row = i / region;                                  // b * N + n
         const int q = (int)(i - row * region);
         const int gy = p.gy_base + q / rw, gx = p.gx_base + q % rw;

@@ -312,7 +312,8 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(const ReduceParams p) {
         const int t = (int)(i / ((int64_t)p.CV * p.CU));
         const float* src = p.partial + ((int64_t)t * p.UP + u) * p.VP + v;
         float acc = 0.0f;
-        for (int s = 0; s < p.ks; ++s) acc += src[s * stride_s];
+#pragma unroll 8
+        for (int s = 0; s < p.ks; ++s) acc += src[s * stride_s];      // loads in flight, fixed summation order
         int slab = 0;
 #pragma unroll
         for (int k = 0; k < 9; ++k)

@@ -414,7 +414,8 @@ __global__ __launch_bounds__(256) void k_wgrad_wino_finish(float* __restrict__ d
     float a[4] = {0.f, 0.f, 0.f, 0.f};
     if (i < cn) {
         const float* src = partial + (int64_t)(4 * g) * cn + i;
-        for (int s = 0; s < slices; ++s) {
+#pragma unroll 4
+        for (int s = 0; s < slices; ++s) {               // 16 independent loads in flight, fixed order
 #pragma unroll
             for (int u = 0; u < 4; ++u) a[u] += src[((int64_t)s * 16 + u) * cn];
         }
