@@ -160,6 +160,16 @@ int sr_upfirdn2d(float* out, const float* x, const float* k, int64_t major, int 
                  int out_h, int out_w, int kh, int kw, int up_x, int up_y, int down_x, int down_y,
                  int pad_x0, int pad_x1, int pad_y0, int pad_y1, sr_stream_t stream);
 
+/* Blur (4x4 FIR, up = down = 1, pad (pad0, pad1) on both axes: reference layers.py:194-203 after the
+ * stride-2 transposed convolution) with the StyledConv tail fused into its store (reference
+ * model.py:26-32): y = lrelu((fir(x) + noise_w[0]*noise[b, p]) + bias[ch], alpha) * gain.
+ * x [n, c, in_h, in_w] -> y [n, c, out_h, out_w], out = in + pad0 + pad1 - 3; noise [n or 1, 1, out_h, out_w]
+ * with batch stride noise_bstride (0 = shared) or NULL; bias [c] or NULL.  One pass instead of two. */
+int sr_blur_noise_bias_act(float* y, const float* x, const float* k, const float* noise, const float* noise_w,
+                           const float* bias, float alpha, float gain, int64_t n, int64_t c, int in_h, int in_w,
+                           int out_h, int out_w, int pad0, int pad1, int64_t noise_bstride, sr_stream_t stream);
+
+
 /* ---------------------------------------------------------------------------------------
  * 3DMM triangle rasterizer (z-buffered, deterministic; results equal the reference's
  * SEQUENTIAL CPU loops bit for bit: op/rasterize.cpp:21-67).

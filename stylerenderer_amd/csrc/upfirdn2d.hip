@@ -72,11 +72,24 @@ constexpr int T_IH = T_OH + T_K - 1;        // 35
 constexpr int T_IW = T_OW + T_K - 1;        // 67
 constexpr int T_LD = 68;                    // LDS row pitch (floats), multiple of 4
 
+// NBA: the StyledConv tail (reference model.py:26-32: NoiseInjection + FusedLeakyReLU) applied to the
+// blurred value before it is stored — y = lrelu((f + nw * noise[b, p]) + bias[c]) * gain, the same
+// operation order as k_nba_fwd — which saves one full read + write of the activation per layer.
+struct FirNba {
+    const float* noise;       // [B or 1, 1, out_h, out_w] or NULL
+    const float* noise_w;     // 1 float (device) when noise != NULL
+    const float* bias;        // [C] or NULL
+    int64_t noise_bstride;
+    int channels;
+    float alpha, gain;
+};
+
+template <bool NBA>
 __global__ __launch_bounds__(256) void k_fir4_tile(float* __restrict__ out,
                                                    const float* __restrict__ x,
                                                    const float* __restrict__ k, int in_h, int in_w,
                                                    int out_h, int out_w, int pad_x0, int pad_y0,
-                                                   int tiles_x, int tiles_y) {
+                                                   int tiles_x, int tiles_y, FirNba nba) {
     __shared__ __attribute__((aligned(16))) float s_in[T_IH * T_LD];
     __shared__ float s_k[16];
     int bid = blockIdx.x;
@@ -148,11 +161,30 @@ __global__ __launch_bounds__(256) void k_fir4_tile(float* __restrict__ out,
                 }
 
     float* dst = out + plane * (int64_t)out_h * out_w;
+    float nw = 0.0f, bb = 0.0f;
+    const float* nz = nullptr;
+    if (NBA) {
+        const int64_t b = plane / nba.channels;
+        if (nba.noise) {
+            nw = nba.noise_w[0];
+            nz = nba.noise + b * nba.noise_bstride;
+        }
+        if (nba.bias) bb = nba.bias[plane - b * nba.channels];
+    }
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
         const int oy = oy0 + ly + r;
         if (oy >= out_h) continue;
         const int ox = ox0 + lx;
+        if (NBA) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                float v = acc[r][c];
+                if (nz && ox + c < out_w) v = v + nw * nz[(int64_t)oy * out_w + ox + c];
+                v += bb;
+                acc[r][c] = ((v > 0.0f) ? v : v * nba.alpha) * nba.gain;
+            }
+        }
         float* q = dst + (int64_t)oy * out_w + ox;
         if (ox + 3 < out_w && ((reinterpret_cast<uintptr_t>(q) & 15) == 0)) {
             *reinterpret_cast<float4*>(q) = make_float4(acc[r][0], acc[r][1], acc[r][2], acc[r][3]);
@@ -185,8 +217,8 @@ extern "C" int sr_upfirdn2d(float* out, const float* x, const float* k, int64_t 
         const int tiles_x = (out_w + T_OW - 1) / T_OW, tiles_y = (out_h + T_OH - 1) / T_OH;
         const int64_t blocks = (int64_t)tiles_x * tiles_y * major;
         if (blocks < 0x7FFFFFFFLL) {
-            hipLaunchKernelGGL(k_fir4_tile, dim3((unsigned)blocks), dim3(256), 0, st, out, x, k, in_h, in_w,
-                               out_h, out_w, pad_x0, pad_y0, tiles_x, tiles_y);
+            hipLaunchKernelGGL(k_fir4_tile<false>, dim3((unsigned)blocks), dim3(256), 0, st, out, x, k, in_h, in_w,
+                               out_h, out_w, pad_x0, pad_y0, tiles_x, tiles_y, FirNba{});
             return sr_launch_status();
         }
     }
@@ -194,5 +226,22 @@ extern "C" int sr_upfirdn2d(float* out, const float* x, const float* k, int64_t 
     const int64_t total = major * (int64_t)out_h * out_w;
     hipLaunchKernelGGL(k_upfirdn_generic, dim3(sr_stream_grid(total, 256)), dim3(256),
                        (size_t)kh * kw * sizeof(float), st, out, x, k, p, total);
+    return sr_launch_status();
+}
+
+extern "C" int sr_blur_noise_bias_act(float* y, const float* x, const float* k, const float* noise,
+                                      const float* noise_w, const float* bias, float alpha, float gain, int64_t n,
+                                      int64_t c, int in_h, int in_w, int out_h, int out_w, int pad0, int pad1,
+                                      int64_t noise_bstride, sr_stream_t stream) {
+    if (n < 0 || c < 0 || in_h < 0 || in_w < 0) return SR_EINVAL;
+    if (in_h + pad0 + pad1 - 4 + 1 != out_h || in_w + pad0 + pad1 - 4 + 1 != out_w) return SR_EINVAL;
+    if (n * c == 0 || out_h <= 0 || out_w <= 0) return SR_OK;
+    if (!y || !x || !k || (noise && !noise_w)) return SR_EINVAL;
+    const int tiles_x = (out_w + T_OW - 1) / T_OW, tiles_y = (out_h + T_OH - 1) / T_OH;
+    const int64_t blocks = (int64_t)tiles_x * tiles_y * n * c;
+    if (blocks >= 0x7FFFFFFFLL) return SR_ERANGE;
+    const FirNba nba{noise, noise_w, bias, noise_bstride, (int)c, alpha, gain};
+    hipLaunchKernelGGL(k_fir4_tile<true>, dim3((unsigned)blocks), dim3(256), 0, sr_stream(stream), y, x, k, in_h,
+                       in_w, out_h, out_w, pad0, pad0, tiles_x, tiles_y, nba);
     return sr_launch_status();
 }

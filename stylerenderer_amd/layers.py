@@ -182,7 +182,7 @@ class ModulatedConv2d(nn.Module):
             self.upsample, self.downsample)
 
     # ---- device tensors: shared weights + operand scaling on the MFMA kernels
-    def _forward_mfma(self, input, style):
+    def _forward_mfma(self, input, style, skip_blur=False):
         s = self.modulation(style)                                       # [B, Ci]
         if (self.kernel_size == 1 and not self.demodulate and not self.upsample and not self.downsample
                 and _smallconv.supported(input, self.out_channel)):
@@ -201,7 +201,7 @@ class ModulatedConv2d(nn.Module):
             if k != 3:
                 raise RuntimeError("ModulatedConv2d: upsample supports kernel_size 3")
             out = _conv.conv2d(input, wt, s, d, None, "t3s2")
-            return self.blur(out)
+            return out if skip_blur else self.blur(out)      # skip_blur: the caller fuses it (StyledConv)
         if self.downsample:
             if k != 3:
                 raise RuntimeError("ModulatedConv2d: downsample supports kernel_size 3")
@@ -235,9 +235,9 @@ class ModulatedConv2d(nn.Module):
                            padding=self.padding, groups=batch)
         return out.view(batch, self.out_channel, out.shape[2], out.shape[3])
 
-    def forward(self, input, style):
+    def forward(self, input, style, skip_blur=False):
         if input.device.type == "cuda":
-            return self._forward_mfma(input, style)
+            return self._forward_mfma(input, style, skip_blur)
         return self._forward_grouped(input, style)
 
 

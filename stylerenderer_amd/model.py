@@ -18,7 +18,7 @@ from torch import nn
 from .layers import (Blur, ConstantInput, ConvLayer, EqualLinear, ModulatedConv2d, NoiseInjection,  # noqa: F401
                      PixelNorm, ResBlock, Upsample)
 from .op import FusedLeakyReLU, rasterize
-from .op.fused_elem import noise_bias_act
+from .op.fused_elem import blur_noise_bias_act, noise_bias_act
 
 CHANNEL_BASE = {4: 512, 8: 512, 16: 512, 32: 512, 64: 256, 128: 128, 256: 64, 512: 32, 1024: 16}
 
@@ -40,6 +40,16 @@ class StyledConv(nn.Module):
         self.activate = FusedLeakyReLU(out_channel)
 
     def forward(self, input, style, noise=None):
+        if input.device.type == "cuda" and self.conv.upsample:
+            # upsampling layer: the blur after the transposed conv, the noise injection, the bias and the
+            # LeakyReLU are one kernel (one pass over the activation instead of three)
+            y = self.conv(input, style, skip_blur=True)
+            blur = self.conv.blur
+            oh, ow = y.shape[2] + sum(blur.pad) - 3, y.shape[3] + sum(blur.pad) - 3
+            if noise is None:
+                noise = y.new_empty(y.shape[0], 1, oh, ow).normal_()
+            return blur_noise_bias_act(y, blur.kernel, blur.pad, noise, self.noise.weight, self.activate.bias,
+                                       self.activate.negative_slope, self.activate.scale)
         out = self.conv(input, style)
         if out.device.type == "cuda":
             # noise injection + bias + LeakyReLU in one pass over the activation

@@ -101,6 +101,61 @@ def noise_bias_act(x, noise, noise_weight, bias, negative_slope=0.2, scale=2 ** 
     return fused_leaky_relu(x, bias, negative_slope, scale)
 
 
+class _BlurNBA(Function):
+    """Blur (4x4 FIR, up = down = 1) + noise + bias + LeakyReLU in ONE pass (csrc/upfirdn2d.hip
+    k_fir4_tile<true>): the tail of an upsampling StyledConv (reference layers.py:304-311 blur after the
+    transposed conv, model.py:26-32).  Its backward is the composition of the two existing differentiable
+    backward operators, so gradients of any order stay on the HIP kernels."""
+
+    @staticmethod
+    def forward(ctx, x, kernel, pad, noise, noise_w, bias, slope, scale):
+        n, c, ih, iw = x.shape
+        p0, p1 = pad
+        oh, ow = ih + p0 + p1 - 3, iw + p0 + p1 - 3
+        x = x.contiguous()
+        k = kernel.contiguous()
+        y = torch.empty((n, c, oh, ow), dtype=x.dtype, device=x.device)
+        bstride = 0 if noise is None or noise.numel() == oh * ow else oh * ow
+        with on_device_of(x):
+            rc = _lib.lib().sr_blur_noise_bias_act(_lib.ptr(y), _lib.ptr(x), _lib.ptr(k), _lib.ptr(noise),
+                                                   _lib.ptr(noise_w), _lib.ptr(bias), float(slope), float(scale), n,
+                                                   c, ih, iw, oh, ow, p0, p1, bstride, stream_of(x))
+        _lib.check(rc, "sr_blur_noise_bias_act")
+        ctx.save_for_backward(y, noise, kernel)
+        ctx.cfg = (slope, scale, p0, p1, tuple(x.shape), (oh, ow))
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        from .upfirdn2d import UpFirDn2dBackward
+
+        y, noise, kernel = ctx.saved_tensors
+        slope, scale, p0, p1, in_size, out_size = ctx.cfg
+        gpre, gb, gnw = _NBABackward.apply(gy, y, noise, slope, scale)
+        g_pad = (3 - p0, in_size[3] - out_size[1] + p0, 3 - p0, in_size[2] - out_size[0] + p0)
+        gx = UpFirDn2dBackward.apply(gpre, kernel, torch.flip(kernel, [0, 1]), (1, 1), (1, 1), (p0, p1, p0, p1),
+                                     g_pad, in_size, out_size)
+        return gx, None, None, None, (gnw if noise is not None else None), gb, None, None
+
+
+def blur_noise_bias_act(x, kernel, pad, noise, noise_weight, bias, negative_slope=0.2, scale=2 ** 0.5):
+    """lrelu(blur(x) + noise_weight*noise + bias) * scale for the 4x4 blur of the upsampling layers; falls
+    back to the two separate operators for anything else."""
+    from .upfirdn2d import upfirdn2d
+
+    ok = (x.device.type == "cuda" and x.dtype == torch.float32 and x.dim() == 4 and tuple(kernel.shape) == (4, 4)
+          and kernel.dtype == torch.float32 and bias is not None and x.numel() > 0)
+    if noise is not None:
+        noise = noise.contiguous()
+        oh, ow = x.size(2) + pad[0] + pad[1] - 3, x.size(3) + pad[0] + pad[1] - 3
+        ok = ok and noise.dtype == torch.float32 and noise.numel() in (oh * ow, x.size(0) * oh * ow)
+    if not ok:
+        return noise_bias_act(upfirdn2d(x, kernel, pad=pad), noise, noise_weight, bias, negative_slope, scale)
+    k = kernel if kernel.device == x.device else kernel.to(x.device)
+    return _BlurNBA.apply(x, k, tuple(pad), noise, noise_weight if noise is not None else None, bias,
+                          negative_slope, scale)
+
+
 def _rowdot_launch(a, b, scale):
     rows = a.size(0) * a.size(1)
     inner = a.numel() // max(rows, 1)
