@@ -76,6 +76,15 @@ int64_t sr_noise_bias_act_bwd_scratch_floats(int64_t n, int64_t c, int64_t inner
 int sr_noise_bias_act_bwd(float* gx, float* gbias, float* gnoise_w, const float* gy, const float* out,
                           const float* noise, float alpha, float scale, int64_t n, int64_t c,
                           int64_t inner, int64_t noise_bstride, float* scratch, sr_stream_t stream);
+/* The same with one more output: rowdot[b*c + ch] = sum_i gx * y0, where y0 is the forward pass's input
+ * rebuilt from its output (out / scale, or out / (alpha*scale) where negative, minus noise_w*noise and bias) —
+ * the demodulation gradient of the modulated convolution in front of the activation, without a separate pass
+ * over two tensors.  Needs alpha != 0 and scale != 0. */
+int64_t sr_noise_bias_act_bwd_dot_scratch_floats(int64_t n, int64_t c, int64_t inner);
+int sr_noise_bias_act_bwd_dot(float* gx, float* gbias, float* gnoise_w, float* rowdot, const float* gy,
+                              const float* out, const float* noise, const float* noise_w, const float* bias,
+                              float alpha, float scale, int64_t n, int64_t c, int64_t inner,
+                              int64_t noise_bstride, float* scratch, sr_stream_t stream);
 /* Row-wise dot products of two [rows, inner] tensors, optionally with a scaled copy in the same
  * sweep: dots[r] = sum_i a[r,i]*b[r,i] ; out_scaled[r,i] = b[r,i]*scale[r] (out_scaled may be NULL).
  * These are the style / demodulation gradients of the modulated convolution (sum_p x*dx', sum_p g*y)
@@ -244,6 +253,14 @@ int sr_conv2d_mfma(float* out, const float* in, const float* wt, const float* is
                    const float* oscale, const float* obias, int64_t B, int64_t C, int64_t N,
                    int64_t wt_ld, int64_t IH, int64_t IW, int64_t OH, int64_t OW, int ksize, int stride,
                    int pad, int transposed, float* scratch, sr_stream_t stream);
+/* The modulated 3x3 stride-1 pad-1 convolution with the StyledConv tail (reference model.py:26-32) fused into
+ * its store: out = lrelu((oscale*conv(iscale*in, wt) + noise_w[0]*noise[b, p]) + abias[n], alpha) * gain.
+ * Served by the Winograd kernel only: SR_EINVAL when the shape is not eligible (H % 8, W % 32, C % 8, N % 64,
+ * C <= 512) — the caller then uses sr_conv2d_mfma + sr_noise_bias_act.  scratch: sr_conv2d_scratch_floats. */
+int sr_conv2d_nba(float* out, const float* in, const float* wt, const float* iscale, const float* oscale,
+                  const float* noise, const float* noise_w, const float* abias, float alpha, float gain, int64_t B,
+                  int64_t C, int64_t N, int64_t wt_ld, int64_t H, int64_t W, int64_t noise_bstride, float* scratch,
+                  sr_stream_t stream);
 
 /* Weight gradient of sr_conv2d_mfma (same geometry arguments):
  *   dwt[ky*k+kx][c][n] = sum_{b, pixels} (xscale[b,c] * x[b,c,window]) * (gscale[b,n] * gy[b,n,pixel])

@@ -835,3 +835,19 @@ extern "C" int sr_conv2d_mfma(float* out, const float* in, const float* wt, cons
         }
     return SR_OK;
 }
+
+// Modulated 3x3 stride-1 convolution with the StyledConv tail fused into the store (Winograd kernel only).
+// SR_EINVAL when the shape is not taken by the Winograd path: the caller then runs sr_conv2d_mfma followed
+// by sr_noise_bias_act.
+extern "C" int sr_conv2d_nba(float* out, const float* in, const float* wt, const float* iscale, const float* oscale,
+                             const float* noise, const float* noise_w, const float* abias, float alpha, float gain,
+                             int64_t B, int64_t C, int64_t N, int64_t wt_ld, int64_t H, int64_t W,
+                             int64_t noise_bstride, float* scratch, sr_stream_t stream) {
+    if (B < 0 || C <= 0 || N <= 0 || H <= 0 || W <= 0) return SR_EINVAL;
+    if (wt_ld < N || wt_ld % 4 != 0 || (reinterpret_cast<uintptr_t>(wt) & 15)) return SR_EINVAL;
+    if (B == 0) return SR_OK;
+    if (!out || !in || !wt || !scratch || (noise && !noise_w)) return SR_EINVAL;
+    if (!wino_enabled() || !sr_wino_eligible(B, C, N, H, W, in, out)) return SR_EINVAL;
+    const WinoNba nba{noise, noise_w, abias, noise_bstride, alpha, gain};
+    return sr_wino_conv3x3(out, in, wt, wt_ld, iscale, oscale, nullptr, B, C, N, H, W, scratch, sr_stream(stream), &nba);
+}

@@ -12,6 +12,21 @@ struct WinoParams {
     float* out;
     int B, C, N, H, W;
     int tiles_x, tiles_y, tiles_n;
+    // optional StyledConv tail fused into the store: lrelu((y + nz_w[0]*nz[b, p]) + abias[n], alpha) * gain
+    int nba;
+    const float* nz;       // [B or 1, 1, H, W] or NULL
+    const float* nz_w;
+    const float* abias;    // [N] or NULL
+    int64_t nz_bstride;
+    float alpha, gain;
+};
+
+struct WinoNba {
+    const float* nz;
+    const float* nz_w;
+    const float* abias;
+    int64_t nz_bstride;
+    float alpha, gain;
 };
 
 // stride-1 3x3 pad-1 convolution with H % 8 == 0, W % 32 == 0, C % 8 == 0, N % 64 == 0
@@ -19,7 +34,7 @@ bool sr_wino_eligible(int64_t B, int64_t C, int64_t N, int64_t H, int64_t W, con
 int64_t sr_wino_scratch_floats(int64_t C, int64_t N);
 int sr_wino_conv3x3(float* out, const float* in, const float* wt, int64_t ldw, const float* iscale,
                     const float* oscale, const float* obias, int64_t B, int64_t C, int64_t N, int64_t H, int64_t W,
-                    float* u_scratch, hipStream_t st);
+                    float* u_scratch, hipStream_t st, const WinoNba* nba = nullptr);
 
 // Winograd weight gradient of the same convolution (csrc/conv_wgrad_wino.hip): H % 2 == 0, W % 16 == 0,
 // C % 64 == 0, N % 64 == 0, B <= 32

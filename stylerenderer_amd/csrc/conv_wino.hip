@@ -310,11 +310,28 @@ __global__ __launch_bounds__(256) void k_conv_wino(const WinoParams p) {
         const float os = p.oscale ? p.oscale[(int64_t)b * p.N + n] : 1.0f;
         const float ob = p.obias ? p.obias[n] : 0.0f;
         float* o = p.out + ((int64_t)b * p.N + n) * plane + (int64_t)oy * p.W + ox;
+        const float ab = (p.nba && p.abias) ? p.abias[n] : 0.0f;
+        const float nw = (p.nba && p.nz) ? p.nz_w[0] : 0.0f;
+        const float* nzp = (p.nba && p.nz) ? p.nz + b * p.nz_bstride + (int64_t)oy * p.W + ox : nullptr;
 #pragma unroll
         for (int a = 0; a < 2; ++a) {
             const float y0 = (s[a][0] + s[a][1]) + s[a][2];
             const float y1 = (s[a][1] - s[a][2]) - s[a][3];
-            *reinterpret_cast<float2*>(o + a * p.W) = make_float2(y0 * os + ob, y1 * os + ob);
+            float v0 = y0 * os + ob, v1 = y1 * os + ob;
+            if (p.nba) {
+                // same operation order as k_nba_fwd: (y + w * noise) + bias, unfused multiply-add
+#pragma clang fp contract(off)
+                if (nzp) {
+                    const float t0 = nw * nzp[a * p.W], t1 = nw * nzp[a * p.W + 1];
+                    v0 = v0 + t0;
+                    v1 = v1 + t1;
+                }
+                v0 = v0 + ab;
+                v1 = v1 + ab;
+                v0 = ((v0 > 0.0f) ? v0 : v0 * p.alpha) * p.gain;
+                v1 = ((v1 > 0.0f) ? v1 : v1 * p.alpha) * p.gain;
+            }
+            *reinterpret_cast<float2*>(o + a * p.W) = make_float2(v0, v1);
         }
     }
 }
@@ -382,9 +399,12 @@ int64_t sr_wino_scratch_floats(int64_t C, int64_t N) { return 16 * C * N; }
 
 int sr_wino_conv3x3(float* out, const float* in, const float* wt, int64_t ldw, const float* iscale,
                     const float* oscale, const float* obias, int64_t B, int64_t C, int64_t N, int64_t H, int64_t W,
-                    float* u_scratch, hipStream_t st) {
+                    float* u_scratch, hipStream_t st, const WinoNba* nba) {
     WinoParams p;
     p.in = in; p.u = u_scratch; p.iscale = iscale; p.oscale = oscale; p.obias = obias; p.out = out;
+    p.nba = nba ? 1 : 0;
+    p.nz = nba ? nba->nz : nullptr; p.nz_w = nba ? nba->nz_w : nullptr; p.abias = nba ? nba->abias : nullptr;
+    p.nz_bstride = nba ? nba->nz_bstride : 0; p.alpha = nba ? nba->alpha : 0.0f; p.gain = nba ? nba->gain : 1.0f;
     p.B = (int)B; p.C = (int)C; p.N = (int)N; p.H = (int)H; p.W = (int)W;
     p.tiles_x = (int)(W / (2 * TW)); p.tiles_y = (int)(H / (2 * TH)); p.tiles_n = (int)(N / NB);
     return launch<8>(p, u_scratch, wt, (int)ldw, st);

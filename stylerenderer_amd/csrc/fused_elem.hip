@@ -73,11 +73,19 @@ __global__ __launch_bounds__(EB) void k_nba_fwd(float* __restrict__ y, const flo
     }
 }
 
+// DOT: also the row sum of gx * y0, y0 = the pre-activation input of the forward pass rebuilt from its
+// output ( out / scale or out / (alpha * scale), minus noise and bias ): the demodulation gradient
+// sum_p g * y of the modulated convolution in front (reference layers.py:298-300), which would otherwise
+// be one more pass over two full tensors (and would keep the convolution output alive for backward).
+template <bool DOT>
 __global__ __launch_bounds__(EB) void k_nba_bwd(float* __restrict__ gx, float* __restrict__ partial,
                                                 const float* __restrict__ gy,
                                                 const float* __restrict__ out,
                                                 const float* __restrict__ noise, float alpha, float scale,
-                                                int c, int64_t inner, int64_t noise_bstride, int chunks) {
+                                                int c, int64_t inner, int64_t noise_bstride, int chunks,
+                                                const float* __restrict__ noise_w,
+                                                const float* __restrict__ bias, float inv_pos, float inv_neg,
+                                                float* __restrict__ dot_partial) {
     __shared__ float lds8[8];
     const int64_t row = blockIdx.y;
     const int64_t b = row / c;
@@ -88,7 +96,9 @@ __global__ __launch_bounds__(EB) void k_nba_bwd(float* __restrict__ gx, float* _
     const float4* os = reinterpret_cast<const float4*>(out + row * inner + off);
     const float4* ns = noise ? reinterpret_cast<const float4*>(noise + b * noise_bstride + off) : nullptr;
     float4* xs = reinterpret_cast<float4*>(gx + row * inner + off);
-    float sb = 0.0f, sn = 0.0f;
+    float sb = 0.0f, sn = 0.0f, sd = 0.0f;
+    const float nw = (DOT && noise) ? noise_w[0] : 0.0f;
+    const float bb = (DOT && bias) ? bias[row - b * c] : 0.0f;
     for (int i = threadIdx.x; i < n4; i += EB) {
         const float4 g = gs[i], o = os[i];
         float4 r;
@@ -98,15 +108,29 @@ __global__ __launch_bounds__(EB) void k_nba_bwd(float* __restrict__ gx, float* _
         r.w = ((o.w > 0.0f) ? g.w : g.w * alpha) * scale;
         xs[i] = r;
         sb += (r.x + r.y) + (r.z + r.w);
+        float4 nz = make_float4(0.f, 0.f, 0.f, 0.f);
         if (noise) {
-            const float4 nz = ns[i];
+            nz = ns[i];
             sn += (r.x * nz.x + r.y * nz.y) + (r.z * nz.z + r.w * nz.w);
         }
+        if (DOT) {
+            const float y0 = ((o.x > 0.0f) ? o.x * inv_pos : o.x * inv_neg) - nw * nz.x - bb;
+            const float y1 = ((o.y > 0.0f) ? o.y * inv_pos : o.y * inv_neg) - nw * nz.y - bb;
+            const float y2 = ((o.z > 0.0f) ? o.z * inv_pos : o.z * inv_neg) - nw * nz.z - bb;
+            const float y3 = ((o.w > 0.0f) ? o.w * inv_pos : o.w * inv_neg) - nw * nz.w - bb;
+            sd += (r.x * y0 + r.y * y1) + (r.z * y2 + r.w * y3);
+        }
     }
+    float dummy = 0.0f;
     block_sum2(sb, sn, lds8);
+    if (DOT) {
+        __syncthreads();
+        block_sum2(sd, dummy, lds8);
+    }
     if (threadIdx.x == 0) {
         partial[(row * chunks + blockIdx.x) * 2] = sb;
         partial[(row * chunks + blockIdx.x) * 2 + 1] = sn;
+        if (DOT) dot_partial[row * chunks + blockIdx.x] = sd;
     }
 }
 
@@ -229,13 +253,44 @@ extern "C" int sr_noise_bias_act_bwd(float* gx, float* gbias, float* gnoise_w, c
     if (!vec_ok(inner, gx, gy, out, noise) || (noise && noise_bstride % 4 != 0)) return SR_EINVAL;
     const int chunks = (int)sr_ceil_div(inner, ECHUNK);
     hipStream_t st = sr_stream(stream);
-    hipLaunchKernelGGL(k_nba_bwd, dim3(chunks, (unsigned)(n * c)), dim3(EB), 0, st, gx, scratch, gy, out,
-                       noise, alpha, scale, (int)c, inner, noise_bstride, chunks);
+    hipLaunchKernelGGL(k_nba_bwd<false>, dim3(chunks, (unsigned)(n * c)), dim3(EB), 0, st, gx, scratch, gy, out,
+                       noise, alpha, scale, (int)c, inner, noise_bstride, chunks, (const float*)nullptr,
+                       (const float*)nullptr, 0.0f, 0.0f, (float*)nullptr);
     float* chan_nw = scratch + 2 * n * c * (int64_t)chunks;
     hipLaunchKernelGGL(k_nba_finish, dim3((unsigned)c), dim3(64), 0, st, gbias, chan_nw, scratch, n, (int)c,
                        chunks);
     if (noise && gnoise_w)
         hipLaunchKernelGGL(k_nba_finish2, dim3(1), dim3(64), 0, st, gnoise_w, chan_nw, (int)c);
+    return sr_launch_status();
+}
+
+extern "C" int64_t sr_noise_bias_act_bwd_dot_scratch_floats(int64_t n, int64_t c, int64_t inner) {
+    if (n <= 0 || c <= 0 || inner <= 0) return 3;
+    return 3 * n * c * sr_ceil_div(inner, ECHUNK) + c + 2;      // partial pairs + row-dot partials + channel shares
+}
+
+extern "C" int sr_noise_bias_act_bwd_dot(float* gx, float* gbias, float* gnoise_w, float* rowdot, const float* gy,
+                                         const float* out, const float* noise, const float* noise_w,
+                                         const float* bias, float alpha, float scale, int64_t n, int64_t c,
+                                         int64_t inner, int64_t noise_bstride, float* scratch,
+                                         sr_stream_t stream) {
+    if (n < 0 || c < 0 || inner < 0) return SR_EINVAL;
+    if (n * c * inner == 0) return SR_OK;
+    if (!gx || !gy || !out || !scratch || !rowdot || n * c > 65535 || (noise && !noise_w) || scale == 0.0f ||
+        alpha == 0.0f)
+        return SR_EINVAL;
+    if (!vec_ok(inner, gx, gy, out, noise) || (noise && noise_bstride % 4 != 0)) return SR_EINVAL;
+    const int chunks = (int)sr_ceil_div(inner, ECHUNK);
+    hipStream_t st = sr_stream(stream);
+    float* dot_partial = scratch + 2 * n * c * (int64_t)chunks;
+    float* chan_nw = dot_partial + n * c * (int64_t)chunks;
+    hipLaunchKernelGGL(k_nba_bwd<true>, dim3(chunks, (unsigned)(n * c)), dim3(EB), 0, st, gx, scratch, gy, out, noise,
+                       alpha, scale, (int)c, inner, noise_bstride, chunks, noise_w, bias, 1.0f / scale,
+                       1.0f / (alpha * scale), dot_partial);
+    hipLaunchKernelGGL(k_nba_finish, dim3((unsigned)c), dim3(64), 0, st, gbias, chan_nw, scratch, n, (int)c, chunks);
+    if (noise && gnoise_w)
+        hipLaunchKernelGGL(k_nba_finish2, dim3(1), dim3(64), 0, st, gnoise_w, chan_nw, (int)c);
+    hipLaunchKernelGGL(k_rowdot_finish, dim3((unsigned)(n * c)), dim3(64), 0, st, rowdot, dot_partial, chunks);
     return sr_launch_status();
 }
 

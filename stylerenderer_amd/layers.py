@@ -212,6 +212,19 @@ class ModulatedConv2d(nn.Module):
             return _conv.conv2d(input, wt, s, d, None, "c1")
         raise RuntimeError("ModulatedConv2d: kernel_size %d is not supported on device" % k)
 
+    def forward_noise_bias_act(self, input, style, noise, noise_weight, act_bias, negative_slope, act_scale):
+        """conv -> noise -> bias -> LeakyReLU of a non-upsampling 3x3 layer as one autograd node (device tensors,
+        Winograd-eligible shapes); None when that path does not apply (the caller runs the separate operators)."""
+        if (input.device.type != "cuda" or self.upsample or self.downsample or self.kernel_size != 3
+                or not self.demodulate or act_bias is None):
+            return None
+        s = self.modulation(style)
+        wt, wsq = _weight_prep(self.weight, self.scale, True)
+        if not (_conv.conv_nba_supported(input.contiguous(), wt, noise) and _style.demod_supported(s, wsq)):
+            return None
+        d = _style.demod_scale(s, wsq, self.eps)
+        return _conv.conv2d_nba(input.contiguous(), wt, s, d, noise, noise_weight, act_bias, negative_slope, act_scale)
+
     # ---- CPU tensors: the reference's grouped-convolution formulation (reference layers.py:293-323)
     def _forward_grouped(self, input, style):
         batch, in_channel, height, width = input.shape

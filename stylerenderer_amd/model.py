@@ -50,13 +50,20 @@ class StyledConv(nn.Module):
                 noise = y.new_empty(y.shape[0], 1, oh, ow).normal_()
             return blur_noise_bias_act(y, blur.kernel, blur.pad, noise, self.noise.weight, self.activate.bias,
                                        self.activate.negative_slope, self.activate.scale)
-        out = self.conv(input, style)
-        if out.device.type == "cuda":
-            # noise injection + bias + LeakyReLU in one pass over the activation
+        if input.device.type == "cuda":
             if noise is None:
-                noise = out.new_empty(out.shape[0], 1, out.shape[2], out.shape[3]).normal_()
+                noise = input.new_empty(input.shape[0], 1, input.shape[2], input.shape[3]).normal_()
+            # 32^2 .. 256^2 layers: the Winograd convolution applies noise + bias + LeakyReLU in its store
+            fused = self.conv.forward_noise_bias_act(input, style, noise.contiguous(), self.noise.weight,
+                                                     self.activate.bias, self.activate.negative_slope,
+                                                     self.activate.scale)
+            if fused is not None:
+                return fused
+            out = self.conv(input, style)
+            # noise injection + bias + LeakyReLU in one pass over the activation
             return noise_bias_act(out, noise, self.noise.weight, self.activate.bias,
                                   self.activate.negative_slope, self.activate.scale)
+        out = self.conv(input, style)
         out = self.noise(out, noise=noise)
         return self.activate(out)
 

@@ -211,6 +211,112 @@ class WgradFn(torch.autograd.Function):
         return gx, g_g, gis, gos, None
 
 
+# ------------------------------------------------------------------------------------------------
+# Modulated 3x3 convolution + noise + bias + LeakyReLU as ONE node (non-upsampling StyledConv, reference
+# model.py:11-32).  Forward: the Winograd kernel applies the tail in its store (the pre-activation tensor
+# is never written).  Backward: the activation backward also emits sum_p g*y0 (the demodulation gradient,
+# y0 rebuilt from the output), then the usual data / weight gradient kernels.  When the backward pass is
+# itself recorded (create_graph) the VJP is re-derived from the two separate differentiable operators.
+def conv_nba_supported(x, wt, noise):
+    import os
+
+    if os.environ.get("SR_WINOGRAD", "1") == "0" or x.device.type != "cuda" or x.dtype != torch.float32:
+        return False
+    b, c, h, w = x.shape
+    n = wt.shape[2]
+    ok = (wt.shape[0] == 9 and h % 8 == 0 and w % 32 == 0 and c % 8 == 0 and c <= 512 and n % 64 == 0
+          and b * n <= 65535 and x.is_contiguous() and x.data_ptr() % 16 == 0)
+    if noise is not None:
+        ok = ok and noise.dtype == torch.float32 and noise.numel() in (h * w, b * h * w) and noise.data_ptr() % 16 == 0
+    return ok
+
+
+def _wt_pitch(wt):
+    taps, cw, n = wt.shape
+    if (wt.stride(2) == 1 and wt.stride(1) % 4 == 0 and wt.stride(1) >= n and wt.stride(0) == cw * wt.stride(1)
+            and wt.data_ptr() % 16 == 0):
+        return wt, wt.stride(1)
+    ldw = (n + 3) // 4 * 4
+    return (torch.nn.functional.pad(wt, (0, ldw - n)) if ldw != n else wt.contiguous()), ldw
+
+
+class ConvNBAFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, wt, iscale, oscale, noise, noise_w, abias, slope, gain):
+        b, c, h, w = x.shape
+        n = wt.shape[2]
+        wtp, ldw = _wt_pitch(wt)
+        out = torch.empty((b, n, h, w), dtype=x.dtype, device=x.device)
+        L = _lib.lib()
+        nscr = L.sr_conv2d_scratch_floats(b, c, n, h, w, h, w, 3, 1, 1, 0)
+        scratch = torch.empty(max(nscr, 1), dtype=x.dtype, device=x.device)
+        bstride = 0 if noise is None or noise.numel() == h * w else h * w
+        flops = 2.0 * b * h * w * c * n * 9
+        with on_device_of(x):
+            rc = _timed("conv", (3, 1, 0, b, c, n, h, w), flops,
+                        lambda: L.sr_conv2d_nba(_lib.ptr(out), _lib.ptr(x), _lib.ptr(wtp), _lib.ptr(iscale),
+                                                _lib.ptr(oscale), _lib.ptr(noise), _lib.ptr(noise_w), _lib.ptr(abias),
+                                                float(slope), float(gain), b, c, n, ldw, h, w, bstride,
+                                                _lib.ptr(scratch), stream_of(x)))
+        _lib.check(rc, "sr_conv2d_nba")
+        ctx.save_for_backward(x, wt, iscale, oscale, noise, noise_w, abias, out)
+        ctx.cfg = (float(slope), float(gain))
+        return out
+
+    @staticmethod
+    def backward(ctx, gy):
+        from .fused_elem import _NBA
+
+        x, wt, iscale, oscale, noise, noise_w, abias, out = ctx.saved_tensors
+        slope, gain = ctx.cfg
+        needs = ctx.needs_input_grad
+        if torch.is_grad_enabled():
+            with torch.enable_grad():
+                y0 = ConvFn.apply(x, wt, iscale, oscale, None, "c3")
+                y = _NBA.apply(y0, noise, noise_w, abias, slope, gain)
+                ins = (x, wt, iscale, oscale, None, noise_w, abias)
+                sel = [t for t, nd in zip(ins, needs[:7]) if nd and t is not None]
+                got = iter(torch.autograd.grad(y, sel, gy, create_graph=True, allow_unused=True)) if sel else iter(())
+                grads = [next(got) if (nd and t is not None) else None for t, nd in zip(ins, needs[:7])]
+            return tuple(grads) + (None, None)
+        gy = gy.contiguous()
+        b, n, h, w = out.shape
+        inner = h * w
+        L = _lib.lib()
+        g = torch.empty_like(out)
+        gb = torch.empty(n, dtype=out.dtype, device=out.device)
+        gnw = torch.zeros(1, dtype=out.dtype, device=out.device)
+        rdot = torch.empty((b, n), dtype=out.dtype, device=out.device)
+        scratch = torch.empty(L.sr_noise_bias_act_bwd_dot_scratch_floats(b, n, inner), dtype=out.dtype, device=out.device)
+        bstride = 0 if noise is None or noise.numel() == inner else inner
+        with on_device_of(out):
+            rc = L.sr_noise_bias_act_bwd_dot(_lib.ptr(g), _lib.ptr(gb), _lib.ptr(gnw), _lib.ptr(rdot), _lib.ptr(gy),
+                                             _lib.ptr(out), _lib.ptr(noise), _lib.ptr(noise_w), _lib.ptr(abias), slope,
+                                             gain, b, n, inner, bstride, _lib.ptr(scratch), stream_of(out))
+        _lib.check(rc, "sr_noise_bias_act_bwd_dot")
+        gx = gw = gis = gos = None
+        if needs[0] or needs[2]:
+            dxu = ConvFn.apply(g, adjoint_weight(wt, "c3"), oscale, None, None, "c3")
+            if needs[2] and needs[0] and iscale is not None:
+                gis, gx = rowdot(x, dxu, iscale)
+            else:
+                if needs[2] and iscale is not None:
+                    gis = rowdot(x, dxu)
+                if needs[0]:
+                    gx = dxu * _bc(iscale) if iscale is not None else dxu
+        if needs[1]:
+            gw = WgradFn.apply(x, g, iscale, oscale, "c3")
+        if needs[3] and oscale is not None:
+            gos = rdot / oscale
+        return (gx, gw, gis, gos, None, (gnw if noise is not None and needs[5] else None),
+                (gb if needs[6] else None), None, None)
+
+
+def conv2d_nba(x, wt, iscale, oscale, noise, noise_w, abias, slope=0.2, gain=2 ** 0.5):
+    """lrelu(oscale*conv3x3(iscale*x, wt) + noise_w*noise + abias) * gain in one node (see ConvNBAFn)."""
+    return ConvNBAFn.apply(x, wt, iscale, oscale, noise, noise_w, abias, slope, gain)
+
+
 def conv2d(x, wt, iscale=None, oscale=None, bias=None, geom="c3"):
     """Differentiable (to any order) MFMA convolution; see ConvFn."""
     return ConvFn.apply(x, wt, iscale, oscale, bias, geom)

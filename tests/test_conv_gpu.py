@@ -367,3 +367,39 @@ def test_winograd_wgrad_vs_float64_and_direct(b, c, n, h, w, scales, monkeypatch
     assert float(((wino - want).abs() / mag).max()) < 4e-6
     assert float(((direct - want).abs() / mag).max()) < 2e-6
     assert not torch.equal(wino, direct)
+
+
+# ---- conv + noise + bias + LeakyReLU as one node (ConvNBAFn) vs the two separate operators
+@pytest.mark.parametrize("b,c,n,h,w,shared_noise", [(2, 16, 64, 8, 32, False), (3, 24, 128, 16, 32, True)])
+def test_conv_nba_node_matches_separate_operators(b, c, n, h, w, shared_noise):
+    from stylerenderer_amd.op import conv as cv
+    from stylerenderer_amd.op.fused_elem import noise_bias_act
+
+    g = torch.Generator().manual_seed(b + c + n)
+    mk = lambda *s: torch.randn(*s, generator=g)  # noqa: E731
+    x0, wt0 = mk(b, c, h, w), mk(9, c, n) / (3 * c ** 0.5)
+    s0, d0 = mk(b, c), mk(b, n).abs() + 0.5
+    noise = mk(1 if shared_noise else b, 1, h, w).to(DEV)
+    nw0, ab0 = mk(1), mk(n)
+    proj = mk(b, n, h, w).to(DEV)
+
+    def run(fused):
+        x, wt, s, d, nw, ab = [t.clone().to(DEV).requires_grad_(True) for t in (x0, wt0, s0, d0, nw0, ab0)]
+        if fused:
+            assert cv.conv_nba_supported(x, wt, noise)
+            y = cv.conv2d_nba(x, wt, s, d, noise, nw, ab)
+        else:
+            y = noise_bias_act(cv.conv2d(x, wt, s, d, None, "c3"), noise, nw, ab)
+        grads = torch.autograd.grad((y * proj).sum(), [x, wt, s, d, nw, ab])
+        return y.detach(), grads
+
+    yf, gf = run(True)
+    yu, gu = run(False)
+    assert torch.equal(yf, yu)                                    # same kernel arithmetic, same operation order
+    for name, a, r in zip(("x", "wt", "s", "d", "noise_w", "bias"), gf, gu):
+        tol = 2e-4 if name == "d" else 1e-5                       # d: y0 rebuilt from the activation output
+        assert rel_err_t(a, r) < tol, name
+
+
+def rel_err_t(a, b):
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
