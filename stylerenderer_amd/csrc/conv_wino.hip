@@ -297,6 +297,18 @@ __global__ __launch_bounds__(256) void k_conv_wino(const WinoParams p) {
     const int tile = wt * 32 + l31;
     const int oy = oy0 + 2 * (tile >> 4), ox = ox0 + 2 * (tile & 15);
     const int64_t plane = (int64_t)p.H * p.W;
+    // noise of this lane's 2x2 output pixels (the same for every channel): w * noise, once
+    float nzv[2][2] = {{0.0f, 0.0f}, {0.0f, 0.0f}};
+    if (p.nba && p.nz) {
+#pragma clang fp contract(off)
+        const float nw = p.nz_w[0];
+        const float* nzp = p.nz + b * p.nz_bstride + (int64_t)oy * p.W + ox;
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            nzv[a][0] = nw * nzp[a * p.W];
+            nzv[a][1] = nw * nzp[a * p.W + 1];
+        }
+    }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int n = n0 + wn * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
@@ -311,8 +323,6 @@ __global__ __launch_bounds__(256) void k_conv_wino(const WinoParams p) {
         const float ob = p.obias ? p.obias[n] : 0.0f;
         float* o = p.out + ((int64_t)b * p.N + n) * plane + (int64_t)oy * p.W + ox;
         const float ab = (p.nba && p.abias) ? p.abias[n] : 0.0f;
-        const float nw = (p.nba && p.nz) ? p.nz_w[0] : 0.0f;
-        const float* nzp = (p.nba && p.nz) ? p.nz + b * p.nz_bstride + (int64_t)oy * p.W + ox : nullptr;
 #pragma unroll
         for (int a = 0; a < 2; ++a) {
             const float y0 = (s[a][0] + s[a][1]) + s[a][2];
@@ -321,11 +331,8 @@ __global__ __launch_bounds__(256) void k_conv_wino(const WinoParams p) {
             if (p.nba) {
                 // same operation order as k_nba_fwd: (y + w * noise) + bias, unfused multiply-add
 #pragma clang fp contract(off)
-                if (nzp) {
-                    const float t0 = nw * nzp[a * p.W], t1 = nw * nzp[a * p.W + 1];
-                    v0 = v0 + t0;
-                    v1 = v1 + t1;
-                }
+                v0 = v0 + nzv[a][0];
+                v1 = v1 + nzv[a][1];
                 v0 = v0 + ab;
                 v1 = v1 + ab;
                 v0 = ((v0 > 0.0f) ? v0 : v0 * p.alpha) * p.gain;
