@@ -26,6 +26,13 @@ from .op import style as _style
 from .op.weight_prep import weight_prep as _weight_prep
 
 
+def _fused_tails():
+    """SR_FUSED_TAILS=0 runs conv / blur / noise+bias+activation as separate autograd nodes (A/B, debugging)."""
+    import os
+
+    return os.environ.get("SR_FUSED_TAILS", "1") != "0"
+
+
 def make_kernel(k):
     k = torch.tensor(k, dtype=torch.float32)
     if k.dim() == 1:
@@ -216,7 +223,7 @@ class ModulatedConv2d(nn.Module):
         """conv -> noise -> bias -> LeakyReLU of a non-upsampling 3x3 layer as one autograd node (device tensors,
         Winograd-eligible shapes); None when that path does not apply (the caller runs the separate operators)."""
         if (input.device.type != "cuda" or self.upsample or self.downsample or self.kernel_size != 3
-                or not self.demodulate or act_bias is None):
+                or not self.demodulate or act_bias is None or not _fused_tails()):
             return None
         s = self.modulation(style)
         wt, wsq = _weight_prep(self.weight, self.scale, True)
@@ -224,6 +231,24 @@ class ModulatedConv2d(nn.Module):
             return None
         d = _style.demod_scale(s, wsq, self.eps)
         return _conv.conv2d_nba(input.contiguous(), wt, s, d, noise, noise_weight, act_bias, negative_slope, act_scale)
+
+    def forward_up_noise_bias_act(self, input, style, noise, noise_weight, act_bias, negative_slope, act_scale):
+        """Upsampling 3x3 layer: transposed conv -> blur -> noise -> bias -> LeakyReLU as one autograd node
+        (device tensors); None when that path does not apply."""
+        if (input.device.type != "cuda" or not self.upsample or self.kernel_size != 3 or not self.demodulate
+                or act_bias is None or not _fused_tails()):
+            return None
+        s = self.modulation(style)
+        wt, wsq = _weight_prep(self.weight, self.scale, True)
+        pad = self.blur.pad
+        oh = 2 * input.shape[2] + 1 + pad[0] + pad[1] - 3
+        ow = 2 * input.shape[3] + 1 + pad[0] + pad[1] - 3
+        if not (_conv.upconv_nba_supported(input, wt, noise, oh, ow) and _style.demod_supported(s, wsq)):
+            return None
+        d = _style.demod_scale(s, wsq, self.eps)
+        kernel = self.blur.kernel
+        return _conv.upconv_nba(input.contiguous(), wt, s, d, kernel, pad, noise, noise_weight, act_bias,
+                                negative_slope, act_scale)
 
     # ---- CPU tensors: the reference's grouped-convolution formulation (reference layers.py:293-323)
     def _forward_grouped(self, input, style):

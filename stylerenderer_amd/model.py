@@ -43,11 +43,17 @@ class StyledConv(nn.Module):
         if input.device.type == "cuda" and self.conv.upsample:
             # upsampling layer: the blur after the transposed conv, the noise injection, the bias and the
             # LeakyReLU are one kernel (one pass over the activation instead of three)
-            y = self.conv(input, style, skip_blur=True)
             blur = self.conv.blur
-            oh, ow = y.shape[2] + sum(blur.pad) - 3, y.shape[3] + sum(blur.pad) - 3
+            oh = 2 * input.shape[2] + 1 + sum(blur.pad) - 3
+            ow = 2 * input.shape[3] + 1 + sum(blur.pad) - 3
             if noise is None:
-                noise = y.new_empty(y.shape[0], 1, oh, ow).normal_()
+                noise = input.new_empty(input.shape[0], 1, oh, ow).normal_()
+            noise = noise.contiguous()
+            fused = self.conv.forward_up_noise_bias_act(input, style, noise, self.noise.weight, self.activate.bias,
+                                                        self.activate.negative_slope, self.activate.scale)
+            if fused is not None:
+                return fused
+            y = self.conv(input, style, skip_blur=True)
             return blur_noise_bias_act(y, blur.kernel, blur.pad, noise, self.noise.weight, self.activate.bias,
                                        self.activate.negative_slope, self.activate.scale)
         if input.device.type == "cuda":

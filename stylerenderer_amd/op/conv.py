@@ -217,6 +217,14 @@ class WgradFn(torch.autograd.Function):
 # is never written).  Backward: the activation backward also emits sum_p g*y0 (the demodulation gradient,
 # y0 rebuilt from the output), then the usual data / weight gradient kernels.  When the backward pass is
 # itself recorded (create_graph) the VJP is re-derived from the two separate differentiable operators.
+def _aliases(*tensors):
+    """Fresh graph nodes for the saved inputs of a fused node.  The second-order fallback re-derives the VJP
+    with autograd.grad; asking it for gradients w.r.t. the saved tensors themselves would also follow the
+    history that links them OUTSIDE the node (the demodulation scale is a function of the style) and count
+    those paths twice.  Gradients w.r.t. the aliases stop at the node boundary, and stay differentiable."""
+    return [t.view_as(t) if t is not None else None for t in tensors]
+
+
 def conv_nba_supported(x, wt, noise):
     import os
 
@@ -272,28 +280,15 @@ class ConvNBAFn(torch.autograd.Function):
         needs = ctx.needs_input_grad
         if torch.is_grad_enabled():
             with torch.enable_grad():
-                y0 = ConvFn.apply(x, wt, iscale, oscale, None, "c3")
-                y = _NBA.apply(y0, noise, noise_w, abias, slope, gain)
-                ins = (x, wt, iscale, oscale, None, noise_w, abias)
+                xa, wa, sa, da, nwa, aba = _aliases(x, wt, iscale, oscale, noise_w, abias)
+                y0 = ConvFn.apply(xa, wa, sa, da, None, "c3")
+                y = _NBA.apply(y0, noise, nwa, aba, slope, gain)
+                ins = (xa, wa, sa, da, None, nwa, aba)
                 sel = [t for t, nd in zip(ins, needs[:7]) if nd and t is not None]
                 got = iter(torch.autograd.grad(y, sel, gy, create_graph=True, allow_unused=True)) if sel else iter(())
                 grads = [next(got) if (nd and t is not None) else None for t, nd in zip(ins, needs[:7])]
             return tuple(grads) + (None, None)
-        gy = gy.contiguous()
-        b, n, h, w = out.shape
-        inner = h * w
-        L = _lib.lib()
-        g = torch.empty_like(out)
-        gb = torch.empty(n, dtype=out.dtype, device=out.device)
-        gnw = torch.zeros(1, dtype=out.dtype, device=out.device)
-        rdot = torch.empty((b, n), dtype=out.dtype, device=out.device)
-        scratch = torch.empty(L.sr_noise_bias_act_bwd_dot_scratch_floats(b, n, inner), dtype=out.dtype, device=out.device)
-        bstride = 0 if noise is None or noise.numel() == inner else inner
-        with on_device_of(out):
-            rc = L.sr_noise_bias_act_bwd_dot(_lib.ptr(g), _lib.ptr(gb), _lib.ptr(gnw), _lib.ptr(rdot), _lib.ptr(gy),
-                                             _lib.ptr(out), _lib.ptr(noise), _lib.ptr(noise_w), _lib.ptr(abias), slope,
-                                             gain, b, n, inner, bstride, _lib.ptr(scratch), stream_of(out))
-        _lib.check(rc, "sr_noise_bias_act_bwd_dot")
+        g, gb, gnw, rdot = _nba_bwd_dot(gy, out, noise, noise_w, abias, slope, gain)
         gx = gw = gis = gos = None
         if needs[0] or needs[2]:
             dxu = ConvFn.apply(g, adjoint_weight(wt, "c3"), oscale, None, None, "c3")
@@ -310,6 +305,104 @@ class ConvNBAFn(torch.autograd.Function):
             gos = rdot / oscale
         return (gx, gw, gis, gos, None, (gnw if noise is not None and needs[5] else None),
                 (gb if needs[6] else None), None, None)
+
+
+def _nba_bwd_dot(gy, out, noise, noise_w, abias, slope, gain):
+    """Activation backward + bias / noise-strength gradients + demodulation row-dots in one pass."""
+    gy = gy.contiguous()
+    b, n, h, w = out.shape
+    inner = h * w
+    L = _lib.lib()
+    g = torch.empty_like(out)
+    gb = torch.empty(n, dtype=out.dtype, device=out.device)
+    gnw = torch.zeros(1, dtype=out.dtype, device=out.device)
+    rdot = torch.empty((b, n), dtype=out.dtype, device=out.device)
+    scratch = torch.empty(L.sr_noise_bias_act_bwd_dot_scratch_floats(b, n, inner), dtype=out.dtype, device=out.device)
+    bstride = 0 if noise is None or noise.numel() == inner else inner
+    with on_device_of(out):
+        rc = L.sr_noise_bias_act_bwd_dot(_lib.ptr(g), _lib.ptr(gb), _lib.ptr(gnw), _lib.ptr(rdot), _lib.ptr(gy),
+                                         _lib.ptr(out), _lib.ptr(noise), _lib.ptr(noise_w), _lib.ptr(abias), slope, gain,
+                                         b, n, inner, bstride, _lib.ptr(scratch), stream_of(out))
+    _lib.check(rc, "sr_noise_bias_act_bwd_dot")
+    return g, gb, gnw, rdot
+
+
+def upconv_nba_supported(x, wt, noise, oh, ow):
+    b = x.shape[0]
+    n = wt.shape[2]
+    ok = (x.device.type == "cuda" and x.dtype == torch.float32 and wt.shape[0] == 9 and (oh * ow) % 4 == 0
+          and b * n <= 65535)
+    if noise is not None:
+        ok = ok and noise.dtype == torch.float32 and noise.numel() in (oh * ow, b * oh * ow) and noise.data_ptr() % 16 == 0
+    return ok
+
+
+class UpConvNBAFn(torch.autograd.Function):
+    """Upsampling StyledConv (reference model.py:11-32 with layers.py:304-311) as one node: stride-2 transposed
+    convolution -> [blur + noise + bias + LeakyReLU] (one kernel).  Backward: the activation backward also
+    yields the demodulation gradient — <blur^T g, y257> = <g, blur(y257)> = sum_p g * y0 with y0 rebuilt from
+    the output — so neither the 257^2 convolution output nor a row-dot pass over it is needed."""
+
+    @staticmethod
+    def forward(ctx, x, wt, iscale, oscale, kernel, pad, noise, noise_w, abias, slope, gain):
+        from .fused_elem import _BlurNBA
+
+        y257 = conv2d_mfma(x, wt, iscale, oscale, None, 3, 2, 0, True)
+        out = _BlurNBA.forward(_NoCtx(), y257, kernel, pad, noise, noise_w, abias, slope, gain)
+        ctx.save_for_backward(x, wt, iscale, oscale, kernel, noise, noise_w, abias, out)
+        ctx.cfg = (tuple(pad), float(slope), float(gain), tuple(y257.shape))
+        return out
+
+    @staticmethod
+    def backward(ctx, gy):
+        from .fused_elem import _BlurNBA
+        from .upfirdn2d import upfirdn2d_op
+
+        x, wt, iscale, oscale, kernel, noise, noise_w, abias, out = ctx.saved_tensors
+        pad, slope, gain, shape257 = ctx.cfg
+        needs = ctx.needs_input_grad
+        if torch.is_grad_enabled():
+            with torch.enable_grad():
+                xa, wa, sa, da, nwa, aba = _aliases(x, wt, iscale, oscale, noise_w, abias)
+                y = ConvFn.apply(xa, wa, sa, da, None, "t3s2")
+                o = _BlurNBA.apply(y, kernel, pad, noise, nwa, aba, slope, gain)
+                ins = (xa, wa, sa, da, None, None, None, nwa, aba)
+                sel = [t for t, nd in zip(ins, needs[:9]) if nd and t is not None]
+                got = iter(torch.autograd.grad(o, sel, gy, create_graph=True, allow_unused=True)) if sel else iter(())
+                grads = [next(got) if (nd and t is not None) else None for t, nd in zip(ins, needs[:9])]
+            return tuple(grads) + (None, None)
+        g, gb, gnw, rdot = _nba_bwd_dot(gy, out, noise, noise_w, abias, slope, gain)
+        p0 = pad[0]
+        oh, ow = out.shape[2], out.shape[3]
+        g257 = upfirdn2d_op(g.reshape(-1, oh, ow, 1), torch.flip(kernel, [0, 1]), 1, 1, 1, 1, 3 - p0,
+                            shape257[3] - ow + p0, 3 - p0, shape257[2] - oh + p0).view(shape257)
+        gx = gw = gis = gos = None
+        if needs[0] or needs[2]:
+            dxu = ConvFn.apply(g257, adjoint_weight(wt, "t3s2"), oscale, None, None, "c3s2")
+            if needs[2] and needs[0] and iscale is not None:
+                gis, gx = rowdot(x, dxu, iscale)
+            else:
+                if needs[2] and iscale is not None:
+                    gis = rowdot(x, dxu)
+                if needs[0]:
+                    gx = dxu * _bc(iscale) if iscale is not None else dxu
+        if needs[1]:
+            gw = WgradFn.apply(x, g257, iscale, oscale, "t3s2")
+        if needs[3] and oscale is not None:
+            gos = rdot / oscale
+        return (gx, gw, gis, gos, None, None, None, (gnw if noise is not None and needs[7] else None),
+                (gb if needs[8] else None), None, None)
+
+
+class _NoCtx:
+    """Stand-in context for calling an autograd Function's forward as a plain launcher."""
+
+    def save_for_backward(self, *a):
+        pass
+
+
+def upconv_nba(x, wt, iscale, oscale, kernel, pad, noise, noise_w, abias, slope=0.2, gain=2 ** 0.5):
+    return UpConvNBAFn.apply(x, wt, iscale, oscale, kernel, tuple(pad), noise, noise_w, abias, slope, gain)
 
 
 def conv2d_nba(x, wt, iscale, oscale, noise, noise_w, abias, slope=0.2, gain=2 ** 0.5):

@@ -403,3 +403,43 @@ def test_conv_nba_node_matches_separate_operators(b, c, n, h, w, shared_noise):
 
 def rel_err_t(a, b):
     return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+@pytest.mark.parametrize("up", [False, True])
+def test_fused_styledconv_nodes_second_order_with_linked_inputs(up):
+    """The fused nodes' create_graph fallback must not follow the history that links their inputs OUTSIDE the
+    node (the demodulation scale is a function of the style): first- and second-order gradients w.r.t. the
+    style equal those of the separate operators."""
+    from stylerenderer_amd.op import conv as cv
+    from stylerenderer_amd.op.fused_elem import blur_noise_bias_act, noise_bias_act
+
+    g = torch.Generator().manual_seed(11 + int(up))
+    mk = lambda *s: torch.randn(*s, generator=g)  # noqa: E731
+    b, c, n, h, w = 2, 16, 64, 8, 32
+    x0, wt0, s0, wsq0 = mk(b, c, h, w), mk(9, c, n) / (3 * c ** 0.5), mk(b, c), mk(c, n).abs() / c
+    oh, ow = (2 * h, 2 * w) if up else (h, w)
+    noise = mk(b, 1, oh, ow).to(DEV)
+    nw0, ab0 = mk(1), mk(n)
+    proj = mk(b, n, oh, ow).to(DEV)
+    k1 = torch.tensor([1.0, 3.0, 3.0, 1.0])
+    kernel = (k1[None, :] * k1[:, None] / 64.0 * 4.0).to(DEV)
+
+    def run(fused):
+        x, wt, s, wsq, nw, ab = [t.clone().to(DEV).requires_grad_(True) for t in (x0, wt0, s0, wsq0, nw0, ab0)]
+        d = torch.rsqrt((s * s) @ wsq + 1e-8)                    # linked to s outside the node
+        if up and fused:
+            y = cv.upconv_nba(x, wt, s, d, kernel, (1, 1), noise, nw, ab)
+        elif up:
+            y = blur_noise_bias_act(cv.conv2d(x, wt, s, d, None, "t3s2"), kernel, (1, 1), noise, nw, ab)
+        elif fused:
+            y = cv.conv2d_nba(x, wt, s, d, noise, nw, ab)
+        else:
+            y = noise_bias_act(cv.conv2d(x, wt, s, d, None, "c3"), noise, nw, ab)
+        (gs,) = torch.autograd.grad((y * proj).sum(), s, create_graph=True)
+        (g2,) = torch.autograd.grad((gs * gs).sum(), wt)
+        return gs.detach(), g2
+
+    gs_f, g2_f = run(True)
+    gs_u, g2_u = run(False)
+    assert rel_err_t(gs_f, gs_u) < 1e-5
+    assert rel_err_t(g2_f, g2_u) < 1e-4
