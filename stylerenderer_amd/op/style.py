@@ -63,8 +63,10 @@ class _Linear(Function):
         needs = ctx.needs_input_grad[:3]
         if torch.is_grad_enabled():
             with torch.enable_grad():
-                out = _linear_composite(x, weight, bias, wscale, bscale, act)
-                gx, gw, gb = _vjp(out, (x, weight, bias), gy, needs)
+                # aliases: gradients stop at the node boundary even if the inputs share history outside it
+                xa, wa, ba = [t.view_as(t) if t is not None else None for t in (x, weight, bias)]
+                out = _linear_composite(xa, wa, ba, wscale, bscale, act)
+                gx, gw, gb = _vjp(out, (xa, wa, ba), gy, needs)
             return gx, gw, gb, None, None, None
         gy = gy.contiguous()
         w = weight.contiguous()
@@ -123,8 +125,9 @@ class _Demod(Function):
         needs = ctx.needs_input_grad[:2]
         if torch.is_grad_enabled():
             with torch.enable_grad():
-                out = _demod_composite(s, wsq, ctx.eps)
-                gs, gw = _vjp(out, (s, wsq), gd, needs)
+                sa, wa = s.view_as(s), wsq.view_as(wsq)
+                out = _demod_composite(sa, wa, ctx.eps)
+                gs, gw = _vjp(out, (sa, wa), gd, needs)
             return gs, gw, None
         gd = gd.contiguous()
         s_, w_ = s.contiguous(), wsq.contiguous()
