@@ -406,39 +406,50 @@ __global__ __launch_bounds__(256) void k_smallconv_dx(float* __restrict__ dx, co
     }
 }
 
-// grid = (chunks, B*C): N partial dot products of one x row chunk with the N gradient rows
-template <int N>
+// grid = (chunks, B*C/CH): N partial dot products of CH x-row chunks with the N gradient rows.  The
+// gradient chunk is loaded once per workgroup and reused for the CH channels (with one channel per
+// workgroup the g rows were re-read C times through L2: 4x the bytes of x).
+template <int N, int CH>
 __global__ __launch_bounds__(256) void k_smallconv_dw(float* __restrict__ partial, const float* __restrict__ g,
                                                       const float* __restrict__ x, int C, int64_t hw,
                                                       int chunks) {
-    __shared__ float lds[4 * SC_MAXN];
-    const int64_t row = blockIdx.y;                  // b * C + c
-    const int64_t b = row / C;
+    __shared__ float lds[CH][4 * SC_MAXN];
+    const int64_t row0 = (int64_t)blockIdx.y * CH;   // b * C + c0, CH consecutive channels of one sample
+    const int64_t b = row0 / C;
     const int64_t off = (int64_t)blockIdx.x * ECHUNK;
     const int64_t remain = hw - off;
     const int n4 = (int)((remain < ECHUNK ? remain : ECHUNK) / 4);
-    const float4* xs = reinterpret_cast<const float4*>(x + row * hw + off);
-    float acc[N];
+    float acc[CH][N];
 #pragma unroll
-    for (int j = 0; j < N; ++j) acc[j] = 0.0f;
+    for (int k = 0; k < CH; ++k)
+#pragma unroll
+        for (int j = 0; j < N; ++j) acc[k][j] = 0.0f;
+#pragma unroll 2
     for (int i = threadIdx.x; i < n4; i += 256) {
-        const float4 v = xs[i];
+        float4 gg[N];
 #pragma unroll
-        for (int j = 0; j < N; ++j) {
-            const float4 gg = reinterpret_cast<const float4*>(g + (b * N + j) * hw + off)[i];
-            acc[j] += (v.x * gg.x + v.y * gg.y) + (v.z * gg.z + v.w * gg.w);
+        for (int j = 0; j < N; ++j) gg[j] = reinterpret_cast<const float4*>(g + (b * N + j) * hw + off)[i];
+#pragma unroll
+        for (int k = 0; k < CH; ++k) {
+            const float4 v = reinterpret_cast<const float4*>(x + (row0 + k) * hw + off)[i];
+#pragma unroll
+            for (int j = 0; j < N; ++j)
+                acc[k][j] += (v.x * gg[j].x + v.y * gg[j].y) + (v.z * gg[j].z + v.w * gg[j].w);
         }
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
-    for (int j = 0; j < N; ++j) {
-        acc[j] = sr_wave_sum(acc[j]);
-        if (lane == 0) lds[j * 4 + wave] = acc[j];
-    }
+    for (int k = 0; k < CH; ++k)
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            const float r = sr_wave_sum(acc[k][j]);
+            if (lane == 0) lds[k][j * 4 + wave] = r;
+        }
     __syncthreads();
-    if (threadIdx.x < N) {
-        const int j = threadIdx.x;
-        partial[(row * chunks + blockIdx.x) * N + j] = (lds[j * 4] + lds[j * 4 + 1]) + (lds[j * 4 + 2] + lds[j * 4 + 3]);
+    if (threadIdx.x < CH * N) {
+        const int k = threadIdx.x / N, j = threadIdx.x % N;
+        partial[((row0 + k) * chunks + blockIdx.x) * N + j] =
+            (lds[k][j * 4] + lds[k][j * 4 + 1]) + (lds[k][j * 4 + 2] + lds[k][j * 4 + 3]);
     }
 }
 
@@ -502,9 +513,24 @@ extern "C" int sr_smallconv_dw(float* dws, const float* g, const float* x, int64
                                int64_t hw, float* scratch, sr_stream_t stream) {
     if (!dws || !g || !x || !scratch || !smallconv_ok(B, C, N, hw, g, x) || B * C > 65535) return SR_EINVAL;
     const int chunks = (int)sr_ceil_div(hw, ECHUNK);
-    const dim3 grid((unsigned)chunks, (unsigned)(B * C));
     hipStream_t st = sr_stream(stream);
-    SR_SMALLCONV_DISPATCH(k_smallconv_dw, grid, dim3(256), 0, st, scratch, g, x, (int)C, hw, chunks);
+    if (C % 4 == 0) {
+        const dim3 grid((unsigned)chunks, (unsigned)(B * C / 4));
+        switch (N) {
+            case 1: hipLaunchKernelGGL((k_smallconv_dw<1, 4>), grid, dim3(256), 0, st, scratch, g, x, (int)C, hw, chunks); break;
+            case 2: hipLaunchKernelGGL((k_smallconv_dw<2, 4>), grid, dim3(256), 0, st, scratch, g, x, (int)C, hw, chunks); break;
+            case 3: hipLaunchKernelGGL((k_smallconv_dw<3, 4>), grid, dim3(256), 0, st, scratch, g, x, (int)C, hw, chunks); break;
+            default: hipLaunchKernelGGL((k_smallconv_dw<4, 4>), grid, dim3(256), 0, st, scratch, g, x, (int)C, hw, chunks); break;
+        }
+    } else {
+        const dim3 grid((unsigned)chunks, (unsigned)(B * C));
+        switch (N) {
+            case 1: hipLaunchKernelGGL((k_smallconv_dw<1, 1>), grid, dim3(256), 0, st, scratch, g, x, (int)C, hw, chunks); break;
+            case 2: hipLaunchKernelGGL((k_smallconv_dw<2, 1>), grid, dim3(256), 0, st, scratch, g, x, (int)C, hw, chunks); break;
+            case 3: hipLaunchKernelGGL((k_smallconv_dw<3, 1>), grid, dim3(256), 0, st, scratch, g, x, (int)C, hw, chunks); break;
+            default: hipLaunchKernelGGL((k_smallconv_dw<4, 1>), grid, dim3(256), 0, st, scratch, g, x, (int)C, hw, chunks); break;
+        }
+    }
     hipLaunchKernelGGL(k_smallconv_dw_finish, dim3((unsigned)(B * C)), dim3(64), 0, st, dws, scratch, (int)C,
                        (int)N, chunks, B * C);
     return sr_launch_status();
