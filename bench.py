@@ -2,25 +2,35 @@
 """Benchmark of the StyleRenderer generator hot path on MI355X.
 
     python bench.py --gpus N --steps K --warmup W
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...   (N > 1)
+        N > 1 and no WORLD_SIZE in the environment: re-launches itself as N ranks under
+        `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...`
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...   (driver form)
 
-Metric (BASELINE.json): generator fwd+bwd images/s at 256x256.  Workload = BASELINE config[1]:
+Headline metric (BASELINE.json): generator fwd+bwd images/s at 256x256.  Workload = BASELINE config[1]:
 `Generator(256, 512, 8, channel_multiplier=2)` forward + backward, batch 16 per GPU, fresh random
 latents every step, fresh per-layer noise, loss = image.sum(), fp32 end to end (exact-fp32 MFMA).
 Inputs are generated on the device (resident in HBM when the timed region starts).
 One process per GPU; N > 1 is data parallel (weak scaling: 16 images per GPU) with the gradient
-all-reduce over RCCL overlapped with backward (torch DDP, nccl backend == RCCL on ROCm).
+all-reduce over RCCL overlapped with backward (nccl backend == RCCL on ROCm).
 
 Prints ONE JSON line on rank 0 with the driver's contract fields plus
   roofline      achieved TFLOP/s of the dominant kernel (3x3 stride-1 MFMA convolution, forward and
                 data-gradient launches) measured with events on the launch stream INSIDE the timed
-                steps, against the 157.3 TFLOP/s fp32-MFMA peak of gfx950;
+                steps, against the 157.3 TFLOP/s fp32-MFMA peak of gfx950 (frac = EXECUTED MFMA flops);
   cpu_baseline  the CPU oracle (oracle/model_oracle.py, a restatement of the reference's grouped-
-                convolution formulation) timed on this host's cores on a bounded sample.
+                convolution formulation) timed on this host's cores on a bounded sample;
+  train_step    BASELINE config[2]: the full G+D iteration (GeneratorWithMap(256) + Discriminator(256),
+                4 images per GPU, synthetic images + 3DMM-size mesh, lazy R1 / path-length cadence 16 / 4,
+                64 timed iterations), images/s, enqueue time, and for N > 1 the measured 125 MB gradient
+                all-reduce against the xGMI ring bound;
+  rasterizer    BASELINE config[3]: Mtri/s forward and forward+backward, its own HBM roofline and the
+                single-thread C oracle (the reference's CPU rasterizer restated) beside it.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -29,39 +39,67 @@ for p in (ROOT, os.path.join(ROOT, "oracle")):
     if p not in sys.path:
         sys.path.insert(0, p)
 
-import torch  # noqa: E402
-import torch.distributed as dist  # noqa: E402
-
 FP32_MFMA_PEAK_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+HBM_PEAK_GBPS = 8000.0                 # MI355X_MICROARCH.md: HBM3E ~8 TB/s
+XGMI_LINK_GBPS = 153.0                 # per link and direction; 7 links per GPU
 FLOP_PER_IMAGE_FWD_BWD = 270.7e9       # 3 x 90.24 GFLOP of convolution per image
+G_PARAM_BYTES = 31.29e6 * 4            # Generator(256) gradients per step
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=16, help="images per GPU")
+    ap.add_argument("--batch", type=int, default=16, help="images per GPU (generator leg)")
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-raster", action="store_true", help="skip the rasterizer (BASELINE config[3]) leg")
+    ap.add_argument("--no-train", action="store_true", help="skip the full G+D step (BASELINE config[2]) leg")
+    ap.add_argument("--train-iters", type=int, default=64, help="timed iterations of the G+D step leg")
+    ap.add_argument("--train-batch", type=int, default=4, help="images per GPU of the G+D step leg")
     ap.add_argument("--cpu-batch", type=int, default=2)
     ap.add_argument("--cpu-iters", type=int, default=6)
     ap.add_argument("--cpu-threads", type=int, default=32)
-    return ap.parse_args()
+    ap.add_argument("--plumbing", action="store_true",
+                    help="CPU-only launch check (gloo, tiny model): exercises --gpus N rank spawning without a GPU")
+    return ap.parse_args(argv)
 
 
-def raster_leg(dev, batch=64, res=256, iters=5):
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: become N ranks (one per GPU) on this node."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    return subprocess.call(cmd, env=env)
+
+
+# ---------------------------------------------------------------------------------------------------
+def raster_leg(dev, world, batch=64, res=256, iters=10, cpu_baseline=True):
     """Second half of the metric: rasterizer Mtri/s on BASELINE config[3] (BFM-size-class mesh,
-    ~50k triangles, 256x256, batch 64, int64 ids as the API demands), forward and forward+backward
-    (fused attribute interpolation + fused gradient scatter).  Algorithmic HBM bytes per image
-    24*nf + 12*nv + 36*h*w."""
+    ~50k triangles, 256x256, batch 64 per GPU, int64 ids as the API demands), forward and forward+backward
+    (fused attribute interpolation + deterministic gradient gather).  Algorithmic HBM bytes per image
+    24*nf + 12*nv + 36*h*w forward, (24+12+4c)*h*w + 24*nv backward."""
+    import torch
+
     import stylerenderer_amd.op as op
     from stylerenderer_amd import synth
+    from stylerenderer_amd.op import rasterize as rz
 
     v0, tri = synth.face_sized_mesh()
-    v = torch.from_numpy(synth.random_poses(v0, batch, seed=1234)).to(dev)
-    nrm = torch.from_numpy(synth.vertex_normals(v.cpu().numpy(), tri)).to(dev)
+    vh = synth.random_poses(v0, batch, seed=1234)
+    v = torch.from_numpy(vh).to(dev)
+    nrm = torch.from_numpy(synth.vertex_normals(vh, tri)).to(dev)
     t = torch.from_numpy(tri).to(dev)
     nf, nv = tri.shape[0], v0.shape[0]
 
@@ -69,13 +107,14 @@ def raster_leg(dev, batch=64, res=256, iters=5):
         fn()
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
+        e0.record()                      # the raster kernels are launched on torch's current stream
         for _ in range(iters):
             fn()
         e1.record()
         torch.cuda.synchronize()
         return e0.elapsed_time(e1) / iters
 
+    ms_api = timed(lambda: rz.forward(v, t, res, res, False, 1e-6))      # index + coeff written (API parity)
     ms_f = timed(lambda: op.rasterize(v, nrm, t, res))
     vg, ng = v.clone().requires_grad_(), nrm.clone().requires_grad_()
 
@@ -84,12 +123,40 @@ def raster_leg(dev, batch=64, res=256, iters=5):
         op.rasterize(vg, ng, t, res).sum().backward()
 
     ms_fb = timed(fb)
-    bytes_img = 24 * nf + 12 * nv + 36 * res * res
-    return {"workload": "BASELINE config[3]: nv=%d nf=%d, %dx%d, batch %d" % (nv, nf, res, res, batch),
-            "fwd_mtri_s": round(batch * nf / ms_f / 1e3, 1), "fwd_ms": round(ms_f, 3),
-            "fwd_bwd_mtri_s": round(batch * nf / ms_fb / 1e3, 1), "fwd_bwd_ms": round(ms_fb, 3),
-            "fwd_algorithmic_GBps": round(batch * bytes_img / ms_f / 1e6, 1),
-            "bit_exact_vs_cpu_oracle": "tests/test_ops_gpu.py"}
+    ms_b = max(ms_fb - ms_f, 1e-6)
+    c = 3
+    fwd_bytes = batch * (24 * nf + 12 * nv + 36 * res * res)
+    bwd_bytes = batch * ((24 + 12 + 4 * c) * res * res + 24 * nv)
+    out = {"workload": "BASELINE config[3]: nv=%d nf=%d, %dx%d, batch %d per GPU" % (nv, nf, res, res, batch),
+           "fwd_mtri_s": round(world * batch * nf / ms_f / 1e3, 1), "fwd_ms": round(ms_f, 4),
+           "fwd_api_ms": round(ms_api, 4),
+           "fwd_bwd_mtri_s": round(world * batch * nf / ms_fb / 1e3, 1), "fwd_bwd_ms": round(ms_fb, 4),
+           "bwd_ms": round(ms_b, 4),
+           "roofline": {"bound": "hbm", "kernel": "sr_rasterize_forward_f32 (k_fill_u64 + k_depth_keys + k_resolve)",
+                        "achieved": round(fwd_bytes / ms_api / 1e6, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                        "frac": round(fwd_bytes / ms_api / 1e6 / HBM_PEAK_GBPS, 4), "traffic": None,
+                        "bytes_per_launch": fwd_bytes,
+                        "note": "setup ALU + 64-bit atomics bound, priced against the HBM roof as SURVEY 8(d) asks"},
+           "roofline_bwd": {"bound": "hbm", "kernel": "sr_rasterize_grad_f32 (k_grad_tri + k_grad_vert)",
+                            "achieved": round(bwd_bytes / ms_b / 1e6, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                            "frac": round(bwd_bytes / ms_b / 1e6 / HBM_PEAK_GBPS, 4), "bytes_per_launch": bwd_bytes},
+           "bit_exact_vs_cpu_oracle": "tests/test_ops_gpu.py"}
+    if cpu_baseline:
+        import raster as oracle_raster
+
+        nb = 8
+        oracle_raster.forward_buffers(vh[:1], tri, res, res, False, 1e-6)              # build + warm
+        t0 = time.perf_counter()
+        reps = 0
+        while reps < 3 or time.perf_counter() - t0 < 2.0:
+            oracle_raster.forward_buffers(vh[:nb], tri, res, res, False, 1e-6)
+            reps += 1
+        dt = (time.perf_counter() - t0) / reps
+        out["cpu_baseline"] = {"value": round(nb * nf / dt / 1e6, 2), "unit": "Mtri/s", "cores": 1, "kind": "port",
+                               "sample": "oracle/rasterize_oracle.c (sequential CPU loops of reference "
+                                         "op/rasterize.cpp:21-67), forward, batch %d of the same mesh, %d repeats, "
+                                         "single thread like the reference" % (nb, reps)}
+    return out
 
 
 def pmc_traffic(kernel_row):
@@ -113,11 +180,130 @@ def pmc_traffic(kernel_row):
     return {}
 
 
+# ---------------------------------------------------------------------------------------------------
+def train_leg(dev, rank, world, iters, batch, size=256):
+    """BASELINE config[2]: the reference's full training iteration (train.py:239-358) — D step, lazy R1
+    every 16, G step, lazy path-length regulariser every 4 on batch // 2 (double backward through every
+    operator), EMA — on GeneratorWithMap + Discriminator, `batch` images per GPU (4 x 8 GPUs = global 32),
+    synthetic in-memory images and a 3DMM-size-class mesh sampled per step.  The timed
+    window starts at iteration 0 of the lazy-regulariser cadence, so `iters` = 64 holds 4 R1 and 16
+    path-length iterations like any aligned window of a long run."""
+    import torch
+    import torch.distributed as dist
+
+    from stylerenderer_amd import train
+
+    tr = train.Trainer(size=size, latent=512, n_mlp=8, channel_multiplier=2, use_mesh=True, device=dev, seed=0)
+    data = train.SyntheticImages(64, size, dev)
+    faces = train.SyntheticFaceSource(dev, seed=0)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(2):                                   # iterations 0 (both regularisers) and 1 (plain)
+        tr.step(data.batch(batch), faces=faces, log=False)
+    tr.iteration = 0
+    fence()
+    t0 = time.perf_counter()
+    last = None
+    for _ in range(iters):
+        last = tr.step(data.batch(batch), faces=faces, log=False)
+    t_enq = time.perf_counter() - t0
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed, t_enq], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed, t_enq = float(t[0]), float(t[1])
+    finite = all(bool(torch.isfinite(v)) for v in last.values())
+    out = {"workload": "BASELINE config[2]: GeneratorWithMap(%d) + Discriminator(%d) full G+D step, %d img/GPU "
+                       "(global %d), d_reg_every 16, g_reg_every 4, path batch %d, synthetic images + mesh "
+                       "nv=24962 nf=49920" % (size, size, batch, batch * world, max(1, batch // 2)),
+           "value": round(batch * world * iters / elapsed, 2), "unit": "images/s", "iters": iters,
+           "ms_per_iter": round(elapsed / iters * 1e3, 3),
+           "host_enqueue_ms_per_iter": round(t_enq / iters * 1e3, 3),
+           "launch_bound": bool(t_enq > 0.95 * elapsed),
+           "losses_finite": finite, "parallelism": "dp%d" % world}
+    if world > 1:
+        n = int(G_PARAM_BYTES // 4)
+        buf = torch.zeros(n, device=dev)
+        for _ in range(3):
+            dist.all_reduce(buf)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            dist.all_reduce(buf)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 10
+        ring = 2.0 * (world - 1) / world * G_PARAM_BYTES / (XGMI_LINK_GBPS * 1e9) * 1e3
+        direct = 2.0 * (G_PARAM_BYTES / world) / (XGMI_LINK_GBPS * 1e9) * 1e3
+        out["allreduce_125MB"] = {"ms": round(ms, 3), "ring_bound_ms": round(ring, 3),
+                                  "direct_mesh_bound_ms": round(direct, 3),
+                                  "busbw_GBps": round(2.0 * (world - 1) / world * G_PARAM_BYTES / ms / 1e6, 1)}
+    del tr, data, faces
+    torch.cuda.empty_cache()
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------
+def plumbing_main(args, rank, world):
+    """CPU stand-in used by tests/test_bench_launch.py: same launch / rendezvous / reduction structure as the
+    GPU run on the gloo backend with a 8x8 generator; the JSON line says so (`plumbing: true`)."""
+    import torch
+    import torch.distributed as dist
+
+    from stylerenderer_amd import distributed as sr_dist
+    from stylerenderer_amd import model
+
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="gloo")
+        assert dist.get_world_size() == args.gpus == world, (dist.get_world_size(), args.gpus, world)
+    torch.manual_seed(0)
+    torch.set_num_threads(2)
+    g = model.Generator(8, 32, 2)
+    sr_dist.freeze_unused_tail(g)
+    net = sr_dist.construct_ddp(g, "cpu")
+    gen = torch.Generator().manual_seed(1234 + rank)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        z = torch.randn(2, 32, generator=gen)
+        for p_ in g.parameters():
+            p_.grad = None
+        img, _ = net([z])
+        img.sum().backward()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"metric": "generator fwd+bwd images/sec at 256^2", "plumbing": True, "n_gpus": world,
+                          "value": round(2 * world * args.steps / elapsed, 2), "unit": "images/s",
+                          "steps": args.steps, "warmup": 0, "data": "synthetic"}))
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch one rank per GPU)" % (args.gpus, world))
+    if args.plumbing:
+        return plumbing_main(args, rank, world)
+
+    import torch
+    import torch.distributed as dist
+
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
     torch.cuda.set_device(local_rank)
@@ -125,24 +311,19 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", device_id=dev)
+        assert dist.get_world_size() == world
 
     from stylerenderer_amd import _lib, model
+    from stylerenderer_amd import distributed as sr_dist
     from stylerenderer_amd.op import conv as conv_op
 
     _lib.lib()          # fail loudly if the HIP library is missing
 
     torch.manual_seed(0)
     g = model.Generator(args.size, 512, 8, channel_multiplier=2).to(dev)
-    # the duplicated ToRGB tail never receives gradients: keep it out of DDP buckets
-    used = len(g.to_rgbs) // 2
-    for m in list(g.to_rgbs)[used:]:
-        for p_ in m.parameters():
-            p_.requires_grad_(False)
-    net = g
-    if world > 1:
-        net = torch.nn.parallel.DistributedDataParallel(
-            g, device_ids=[local_rank], broadcast_buffers=False, bucket_cap_mb=32,
-            gradient_as_bucket_view=True)
+    # the duplicated ToRGB tail never receives gradients: keep it out of the buckets
+    sr_dist.freeze_unused_tail(g)
+    net = sr_dist.construct_ddp(g, dev) if world > 1 else g
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
 
     def step():
@@ -171,17 +352,17 @@ def main():
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    del net
+    for p_ in g.parameters():
+        p_.grad = None
 
-    result = None
+    roof, breakdown = None, None
     if rank == 0:
-        images = args.batch * world * args.steps
-        value = images / elapsed
         # ---- roofline of the dominant kernel: the stride-1 3x3 convolution (forward and data-gradient
         # launches of the 64^2..256^2 layers; k_conv_wino, or k_conv_mfma with SR_WINOGRAD=0), timed
         # inside the steps above
         dom = [(fl, e0.elapsed_time(e1)) for (kind, geom, fl, e0, e1) in prof
                if kind == "conv" and geom[0] == 3 and geom[1] == 1 and geom[2] == 0 and geom[7] > 16]
-        roof = None
         by_kind = {}
         for (kind, geom, fl, e0, e1) in prof:
             k = "%s_k%d_s%d_t%d" % (kind, geom[0], geom[1], geom[2])
@@ -192,24 +373,38 @@ def main():
         if dom:
             fl = sum(d[0] for d in dom) / len(dom)
             ms = sum(d[1] for d in dom) / len(dom)
-            ach = fl / (ms * 1e-3) / 1e12
+            alg = fl / (ms * 1e-3) / 1e12
             wino = os.environ.get("SR_WINOGRAD", "1") != "0"
+            # Winograd F(2x2,3x3) issues 16/36 of the direct-convolution multiplies on the matrix cores:
+            # `achieved` / `frac` are the EXECUTED MFMA flops (what the 157.3 TFLOP/s roof bounds); the
+            # algorithmic (direct-convolution) rate is reported beside it
+            exe = alg * 16.0 / 36.0 if wino else alg
             roof = {"bound": "mfma", "kernel": "k_conv_wino<8>" if wino else "k_conv_mfma<1,3,3,32,4,1>",
-                    "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None, "launches": len(dom),
-                    "avg_launch_ms": round(ms, 4), "flop_per_launch": fl}
+                    "achieved": round(exe, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(exe / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None, "launches": len(dom),
+                    "avg_launch_ms": round(ms, 4), "flop_per_launch": fl,
+                    "algorithmic_tflops": round(alg, 2),
+                    "algorithmic_frac": round(alg / FP32_MFMA_PEAK_TFLOPS, 4)}
             if wino:
-                # `achieved` counts the ALGORITHMIC (direct-convolution) FLOPs of SURVEY.md 8(d); the
-                # Winograd F(2x2,3x3) kernel issues 16/36 of them on the matrix cores
-                roof["executed_tflops"] = round(ach * 16.0 / 36.0, 2)
-                roof["executed_frac"] = round(ach * 16.0 / 36.0 / FP32_MFMA_PEAK_TFLOPS, 4)
-                roof["note"] = ("Winograd F(2x2,3x3): achieved = direct-conv FLOPs / time, so frac can exceed 1; "
-                                "executed_* = MFMA FLOPs actually issued (x16/36)")
+                roof["note"] = ("Winograd F(2x2,3x3): achieved/frac = MFMA flops actually issued (algorithmic x16/36); "
+                                "algorithmic_* = direct-convolution flops of SURVEY 8(d) / time (can exceed the roof)")
             roof.update(pmc_traffic("k_conv_wino<8>" if wino else "k_conv_mfma<1; 3; 3; 32; 4; 1; true>"))
         breakdown = {k: {"ms_per_step": round(v[1] / args.steps, 3),
                          "tflops": round(v[0] / (v[1] * 1e-3) / 1e12, 1) if v[1] > 0 else None,
                          "launches_per_step": v[2] // max(args.steps, 1)} for k, v in sorted(by_kind.items())}
-        raster = raster_leg(dev) if not args.no_raster else None
+    del g
+    torch.cuda.empty_cache()
+
+    train_res = None
+    if not args.no_train:
+        train_res = train_leg(dev, rank, world, args.train_iters, args.train_batch, args.size)
+    raster = None
+    if not args.no_raster and rank == 0:
+        raster = raster_leg(dev, 1, cpu_baseline=(world == 1 and not args.no_cpu_baseline))
+    result = None
+    if rank == 0:
+        images = args.batch * world * args.steps
+        value = images / elapsed
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             import model_oracle
@@ -235,7 +430,8 @@ def main():
                        "parallelism": "dp%d" % world,
                        "step": "zero_grad + forward + backward" + (" + DDP all-reduce (RCCL)" if world > 1 else "")},
             "model_flop_frac_of_mfma_peak": round(value / world * FLOP_PER_IMAGE_FWD_BWD / (FP32_MFMA_PEAK_TFLOPS * 1e12), 4),
-            "roofline": roof, "cpu_baseline": cpu, "kernel_breakdown": breakdown, "rasterizer": raster,
+            "roofline": roof, "cpu_baseline": cpu, "kernel_breakdown": breakdown,
+            "train_step": train_res, "rasterizer": raster,
         }
     if world > 1:
         dist.barrier()

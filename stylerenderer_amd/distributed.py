@@ -41,9 +41,10 @@ def reduce_sum(tensor):
     return tensor
 
 
-def reduce_scalars(values):
+def reduce_scalars(values, to_host=True):
     """dict name -> 0-d tensor/float  ->  dict name -> python float, averaged over ranks with ONE
-    collective and ONE device->host copy."""
+    collective and ONE device->host copy.  to_host=False skips the copy (no host synchronisation:
+    the step keeps enqueueing) and returns 0-d device tensors."""
     keys = sorted(values)
     if not keys:
         return {}
@@ -55,6 +56,8 @@ def reduce_scalars(values):
     if world > 1:
         dist.all_reduce(packed, op=dist.ReduceOp.SUM)
         packed = packed / world
+    if not to_host:
+        return dict(zip(keys, packed.unbind(0)))
     host = packed.cpu().tolist()
     return dict(zip(keys, host))
 

@@ -59,20 +59,24 @@ def g_nonsaturating_loss(fake_pred):
     return F.softplus(-fake_pred).mean()
 
 
-def g_path_regularize(fake_img, latents, mean_path_length, decay=0.01, noise=None):
-    """latents: tensor or list of tensors the Jacobian is taken against."""
+def g_path_regularize(fake_img, latents, mean_path_length, decay=0.01, lambda_=1., noise=None):
+    """Path-length regulariser (reference train.py:118-134).  `latents`: tensor or list of tensors the
+    Jacobian is taken against; `lambda_`: scalar or sequence of per-target weights, padded with ones
+    like the reference; `noise` (extension, tests): the image-space probe in place of randn_like."""
     if noise is None:
         noise = torch.randn_like(fake_img)
     noise = noise / math.sqrt(fake_img.shape[2] * fake_img.shape[3])
     if not isinstance(latents, (list, tuple)):
         latents = [latents]
+    lambda_ = [float(x) for x in np.reshape(lambda_, -1)]
+    lambda_ += [1.0] * (len(latents) - len(lambda_))
     grads = autograd.grad(outputs=(fake_img * noise).sum(), inputs=list(latents), create_graph=True,
                           allow_unused=True)
     path_lengths = 0
-    for g in grads:
+    for lam, g in zip(lambda_, grads):
         if g is not None:
             flat = g.reshape(g.shape[0], -1)
-            path_lengths = path_lengths + torch.sqrt((flat * flat).sum(1))
+            path_lengths = path_lengths + torch.sqrt((flat * flat).sum(1)) * lam
     path_mean = mean_path_length + decay * (path_lengths.mean() - mean_path_length)
     path_penalty = (path_lengths - path_mean).pow(2).mean()
     return path_penalty, path_mean.detach(), path_lengths
@@ -91,14 +95,18 @@ def mixing_noise(batch, latent_dim, prob, device, rng=np.random, generator=None)
 
 
 class Trainer:
-    """Owns G, D, the EMA copy and both optimisers; `step()` is one reference iteration."""
+    """Owns G, D, the EMA copy and both optimisers; `step()` is one reference iteration
+    (reference train.py:239-358)."""
 
     def __init__(self, size=256, latent=512, n_mlp=8, channel_multiplier=2, lr=0.002, r1=10.0,
                  path_regularize=2.0, path_batch_shrink=2, d_reg_every=16, g_reg_every=4, mixing=0.9,
-                 use_mesh=False, device="cpu", seed=0):
+                 use_mesh=False, device="cpu", seed=0, augment=False, augment_p=0.0, ada_target=0.6,
+                 ada_length=500 * 1000):
         self.args = dict(size=size, latent=latent, r1=r1, path_regularize=path_regularize,
                          path_batch_shrink=path_batch_shrink, d_reg_every=d_reg_every,
-                         g_reg_every=g_reg_every, mixing=mixing)
+                         g_reg_every=g_reg_every, mixing=mixing, augment=augment, augment_p=augment_p,
+                         ada_target=ada_target, ada_length=ada_length, lr=lr, n_mlp=n_mlp,
+                         channel_multiplier=channel_multiplier, seed=seed)
         self.device = torch.device(device)
         self.use_mesh = use_mesh
         torch.manual_seed(seed)                     # identical initial weights on every rank
@@ -108,6 +116,11 @@ class Trainer:
         self.g_ema = cls(size, latent, n_mlp, channel_multiplier=channel_multiplier).to(self.device)
         self.g_ema.load_state_dict(self.generator.state_dict())
         self.g_ema.eval()
+        # from here on every rank draws its OWN latents / noise / meshes / poses: the reference seeds
+        # each process with seed + rank (reference distributed.py:93-95); a shared stream would make the
+        # N replicas' fake batches duplicates of each other
+        rank = sr_dist.get_rank()
+        torch.manual_seed(seed + 1 + rank)
         sr_dist.freeze_unused_tail(self.generator)
         self.frozen = {n for n, p in self.generator.named_parameters() if not p.requires_grad}
         g_ratio = g_reg_every / (g_reg_every + 1)
@@ -120,8 +133,12 @@ class Trainer:
         self.d_ddp = sr_dist.construct_ddp(self.discriminator, self.device)
         self.mean_path_length = torch.zeros((), device=self.device)
         self.accum = 0.5 ** (32 / (10 * 1000))
-        self.np_rng = np.random.RandomState(seed + 17 * sr_dist.get_rank())
+        self.np_rng = np.random.RandomState(seed + 17 * rank)
         self.iteration = 0
+        # adaptive discriminator augmentation state (reference train.py:222-225, 269-280)
+        self.ada_aug_p = augment_p if augment_p > 0 else 0.0
+        self.ada_augment = torch.zeros(2, device=self.device)
+        self.r_t_stat = 0.0
 
     def _generate(self, net, noise, mesh, **kw):
         if self.use_mesh:
@@ -129,7 +146,23 @@ class Trainer:
         out = net(noise, **{k: v for k, v in kw.items() if k != "return_normals"})
         return out[0], out[1], None
 
-    def step(self, real_img, mesh=None):
+    def _mesh(self, mesh, faces, batch):
+        if not self.use_mesh:
+            return None
+        return faces.sample(batch) if faces is not None else mesh
+
+    def _augment(self, img):
+        if not self.args["augment"]:
+            return img
+        from .utils_3d import augment
+
+        return augment(img, self.ada_aug_p)
+
+    def step(self, real_img, mesh=None, faces=None, log=True):
+        """One iteration.  `faces` (an object with .sample(batch) -> (vert, normals, tri), e.g.
+        SyntheticFaceSource) is sampled once for the D step and once for the G step like the reference
+        (train.py:246-251, 303-306); a fixed `mesh` tuple is used for both otherwise.  With log=False the
+        packed scalar all-reduce is still issued but nothing is copied to the host (returns tensors)."""
         a = self.args
         dev = self.device
         batch = real_img.shape[0]
@@ -141,9 +174,11 @@ class Trainer:
         requires_grad(d, True)
         noise = mixing_noise(batch, a["latent"], a["mixing"], dev, self.np_rng)
         with torch.no_grad():
-            fake_img, _, _ = self._generate(g, noise, mesh)
+            fake_img, _, _ = self._generate(g, noise, self._mesh(mesh, faces, batch))
+            fake_img = self._augment(fake_img)
+            real_aug = self._augment(real_img)
         fake_pred = self.d_ddp(fake_img)
-        real_pred = self.d_ddp(real_img)
+        real_pred = self.d_ddp(real_aug)
         d_loss = d_logistic_loss(real_pred, fake_pred)
         losses["d"] = d_loss
         losses["real_score"] = real_pred.mean()
@@ -151,6 +186,17 @@ class Trainer:
         d.zero_grad(set_to_none=True)
         d_loss.backward()
         self.d_optim.step()
+        if a["augment"] and a["augment_p"] <= 0:
+            # ADA: p follows the sign statistics of D(real), all-reduced over ranks (train.py:269-280)
+            stat = torch.stack([torch.sign(real_pred.detach()).sum(),
+                                torch.tensor(float(real_pred.shape[0]), device=dev)])
+            self.ada_augment += sr_dist.reduce_sum(stat)
+            if float(self.ada_augment[1]) > 255:
+                pred_signs, n_pred = self.ada_augment.tolist()
+                self.r_t_stat = pred_signs / n_pred
+                sign = 1 if self.r_t_stat > a["ada_target"] else -1
+                self.ada_aug_p = min(1.0, max(0.0, self.ada_aug_p + sign * a["ada_target"] / a["ada_length"] * n_pred))
+                self.ada_augment.mul_(0)
         if i % a["d_reg_every"] == 0:
             real_req = real_img.detach().requires_grad_(True)
             real_pred = self.d_ddp(real_req)
@@ -162,22 +208,25 @@ class Trainer:
         # ---- G  (D is a fixed critic here: its plain module with frozen parameters)
         requires_grad(d, False)
         noise = mixing_noise(batch, a["latent"], a["mixing"], dev, self.np_rng)
-        fake_img, _, _ = self._generate(self.g_ddp, noise, mesh)
-        g_loss = g_nonsaturating_loss(d(fake_img))
+        g_mesh = self._mesh(mesh, faces, batch)
+        fake_img, _, _ = self._generate(self.g_ddp, noise, g_mesh)
+        g_loss = g_nonsaturating_loss(d(self._augment(fake_img)))
         losses["g"] = g_loss
         g.zero_grad(set_to_none=True)
         g_loss.backward()
         self.g_optim.step()
         if i % a["g_reg_every"] == 0:
-            pb = max(1, batch // a["path_batch_shrink"])
+            pb = max(1, batch // a["path_batch_shrink"]) if a["path_batch_shrink"] else batch
             noise = mixing_noise(pb, a["latent"], a["mixing"], dev, self.np_rng)
             sub_mesh = None
-            if mesh is not None:
-                sub_mesh = (mesh[0][:pb].detach().requires_grad_(True),
-                            mesh[1][:pb].detach().requires_grad_(True), mesh[2])
+            if g_mesh is not None:
+                sub_mesh = (g_mesh[0][:pb].detach().requires_grad_(True),
+                            g_mesh[1][:pb].detach().requires_grad_(True), g_mesh[2])
             fake_img, latents, normals = self._generate(self.g_ddp, noise, sub_mesh, return_latents=True,
                                                         return_normals=True)
             targets = [latents] + (list(normals) if normals else [])
+            # the EMA of the path length stays rank-local like the reference's (train.py:345-346); only
+            # its logged value is averaged over ranks (train.py:353-354)
             path_loss, self.mean_path_length, path_lengths = g_path_regularize(
                 fake_img, targets, self.mean_path_length)
             g.zero_grad(set_to_none=True)
@@ -191,10 +240,13 @@ class Trainer:
             losses["mean_path"] = self.mean_path_length
         accumulate(self.g_ema, g, self.accum)
         self.iteration += 1
-        reduced = sr_dist.reduce_scalars(losses)         # one collective, one host read
-        if "mean_path" in reduced:
-            self.mean_path_length = torch.tensor(reduced.pop("mean_path"), device=dev)
-        return reduced
+        return sr_dist.reduce_scalars(losses, to_host=log)   # one collective (+ one host read when logging)
+
+    # ---- checkpoint contract of the reference (train.py:411-420): see checkpoint.py
+    def state_dict(self):
+        from . import checkpoint
+
+        return checkpoint.trainer_state(self)
 
 
 class SyntheticImages:
@@ -267,11 +319,22 @@ def main():
     ap.add_argument("--channel_multiplier", type=int, default=2)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--mesh", action="store_true", help="GeneratorWithMap + rasterised normal maps")
+    ap.add_argument("--augment", action="store_true", help="adaptive discriminator augmentation")
+    ap.add_argument("--augment_p", type=float, default=0)
+    ap.add_argument("--ada_target", type=float, default=0.6)
+    ap.add_argument("--ada_length", type=int, default=500 * 1000)
+    ap.add_argument("--ckpt", type=str, default=None, help="checkpoint to resume from (reference layout)")
+    ap.add_argument("--save", type=str, default=None, help="write a checkpoint here after the last iteration")
     args = ap.parse_args()
     rank, _, world, device = sr_dist.initialize(seed=args.seed)
     tr = Trainer(args.size, args.latent, args.n_mlp, args.channel_multiplier, args.lr, args.r1,
                  args.path_regularize, args.path_batch_shrink, args.d_reg_every, args.g_reg_every,
-                 args.mixing, args.mesh, device, args.seed)
+                 args.mixing, args.mesh, device, args.seed, args.augment, args.augment_p, args.ada_target,
+                 args.ada_length)
+    if args.ckpt:
+        from . import checkpoint
+
+        checkpoint.load_checkpoint(args.ckpt, tr, map_location=device)
     data = SyntheticImages(max(64, args.batch * 4), args.size, device)
     faces = SyntheticFaceSource(device, seed=args.seed) if args.mesh else None
     t0 = None
@@ -280,7 +343,7 @@ def main():
             if device.type == "cuda":
                 torch.cuda.synchronize()
             t0 = time.perf_counter()
-        out = tr.step(data.batch(args.batch), faces.sample(args.batch) if faces else None)
+        out = tr.step(data.batch(args.batch), faces=faces)
         if rank == 0:
             print("iter %d  " % it + "  ".join("%s %.4f" % kv for kv in sorted(out.items())), flush=True)
     if device.type == "cuda":
@@ -289,6 +352,10 @@ def main():
         dt = time.perf_counter() - t0
         print("%.2f img/s over %d GPUs (%d timed iterations)" % (args.batch * world * (args.iter - 1) / dt,
                                                               world, args.iter - 1))
+    if args.save and rank == 0:
+        from . import checkpoint
+
+        checkpoint.save_checkpoint(args.save, tr)
 
 
 if __name__ == "__main__":

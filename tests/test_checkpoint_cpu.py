@@ -1,0 +1,114 @@
+"""CPU: checkpoint / dataset contract of the reference (train.py:411-420, 537-556,
+generate.py:61-69, dataset.py:56-92, prepare_data.py:95-124)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from stylerenderer_amd import checkpoint, dataset, model, train
+
+SIZE, LATENT, NMLP = 8, 32, 2
+
+
+def make_trainer(seed=1):
+    return train.Trainer(size=SIZE, latent=LATENT, n_mlp=NMLP, device="cpu", seed=seed)
+
+
+def test_checkpoint_keys_and_name():
+    tr = make_trainer()
+    st = tr.state_dict()
+    assert set(checkpoint.CKPT_KEYS) <= set(st)               # the reference's seven keys
+    assert checkpoint.checkpoint_name(10000) == "010000.pt"
+    assert checkpoint.checkpoint_name(1234567, 2000000) == "1234567.pt"
+    assert checkpoint.start_iter_from_name("/x/checkpoint/020000.pt") == 20000
+    assert checkpoint.start_iter_from_name("/x/stylegan2-ffhq-config-f.pt") == 0
+    # g_optim is written in the reference's indexing: one slot per generator parameter
+    assert len(st["g_optim"]["param_groups"][0]["params"]) == sum(1 for _ in tr.generator.parameters())
+
+
+def test_save_resume_continues_bit_identically(tmp_path):
+    data = train.SyntheticImages(8, SIZE, "cpu", seed=5)
+    batches = [data.batch(4) for _ in range(4)]
+
+    def run(tr, bs, start):
+        logs = []
+        for j, b in enumerate(bs):
+            tr.np_rng = np.random.RandomState(100 + start + j)
+            np.random.seed(300 + start + j)         # style-mixing inject_index uses numpy's global stream
+            torch.manual_seed(200 + start + j)
+            logs.append(tr.step(b))
+        return logs
+
+    a = make_trainer()
+    run(a, batches[:2], 0)
+    path = checkpoint.save_checkpoint(str(tmp_path / checkpoint.checkpoint_name(2)), a)
+    logs_a = run(a, batches[2:], 2)
+
+    b = make_trainer(seed=9)                                  # different init: everything must come from the file
+    ck = checkpoint.load_checkpoint(path, b)
+    assert b.iteration == 2 and set(checkpoint.CKPT_KEYS) <= set(ck)
+    logs_b = run(b, batches[2:], 2)
+    assert logs_a == logs_b
+    for (n, p), (_, q) in zip(a.generator.named_parameters(), b.generator.named_parameters()):
+        assert torch.equal(p, q), n
+    for (n, p), (_, q) in zip(a.g_ema.named_parameters(), b.g_ema.named_parameters()):
+        assert torch.equal(p, q), n
+    for (n, p), (_, q) in zip(a.discriminator.named_parameters(), b.discriminator.named_parameters()):
+        assert torch.equal(p, q), n
+
+
+def test_reference_style_checkpoint_loads(tmp_path):
+    """A checkpoint as the reference writes it: optimiser over ALL generator parameters (incl. the dead
+    ToRGB tail), no extension keys, iteration only in the file name."""
+    g = model.Generator(SIZE, LATENT, NMLP)
+    d = model.Discriminator(SIZE)
+    g_optim = torch.optim.Adam(g.parameters(), lr=0.0016, betas=(0.0, 0.99 ** 0.8))
+    d_optim = torch.optim.Adam(d.parameters(), lr=0.0019, betas=(0.0, 0.99 ** (16 / 17)))
+    img, _ = g([torch.randn(2, LATENT)])
+    (img.sum() + 0 * sum(p.sum() for p in g.parameters())).backward()       # every parameter gets Adam state
+    g_optim.step()
+    d(img.detach()).sum().backward()
+    d_optim.step()
+    path = str(tmp_path / "030000.pt")
+    torch.save({"g": g.state_dict(), "d": d.state_dict(), "g_ema": g.state_dict(), "g_optim": g_optim.state_dict(),
+                "d_optim": d_optim.state_dict(), "args": {"size": SIZE}, "ada_aug_p": 0.25}, path)
+    tr = make_trainer()
+    checkpoint.load_checkpoint(path, tr)
+    assert tr.iteration == 30000 and tr.ada_aug_p == 0.25
+    names = [n for n, _ in tr.generator.named_parameters()]
+    used = [n for n in names if n not in tr.frozen]
+    st = tr.g_optim.state_dict()["state"]
+    ref = g_optim.state_dict()["state"]
+    for i, n in enumerate(used):
+        assert torch.equal(st[i]["exp_avg"], ref[names.index(n)]["exp_avg"]), n
+    gen = checkpoint.load_generator(path, SIZE, LATENT, NMLP)
+    assert not gen.training
+    for (n, p), (_, q) in zip(gen.named_parameters(), g.named_parameters()):
+        assert torch.equal(p, q), n
+    tr.step(train.SyntheticImages(8, SIZE, "cpu").batch(4))                # and training continues
+
+
+def test_multi_resolution_store_roundtrip(tmp_path):
+    rng = np.random.RandomState(0)
+    imgs = [{16: rng.randint(0, 256, (16, 16, 3)).astype(np.uint8),
+             8: rng.randint(0, 256, (8, 8, 3)).astype(np.uint8)} for _ in range(3)]
+    store = {}
+    assert dataset.write_store(store, imgs, (8, 16), fmt="NPY") == 3
+    assert store[b"length"] == b"3" and b"16-00002" in store and b"8-00000" in store      # reference key format
+    ds = dataset.MultiResolutionDataset(store, resolution=16)
+    assert len(ds) == 3
+    x = ds[1]
+    assert x.shape == (3, 16, 16) and x.dtype == torch.float32 and -1 <= float(x.min()) and float(x.max()) <= 1
+    want = torch.from_numpy(imgs[1][16]).permute(2, 0, 1).float() / 255 * 2 - 1
+    assert torch.allclose(x, want, atol=1e-6)
+    with pytest.raises(KeyError):
+        dataset.MultiResolutionDataset(store, resolution=32)
+    # directory-backed store with JPEG payloads (what prepare_data.py writes into LMDB values)
+    d = str(tmp_path / "ds")
+    dataset.write_store(d, imgs, (16,), fmt="JPEG")
+    ds2 = dataset.MultiResolutionDataset(d, transform=dataset.train_transform(np.random.RandomState(1)), resolution=16)
+    loader = torch.utils.data.DataLoader(ds2, batch_size=2, drop_last=True)
+    batch = next(dataset.sample_data(loader))
+    assert batch.shape == (2, 3, 16, 16) and torch.isfinite(batch).all()
+    assert os.path.isfile(os.path.join(d, "length"))

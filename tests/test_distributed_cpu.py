@@ -66,11 +66,16 @@ def worker(rank, world, port, outdir):
     red = sr_dist.reduce_scalars({"a": torch.tensor(float(rank + 1)), "b": 2.0 * rank, "loss": loss})
     # --- (3) two full training iterations (i = 0 runs R1 and the path-length regulariser)
     tr = train.Trainer(size=SIZE, latent=LATENT, n_mlp=NMLP, device="cpu", seed=3)
+    init_sum = torch.stack([p.detach().double().sum() for p in tr.generator.parameters()])
+    state = torch.get_rng_state()
+    z_probe = torch.randn(4, LATENT)                  # what the first mixing_noise() of this rank will draw
+    torch.set_rng_state(state)
     data = train.SyntheticImages(16, SIZE, "cpu")
     logs = [tr.step(data.batch(4)) for _ in range(2)]
     checksum = torch.stack([p.detach().double().sum() for p in tr.generator.parameters()]
                            + [p.detach().double().sum() for p in tr.discriminator.parameters()])
-    torch.save({"grads": grads, "red": red, "logs": logs, "checksum": checksum, "loss": loss},
+    torch.save({"grads": grads, "red": red, "logs": logs, "checksum": checksum, "loss": loss,
+                "init_sum": init_sum, "z_probe": z_probe},
                os.path.join(outdir, "rank%d.pt" % rank))
     sr_dist.synchronize()
     torch.distributed.destroy_process_group()
@@ -113,6 +118,15 @@ def test_training_step_keeps_replicas_identical(two_rank_run):
         assert all(np.isfinite(v) for v in log.values())
     assert {"r1", "path", "path_length"} <= set(r0["logs"][0])     # lazy regularisers fire at i = 0
     assert "r1" not in r0["logs"][1]
+
+
+def test_ranks_share_weights_but_not_sample_streams(two_rank_run):
+    """the model is built under the shared seed, the latent / noise / mesh streams are per rank
+    (reference distributed.py:93-95 seeds with seed + rank) — otherwise N GPUs render N copies of one batch."""
+    r0, r1 = two_rank_run
+    assert torch.equal(r0["init_sum"], r1["init_sum"])
+    assert not torch.equal(r0["z_probe"], r1["z_probe"])
+    assert float((r0["z_probe"] - r1["z_probe"]).abs().mean()) > 0.5
 
 
 def test_single_process_training_step_updates_parameters():
