@@ -90,11 +90,14 @@ def raster_leg(dev, world, batch=64, res=256, iters=10, cpu_baseline=True):
     ~50k triangles, 256x256, batch 64 per GPU, int64 ids as the API demands), forward and forward+backward
     (fused attribute interpolation + deterministic gradient gather).  Algorithmic HBM bytes per image
     24*nf + 12*nv + 36*h*w forward, (24+12+4c)*h*w + 24*nv backward."""
+    import importlib
+
     import torch
 
     import stylerenderer_amd.op as op
     from stylerenderer_amd import synth
-    from stylerenderer_amd.op import rasterize as rz
+
+    rz = importlib.import_module("stylerenderer_amd.op.rasterize")      # (op.rasterize is the function)
 
     v0, tri = synth.face_sized_mesh()
     vh = synth.random_poses(v0, batch, seed=1234)
@@ -220,7 +223,8 @@ def train_leg(dev, rank, world, iters, batch, size=256):
     finite = all(bool(torch.isfinite(v)) for v in last.values())
     out = {"workload": "BASELINE config[2]: GeneratorWithMap(%d) + Discriminator(%d) full G+D step, %d img/GPU "
                        "(global %d), d_reg_every 16, g_reg_every 4, path batch %d, synthetic images + mesh "
-                       "nv=24962 nf=49920" % (size, size, batch, batch * world, max(1, batch // 2)),
+                       "nv=%d nf=%d" % (size, size, batch, batch * world, max(1, batch // 2),
+                                        faces.model.dim[2] // 3, faces.tri.shape[0]),
            "value": round(batch * world * iters / elapsed, 2), "unit": "images/s", "iters": iters,
            "ms_per_iter": round(elapsed / iters * 1e3, 3),
            "host_enqueue_ms_per_iter": round(t_enq / iters * 1e3, 3),

@@ -191,17 +191,21 @@ int sr_blur_noise_bias_act(float* y, const float* x, const float* k, const float
  * (uncovered: index 0, coeff 0, zbuf -MAX).  `work` is caller scratch of
  * sr_rasterize_scratch_bytes(b, h, w, is_double) bytes.
  * Optional fused attribute interpolation (reference op/rasterize.py:29-37): when `tex` != NULL,
- * attr[b,h,w,c] = sum_k tex[index_k, :] * coeff_k  with tex [b*nv (or nv), c]. */
+ * attr[b,h,w,c] = sum_k tex[index_k, :] * coeff_k  with tex [b*nv (or nv), c].
+ * Optional winner map `win` int32 [b,h,w]: id of the triangle that owns the pixel, -1 where uncovered
+ * (what sr_rasterize_grad_* walks; index / coeff may then be NULL: the fused autograd path writes
+ * 16 B per pixel instead of 48).  Triangles whose bounding box exceeds 64 pixels are walked by the whole
+ * workgroup (LDS queue) instead of one lane. */
 int64_t sr_rasterize_scratch_bytes(int64_t b, int64_t h, int64_t w, int is_double);
 int sr_rasterize_forward_f32(int64_t b, int64_t nv, int64_t nf, int64_t h, int64_t w, int repeat_v,
                              int repeat_f, int perspective, const float* v, const int64_t* tri,
                              int64_t* index, float* coeff, float* zbuf, float eps,
-                             const float* tex, int64_t tex_c, float* attr, void* work,
+                             const float* tex, int64_t tex_c, float* attr, int32_t* win, void* work,
                              sr_stream_t stream);
 int sr_rasterize_forward_f64(int64_t b, int64_t nv, int64_t nf, int64_t h, int64_t w, int repeat_v,
                              int repeat_f, int perspective, const double* v, const int64_t* tri,
                              int64_t* index, double* coeff, double* zbuf, double eps,
-                             const double* tex, int64_t tex_c, double* attr, void* work,
+                             const double* tex, int64_t tex_c, double* attr, int32_t* win, void* work,
                              sr_stream_t stream);
 
 /* d(coeff)/d(vertex) per pixel.  Replaces  bool rasterize_gpu_backward<scalar,index>(b, n, h, w,
@@ -216,20 +220,45 @@ int sr_rasterize_backward_f64(int64_t b, int64_t n, int64_t h, int64_t w, int re
                               double* dcoeff, double eps, sr_stream_t stream);
 
 /* Fused backward of `rasterize` (reference op/rasterize.py:39-80: dcoeff, [1x3]@[3x9], and two
- * sparse scatter matmuls) without materialising dcoeff or a COO matrix:
- *   grad_v  [rows, 3] += sum_pixels (grad_out . tex[index_i]) * dcoeff[i, :]
- *   grad_tex[rows, c] += grad_out * coeff_k
- * rows = b*nv.  Both outputs must be zeroed by the caller; either may be NULL.  Accumulation
- * uses fp32/fp64 atomics (summation order is not fixed — the reference's sparse mm is not
- * ordered either). */
-int sr_rasterize_grad_f32(int64_t b, int64_t nv, int64_t h, int64_t w, int repeat_v, int perspective,
-                          const float* v, const float* tex, int64_t tex_c, const int64_t* index,
-                          const float* coeff, const float* grad_out, float* grad_v,
-                          float* grad_tex, float eps, sr_stream_t stream);
-int sr_rasterize_grad_f64(int64_t b, int64_t nv, int64_t h, int64_t w, int repeat_v, int perspective,
-                          const double* v, const double* tex, int64_t tex_c, const int64_t* index,
-                          const double* coeff, const double* grad_out, double* grad_v,
-                          double* grad_tex, double eps, sr_stream_t stream);
+ * sparse scatter matmuls) without materialising dcoeff or a COO matrix, and WITHOUT atomics — a
+ * deterministic two-phase gather (run-to-run identical results):
+ *   phase 1  per (sample, triangle): sums over the pixels the triangle won (`win` of the forward call), in
+ *            pixel order, of (grad_out . tex[vertex_i]) * dcoeff[i, :] and grad_out * coeff_k;
+ *   phase 2  per (sample, vertex): sum over its incident triangles in the order of the incidence list.
+ *   grad_v  [b, nv, 3], grad_tex [b, nv, c]: every row is written (no pre-zeroing); either may be NULL.
+ * v [b, nv, 3]; tex [b, nv, c]; tri int64 [nf, 3] (or [b, nf, 3] when !repeat_f); grad_out [b, h, w, c].
+ * Incidence list (CSR, built once per topology by the caller): adj_off int32 [nv + 1], adj int32 [3 nf] holding
+ * corner-major entries k * nf + f with tri[f][k] == vertex, ascending; per-sample topologies pass batch strides
+ * (elements) adj_off_bstride / adj_bstride, shared ones pass 0.
+ * `work`: sr_rasterize_grad_scratch_bytes(b, nf, c, is_double) bytes. */
+int64_t sr_rasterize_grad_scratch_bytes(int64_t b, int64_t nf, int64_t tex_c, int is_double);
+int sr_rasterize_grad_f32(int64_t b, int64_t nv, int64_t nf, int64_t h, int64_t w, int repeat_f,
+                          int perspective, const float* v, const float* tex, int64_t tex_c,
+                          const int64_t* tri, const int32_t* win, const float* grad_out,
+                          const int32_t* adj_off, const int32_t* adj, int64_t adj_off_bstride,
+                          int64_t adj_bstride, float* grad_v, float* grad_tex, float eps, void* work,
+                          sr_stream_t stream);
+int sr_rasterize_grad_f64(int64_t b, int64_t nv, int64_t nf, int64_t h, int64_t w, int repeat_f,
+                          int perspective, const double* v, const double* tex, int64_t tex_c,
+                          const int64_t* tri, const int32_t* win, const double* grad_out,
+                          const int32_t* adj_off, const int32_t* adj, int64_t adj_off_bstride,
+                          int64_t adj_bstride, double* grad_v, double* grad_tex, double eps, void* work,
+                          sr_stream_t stream);
+
+/* Host (CPU) path for HOST pointers: the reference's extension also serves CPU tensors
+ * (rasterize_cpu / rasterize_cpu_backward, reference op/rasterize.cpp:21-95, dispatched at :126-150).
+ * Sequential loops on the same arithmetic as the kernels (this file's functions are __host__ __device__);
+ * outputs are initialised by the callee; zbuf may be NULL.  No stream: runs on the calling thread. */
+int sr_rasterize_forward_cpu_f32(int64_t b, int64_t nv, int64_t nf, int64_t h, int64_t w, int repeat_v,
+                                 int repeat_f, int perspective, const float* v, const int64_t* tri,
+                                 int64_t* index, float* coeff, float* zbuf, float eps);
+int sr_rasterize_forward_cpu_f64(int64_t b, int64_t nv, int64_t nf, int64_t h, int64_t w, int repeat_v,
+                                 int repeat_f, int perspective, const double* v, const int64_t* tri,
+                                 int64_t* index, double* coeff, double* zbuf, double eps);
+int sr_rasterize_backward_cpu_f32(int64_t b, int64_t n, int64_t h, int64_t w, int perspective,
+                                  const float* v, const int64_t* index, float* dcoeff, float eps);
+int sr_rasterize_backward_cpu_f64(int64_t b, int64_t n, int64_t h, int64_t w, int perspective,
+                                  const double* v, const int64_t* index, double* dcoeff, double eps);
 
 /* ---------------------------------------------------------------------------------------
  * Dense contraction of the modulated convolution on the matrix cores (exact fp32 MFMA).

@@ -1,7 +1,7 @@
 // Library-level entry points of libstylerenderer_hip.so (error strings, ABI version).
 #include "common.h"
 
-extern "C" int sr_abi_version(void) { return 1; }
+extern "C" int sr_abi_version(void) { return 2; }
 
 extern "C" const char* sr_error_string(int code) {
     if (code == SR_OK) return "ok";

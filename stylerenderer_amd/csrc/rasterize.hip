@@ -22,13 +22,35 @@
 // reference's double-literal form for every float input), (h, w) passed swapped into the setup
 // exactly like the reference's call sites, float->int64 casts with x86 semantics.
 //
-// Backward: k_dcoeff (API parity with rasterize_gpu_backward, coalesced through LDS) and
-// k_grad_fused (dcoeff never materialised; atomics scatter straight to grad_v / grad_tex).
+//   large triangles: a lane whose bounding box exceeds BIG_BOX pixels parks its triangle in an LDS queue and
+//           the whole workgroup walks such boxes together afterwards (same per-pixel arithmetic, so the same
+//           bits) — one lane per triangle is right at ~1 px per triangle (a 50k-triangle face at 256^2) and
+//           would serialise on a few screen-filling triangles.
+//
+// Backward: k_dcoeff (API parity with rasterize_gpu_backward, coalesced through LDS), and the fused gradient
+// of the autograd Function as a deterministic two-phase GATHER — no float atomics, run-to-run identical:
+//   k_grad_tri   one lane per (sample, triangle) (workgroup-cooperative for large boxes, fixed-order tree):
+//                re-walks its box, and for the pixels it WON (winner map written by k_resolve) accumulates, in
+//                pixel order, d/d(3 vertices x xyz) and d/d(3 vertex attribute rows) into its own scratch row;
+//   k_grad_vert  one lane per (sample, vertex): sums the rows of its incident triangles in the fixed order of
+//                a per-topology incidence list (corner-major, ascending triangle id) and writes grad_v / grad_tex.
+// (The reference builds a COO matrix per call and runs sparse.mm, op/rasterize.py:46-77; round 1 of this repo
+// scattered with float atomics.)
+//
+// Host path: the same setup / shading functions are __host__ __device__; sr_rasterize_*_cpu_* run the
+// reference's sequential loops (op/rasterize.cpp:21-95) for CPU tensors, which the reference's extension also
+// accepts (op/rasterize.cpp:126-150).  Device tensors never take it.
 #include <float.h>
+
+#include <vector>
 
 #include "common.h"
 
+#define SR_HD __host__ __device__ __forceinline__
+
 namespace {
+
+constexpr int BIG_BOX = 64;     // bounding boxes with more pixels than this are walked by the whole workgroup
 
 template <typename R> struct Lim;
 template <> struct Lim<float> {
@@ -51,21 +73,21 @@ struct Tri {
 
 // (int64_t) cast as x86-64 cvtts[sd]2si performs it: NaN / out of range -> INT64_MIN.
 template <typename R>
-__device__ __forceinline__ long long to_i64_x86(R f) {
+SR_HD long long to_i64_x86(R f) {
     if (f >= (R)-9223372036854775808.0 && f < (R)9223372036854775808.0) return (long long)f;
     return (long long)0x8000000000000000ULL;
 }
 
-template <typename R> __device__ __forceinline__ R r_ceil(R x);
-template <> __device__ __forceinline__ float r_ceil<float>(float x) { return ceilf(x); }
-template <> __device__ __forceinline__ double r_ceil<double>(double x) { return ceil(x); }
-template <typename R> __device__ __forceinline__ R r_floor(R x);
-template <> __device__ __forceinline__ float r_floor<float>(float x) { return floorf(x); }
-template <> __device__ __forceinline__ double r_floor<double>(double x) { return floor(x); }
+template <typename R> SR_HD R r_ceil(R x);
+template <> SR_HD float r_ceil<float>(float x) { return ceilf(x); }
+template <> SR_HD double r_ceil<double>(double x) { return ceil(x); }
+template <typename R> SR_HD R r_floor(R x);
+template <> SR_HD float r_floor<float>(float x) { return floorf(x); }
+template <> SR_HD double r_floor<double>(double x) { return floor(x); }
 
 // One vertex to screen space; false = rejected by the perspective near test.
 template <typename R>
-__device__ __forceinline__ bool to_screen(R& x, R& y, const R z, R sw, R sh, bool perspective, R eps) {
+SR_HD bool to_screen(R& x, R& y, const R z, R sw, R sh, bool perspective, R eps) {
     if (perspective) {
         if (z >= -eps) return false;
         x = x / -z;
@@ -79,7 +101,7 @@ __device__ __forceinline__ bool to_screen(R& x, R& y, const R z, R sw, R sh, boo
 }
 
 template <typename R>
-__device__ __forceinline__ void grow(R& lo, R& hi, R q) {
+SR_HD void grow(R& lo, R& hi, R q) {
     // `if (lo > q) lo = q; else if (hi < q) hi = q;` as value selects (reference op/rasterize.h:27-34)
     const bool below = lo > q;
     const bool above = !below && (hi < q);
@@ -90,7 +112,7 @@ __device__ __forceinline__ void grow(R& lo, R& hi, R q) {
 // Triangle setup.  sw / sh are what the reference's barycentric() receives as (w, h): the callers
 // pass (h_arg, w_arg).  Returns false when the triangle is rejected.
 template <typename R>
-__device__ __forceinline__ bool tri_setup(Tri<R>& t, long long sw, long long sh, bool perspective,
+SR_HD bool tri_setup(Tri<R>& t, long long sw, long long sh, bool perspective,
                                           R eps) {
     const R fw = (R)sw, fh = (R)sh;
     if (!to_screen<R>(t.p0, t.p1, t.p2, fw, fh, perspective, eps)) return false;
@@ -137,7 +159,7 @@ __device__ __forceinline__ bool tri_setup(Tri<R>& t, long long sw, long long sh,
 }
 
 template <typename R>
-__device__ __forceinline__ void edge_values(const Tri<R>& t, R px, R py, R& c0, R& c1, R& c2) {
+SR_HD void edge_values(const Tri<R>& t, R px, R py, R& c0, R& c1, R& c2) {
     R gx = t.e3 * px, gy = t.e6 * py;
     R a = t.e0 + gx;
     c0 = a + gy;
@@ -154,12 +176,22 @@ __device__ __forceinline__ void edge_values(const Tri<R>& t, R px, R py, R& c0, 
 // Launders a value through an empty asm so that a later select between such values cannot be
 // folded back into a runtime-indexed load of the triangle struct (which would force the whole
 // struct into scratch memory).  Emits no instruction.
-__device__ __forceinline__ float opaque(float x) { asm volatile("" : "+v"(x)); return x; }
-__device__ __forceinline__ double opaque(double x) { asm volatile("" : "+v"(x)); return x; }
+SR_HD float opaque(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+v"(x));
+#endif
+    return x;
+}
+SR_HD double opaque(double x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+v"(x));
+#endif
+    return x;
+}
 
 // Barycentric weights from the edge values; false = pixel outside.
 template <typename R>
-__device__ __forceinline__ bool pixel_weights(const Tri<R>& t, R px, R py, R& c0, R& c1, R& c2, R eps) {
+SR_HD bool pixel_weights(const Tri<R>& t, R px, R py, R& c0, R& c1, R& c2, R eps) {
     if (c0 < -eps || c1 < -eps || c2 < -eps) return false;
     if (t.area > eps) {
         R s = c0 + c1;
@@ -223,7 +255,7 @@ __device__ __forceinline__ bool pixel_weights(const Tri<R>& t, R px, R py, R& c0
 }
 
 template <typename R>
-__device__ __forceinline__ bool pixel_depth(const Tri<R>& t, R& c0, R& c1, R& c2, bool perspective,
+SR_HD bool pixel_depth(const Tri<R>& t, R& c0, R& c1, R& c2, bool perspective,
                                             R eps, R& z) {
     if (perspective) {
         c0 = c0 / t.p2;
@@ -262,7 +294,7 @@ __host__ __device__ inline unsigned long long key_init_f32() {
 __host__ __device__ inline unsigned long long key_init_f64() { return 0x0010000000000000ULL; }
 
 template <typename R>
-__device__ __forceinline__ bool load_tri(Tri<R>& t, const R* __restrict__ vs,
+SR_HD bool load_tri(Tri<R>& t, const R* __restrict__ vs,
                                          const long long* __restrict__ fs, long long ti,
                                          long long nv, long long& i0, long long& i1, long long& i2) {
     i0 = fs[3 * ti];
@@ -285,7 +317,39 @@ __global__ __launch_bounds__(256) void k_fill_u32(unsigned* p, unsigned v, long 
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) p[i] = v;
 }
 
+// Weights + depth of triangle `t` at pixel (x, y); false = not covered.  The ONE per-pixel evaluation every
+// pass uses (depth keys, resolve, gradient walk, host loops), so they all see the same bits.
+template <typename R>
+SR_HD bool shade(const Tri<R>& t, int x, int y, bool perspective, R eps, R& c0, R& c1, R& c2, R& z) {
+    const R px = (R)x, py = (R)y;
+    edge_values<R>(t, px, py, c0, c1, c2);
+    if (!pixel_weights<R>(t, px, py, c0, c1, c2, eps)) return false;
+    return pixel_depth<R>(t, c0, c1, c2, perspective, eps, z);
+}
+
 // MODE 0: fp32 packed key.  MODE 1: fp64 depth max.  MODE 2: fp64 lowest id among depth-maxima.
+template <typename R, int MODE>
+__device__ __forceinline__ void depth_test(const Tri<R>& t, int x, int y, long long w, long long hw,
+                                           bool perspective, R eps, unsigned long long* __restrict__ ks,
+                                           unsigned* __restrict__ tm, unsigned ti) {
+    const long long pix = x + (long long)y * w;
+    if (pix >= hw) return;                  // the reference would write out of bounds (w > h)
+    R c0, c1, c2, z;
+    if (!shade<R>(t, x, y, perspective, eps, c0, c1, c2, z)) return;
+    if (!(z == z)) return;                  // NaN never passes `zB < z`
+    if (MODE == 0) {
+        const unsigned long long key =
+            ((unsigned long long)ord32((float)z) << 32) | (unsigned long long)(0xFFFFFFFEu - ti);
+        if (key > ks[pix]) atomicMax(&ks[pix], key);
+    } else if (MODE == 1) {
+        const unsigned long long key = ord64((double)z);
+        if (key > ks[pix]) atomicMax(&ks[pix], key);
+    } else {
+        const unsigned long long key = ord64((double)z);
+        if (key == ks[pix] && key > key_init_f64()) atomicMin(&tm[pix], ti);
+    }
+}
+
 template <typename R, int MODE>
 __global__ __launch_bounds__(256) void k_depth_keys(long long b, long long nv, long long nf,
                                                     long long h, long long w, bool repeat_v,
@@ -294,39 +358,52 @@ __global__ __launch_bounds__(256) void k_depth_keys(long long b, long long nv, l
                                                     const long long* __restrict__ f,
                                                     unsigned long long* __restrict__ keys,
                                                     unsigned* __restrict__ tmin, R eps) {
-    const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= b * nf) return;
-    const long long s = g / nf, ti = g - s * nf;
-    const R* vs = repeat_v ? v : v + s * nv * 3;
-    const long long* fs = repeat_f ? f : f + s * nf * 3;
-    Tri<R> t;
-    long long i0, i1, i2;
-    if (!load_tri<R>(t, vs, fs, ti, nv, i0, i1, i2)) return;
-    if (!tri_setup<R>(t, h, w, perspective, eps)) return;
+    __shared__ int s_nbig;
+    __shared__ int s_big[256];
+    if (threadIdx.x == 0) s_nbig = 0;
+    __syncthreads();
     const long long hw = h * w;
-    unsigned long long* ks = keys + s * hw;
-    for (int y = t.y0; y <= t.y1; ++y)
-        for (int x = t.x0; x <= t.x1; ++x) {
-            const long long pix = x + (long long)y * w;
-            if (pix >= hw) continue;        // the reference would write out of bounds (w > h)
-            const R px = (R)x, py = (R)y;
-            R c0, c1, c2, z;
-            edge_values<R>(t, px, py, c0, c1, c2);
-            if (!pixel_weights<R>(t, px, py, c0, c1, c2, eps)) continue;
-            if (!pixel_depth<R>(t, c0, c1, c2, perspective, eps, z)) continue;
-            if (!(z == z)) continue;        // NaN never passes `zB < z`
-            if (MODE == 0) {
-                const unsigned long long key =
-                    ((unsigned long long)ord32((float)z) << 32) | (unsigned long long)(0xFFFFFFFEu - (unsigned)ti);
-                if (key > ks[pix]) atomicMax(&ks[pix], key);
-            } else if (MODE == 1) {
-                const unsigned long long key = ord64((double)z);
-                if (key > ks[pix]) atomicMax(&ks[pix], key);
-            } else {
-                const unsigned long long key = ord64((double)z);
-                if (key == ks[pix] && key > key_init_f64()) atomicMin(&tmin[s * hw + pix], (unsigned)ti);
+    const long long base = (long long)blockIdx.x * 256;
+    {
+        const long long g = base + threadIdx.x;
+        if (g < b * nf) {
+            const long long s = g / nf, ti = g - s * nf;
+            const R* vs = repeat_v ? v : v + s * nv * 3;
+            const long long* fs = repeat_f ? f : f + s * nf * 3;
+            Tri<R> t;
+            long long i0, i1, i2;
+            if (load_tri<R>(t, vs, fs, ti, nv, i0, i1, i2) && tri_setup<R>(t, h, w, perspective, eps)) {
+                const long long box = (long long)(t.x1 - t.x0 + 1) * (t.y1 - t.y0 + 1);
+                if (box > BIG_BOX) {
+                    s_big[atomicAdd(&s_nbig, 1)] = threadIdx.x;        // walked by the workgroup below
+                } else {
+                    for (int y = t.y0; y <= t.y1; ++y)
+                        for (int x = t.x0; x <= t.x1; ++x)
+                            depth_test<R, MODE>(t, x, y, w, hw, perspective, eps, keys + s * hw, tmin + s * hw,
+                                                (unsigned)ti);
+                }
             }
         }
+    }
+    __syncthreads();
+    const int nbig = s_nbig;
+    for (int q = 0; q < nbig; ++q) {
+        const long long g = base + s_big[q];
+        const long long s = g / nf, ti = g - s * nf;
+        const R* vs = repeat_v ? v : v + s * nv * 3;
+        const long long* fs = repeat_f ? f : f + s * nf * 3;
+        Tri<R> t;
+        long long i0, i1, i2;
+        load_tri<R>(t, vs, fs, ti, nv, i0, i1, i2);
+        tri_setup<R>(t, h, w, perspective, eps);
+        const int bw = t.x1 - t.x0 + 1;
+        const long long npx = (long long)bw * (t.y1 - t.y0 + 1);
+        for (long long p = threadIdx.x; p < npx; p += 256) {
+            const int yy = (int)(p / bw);
+            depth_test<R, MODE>(t, t.x0 + (int)(p - (long long)yy * bw), t.y0 + yy, w, hw, perspective, eps,
+                                keys + s * hw, tmin + s * hw, (unsigned)ti);
+        }
+    }
 }
 
 template <typename R>
@@ -338,7 +415,8 @@ __global__ __launch_bounds__(256) void k_resolve(long long b, long long nv, long
                                                  const unsigned* __restrict__ tmin,
                                                  long long* __restrict__ index, R* __restrict__ coeff,
                                                  R* __restrict__ zbuf, const R* __restrict__ tex,
-                                                 long long tex_c, R* __restrict__ attr, R eps) {
+                                                 long long tex_c, R* __restrict__ attr,
+                                                 int* __restrict__ win, R eps) {
     const long long hw = h * w;
     const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= b * hw) return;
@@ -361,10 +439,7 @@ __global__ __launch_bounds__(256) void k_resolve(long long b, long long nv, long
         load_tri<R>(t, vs, fs, ti, nv, i0, i1, i2);
         tri_setup<R>(t, h, w, perspective, eps);
         const int y = (int)(pix / w), x = (int)(pix - (long long)y * w);
-        const R px = (R)x, py = (R)y;
-        edge_values<R>(t, px, py, c0, c1, c2);
-        pixel_weights<R>(t, px, py, c0, c1, c2, eps);
-        pixel_depth<R>(t, c0, c1, c2, perspective, eps, z);
+        shade<R>(t, x, y, perspective, eps, c0, c1, c2, z);
         const long long shift = repeat_v ? 0 : nv * s;
         i0 += shift; i1 += shift; i2 += shift;
     }
@@ -379,6 +454,7 @@ __global__ __launch_bounds__(256) void k_resolve(long long b, long long nv, long
         coeff[3 * g + 2] = c2;
     }
     if (zbuf) zbuf[g] = z;
+    if (win) win[g] = (int)ti;
     if (attr) {
         for (long long ch = 0; ch < tex_c; ++ch) {
             const R a0 = tex[i0 * tex_c + ch] * c0;
@@ -393,7 +469,7 @@ __global__ __launch_bounds__(256) void k_resolve(long long b, long long nv, long
 // d(3 weights)/d(3 vertices x xyz) at one pixel (reference op/rasterize.h:169-228).  `g` = 27 values
 // [weight][vertex][component]; returns false (g untouched) for a degenerate triangle.
 template <typename R>
-__device__ __forceinline__ bool weight_jacobian(const R p[9], R px, R py, R sw, R sh, R g[27],
+SR_HD bool weight_jacobian(const R p[9], R px, R py, R sw, R sh, R g[27],
                                                 bool perspective, R eps) {
     const R u = (px * 2 - sw + 1) / sw;
     const R vv = (py * -2 + sh - 1) / sh;
@@ -466,7 +542,7 @@ __device__ __forceinline__ bool weight_jacobian(const R p[9], R px, R py, R sw, 
 }
 
 template <typename R>
-__device__ __forceinline__ bool load_pixel_tri(const long long* __restrict__ index, long long g,
+SR_HD bool load_pixel_tri(const long long* __restrict__ index, long long g,
                                                long long rows, const R* __restrict__ v, R p[9],
                                                long long ids[3]) {
     ids[0] = index[3 * g];
@@ -514,56 +590,229 @@ __global__ __launch_bounds__(256) void k_dcoeff(long long b, long long n, long l
     for (int i = threadIdx.x; i < cnt; i += 256) dcoeff[base * 27 + i] = s_g[i];
 }
 
-template <typename R>
-__global__ __launch_bounds__(256) void k_grad_fused(long long b, long long nv, long long h,
-                                                    long long w, bool perspective,
-                                                    const R* __restrict__ v, const R* __restrict__ tex,
-                                                    long long tex_c, const long long* __restrict__ index,
-                                                    const R* __restrict__ coeff,
-                                                    const R* __restrict__ grad_out,
-                                                    R* __restrict__ grad_v, R* __restrict__ grad_tex,
-                                                    R eps) {
-    const long long hw = h * w, total = b * hw;
-    const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= total) return;
-    R p[9];
-    long long ids[3];
-    if (!load_pixel_tri<R>(index, g, nv * b, v, p, ids)) return;
-    const R* go = grad_out + g * tex_c;
-    if (grad_tex) {
+// ---- fused gradient, phase 1: per-triangle sums over the pixels the triangle won ----------------------------
+// Row layout of the scratch `tg` (ROW = 9 + 3*CT values per (sample, triangle)):
+//   [0..8]            d loss / d (vertex k, component j) at 3k + j
+//   [9 + k*CT + j]    d loss / d tex[vertex k][ch0 + j]
+template <typename R, int CT>
+struct TriAcc {
+    R gv[9];
+    R gt[3 * CT];
+    int n;
+};
+
+template <typename R, int CT>
+__device__ __forceinline__ void grad_pixel(TriAcc<R, CT>& acc, const Tri<R>& t, const R praw[9], bool want_v,
+                                           int x, int y, long long w, long long hw, long long h_arg,
+                                           bool perspective, R eps, const int* __restrict__ wins, int ti,
+                                           const R* __restrict__ gos, const R* __restrict__ tex0,
+                                           const R* __restrict__ tex1, const R* __restrict__ tex2,
+                                           int tex_c, int ch0) {
+    const long long pix = x + (long long)y * w;
+    if (pix >= hw || wins[pix] != ti) return;
+    R c0, c1, c2, z;
+    shade<R>(t, x, y, perspective, eps, c0, c1, c2, z);        // same bits as k_resolve wrote into coeff
+    const R* go = gos + pix * tex_c;
+    acc.n += 1;
 #pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            const R ck = coeff[3 * g + k];
-            if (ck != 0)
-                for (long long ch = 0; ch < tex_c; ++ch)
-                    unsafeAtomicAdd(&grad_tex[ids[k] * tex_c + ch], go[ch] * ck);
+    for (int j = 0; j < CT; ++j) {
+        if (ch0 + j < tex_c) {
+            const R gch = go[ch0 + j];
+            acc.gt[j] += gch * c0;
+            acc.gt[CT + j] += gch * c1;
+            acc.gt[2 * CT + j] += gch * c2;
         }
     }
-    if (grad_v) {
+    if (want_v) {
         R jac[27];
-        const long long pix = g % hw;
-        if (!weight_jacobian<R>(p, (R)(pix % w), (R)(pix / w), (R)h, (R)w, jac, perspective, eps)) return;
-        R dw[3] = {0, 0, 0};
-        for (long long ch = 0; ch < tex_c; ++ch) {
+        if (!weight_jacobian<R>(praw, (R)x, (R)y, (R)h_arg, (R)w, jac, perspective, eps)) return;
+        R d0 = 0, d1 = 0, d2 = 0;
+        for (int ch = 0; ch < tex_c; ++ch) {
             const R gch = go[ch];
-#pragma unroll
-            for (int k = 0; k < 3; ++k) dw[k] += gch * tex[ids[k] * tex_c + ch];
+            d0 += gch * tex0[ch];
+            d1 += gch * tex1[ch];
+            d2 += gch * tex2[ch];
         }
+#pragma unroll
+        for (int j = 0; j < 9; ++j) acc.gv[j] += d0 * jac[j] + d1 * jac[9 + j] + d2 * jac[18 + j];
+    }
+}
+
+__device__ __forceinline__ float sr_shfl_down(float x, int off) { return __shfl_down(x, off, SR_WAVE); }
+__device__ __forceinline__ double sr_shfl_down(double x, int off) { return __shfl_down(x, off, SR_WAVE); }
+
+// Fixed-order sum over the 256 lanes of the workgroup (wave tree, then waves 0..3 in order); result on lane 0.
+template <typename R>
+__device__ __forceinline__ R block_sum_256(R x, R* s_part) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) x += sr_shfl_down(x, off);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = x;
+    __syncthreads();
+    R tot = s_part[0];
+    tot += s_part[1];
+    tot += s_part[2];
+    tot += s_part[3];
+    return tot;
+}
+
+template <typename R, int CT>
+__global__ __launch_bounds__(256) void k_grad_tri(long long b, long long nv, long long nf, long long h,
+                                                  long long w, bool repeat_f, bool perspective,
+                                                  const R* __restrict__ v, const R* __restrict__ tex,
+                                                  int tex_c, int ch0, const long long* __restrict__ f,
+                                                  const int* __restrict__ win,
+                                                  const R* __restrict__ grad_out, bool want_v,
+                                                  R* __restrict__ tg, unsigned char* __restrict__ flag, R eps) {
+    constexpr int ROW = 9 + 3 * CT;
+    __shared__ int s_nbig;
+    __shared__ int s_big[256];
+    __shared__ R s_part[4];
+    if (threadIdx.x == 0) s_nbig = 0;
+    __syncthreads();
+    const long long hw = h * w;
+    const long long base = (long long)blockIdx.x * 256;
+    {
+        const long long g = base + threadIdx.x;
+        if (g < b * nf) {
+            const long long s = g / nf, ti = g - s * nf;
+            const R* vs = v + s * nv * 3;
+            const long long* fs = repeat_f ? f : f + s * nf * 3;
+            Tri<R> t;
+            long long i0, i1, i2;
+            bool deferred = false;
+            TriAcc<R, CT> acc;
+            acc.n = 0;
+            if (load_tri<R>(t, vs, fs, ti, nv, i0, i1, i2)) {
+                const R praw[9] = {t.p0, t.p1, t.p2, t.p3, t.p4, t.p5, t.p6, t.p7, t.p8};
+                if (tri_setup<R>(t, h, w, perspective, eps)) {
+                    const long long box = (long long)(t.x1 - t.x0 + 1) * (t.y1 - t.y0 + 1);
+                    if (box > BIG_BOX) {
+                        s_big[atomicAdd(&s_nbig, 1)] = threadIdx.x;
+                        deferred = true;
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 9; ++j) acc.gv[j] = 0;
+#pragma unroll
+                        for (int j = 0; j < 3 * CT; ++j) acc.gt[j] = 0;
+                        const bool distinct = want_v && i0 != i1 && i0 != i2 && i1 != i2;
+                        const R* tb = tex + s * nv * tex_c;
+                        for (int y = t.y0; y <= t.y1; ++y)
+                            for (int x = t.x0; x <= t.x1; ++x)
+                                grad_pixel<R, CT>(acc, t, praw, distinct, x, y, w, hw, h, perspective, eps,
+                                                  win + s * hw, (int)ti, grad_out + s * hw * tex_c,
+                                                  tb + i0 * tex_c, tb + i1 * tex_c, tb + i2 * tex_c, tex_c, ch0);
+                    }
+                }
+            }
+            if (!deferred) {
+                flag[g] = acc.n > 0 ? 1 : 0;
+                if (acc.n > 0) {
+                    R* row = tg + g * ROW;
+#pragma unroll
+                    for (int j = 0; j < 9; ++j) row[j] = acc.gv[j];
+#pragma unroll
+                    for (int j = 0; j < 3 * CT; ++j) row[9 + j] = acc.gt[j];
+                }
+            }
+        }
+    }
+    __syncthreads();
+    const int nbig = s_nbig;
+    for (int q = 0; q < nbig; ++q) {
+        // deterministic regardless of the queue order: each deferred triangle owns its scratch row
+        const long long g = base + s_big[q];
+        const long long s = g / nf, ti = g - s * nf;
+        const R* vs = v + s * nv * 3;
+        const long long* fs = repeat_f ? f : f + s * nf * 3;
+        Tri<R> t;
+        long long i0, i1, i2;
+        load_tri<R>(t, vs, fs, ti, nv, i0, i1, i2);
+        const R praw[9] = {t.p0, t.p1, t.p2, t.p3, t.p4, t.p5, t.p6, t.p7, t.p8};
+        tri_setup<R>(t, h, w, perspective, eps);
+        TriAcc<R, CT> acc;
+        acc.n = 0;
+#pragma unroll
+        for (int j = 0; j < 9; ++j) acc.gv[j] = 0;
+#pragma unroll
+        for (int j = 0; j < 3 * CT; ++j) acc.gt[j] = 0;
+        const bool distinct = want_v && i0 != i1 && i0 != i2 && i1 != i2;
+        const R* tb = tex + s * nv * tex_c;
+        const int bw = t.x1 - t.x0 + 1;
+        const long long npx = (long long)bw * (t.y1 - t.y0 + 1);
+        for (long long p = threadIdx.x; p < npx; p += 256) {
+            const int yy = (int)(p / bw);
+            grad_pixel<R, CT>(acc, t, praw, distinct, t.x0 + (int)(p - (long long)yy * bw), t.y0 + yy, w, hw, h,
+                              perspective, eps, win + s * hw, (int)ti, grad_out + s * hw * tex_c,
+                              tb + i0 * tex_c, tb + i1 * tex_c, tb + i2 * tex_c, tex_c, ch0);
+        }
+        const R cnt = block_sum_256<R>((R)acc.n, s_part);
+        R* row = tg + g * ROW;
 #pragma unroll
         for (int j = 0; j < 9; ++j) {
-            const R val = dw[0] * jac[j] + dw[1] * jac[9 + j] + dw[2] * jac[18 + j];
-            if (val != 0) unsafeAtomicAdd(&grad_v[ids[j / 3] * 3 + (j % 3)], val);
+            const R tot = block_sum_256<R>(acc.gv[j], s_part);
+            if (threadIdx.x == 0 && cnt > 0) row[j] = tot;
         }
+#pragma unroll
+        for (int j = 0; j < 3 * CT; ++j) {
+            const R tot = block_sum_256<R>(acc.gt[j], s_part);
+            if (threadIdx.x == 0 && cnt > 0) row[9 + j] = tot;
+        }
+        if (threadIdx.x == 0) flag[g] = cnt > 0 ? 1 : 0;
+    }
+}
+
+// ---- fused gradient, phase 2: per-vertex gather over the incident triangles, fixed order ----------------------
+template <typename R, int CT>
+__global__ __launch_bounds__(256) void k_grad_vert(long long nv, long long nf, const int* __restrict__ adj_off,
+                                                   const int* __restrict__ adj, long long off_bstride,
+                                                   long long adj_bstride, const R* __restrict__ tg,
+                                                   const unsigned char* __restrict__ flag, int tex_c, int ch0,
+                                                   R* __restrict__ grad_v, R* __restrict__ grad_tex) {
+    constexpr int ROW = 9 + 3 * CT;
+    const long long vert = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long s = blockIdx.y;
+    if (vert >= nv) return;
+    const int* off = adj_off + s * off_bstride;
+    const int* ad = adj + s * adj_bstride;
+    R av0 = 0, av1 = 0, av2 = 0;
+    R at[CT];
+#pragma unroll
+    for (int j = 0; j < CT; ++j) at[j] = 0;
+    const int e1 = off[vert + 1];
+    for (int e = off[vert]; e < e1; ++e) {
+        const int idx = ad[e];                       // corner-major: k * nf + f
+        const int k = idx / (int)nf;
+        const long long row = s * nf + (idx - k * (int)nf);
+        if (!flag[row]) continue;
+        const R* r = tg + row * ROW;
+        av0 += r[3 * k];
+        av1 += r[3 * k + 1];
+        av2 += r[3 * k + 2];
+#pragma unroll
+        for (int j = 0; j < CT; ++j) at[j] += r[9 + k * CT + j];
+    }
+    if (grad_v && ch0 == 0) {
+        R* o = grad_v + (s * nv + vert) * 3;
+        o[0] = av0;
+        o[1] = av1;
+        o[2] = av2;
+    }
+    if (grad_tex) {
+        R* o = grad_tex + (s * nv + vert) * tex_c + ch0;
+#pragma unroll
+        for (int j = 0; j < CT; ++j)
+            if (ch0 + j < tex_c) o[j] = at[j];
     }
 }
 
 template <typename R>
 int forward_impl(long long b, long long nv, long long nf, long long h, long long w, int repeat_v,
                  int repeat_f, int perspective, const R* v, const long long* tri, long long* index,
-                 R* coeff, R* zbuf, R eps, const R* tex, long long tex_c, R* attr, void* work,
+                 R* coeff, R* zbuf, R eps, const R* tex, long long tex_c, R* attr, int* win, void* work,
                  hipStream_t st) {
     if (b < 0 || nv < 0 || nf < 0 || h <= 0 || w <= 0) return SR_EINVAL;
-    if (nf >= 0xFFFFFFFELL) return SR_ERANGE;
+    if (nf >= 0xFFFFFFFELL || (win && nf >= 0x7FFFFFFFLL)) return SR_ERANGE;
     if (b == 0) return SR_OK;
     if (!work || (nf > 0 && (!v || !tri))) return SR_EINVAL;
     if (attr && (!tex || tex_c <= 0)) return SR_EINVAL;
@@ -592,7 +841,7 @@ int forward_impl(long long b, long long nv, long long nf, long long h, long long
     }
     hipLaunchKernelGGL((k_resolve<R>), dim3((unsigned)sr_ceil_div(npix, 256)), dim3(256), 0, st, b, nv, nf,
                        h, w, repeat_v != 0, repeat_f != 0, perspective != 0, v, tri, keys, tmin, index,
-                       coeff, zbuf, tex, tex_c, attr, eps);
+                       coeff, zbuf, tex, tex_c, attr, win, eps);
     return sr_launch_status();
 }
 
@@ -609,18 +858,113 @@ int backward_impl(long long b, long long n, long long h, long long w, int perspe
     return sr_launch_status();
 }
 
+inline long long grad_row_values(long long tex_c) { return 9 + 3 * (tex_c < 4 ? tex_c : 4); }
+
+template <typename R, int CT>
+void grad_launch(long long b, long long nv, long long nf, long long h, long long w, bool repeat_f,
+                 bool perspective, const R* v, const R* tex, int tex_c, int ch0, const long long* tri,
+                 const int* win, const R* grad_out, const int* adj_off, const int* adj, long long off_bs,
+                 long long adj_bs, R* grad_v, R* grad_tex, R eps, R* tg, unsigned char* flag, hipStream_t st) {
+    const bool want_v = grad_v != nullptr && ch0 == 0;
+    hipLaunchKernelGGL((k_grad_tri<R, CT>), dim3((unsigned)sr_ceil_div(b * nf, 256)), dim3(256), 0, st, b, nv, nf,
+                       h, w, repeat_f, perspective, v, tex, tex_c, ch0, tri, win, grad_out, want_v, tg, flag, eps);
+    hipLaunchKernelGGL((k_grad_vert<R, CT>), dim3((unsigned)sr_ceil_div(nv, 256), (unsigned)b), dim3(256), 0, st,
+                       nv, nf, adj_off, adj, off_bs, adj_bs, tg, flag, tex_c, ch0, grad_v, grad_tex);
+}
+
 template <typename R>
-int grad_impl(long long b, long long nv, long long h, long long w, int perspective, const R* v,
-              const R* tex, long long tex_c, const long long* index, const R* coeff, const R* grad_out,
-              R* grad_v, R* grad_tex, R eps, hipStream_t st) {
-    if (b < 0 || nv < 0 || h < 0 || w < 0 || tex_c <= 0) return SR_EINVAL;
-    const long long total = b * h * w;
-    if (total == 0 || (!grad_v && !grad_tex)) return SR_OK;
-    if (!v || !index || !grad_out || (grad_v && !tex) || (grad_tex && !coeff)) return SR_EINVAL;
+int grad_impl(long long b, long long nv, long long nf, long long h, long long w, int repeat_f, int perspective,
+              const R* v, const R* tex, long long tex_c, const long long* tri, const int* win,
+              const R* grad_out, const int* adj_off, const int* adj, long long off_bs, long long adj_bs,
+              R* grad_v, R* grad_tex, R eps, void* work, hipStream_t st) {
+    if (b < 0 || nv < 0 || nf < 0 || h < 0 || w < 0 || tex_c <= 0) return SR_EINVAL;
+    if (b == 0 || nv == 0 || (!grad_v && !grad_tex)) return SR_OK;
+    if (b > 65535 || nf >= 0x7FFFFFFFLL / 3 || tex_c > 0x7FFFFFFF) return SR_ERANGE;
+    if (!v || !tex || !grad_out || !adj_off || !work || (nf > 0 && (!tri || !adj || !win))) return SR_EINVAL;
     if (eps < 0) eps = -eps;
-    hipLaunchKernelGGL((k_grad_fused<R>), dim3((unsigned)sr_ceil_div(total, 256)), dim3(256), 0, st, b, nv,
-                       h, w, perspective != 0, v, tex, tex_c, index, coeff, grad_out, grad_v, grad_tex, eps);
+    R* tg = reinterpret_cast<R*>(work);
+    unsigned char* flag = reinterpret_cast<unsigned char*>(tg + b * nf * grad_row_values(tex_c));
+    // attribute channels in chunks of <= 4 register accumulators; the vertex gradient rides with chunk 0
+    for (long long ch0 = 0; ch0 < (grad_tex ? tex_c : 1); ch0 += 4) {
+        const long long ct = tex_c - ch0 < 4 ? tex_c - ch0 : 4;
+#define SR_GRAD_CASE(CT)                                                                                        \
+    grad_launch<R, CT>(b, nv, nf, h, w, repeat_f != 0, perspective != 0, v, tex, (int)tex_c, (int)ch0, tri, win, \
+                       grad_out, adj_off, adj, off_bs, adj_bs, grad_v, grad_tex, eps, tg, flag, st)
+        if (ct == 1) SR_GRAD_CASE(1);
+        else if (ct == 2) SR_GRAD_CASE(2);
+        else if (ct == 3) SR_GRAD_CASE(3);
+        else SR_GRAD_CASE(4);
+#undef SR_GRAD_CASE
+    }
     return sr_launch_status();
+}
+
+// ---- host path: the reference's sequential loops (op/rasterize.cpp:21-67, 69-95) on the shared arithmetic ------
+template <typename R>
+int forward_cpu(long long b, long long nv, long long nf, long long h, long long w, int repeat_v, int repeat_f,
+                int perspective, const R* v, const long long* tri, long long* index, R* coeff, R* zbuf, R eps) {
+    if (b < 0 || nv < 0 || nf < 0 || h <= 0 || w <= 0) return SR_EINVAL;
+    if (b == 0) return SR_OK;
+    if (!index || !coeff || (nf > 0 && (!v || !tri))) return SR_EINVAL;
+    if (eps < 0) eps = -eps;
+    const long long hw = h * w;
+    std::vector<R> own;
+    if (!zbuf) {
+        own.resize((size_t)(b * hw));
+        zbuf = own.data();
+    }
+    for (long long i = 0; i < b * hw; ++i) {
+        zbuf[i] = Lim<R>::lowest();
+        index[3 * i] = index[3 * i + 1] = index[3 * i + 2] = 0;
+        coeff[3 * i] = coeff[3 * i + 1] = coeff[3 * i + 2] = 0;
+    }
+    for (long long s = 0; s < b; ++s) {
+        const R* vs = repeat_v ? v : v + s * nv * 3;
+        const long long* fs = repeat_f ? tri : tri + s * nf * 3;
+        const long long shift = repeat_v ? 0 : nv * s;
+        for (long long ti = 0; ti < nf; ++ti) {
+            Tri<R> t;
+            long long i0, i1, i2;
+            if (!load_tri<R>(t, vs, fs, ti, nv, i0, i1, i2)) continue;
+            if (!tri_setup<R>(t, h, w, perspective != 0, eps)) continue;
+            for (int y = t.y0; y <= t.y1; ++y)
+                for (int x = t.x0; x <= t.x1; ++x) {
+                    const long long pix = x + (long long)y * w;
+                    if (pix >= hw) continue;
+                    R c0, c1, c2, z;
+                    if (!shade<R>(t, x, y, perspective != 0, eps, c0, c1, c2, z)) continue;
+                    const long long o = s * hw + pix;
+                    if (zbuf[o] < z) {                     // in order: later triangles win only when nearer
+                        zbuf[o] = z;
+                        coeff[3 * o] = c0; coeff[3 * o + 1] = c1; coeff[3 * o + 2] = c2;
+                        index[3 * o] = i0 + shift; index[3 * o + 1] = i1 + shift; index[3 * o + 2] = i2 + shift;
+                    }
+                }
+        }
+    }
+    return SR_OK;
+}
+
+template <typename R>
+int backward_cpu(long long b, long long n, long long h, long long w, int perspective, const R* v,
+                 const long long* index, R* dcoeff, R eps) {
+    if (b < 0 || n < 0 || h < 0 || w < 0) return SR_EINVAL;
+    const long long hw = h * w, total = b * hw;
+    if (total == 0) return SR_OK;
+    if (!v || !index || !dcoeff) return SR_EINVAL;
+    if (eps < 0) eps = -eps;
+    for (long long g = 0; g < total; ++g) {
+        R jac[27];
+        for (int l = 0; l < 27; ++l) jac[l] = 0;
+        R p[9];
+        long long ids[3];
+        if (load_pixel_tri<R>(index, g, n * b, v, p, ids)) {
+            const long long pix = g % hw;
+            weight_jacobian<R>(p, (R)(pix % w), (R)(pix / w), (R)h, (R)w, jac, perspective != 0, eps);
+        }
+        for (int l = 0; l < 27; ++l) dcoeff[g * 27 + l] = jac[l];
+    }
+    return SR_OK;
 }
 
 }  // namespace
@@ -629,26 +973,30 @@ extern "C" int64_t sr_rasterize_scratch_bytes(int64_t b, int64_t h, int64_t w, i
     const int64_t npix = (b > 0 ? b : 0) * (h > 0 ? h : 0) * (w > 0 ? w : 0);
     return npix * (is_double ? 12 : 8) + 16;
 }
+extern "C" int64_t sr_rasterize_grad_scratch_bytes(int64_t b, int64_t nf, int64_t tex_c, int is_double) {
+    const int64_t rows = (b > 0 ? b : 0) * (nf > 0 ? nf : 0);
+    return rows * grad_row_values(tex_c > 0 ? tex_c : 1) * (is_double ? 8 : 4) + rows + 16;
+}
 
 extern "C" int sr_rasterize_forward_f32(int64_t b, int64_t nv, int64_t nf, int64_t h, int64_t w,
                                         int repeat_v, int repeat_f, int perspective, const float* v,
                                         const int64_t* tri, int64_t* index, float* coeff, float* zbuf,
                                         float eps, const float* tex, int64_t tex_c, float* attr,
-                                        void* work, sr_stream_t stream) {
+                                        int32_t* win, void* work, sr_stream_t stream) {
     return forward_impl<float>(b, nv, nf, h, w, repeat_v, repeat_f, perspective, v,
                                reinterpret_cast<const long long*>(tri),
                                reinterpret_cast<long long*>(index), coeff, zbuf, eps, tex, tex_c, attr,
-                               work, sr_stream(stream));
+                               win, work, sr_stream(stream));
 }
 extern "C" int sr_rasterize_forward_f64(int64_t b, int64_t nv, int64_t nf, int64_t h, int64_t w,
                                         int repeat_v, int repeat_f, int perspective, const double* v,
                                         const int64_t* tri, int64_t* index, double* coeff,
                                         double* zbuf, double eps, const double* tex, int64_t tex_c,
-                                        double* attr, void* work, sr_stream_t stream) {
+                                        double* attr, int32_t* win, void* work, sr_stream_t stream) {
     return forward_impl<double>(b, nv, nf, h, w, repeat_v, repeat_f, perspective, v,
                                 reinterpret_cast<const long long*>(tri),
                                 reinterpret_cast<long long*>(index), coeff, zbuf, eps, tex, tex_c, attr,
-                                work, sr_stream(stream));
+                                win, work, sr_stream(stream));
 }
 extern "C" int sr_rasterize_backward_f32(int64_t b, int64_t n, int64_t h, int64_t w, int repeat_v,
                                          int perspective, const float* v, const int64_t* index,
@@ -664,22 +1012,45 @@ extern "C" int sr_rasterize_backward_f64(int64_t b, int64_t n, int64_t h, int64_
     return backward_impl<double>(b, n, h, w, perspective, v, reinterpret_cast<const long long*>(index),
                                  dcoeff, eps, sr_stream(stream));
 }
-extern "C" int sr_rasterize_grad_f32(int64_t b, int64_t nv, int64_t h, int64_t w, int repeat_v,
+extern "C" int sr_rasterize_grad_f32(int64_t b, int64_t nv, int64_t nf, int64_t h, int64_t w, int repeat_f,
                                      int perspective, const float* v, const float* tex, int64_t tex_c,
-                                     const int64_t* index, const float* coeff, const float* grad_out,
-                                     float* grad_v, float* grad_tex, float eps, sr_stream_t stream) {
-    (void)repeat_v;
-    return grad_impl<float>(b, nv, h, w, perspective, v, tex, tex_c,
-                            reinterpret_cast<const long long*>(index), coeff, grad_out, grad_v, grad_tex,
-                            eps, sr_stream(stream));
+                                     const int64_t* tri, const int32_t* win, const float* grad_out,
+                                     const int32_t* adj_off, const int32_t* adj, int64_t adj_off_bstride,
+                                     int64_t adj_bstride, float* grad_v, float* grad_tex, float eps,
+                                     void* work, sr_stream_t stream) {
+    return grad_impl<float>(b, nv, nf, h, w, repeat_f, perspective, v, tex, tex_c,
+                            reinterpret_cast<const long long*>(tri), win, grad_out, adj_off, adj,
+                            adj_off_bstride, adj_bstride, grad_v, grad_tex, eps, work, sr_stream(stream));
 }
-extern "C" int sr_rasterize_grad_f64(int64_t b, int64_t nv, int64_t h, int64_t w, int repeat_v,
-                                     int perspective, const double* v, const double* tex,
-                                     int64_t tex_c, const int64_t* index, const double* coeff,
-                                     const double* grad_out, double* grad_v, double* grad_tex,
-                                     double eps, sr_stream_t stream) {
-    (void)repeat_v;
-    return grad_impl<double>(b, nv, h, w, perspective, v, tex, tex_c,
-                             reinterpret_cast<const long long*>(index), coeff, grad_out, grad_v,
-                             grad_tex, eps, sr_stream(stream));
+extern "C" int sr_rasterize_grad_f64(int64_t b, int64_t nv, int64_t nf, int64_t h, int64_t w, int repeat_f,
+                                     int perspective, const double* v, const double* tex, int64_t tex_c,
+                                     const int64_t* tri, const int32_t* win, const double* grad_out,
+                                     const int32_t* adj_off, const int32_t* adj, int64_t adj_off_bstride,
+                                     int64_t adj_bstride, double* grad_v, double* grad_tex, double eps,
+                                     void* work, sr_stream_t stream) {
+    return grad_impl<double>(b, nv, nf, h, w, repeat_f, perspective, v, tex, tex_c,
+                             reinterpret_cast<const long long*>(tri), win, grad_out, adj_off, adj,
+                             adj_off_bstride, adj_bstride, grad_v, grad_tex, eps, work, sr_stream(stream));
+}
+extern "C" int sr_rasterize_forward_cpu_f32(int64_t b, int64_t nv, int64_t nf, int64_t h, int64_t w, int repeat_v,
+                                            int repeat_f, int perspective, const float* v, const int64_t* tri,
+                                            int64_t* index, float* coeff, float* zbuf, float eps) {
+    return forward_cpu<float>(b, nv, nf, h, w, repeat_v, repeat_f, perspective, v,
+                              reinterpret_cast<const long long*>(tri), reinterpret_cast<long long*>(index), coeff,
+                              zbuf, eps);
+}
+extern "C" int sr_rasterize_forward_cpu_f64(int64_t b, int64_t nv, int64_t nf, int64_t h, int64_t w, int repeat_v,
+                                            int repeat_f, int perspective, const double* v, const int64_t* tri,
+                                            int64_t* index, double* coeff, double* zbuf, double eps) {
+    return forward_cpu<double>(b, nv, nf, h, w, repeat_v, repeat_f, perspective, v,
+                               reinterpret_cast<const long long*>(tri), reinterpret_cast<long long*>(index), coeff,
+                               zbuf, eps);
+}
+extern "C" int sr_rasterize_backward_cpu_f32(int64_t b, int64_t n, int64_t h, int64_t w, int perspective,
+                                             const float* v, const int64_t* index, float* dcoeff, float eps) {
+    return backward_cpu<float>(b, n, h, w, perspective, v, reinterpret_cast<const long long*>(index), dcoeff, eps);
+}
+extern "C" int sr_rasterize_backward_cpu_f64(int64_t b, int64_t n, int64_t h, int64_t w, int perspective,
+                                             const double* v, const int64_t* index, double* dcoeff, double eps) {
+    return backward_cpu<double>(b, n, h, w, perspective, v, reinterpret_cast<const long long*>(index), dcoeff, eps);
 }

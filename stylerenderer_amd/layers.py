@@ -225,12 +225,17 @@ class ModulatedConv2d(nn.Module):
         if (input.device.type != "cuda" or self.upsample or self.downsample or self.kernel_size != 3
                 or not self.demodulate or act_bias is None or not _fused_tails()):
             return None
+        # shape-only eligibility first: the 4^2 .. 16^2 layers fail it, and computing the modulation and the
+        # weight prep here would repeat those launches in the caller's fallback
+        input = input.contiguous()
+        if not _conv.conv_nba_shape_ok(input, self.out_channel, noise):
+            return None
         s = self.modulation(style)
         wt, wsq = _weight_prep(self.weight, self.scale, True)
-        if not (_conv.conv_nba_supported(input.contiguous(), wt, noise) and _style.demod_supported(s, wsq)):
+        if not (_conv.conv_nba_supported(input, wt, noise) and _style.demod_supported(s, wsq)):
             return None
         d = _style.demod_scale(s, wsq, self.eps)
-        return _conv.conv2d_nba(input.contiguous(), wt, s, d, noise, noise_weight, act_bias, negative_slope, act_scale)
+        return _conv.conv2d_nba(input, wt, s, d, noise, noise_weight, act_bias, negative_slope, act_scale)
 
     def forward_up_noise_bias_act(self, input, style, noise, noise_weight, act_bias, negative_slope, act_scale):
         """Upsampling 3x3 layer: transposed conv -> blur -> noise -> bias -> LeakyReLU as one autograd node

@@ -40,6 +40,10 @@ class StyledConv(nn.Module):
         self.activate = FusedLeakyReLU(out_channel)
 
     def forward(self, input, style, noise=None):
+        if noise is not None and noise.requires_grad:
+            # optimising the noise maps (projector-style use): the fused nodes do not differentiate with
+            # respect to `noise`, the separate operators do (reference layers.py:324-332)
+            return self.activate(self.noise(self.conv(input, style), noise=noise))
         if input.device.type == "cuda" and self.conv.upsample:
             # upsampling layer: the blur after the transposed conv, the noise injection, the bias and the
             # LeakyReLU are one kernel (one pass over the activation instead of three)

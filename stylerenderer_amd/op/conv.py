@@ -225,18 +225,22 @@ def _aliases(*tensors):
     return [t.view_as(t) if t is not None else None for t in tensors]
 
 
-def conv_nba_supported(x, wt, noise):
+def conv_nba_shape_ok(x, n, noise):
+    """Shape / layout part of `conv_nba_supported` (no weights needed)."""
     import os
 
     if os.environ.get("SR_WINOGRAD", "1") == "0" or x.device.type != "cuda" or x.dtype != torch.float32:
         return False
     b, c, h, w = x.shape
-    n = wt.shape[2]
-    ok = (wt.shape[0] == 9 and h % 8 == 0 and w % 32 == 0 and c % 8 == 0 and c <= 512 and n % 64 == 0
+    ok = (h % 8 == 0 and w % 32 == 0 and c % 8 == 0 and c <= 512 and n % 64 == 0
           and b * n <= 65535 and x.is_contiguous() and x.data_ptr() % 16 == 0)
     if noise is not None:
         ok = ok and noise.dtype == torch.float32 and noise.numel() in (h * w, b * h * w) and noise.data_ptr() % 16 == 0
     return ok
+
+
+def conv_nba_supported(x, wt, noise):
+    return wt.shape[0] == 9 and conv_nba_shape_ok(x, wt.shape[2], noise)
 
 
 def _wt_pitch(wt):

@@ -11,10 +11,13 @@ h<=0 -> 1, w<=0 -> h, float32/float64 + int64 only); violations raise RuntimeErr
 
 Device tensors run the deterministic HIP rasterizer, whose outputs equal the reference's
 sequential CPU loops bit for bit.  The autograd Function fuses what the reference does in Python:
-attribute interpolation happens in the resolve pass, and the backward scatters straight into
-grad_v / grad_tex instead of building a COO matrix per call (reference op/rasterize.py:46-77).
-There is no CPU implementation in the product: CPU tensors raise (the CPU restatement lives in
-oracle/ and is test infrastructure).
+attribute interpolation happens in the resolve pass (index / coeff are not even written: the backward
+walks a 4-byte winner map), and the backward is a deterministic two-phase gather into grad_v / grad_tex
+instead of a COO matrix + sparse.mm per call (reference op/rasterize.py:46-77).
+
+CPU tensors take the library's host loops (sr_rasterize_*_cpu_*: the reference's extension also serves
+CPU tensors, op/rasterize.cpp:126-150) with the interpolation / scatter in torch like the reference's
+Python; that branch is keyed on the tensors' device and never reached for `cuda` tensors.
 """
 import types
 
@@ -54,11 +57,10 @@ def _suffix(t):
     raise RuntimeError(" type error")
 
 
-def _forward_impl(vertices, triangles, height, width, perspective, eps, tex=None, want_z=False):
-    if not (is_device_tensor(vertices) and is_device_tensor(triangles)):
-        if vertices.device.type != triangles.device.type:
-            raise RuntimeError(" cuda input error")
-        raise RuntimeError("rasterize: device tensors required (the CPU path is oracle/raster.py)")
+def _forward_impl(vertices, triangles, height, width, perspective, eps, tex=None, want_z=False,
+                  want_index=True, want_win=False):
+    if vertices.device != triangles.device:
+        raise RuntimeError(" cuda input error")
     if triangles.dtype != torch.int64:
         raise RuntimeError(" type error")
     suf = _suffix(vertices)
@@ -66,9 +68,31 @@ def _forward_impl(vertices, triangles, height, width, perspective, eps, tex=None
     h = 1 if height <= 0 else int(height)
     w = h if width <= 0 else int(width)
     dev, dt = vertices.device, vertices.dtype
-    index = torch.empty((b, h, w, 3), dtype=torch.int64, device=dev)
-    coeff = torch.empty((b, h, w, 3), dtype=dt, device=dev)
+    L = _lib.lib()
+    if not is_device_tensor(vertices):
+        # host loops of the library (reference rasterize_cpu, op/rasterize.cpp:21-67)
+        index = torch.empty((b, h, w, 3), dtype=torch.int64)
+        coeff = torch.empty((b, h, w, 3), dtype=dt)
+        zbuf = torch.empty((b, h, w), dtype=dt) if want_z else None
+        rc = getattr(L, "sr_rasterize_forward_cpu_" + suf)(
+            b, nv, nf, h, w, int(rv), int(rf), int(bool(perspective)), _lib.ptr(vertices), _lib.ptr(triangles),
+            _lib.ptr(index), _lib.ptr(coeff), _lib.ptr(zbuf), abs(float(eps)))
+        _lib.check(rc, "sr_rasterize_forward_cpu")
+        attr = None
+        if tex is not None:
+            tex_c = 1 if tex.dim() == vertices.dim() - 1 else int(tex.shape[-1])
+            flat = tex.contiguous().view(-1, tex_c)
+            if flat.dtype != dt:
+                raise RuntimeError(" type error")
+            taken = flat[index.view(-1)].view(b, h, w, 3, tex_c) * coeff.unsqueeze(-1)
+            attr = (taken[..., 0, :] + taken[..., 1, :]) + taken[..., 2, :]
+        if rv and rf:
+            return index[0], coeff[0], (zbuf[0] if zbuf is not None else None), (attr[0] if attr is not None else None), None
+        return index, coeff, zbuf, attr, None
+    index = torch.empty((b, h, w, 3), dtype=torch.int64, device=dev) if want_index else None
+    coeff = torch.empty((b, h, w, 3), dtype=dt, device=dev) if want_index else None
     zbuf = torch.empty((b, h, w), dtype=dt, device=dev) if want_z else None
+    win = torch.empty((b, h, w), dtype=torch.int32, device=dev) if want_win else None
     attr, tex_c, tex_flat = None, 0, None
     if tex is not None:
         tex_c = 1 if tex.dim() == vertices.dim() - 1 else int(tex.shape[-1])
@@ -76,36 +100,36 @@ def _forward_impl(vertices, triangles, height, width, perspective, eps, tex=None
         if tex_flat.dtype != dt:
             raise RuntimeError(" type error")
         attr = torch.empty((b, h, w, tex_c), dtype=dt, device=dev)
-    L = _lib.lib()
     work = torch.empty(L.sr_rasterize_scratch_bytes(b, h, w, int(suf == "f64")), dtype=torch.uint8,
                        device=dev)
     with on_device_of(vertices):
         rc = getattr(L, "sr_rasterize_forward_" + suf)(
             b, nv, nf, h, w, int(rv), int(rf), int(bool(perspective)), _lib.ptr(vertices),
             _lib.ptr(triangles), _lib.ptr(index), _lib.ptr(coeff), _lib.ptr(zbuf), abs(float(eps)),
-            _lib.ptr(tex_flat), tex_c, _lib.ptr(attr), _lib.ptr(work), stream_of(vertices))
+            _lib.ptr(tex_flat), tex_c, _lib.ptr(attr), _lib.ptr(win), _lib.ptr(work), stream_of(vertices))
     _lib.check(rc, "sr_rasterize_forward")
     if rv and rf:
-        index, coeff = index[0], coeff[0]
+        index = index[0] if index is not None else None
+        coeff = coeff[0] if coeff is not None else None
         zbuf = zbuf[0] if zbuf is not None else None
         attr = attr[0] if attr is not None else None
-    return index, coeff, zbuf, attr
+    return index, coeff, zbuf, attr, win
 
 
 def forward(vertices, triangles, height, width, perspective=False, eps=1e-9):
-    index, coeff, _, _ = _forward_impl(vertices, triangles, height, width, perspective, eps)
+    index, coeff, _, _, _ = _forward_impl(vertices, triangles, height, width, perspective, eps)
     return [index, coeff]
 
 
 def forward_with_depth(vertices, triangles, height, width, perspective=False, eps=1e-9):
     """Extension used by tests: also returns the z-buffer the reference keeps internal."""
-    index, coeff, zbuf, _ = _forward_impl(vertices, triangles, height, width, perspective, eps,
-                                          want_z=True)
+    index, coeff, zbuf, _, _ = _forward_impl(vertices, triangles, height, width, perspective, eps,
+                                             want_z=True)
     return index, coeff, zbuf
 
 
 def backward(vertices, index, perspective=False, eps=1e-9):
-    if not (is_device_tensor(vertices) and is_device_tensor(index)):
+    if vertices.device != index.device:
         raise RuntimeError(" cuda error")
     if index.dtype != torch.int64:
         raise RuntimeError(" type error")
@@ -121,6 +145,12 @@ def backward(vertices, index, perspective=False, eps=1e-9):
     if index.size(-1) != 3 or not index.is_contiguous() or not vertices.is_contiguous():
         raise RuntimeError("index input error")
     dcoeff = torch.empty(tuple(index.shape) + (9,), dtype=vertices.dtype, device=vertices.device)
+    if not is_device_tensor(vertices):
+        rc = getattr(_lib.lib(), "sr_rasterize_backward_cpu_" + suf)(
+            b, n, h, w, int(bool(perspective)), _lib.ptr(vertices), _lib.ptr(index), _lib.ptr(dcoeff),
+            abs(float(eps)))
+        _lib.check(rc, "sr_rasterize_backward_cpu")
+        return dcoeff
     with on_device_of(vertices):
         rc = getattr(_lib.lib(), "sr_rasterize_backward_" + suf)(
             b, n, h, w, int(rv), int(bool(perspective)), _lib.ptr(vertices), _lib.ptr(index),
@@ -133,13 +163,57 @@ def backward(vertices, index, perspective=False, eps=1e-9):
 rasterize_op = types.SimpleNamespace(forward=forward, backward=backward)
 
 
+# ---- per-topology incidence list for the gradient gather ------------------------------------------
+_INC_CACHE = {}
+
+
+def _incidence_one(tri, nv):
+    """CSR incidence of one [nf, 3] triangle list: (off int32 [nv + 2], adj int32 [3 nf]); the entries of vertex
+    i are the ascending corner-major indices k * nf + f with tri[f, k] == i.  Out-of-range ids (triangles the
+    rasterizer skips, reference op/rasterize.cpp:30-33) are filed under the extra bucket nv."""
+    flat = tri.t().reshape(-1)
+    flat = torch.where((flat < 0) | (flat >= nv), torch.full_like(flat, nv), flat)
+    order = torch.sort(flat, stable=True)[1].to(torch.int32)
+    counts = torch.bincount(flat, minlength=nv + 1)
+    off = torch.zeros(nv + 2, dtype=torch.int32, device=tri.device)
+    off[1:] = torch.cumsum(counts, 0).to(torch.int32)
+    return off, order.contiguous()
+
+
+def incidence(tri, nv):
+    """(adj_off, adj, off_bstride, adj_bstride) for tri [nf, 3] (shared) or [b, nf, 3]; cached per tensor."""
+    key = (tri.data_ptr(), tuple(tri.shape), tri._version, str(tri.device), int(nv))
+    hit = _INC_CACHE.get(key)
+    if hit is not None:
+        return hit[:4]
+    if tri.dim() == 2:
+        off, adj = _incidence_one(tri, nv)
+        val = (off, adj, 0, 0, tri)
+    else:
+        parts = [_incidence_one(t, nv) for t in tri]
+        off = torch.stack([p[0] for p in parts]).contiguous()
+        adj = torch.stack([p[1] for p in parts]).contiguous()
+        val = (off, adj, off.shape[1], adj.shape[1], tri)
+    if len(_INC_CACHE) > 16:
+        _INC_CACHE.clear()
+    _INC_CACHE[key] = val                                    # holds `tri`: the key is its address
+    return val[:4]
+
+
 class Rasterize(Function):
     @staticmethod
     def forward(ctx, v, tex, tri, h, w, perspective, eps):
         v = v.contiguous()
         tri = tri.contiguous()
-        ind, coeff, _, out = _forward_impl(v, tri, h, w, perspective, eps, tex=tex)
-        ctx.save_for_backward(v, tex, ind, coeff)
+        on_dev = is_device_tensor(v)
+        need_grad = on_dev and (ctx.needs_input_grad[0] or ctx.needs_input_grad[1])
+        ind, coeff, _, out, win = _forward_impl(v, tri, h, w, perspective, eps, tex=tex,
+                                                want_index=not on_dev, want_win=need_grad)
+        if on_dev:
+            ctx.save_for_backward(v, tex, tri, win)
+        else:
+            ctx.save_for_backward(v, tex, tri, ind, coeff)
+        ctx.on_dev = on_dev
         ctx.perspective = perspective
         ctx.eps = eps
         ctx.no_channel = tex.dim() == v.dim() - 1
@@ -147,26 +221,60 @@ class Rasterize(Function):
 
     @staticmethod
     def backward(ctx, grad_out):
-        v, tex, ind, coeff = ctx.saved_tensors
         need_v, need_t = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
         if not (need_v or need_t):
             return (None,) * 7
+        if not ctx.on_dev:
+            return Rasterize._backward_host(ctx, grad_out, need_v, need_t)
+        v, tex, tri, win = ctx.saved_tensors
         if v.dim() != 3:
             raise RuntimeError("rasterize backward: batched vertices [b, n, 3] required")
+        if win is None:
+            raise RuntimeError("rasterize backward: the forward pass recorded no gradient state")
         suf = _suffix(v)
         b, nv = v.size(0), v.size(1)
-        h, w = ind.shape[-3], ind.shape[-2]
+        nf = tri.size(-2)
+        h, w = win.shape[-2], win.shape[-1]
         c = 1 if ctx.no_channel else int(tex.shape[-1])
         go = grad_out.contiguous()
         tex_c = tex.contiguous()
-        grad_v = torch.zeros_like(v) if need_v else None
-        grad_t = torch.zeros_like(tex_c) if need_t else None
+        if tex_c.dim() < 2 or tex_c.shape[0] != b or tex_c.shape[1] != nv:
+            raise RuntimeError("rasterize backward: batched attributes [b, n(, c)] required")
+        grad_v = torch.empty_like(v) if need_v else None
+        grad_t = torch.empty_like(tex_c) if need_t else None
+        off, adj, off_bs, adj_bs = incidence(tri, nv)
+        L = _lib.lib()
+        work = torch.empty(L.sr_rasterize_grad_scratch_bytes(b, nf, c, int(suf == "f64")), dtype=torch.uint8,
+                           device=v.device)
         with on_device_of(v):
-            rc = getattr(_lib.lib(), "sr_rasterize_grad_" + suf)(
-                b, nv, h, w, 0, int(bool(ctx.perspective)), _lib.ptr(v), _lib.ptr(tex_c), c,
-                _lib.ptr(ind), _lib.ptr(coeff), _lib.ptr(go), _lib.ptr(grad_v), _lib.ptr(grad_t),
-                abs(float(ctx.eps)), stream_of(v))
+            rc = getattr(L, "sr_rasterize_grad_" + suf)(
+                b, nv, nf, h, w, int(tri.dim() == 2), int(bool(ctx.perspective)), _lib.ptr(v), _lib.ptr(tex_c), c,
+                _lib.ptr(tri), _lib.ptr(win), _lib.ptr(go), _lib.ptr(off), _lib.ptr(adj), off_bs, adj_bs,
+                _lib.ptr(grad_v), _lib.ptr(grad_t), abs(float(ctx.eps)), _lib.ptr(work), stream_of(v))
         _lib.check(rc, "sr_rasterize_grad")
+        return grad_v, grad_t, None, None, None, None, None
+
+    @staticmethod
+    def _backward_host(ctx, grad_out, need_v, need_t):
+        """CPU tensors: dcoeff from the host loop, then the reference's algebra (op/rasterize.py:46-77) with
+        index_add in place of the COO sparse matmul."""
+        v, tex, tri, ind, coeff = ctx.saved_tensors
+        if v.dim() != 3:
+            raise RuntimeError("rasterize backward: batched vertices [b, n, 3] required")
+        b, nv = v.size(0), v.size(1)
+        c = 1 if ctx.no_channel else int(tex.shape[-1])
+        go = grad_out.reshape(tuple(ind.shape[:-1]) + (c,))
+        flat_idx = ind.reshape(-1)
+        grad_v = grad_t = None
+        if need_v:
+            dcoeff = backward(v, ind, ctx.perspective, ctx.eps)                     # [b,h,w,3,9]
+            tex_rast = tex.reshape(-1, c)[flat_idx].view(tuple(ind.shape) + (c,))   # [b,h,w,3,c]
+            dl_dw = (go.unsqueeze(-2) * tex_rast).sum(-1)                           # [b,h,w,3]
+            diff = torch.matmul(dl_dw.unsqueeze(-2), dcoeff).reshape(-1, 3)         # [b*h*w*3, 3]
+            grad_v = torch.zeros(b * nv, 3, dtype=v.dtype).index_add_(0, flat_idx, diff).view_as(v)
+        if need_t:
+            contrib = (go.unsqueeze(-2) * coeff.unsqueeze(-1)).reshape(-1, c)
+            grad_t = torch.zeros(b * nv, c, dtype=tex.dtype).index_add_(0, flat_idx, contrib).view_as(tex)
         return grad_v, grad_t, None, None, None, None, None
 
 

@@ -40,10 +40,14 @@ def requires_grad_trainable(model, flag, frozen):
 
 
 def accumulate(model1, model2, decay=0.999):
+    """EMA of the parameters (reference train.py:100-104) as two multi-tensor launches instead of two
+    launches per parameter (~300 per iteration at 256x256)."""
     par1, par2 = dict(model1.named_parameters()), dict(model2.named_parameters())
     with torch.no_grad():
-        for k in par1:
-            par1[k].mul_(decay).add_(par2[k].detach(), alpha=1 - decay)
+        dst = [par1[k] for k in par1]
+        src = [par2[k].detach() for k in par1]
+        torch._foreach_mul_(dst, decay)
+        torch._foreach_add_(dst, src, alpha=1 - decay)
 
 
 def d_logistic_loss(real_pred, fake_pred):
@@ -177,8 +181,16 @@ class Trainer:
             fake_img, _, _ = self._generate(g, noise, self._mesh(mesh, faces, batch))
             fake_img = self._augment(fake_img)
             real_aug = self._augment(real_img)
-        fake_pred = self.d_ddp(fake_img)
-        real_pred = self.d_ddp(real_aug)
+        # one discriminator pass over both halves.  Interleaving keeps the minibatch-stddev groups of the two
+        # separate calls of the reference (model.py:325-332 views the batch as [group, batch // group]: sample b
+        # falls into sub-batch b % 2), so fake and real statistics never mix and the outputs are identical
+        if batch == fake_img.shape[0] and batch % min(batch, d.stddev_group) == 0:
+            both = torch.stack([fake_img, real_aug], 1).reshape(2 * batch, *real_aug.shape[1:])
+            pred = self.d_ddp(both)
+            fake_pred, real_pred = pred[0::2], pred[1::2]
+        else:
+            fake_pred = self.d_ddp(fake_img)
+            real_pred = self.d_ddp(real_aug)
         d_loss = d_logistic_loss(real_pred, fake_pred)
         losses["d"] = d_loss
         losses["real_score"] = real_pred.mean()
@@ -272,11 +284,27 @@ def synthetic_mesh(batch, device, seed=0, face_sized=True):
     return (torch.from_numpy(v).to(device), torch.from_numpy(nrm).to(device), torch.from_numpy(tri).to(device))
 
 
+def smooth_basis(v0, dim, key, amplitude):
+    """[dim, nv*3] deformation basis whose rows are LOW-FREQUENCY displacement fields of the mean mesh
+    (direction_k * sin(2 pi f_k . v + phase_k), |f_k| <= 1.5 cycles per unit): neighbouring vertices move
+    together, as the PCA modes of a real 3DMM do.  (Independent per-vertex noise — e.g. the reference's own
+    random initialisation, face_model.py:16-19 — turns the surface into a triangle soup with ~20 px triangles
+    and 100x overdraw, which no face mesh produces.)"""
+    freq = synth.det_uniform((dim, 3), key) * 1.5
+    phase = synth.det_uniform((dim,), key + 1) * np.pi
+    direc = synth.det_normal((dim, 3), key + 2)
+    direc /= np.maximum(np.linalg.norm(direc, axis=1, keepdims=True), 1e-6)
+    field = np.sin(2 * np.pi * (v0.astype(np.float64) @ freq.T.astype(np.float64)) + phase[None])      # [nv, dim]
+    basis = field.T[:, :, None] * direc[:, None, :].astype(np.float64)                                    # [dim, nv, 3]
+    return (basis.reshape(dim, -1) * amplitude).astype(np.float32)
+
+
 class SyntheticFaceSource:
     """Per-iteration mesh sampling of the reference's training loop (train.py:246-251: coefficients ->
     3DMM vertices -> random pose -> vertex normals), with a synthetic 3DMM: the face-sized UV mesh as the
-    mean (BFM itself is licensed and absent) and small random shape / expression bases.  Everything runs
-    on the device: one GEMM, one small matmul, one gather kernel (utils_3d.mesh_point_normal)."""
+    mean (BFM itself is licensed and absent) and smooth shape / expression bases (`smooth_basis`) scaled so
+    that a sample deforms the surface by a few percent of its size.  Everything runs on the device: one
+    GEMM, one small matmul, one gather kernel (utils_3d.mesh_point_normal)."""
 
     def __init__(self, device, shape_dim=80, expression_dim=64, seed=0, face_sized=True):
         from . import face_model, utils_3d
@@ -286,8 +314,9 @@ class SyntheticFaceSource:
         state = np.random.get_state()
         np.random.seed(seed)
         try:
-            wsh = synth.det_normal((shape_dim, nv * 3), 901) * 0.01
-            wex = synth.det_normal((expression_dim, nv * 3), 902) * 0.5
+            # coefficient sigmas are the reference's defaults (shape 1, expression 0.01, face_model.py:9-10)
+            wsh = smooth_basis(v0, shape_dim, 901, 0.05 / np.sqrt(max(shape_dim, 1)))
+            wex = smooth_basis(v0, expression_dim, 905, 3.0 / np.sqrt(max(expression_dim, 1)))
             self.model = face_model.LinearMorphableModel(nv, shape_dim, expression_dim, v0, wsh, wex).to(device)
         finally:
             np.random.set_state(state)

@@ -267,6 +267,90 @@ def test_rasterize_batch64_properties():
         assert torch.equal(c1, coeff[s:s + 1])
 
 
+def _oracle_grads(v, tex, tri, go, res):
+    return raster.rasterize_grads(v, tex, tri, go, res)
+
+
+def test_rasterize_gradients_are_deterministic_and_match_oracle_256():
+    """BFM-size-class mesh at 256x256: the two-phase gather (no float atomics) gives byte-identical grad_v /
+    grad_tex on every launch, and agrees with the float64-accumulated oracle."""
+    import stylerenderer_amd.op as op
+    from stylerenderer_amd import synth
+
+    v0, tri = synth.face_sized_mesh()
+    vh = synth.random_poses(v0, 2, seed=21)
+    nh = synth.vertex_normals(vh, tri)
+    go = synth.det_normal((2, 256, 256, 3), 77)
+    t = T(tri)
+    runs = []
+    for _ in range(3):
+        v, n = T(vh).requires_grad_(), T(nh).requires_grad_()
+        out = op.rasterize(v, n, t, 256)
+        runs.append(torch.autograd.grad(out, [v, n], T(go)))
+    for gv, gt in runs[1:]:
+        assert torch.equal(gv, runs[0][0]) and torch.equal(gt, runs[0][1])
+    wv, wt = _oracle_grads(vh, nh, tri, go, 256)
+    assert np.abs(runs[0][0].cpu().numpy() - wv).max() <= 2e-5 * np.abs(wv).max()
+    assert np.abs(runs[0][1].cpu().numpy() - wt).max() <= 2e-6 * np.abs(wt).max()
+
+
+@pytest.mark.parametrize("c", [1, 2, 3, 6])
+def test_rasterize_large_triangles_forward_and_gradients(c):
+    """A 218-triangle mesh at 256x256: every bounding box exceeds 64 pixels, so the workgroup-cooperative
+    paths of k_depth_keys and k_grad_tri run; forward bitwise vs the C oracle, gradients vs the oracle, any
+    attribute width (register accumulators are chunked by 4 channels), run-to-run identical."""
+    import stylerenderer_amd.op as op
+    from stylerenderer_amd import synth
+    R = importlib.import_module("stylerenderer_amd.op.rasterize")
+
+    v0, tri = synth.uv_ellipsoid(10, 12)
+    vh = synth.random_poses(v0, 3, seed=31)
+    tex = synth.det_normal((3, v0.shape[0], c), 32)
+    idx, coeff, zbuf = R.forward_with_depth(T(vh), T(tri), 256, 256, False, 1e-6)
+    wi, wc, wz = raster.forward_buffers(vh, tri, 256, 256, False, 1e-6)
+    assert np.array_equal(idx.cpu().numpy(), wi) and bits_equal(coeff.cpu().numpy(), wc)
+    assert bits_equal(zbuf.cpu().numpy(), wz)
+    go = synth.det_normal((3, 256, 256, c), 33)
+    got = []
+    for _ in range(2):
+        v, tx = T(vh).requires_grad_(), T(tex).requires_grad_()
+        out = op.rasterize(v, tx, T(tri), 256)
+        assert bits_equal(out.detach().cpu().numpy(), raster.rasterize(vh, tex, tri, 256))
+        got.append(torch.autograd.grad(out, [v, tx], T(go)))
+    assert torch.equal(got[0][0], got[1][0]) and torch.equal(got[0][1], got[1][1])
+    wv, wt = _oracle_grads(vh, tex, tri, go, 256)
+    assert np.abs(got[0][0].cpu().numpy() - wv).max() <= 5e-5 * np.abs(wv).max()
+    assert np.abs(got[0][1].cpu().numpy() - wt).max() <= 5e-6 * np.abs(wt).max()
+
+
+def test_rasterize_gradients_misc():
+    """No-channel attributes, per-sample topology [b, nf, 3], only one of the two gradients requested, a
+    triangle with a repeated vertex id and out-of-range ids (skipped like the reference does)."""
+    import stylerenderer_amd.op as op
+    from stylerenderer_amd import synth
+
+    v0, tri = synth.uv_ellipsoid(12, 10)
+    vh = synth.random_poses(v0, 2, seed=41)
+    nv = v0.shape[0]
+    tri = np.concatenate([tri, [[0, 0, 5]], [[1, 2, nv]], [[-1, 2, 3]]], 0)
+    tri_b = np.stack([tri, tri[::-1].copy()], 0)
+    tex1 = synth.det_normal((2, nv), 42)
+    go = synth.det_normal((2, 48, 48), 43)
+    v, tx = T(vh).requires_grad_(), T(tex1).requires_grad_()
+    out = op.rasterize(v, tx, T(tri_b), 48)
+    assert out.shape == (2, 48, 48)
+    gv, gt = torch.autograd.grad(out, [v, tx], T(go))
+    wv, wt = _oracle_grads(vh, tex1, tri_b, go, 48)
+    assert np.abs(gv.cpu().numpy() - wv).max() <= 5e-5 * np.abs(wv).max()
+    assert np.abs(gt.cpu().numpy() - wt).max() <= 5e-6 * np.abs(wt).max()
+    v2 = T(vh).requires_grad_()
+    (gv2,) = torch.autograd.grad(op.rasterize(v2, T(tex1), T(tri_b), 48), [v2], T(go))
+    assert torch.equal(gv2, gv)
+    tx2 = T(tex1).requires_grad_()
+    (gt2,) = torch.autograd.grad(op.rasterize(T(vh), tx2, T(tri_b), 48), [tx2], T(go))
+    assert torch.equal(gt2, gt)
+
+
 def test_rasterize_rejects_bad_inputs():
     R = importlib.import_module("stylerenderer_amd.op.rasterize")
 
@@ -275,8 +359,11 @@ def test_rasterize_rejects_bad_inputs():
         R.forward(v, torch.zeros(1, 3, dtype=torch.int32, device=DEV), 4, 4)
     with pytest.raises(RuntimeError):
         R.forward(v.half(), torch.zeros(1, 3, dtype=torch.int64, device=DEV), 4, 4)
-    with pytest.raises(RuntimeError):
-        R.forward(torch.zeros(1, 3, 3), torch.zeros(1, 3, dtype=torch.int64), 4, 4)
+    with pytest.raises(RuntimeError):                     # both tensors on the same device (op/rasterize.cpp:122)
+        R.forward(v, torch.zeros(1, 3, dtype=torch.int64), 4, 4)
+    # CPU tensors are served by the host loops, like the reference's extension (op/rasterize.cpp:126-150)
+    ic, cc = R.forward(torch.zeros(1, 3, 3), torch.zeros(1, 3, dtype=torch.int64), 4, 4)
+    assert ic.device.type == "cpu" and not ic.any() and not cc.any()
     # empty triangle list: all background
     idx, coeff = R.forward(v, torch.zeros(0, 3, dtype=torch.int64, device=DEV), 4, 4)
     assert not idx.any() and not coeff.any()
