@@ -195,18 +195,19 @@ int sr_blur_noise_bias_act(float* y, const float* x, const float* k, const float
  * Optional winner map `win` int32 [b,h,w]: id of the triangle that owns the pixel, -1 where uncovered
  * (what sr_rasterize_grad_* walks; index / coeff may then be NULL: the fused autograd path writes
  * 16 B per pixel instead of 48).  Triangles whose bounding box exceeds 64 pixels are walked by the whole
- * workgroup (LDS queue) instead of one lane. */
+ * workgroup (LDS queue) instead of one lane; optional `big` int32 [1 + b*nf] receives their count and the
+ * flat ids sample * nf + triangle (any order) for sr_rasterize_grad_*. */
 int64_t sr_rasterize_scratch_bytes(int64_t b, int64_t h, int64_t w, int is_double);
 int sr_rasterize_forward_f32(int64_t b, int64_t nv, int64_t nf, int64_t h, int64_t w, int repeat_v,
                              int repeat_f, int perspective, const float* v, const int64_t* tri,
                              int64_t* index, float* coeff, float* zbuf, float eps,
-                             const float* tex, int64_t tex_c, float* attr, int32_t* win, void* work,
-                             sr_stream_t stream);
+                             const float* tex, int64_t tex_c, float* attr, int32_t* win, int32_t* big,
+                             void* work, sr_stream_t stream);
 int sr_rasterize_forward_f64(int64_t b, int64_t nv, int64_t nf, int64_t h, int64_t w, int repeat_v,
                              int repeat_f, int perspective, const double* v, const int64_t* tri,
                              int64_t* index, double* coeff, double* zbuf, double eps,
-                             const double* tex, int64_t tex_c, double* attr, int32_t* win, void* work,
-                             sr_stream_t stream);
+                             const double* tex, int64_t tex_c, double* attr, int32_t* win, int32_t* big,
+                             void* work, sr_stream_t stream);
 
 /* d(coeff)/d(vertex) per pixel.  Replaces  bool rasterize_gpu_backward<scalar,index>(b, n, h, w,
  *   repeat_v, perspective, const scalar* v, const index* i, scalar* dcoeff, scalar eps)
@@ -223,7 +224,8 @@ int sr_rasterize_backward_f64(int64_t b, int64_t n, int64_t h, int64_t w, int re
  * sparse scatter matmuls) without materialising dcoeff or a COO matrix, and WITHOUT atomics — a
  * deterministic two-phase gather (run-to-run identical results):
  *   phase 1  per (sample, triangle): sums over the pixels the triangle won (`win` of the forward call), in
- *            pixel order, of (grad_out . tex[vertex_i]) * dcoeff[i, :] and grad_out * coeff_k;
+ *            pixel order, of (grad_out . tex[vertex_i]) * dcoeff[i, :] and grad_out * coeff_k — pixel-parallel
+ *            with the triangle's first pixel as its leader; workgroup-cooperative for the triangles in `big`;
  *   phase 2  per (sample, vertex): sum over its incident triangles in the order of the incidence list.
  *   grad_v  [b, nv, 3], grad_tex [b, nv, c]: every row is written (no pre-zeroing); either may be NULL.
  * v [b, nv, 3]; tex [b, nv, c]; tri int64 [nf, 3] (or [b, nf, 3] when !repeat_f); grad_out [b, h, w, c].
@@ -234,13 +236,13 @@ int sr_rasterize_backward_f64(int64_t b, int64_t n, int64_t h, int64_t w, int re
 int64_t sr_rasterize_grad_scratch_bytes(int64_t b, int64_t nf, int64_t tex_c, int is_double);
 int sr_rasterize_grad_f32(int64_t b, int64_t nv, int64_t nf, int64_t h, int64_t w, int repeat_f,
                           int perspective, const float* v, const float* tex, int64_t tex_c,
-                          const int64_t* tri, const int32_t* win, const float* grad_out,
+                          const int64_t* tri, const int32_t* win, const int32_t* big, const float* grad_out,
                           const int32_t* adj_off, const int32_t* adj, int64_t adj_off_bstride,
                           int64_t adj_bstride, float* grad_v, float* grad_tex, float eps, void* work,
                           sr_stream_t stream);
 int sr_rasterize_grad_f64(int64_t b, int64_t nv, int64_t nf, int64_t h, int64_t w, int repeat_f,
                           int perspective, const double* v, const double* tex, int64_t tex_c,
-                          const int64_t* tri, const int32_t* win, const double* grad_out,
+                          const int64_t* tri, const int32_t* win, const int32_t* big, const double* grad_out,
                           const int32_t* adj_off, const int32_t* adj, int64_t adj_off_bstride,
                           int64_t adj_bstride, double* grad_v, double* grad_tex, double eps, void* work,
                           sr_stream_t stream);

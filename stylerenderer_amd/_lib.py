@@ -47,8 +47,8 @@ SIGNATURES = {
     "sr_upfirdn2d": (_i, [_p, _p, _p, _l] + [_i] * 14 + [_p]),
     "sr_blur_noise_bias_act": (_i, [_p] * 6 + [_f, _f, _l, _l] + [_i] * 6 + [_l, _p]),
     "sr_rasterize_scratch_bytes": (_l, [_l, _l, _l, _i]),
-    "sr_rasterize_forward_f32": (_i, [_l] * 5 + [_i] * 3 + [_p] * 5 + [_f, _p, _l, _p, _p, _p, _p]),
-    "sr_rasterize_forward_f64": (_i, [_l] * 5 + [_i] * 3 + [_p] * 5 + [_d, _p, _l, _p, _p, _p, _p]),
+    "sr_rasterize_forward_f32": (_i, [_l] * 5 + [_i] * 3 + [_p] * 5 + [_f, _p, _l, _p, _p, _p, _p, _p]),
+    "sr_rasterize_forward_f64": (_i, [_l] * 5 + [_i] * 3 + [_p] * 5 + [_d, _p, _l, _p, _p, _p, _p, _p]),
     "sr_rasterize_grad_scratch_bytes": (_l, [_l, _l, _l, _i]),
     "sr_rasterize_forward_cpu_f32": (_i, [_l] * 5 + [_i] * 3 + [_p] * 5 + [_f]),
     "sr_rasterize_forward_cpu_f64": (_i, [_l] * 5 + [_i] * 3 + [_p] * 5 + [_d]),
@@ -56,12 +56,12 @@ SIGNATURES = {
     "sr_rasterize_backward_cpu_f64": (_i, [_l] * 4 + [_i] + [_p] * 3 + [_d]),
     "sr_rasterize_backward_f32": (_i, [_l] * 4 + [_i] * 2 + [_p] * 3 + [_f, _p]),
     "sr_rasterize_backward_f64": (_i, [_l] * 4 + [_i] * 2 + [_p] * 3 + [_d, _p]),
-    "sr_rasterize_grad_f32": (_i, [_l] * 5 + [_i] * 2 + [_p, _p, _l] + [_p] * 5 + [_l, _l, _p, _p, _f, _p, _p]),
+    "sr_rasterize_grad_f32": (_i, [_l] * 5 + [_i] * 2 + [_p, _p, _l] + [_p] * 6 + [_l, _l, _p, _p, _f, _p, _p]),
     "sr_conv2d_wgrad_scratch_floats": (_l, [_l] * 7 + [_i] * 4),
     "sr_conv2d_wgrad_mfma": (_i, [_p] * 5 + [_l] * 7 + [_i] * 4 + [_p, _p]),
     "sr_conv2d_scratch_floats": (_l, [_l] * 7 + [_i] * 4),
     "sr_conv2d_mfma": (_i, [_p] * 6 + [_l] * 8 + [_i] * 4 + [_p, _p]),
-    "sr_rasterize_grad_f64": (_i, [_l] * 5 + [_i] * 2 + [_p, _p, _l] + [_p] * 5 + [_l, _l, _p, _p, _d, _p, _p]),
+    "sr_rasterize_grad_f64": (_i, [_l] * 5 + [_i] * 2 + [_p, _p, _l] + [_p] * 6 + [_l, _l, _p, _p, _d, _p, _p]),
 }
 
 _lib = None

@@ -29,11 +29,12 @@
 //
 // Backward: k_dcoeff (API parity with rasterize_gpu_backward, coalesced through LDS), and the fused gradient
 // of the autograd Function as a deterministic two-phase GATHER — no float atomics, run-to-run identical:
-//   k_grad_tri   one lane per (sample, triangle) (workgroup-cooperative for large boxes, fixed-order tree):
-//                re-walks its box, and for the pixels it WON (winner map written by k_resolve) accumulates, in
-//                pixel order, d/d(3 vertices x xyz) and d/d(3 vertex attribute rows) into its own scratch row;
-//   k_grad_vert  one lane per (sample, vertex): sums the rows of its incident triangles in the fixed order of
-//                a per-topology incidence list (corner-major, ascending triangle id) and writes grad_v / grad_tex.
+//   k_grad_pix   one lane per PIXEL (coalesced winner-map / grad_out reads): the first pixel a triangle won, in
+//                box order, is its leader and sums, in box order, d/d(3 vertices) and d/d(3 attribute rows) over
+//                the triangle's pixels (winner map written by k_resolve) into the triangle's three corner records;
+//   k_grad_big   the large triangles k_depth_keys listed: one workgroup each, fixed-order tree over the lanes;
+//   k_grad_vert  one lane per (sample, vertex): sums the corner blocks of its incident triangles in the fixed
+//                order of a per-topology incidence list (corner-major, ascending triangle id).
 // (The reference builds a COO matrix per call and runs sparse.mm, op/rasterize.py:46-77; round 1 of this repo
 // scattered with float atomics.)
 //
@@ -308,7 +309,8 @@ SR_HD bool load_tri(Tri<R>& t, const R* __restrict__ vs,
 }
 
 __global__ __launch_bounds__(256) void k_fill_u64(unsigned long long* p, unsigned long long v,
-                                                  long long n) {
+                                                  long long n, int* counter) {
+    if (counter && blockIdx.x == 0 && threadIdx.x == 0) *counter = 0;
     const long long stride = (long long)gridDim.x * blockDim.x;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) p[i] = v;
 }
@@ -357,7 +359,8 @@ __global__ __launch_bounds__(256) void k_depth_keys(long long b, long long nv, l
                                                     const R* __restrict__ v,
                                                     const long long* __restrict__ f,
                                                     unsigned long long* __restrict__ keys,
-                                                    unsigned* __restrict__ tmin, R eps) {
+                                                    unsigned* __restrict__ tmin, int* __restrict__ big,
+                                                    R eps) {
     __shared__ int s_nbig;
     __shared__ int s_big[256];
     if (threadIdx.x == 0) s_nbig = 0;
@@ -376,6 +379,8 @@ __global__ __launch_bounds__(256) void k_depth_keys(long long b, long long nv, l
                 const long long box = (long long)(t.x1 - t.x0 + 1) * (t.y1 - t.y0 + 1);
                 if (box > BIG_BOX) {
                     s_big[atomicAdd(&s_nbig, 1)] = threadIdx.x;        // walked by the workgroup below
+                    // ... and remembered for the gradient pass (list order is irrelevant: one row each)
+                    if (MODE != 2 && big) big[1 + atomicAdd(big, 1)] = (int)g;
                 } else {
                     for (int y = t.y0; y <= t.y1; ++y)
                         for (int x = t.x0; x <= t.x1; ++x)
@@ -591,27 +596,98 @@ __global__ __launch_bounds__(256) void k_dcoeff(long long b, long long n, long l
 }
 
 // ---- fused gradient, phase 1: per-triangle sums over the pixels the triangle won ----------------------------
-// Row layout of the scratch `tg` (ROW = 9 + 3*CT values per (sample, triangle)):
-//   [0..8]            d loss / d (vertex k, component j) at 3k + j
-//   [9 + k*CT + j]    d loss / d tex[vertex k][ch0 + j]
-template <typename R, int CT>
-struct TriAcc {
-    R gv[9];
-    R gt[3 * CT];
-    int n;
+// Scratch layout: one 16-byte aligned row of RS floats per (sample, triangle), written whole with float4 stores
+// (scattered 4-byte stores cost one L2 transaction each: measured 130 of 217 us):
+//   corner k at [k * (NVC + CT)]:  NVC vertex-gradient values (x, y[, z]), then CT attribute-gradient values;
+// NVC = 2 orthographic (d/dz is identically zero there), 3 perspective.  A byte per row marks the written ones.
+//
+// Per-triangle constants of d(weights)/d(vertices) (reference barycentric_grad, op/rasterize.h:169-228).
+// Orthographic: dcoeff[wi][vert][comp] = -c[vert] * E[wi + 3*((comp+1)%3)] with the z column zeroed, so the
+// 27-entry Jacobian collapses to   g_vert.x = -c[vert] * sum_wi d_wi E[3+wi],  g_vert.y = -c[vert] * sum_wi d_wi E[6+wi]
+// (the same products re-associated): 9 triangle constants, ~20 flops per pixel, no 27-register array.
+template <typename R, bool PERSP>
+struct JacTri;
+
+template <typename R>
+struct JacTri<R, false> {
+    static constexpr int NV = 6;           // accumulated vertex-gradient values: (vertex, x|y)
+    R E0, E1, E2, E3, E4, E5, E6, E7, E8;
+    bool ok;
+    __device__ __forceinline__ void init(const R p[9], R eps) {
+        R m0 = p[3] * p[7], m1 = p[4] * p[6];
+        const R e0 = m0 - m1;
+        m0 = p[1] * p[6]; m1 = p[0] * p[7];
+        const R e1 = m0 - m1;
+        m0 = p[0] * p[4]; m1 = p[1] * p[3];
+        const R e2 = m0 - m1;
+        R det = e0 + e1;
+        det = det + e2;
+        ok = det < -eps || det > eps;
+        E0 = e0 / det; E1 = e1 / det; E2 = e2 / det;
+        E3 = (p[4] - p[7]) / det; E4 = (p[7] - p[1]) / det; E5 = (p[1] - p[4]) / det;
+        E6 = (p[6] - p[3]) / det; E7 = (p[0] - p[6]) / det; E8 = (p[3] - p[0]) / det;
+    }
+    __device__ __forceinline__ void add(R (&gv)[NV], R d0, R d1, R d2, R px, R py, R sw, R sh, R eps) const {
+        const R u = (px * 2 - sw + 1) / sw;
+        const R vv = (py * -2 + sh - 1) / sh;
+        const R c0 = (E0 + E3 * u) + E6 * vv;
+        const R c1 = (E1 + E4 * u) + E7 * vv;
+        const R c2 = (E2 + E5 * u) + E8 * vv;
+        const R qx = (d0 * E3 + d1 * E4) + d2 * E5;
+        const R qy = (d0 * E6 + d1 * E7) + d2 * E8;
+        gv[0] -= c0 * qx; gv[1] -= c0 * qy;
+        gv[2] -= c1 * qx; gv[3] -= c1 * qy;
+        gv[4] -= c2 * qx; gv[5] -= c2 * qy;
+    }
+    // value j of vertex k (0: x, 1: y, 2: z)
+    static __device__ __forceinline__ R get(const R (&gv)[NV], int k, int j) { return j == 2 ? (R)0 : gv[2 * k + j]; }
 };
 
-template <typename R, int CT>
-__device__ __forceinline__ void grad_pixel(TriAcc<R, CT>& acc, const Tri<R>& t, const R praw[9], bool want_v,
-                                           int x, int y, long long w, long long hw, long long h_arg,
-                                           bool perspective, R eps, const int* __restrict__ wins, int ti,
+template <typename R>
+struct JacTri<R, true> {
+    static constexpr int NV = 9;
+    R p[9];
+    bool ok;
+    __device__ __forceinline__ void init(const R q[9], R) {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) p[i] = q[i];
+        ok = true;
+    }
+    __device__ __forceinline__ void add(R (&gv)[NV], R d0, R d1, R d2, R px, R py, R sw, R sh, R eps) const {
+        R jac[27];
+        if (!weight_jacobian<R>(p, px, py, sw, sh, jac, true, eps)) return;
+#pragma unroll
+        for (int j = 0; j < 9; ++j) gv[j] += d0 * jac[j] + d1 * jac[9 + j] + d2 * jac[18 + j];
+    }
+    static __device__ __forceinline__ R get(const R (&gv)[NV], int k, int j) { return gv[3 * k + j]; }
+};
+
+template <typename R, int CT, bool PERSP>
+struct TriAcc {
+    R gv[JacTri<R, PERSP>::NV];
+    R gt[3 * CT];
+    int n;
+    __device__ __forceinline__ void clear() {
+        n = 0;
+#pragma unroll
+        for (int j = 0; j < JacTri<R, PERSP>::NV; ++j) gv[j] = 0;
+#pragma unroll
+        for (int j = 0; j < 3 * CT; ++j) gt[j] = 0;
+    }
+};
+
+// One pixel of triangle `ti` (skipped unless the triangle won it).
+template <typename R, int CT, bool PERSP>
+__device__ __forceinline__ void grad_pixel(TriAcc<R, CT, PERSP>& acc, const Tri<R>& t, const JacTri<R, PERSP>& jt,
+                                           bool want_v, int x, int y, long long w, long long hw, long long h_arg,
+                                           R eps, const int* __restrict__ wins, int ti,
                                            const R* __restrict__ gos, const R* __restrict__ tex0,
                                            const R* __restrict__ tex1, const R* __restrict__ tex2,
                                            int tex_c, int ch0) {
     const long long pix = x + (long long)y * w;
     if (pix >= hw || wins[pix] != ti) return;
     R c0, c1, c2, z;
-    shade<R>(t, x, y, perspective, eps, c0, c1, c2, z);        // same bits as k_resolve wrote into coeff
+    shade<R>(t, x, y, PERSP, eps, c0, c1, c2, z);        // same bits as k_resolve used for the interpolation
     const R* go = gos + pix * tex_c;
     acc.n += 1;
 #pragma unroll
@@ -624,8 +700,6 @@ __device__ __forceinline__ void grad_pixel(TriAcc<R, CT>& acc, const Tri<R>& t, 
         }
     }
     if (want_v) {
-        R jac[27];
-        if (!weight_jacobian<R>(praw, (R)x, (R)y, (R)h_arg, (R)w, jac, perspective, eps)) return;
         R d0 = 0, d1 = 0, d2 = 0;
         for (int ch = 0; ch < tex_c; ++ch) {
             const R gch = go[ch];
@@ -633,15 +707,14 @@ __device__ __forceinline__ void grad_pixel(TriAcc<R, CT>& acc, const Tri<R>& t, 
             d1 += gch * tex1[ch];
             d2 += gch * tex2[ch];
         }
-#pragma unroll
-        for (int j = 0; j < 9; ++j) acc.gv[j] += d0 * jac[j] + d1 * jac[9 + j] + d2 * jac[18 + j];
+        jt.add(acc.gv, d0, d1, d2, (R)x, (R)y, (R)h_arg, (R)w, eps);
     }
 }
 
 __device__ __forceinline__ float sr_shfl_down(float x, int off) { return __shfl_down(x, off, SR_WAVE); }
 __device__ __forceinline__ double sr_shfl_down(double x, int off) { return __shfl_down(x, off, SR_WAVE); }
 
-// Fixed-order sum over the 256 lanes of the workgroup (wave tree, then waves 0..3 in order); result on lane 0.
+// Fixed-order sum over the 256 lanes of the workgroup (wave tree, then waves 0..3 in order); same value on all lanes.
 template <typename R>
 __device__ __forceinline__ R block_sum_256(R x, R* s_part) {
 #pragma unroll
@@ -656,72 +729,56 @@ __device__ __forceinline__ R block_sum_256(R x, R* s_part) {
     return tot;
 }
 
-template <typename R, int CT>
-__global__ __launch_bounds__(256) void k_grad_tri(long long b, long long nv, long long nf, long long h,
-                                                  long long w, bool repeat_f, bool perspective,
-                                                  const R* __restrict__ v, const R* __restrict__ tex,
-                                                  int tex_c, int ch0, const long long* __restrict__ f,
-                                                  const int* __restrict__ win,
-                                                  const R* __restrict__ grad_out, bool want_v,
-                                                  R* __restrict__ tg, unsigned char* __restrict__ flag, R eps) {
-    constexpr int ROW = 9 + 3 * CT;
-    __shared__ int s_nbig;
-    __shared__ int s_big[256];
-    __shared__ R s_part[4];
-    if (threadIdx.x == 0) s_nbig = 0;
-    __syncthreads();
-    const long long hw = h * w;
-    const long long base = (long long)blockIdx.x * 256;
-    {
-        const long long g = base + threadIdx.x;
-        if (g < b * nf) {
-            const long long s = g / nf, ti = g - s * nf;
-            const R* vs = v + s * nv * 3;
-            const long long* fs = repeat_f ? f : f + s * nf * 3;
-            Tri<R> t;
-            long long i0, i1, i2;
-            bool deferred = false;
-            TriAcc<R, CT> acc;
-            acc.n = 0;
-            if (load_tri<R>(t, vs, fs, ti, nv, i0, i1, i2)) {
-                const R praw[9] = {t.p0, t.p1, t.p2, t.p3, t.p4, t.p5, t.p6, t.p7, t.p8};
-                if (tri_setup<R>(t, h, w, perspective, eps)) {
-                    const long long box = (long long)(t.x1 - t.x0 + 1) * (t.y1 - t.y0 + 1);
-                    if (box > BIG_BOX) {
-                        s_big[atomicAdd(&s_nbig, 1)] = threadIdx.x;
-                        deferred = true;
-                    } else {
+template <int CT, bool PERSP>
+struct RowShape {
+    static constexpr int NVC = PERSP ? 3 : 2;
+    static constexpr int CORNER = NVC + CT;
+    static constexpr int RS = (3 * CORNER + 3) / 4 * 4;          // floats per row, multiple of 4
+};
+
+template <typename R, int CT, bool PERSP>
+__device__ __forceinline__ void store_row(const TriAcc<R, CT, PERSP>& acc, R* __restrict__ tg,
+                                          unsigned char* __restrict__ flag, long long rowid) {
+    using S = RowShape<CT, PERSP>;
+    R vals[S::RS];
 #pragma unroll
-                        for (int j = 0; j < 9; ++j) acc.gv[j] = 0;
+    for (int i = 0; i < S::RS; ++i) vals[i] = 0;
 #pragma unroll
-                        for (int j = 0; j < 3 * CT; ++j) acc.gt[j] = 0;
-                        const bool distinct = want_v && i0 != i1 && i0 != i2 && i1 != i2;
-                        const R* tb = tex + s * nv * tex_c;
-                        for (int y = t.y0; y <= t.y1; ++y)
-                            for (int x = t.x0; x <= t.x1; ++x)
-                                grad_pixel<R, CT>(acc, t, praw, distinct, x, y, w, hw, h, perspective, eps,
-                                                  win + s * hw, (int)ti, grad_out + s * hw * tex_c,
-                                                  tb + i0 * tex_c, tb + i1 * tex_c, tb + i2 * tex_c, tex_c, ch0);
-                    }
-                }
-            }
-            if (!deferred) {
-                flag[g] = acc.n > 0 ? 1 : 0;
-                if (acc.n > 0) {
-                    R* row = tg + g * ROW;
+    for (int k = 0; k < 3; ++k) {
 #pragma unroll
-                    for (int j = 0; j < 9; ++j) row[j] = acc.gv[j];
+        for (int j = 0; j < S::NVC; ++j) vals[k * S::CORNER + j] = JacTri<R, PERSP>::get(acc.gv, k, j);
 #pragma unroll
-                    for (int j = 0; j < 3 * CT; ++j) row[9 + j] = acc.gt[j];
-                }
-            }
-        }
+        for (int j = 0; j < CT; ++j) vals[k * S::CORNER + S::NVC + j] = acc.gt[k * CT + j];
     }
-    __syncthreads();
-    const int nbig = s_nbig;
-    for (int q = 0; q < nbig; ++q) {
-        // deterministic regardless of the queue order: each deferred triangle owns its scratch row
-        const long long g = base + s_big[q];
+    R* row = tg + rowid * S::RS;
+    if (sizeof(R) == 4) {
+        float4* dst = reinterpret_cast<float4*>(row);
+#pragma unroll
+        for (int i = 0; i < S::RS / 4; ++i)
+            dst[i] = make_float4((float)vals[4 * i], (float)vals[4 * i + 1], (float)vals[4 * i + 2], (float)vals[4 * i + 3]);
+    } else {
+        double2* dst = reinterpret_cast<double2*>(row);
+#pragma unroll
+        for (int i = 0; i < S::RS / 2; ++i) dst[i] = make_double2((double)vals[2 * i], (double)vals[2 * i + 1]);
+    }
+    flag[rowid] = 1;
+}
+
+// Large triangles (the list k_depth_keys recorded): one workgroup per triangle walks the box together; each lane
+// sums its pixels in order, then a fixed-order tree over the 256 lanes.
+template <typename R, int CT, bool PERSP>
+__global__ __launch_bounds__(256) void k_grad_big(long long nv, long long nf, long long h, long long w,
+                                                  bool repeat_f, const R* __restrict__ v,
+                                                  const R* __restrict__ tex, int tex_c, int ch0,
+                                                  const long long* __restrict__ f, const int* __restrict__ win,
+                                                  const int* __restrict__ big, const R* __restrict__ grad_out,
+                                                  bool want_v, R* __restrict__ tg,
+                                                  unsigned char* __restrict__ flag, R eps) {
+    __shared__ R s_part[4];
+    const long long hw = h * w;
+    const int count = big[0];
+    for (int q = blockIdx.x; q < count; q += gridDim.x) {
+        const long long g = big[1 + q];
         const long long s = g / nf, ti = g - s * nf;
         const R* vs = v + s * nv * 3;
         const long long* fs = repeat_f ? f : f + s * nf * 3;
@@ -729,53 +786,112 @@ __global__ __launch_bounds__(256) void k_grad_tri(long long b, long long nv, lon
         long long i0, i1, i2;
         load_tri<R>(t, vs, fs, ti, nv, i0, i1, i2);
         const R praw[9] = {t.p0, t.p1, t.p2, t.p3, t.p4, t.p5, t.p6, t.p7, t.p8};
-        tri_setup<R>(t, h, w, perspective, eps);
-        TriAcc<R, CT> acc;
-        acc.n = 0;
-#pragma unroll
-        for (int j = 0; j < 9; ++j) acc.gv[j] = 0;
-#pragma unroll
-        for (int j = 0; j < 3 * CT; ++j) acc.gt[j] = 0;
-        const bool distinct = want_v && i0 != i1 && i0 != i2 && i1 != i2;
+        JacTri<R, PERSP> jt;
+        jt.init(praw, eps);
+        tri_setup<R>(t, h, w, PERSP, eps);
+        TriAcc<R, CT, PERSP> acc;
+        acc.clear();
+        const bool distinct = want_v && jt.ok && i0 != i1 && i0 != i2 && i1 != i2;
         const R* tb = tex + s * nv * tex_c;
         const int bw = t.x1 - t.x0 + 1;
         const long long npx = (long long)bw * (t.y1 - t.y0 + 1);
         for (long long p = threadIdx.x; p < npx; p += 256) {
             const int yy = (int)(p / bw);
-            grad_pixel<R, CT>(acc, t, praw, distinct, t.x0 + (int)(p - (long long)yy * bw), t.y0 + yy, w, hw, h,
-                              perspective, eps, win + s * hw, (int)ti, grad_out + s * hw * tex_c,
-                              tb + i0 * tex_c, tb + i1 * tex_c, tb + i2 * tex_c, tex_c, ch0);
+            grad_pixel<R, CT, PERSP>(acc, t, jt, distinct, t.x0 + (int)(p - (long long)yy * bw), t.y0 + yy, w, hw, h,
+                                     eps, win + s * hw, (int)ti, grad_out + s * hw * tex_c, tb + i0 * tex_c,
+                                     tb + i1 * tex_c, tb + i2 * tex_c, tex_c, ch0);
         }
         const R cnt = block_sum_256<R>((R)acc.n, s_part);
-        R* row = tg + g * ROW;
 #pragma unroll
-        for (int j = 0; j < 9; ++j) {
-            const R tot = block_sum_256<R>(acc.gv[j], s_part);
-            if (threadIdx.x == 0 && cnt > 0) row[j] = tot;
-        }
+        for (int j = 0; j < JacTri<R, PERSP>::NV; ++j) acc.gv[j] = block_sum_256<R>(acc.gv[j], s_part);
 #pragma unroll
-        for (int j = 0; j < 3 * CT; ++j) {
-            const R tot = block_sum_256<R>(acc.gt[j], s_part);
-            if (threadIdx.x == 0 && cnt > 0) row[9 + j] = tot;
-        }
-        if (threadIdx.x == 0) flag[g] = cnt > 0 ? 1 : 0;
+        for (int j = 0; j < 3 * CT; ++j) acc.gt[j] = block_sum_256<R>(acc.gt[j], s_part);
+        if (threadIdx.x == 0 && cnt > 0) store_row<R, CT, PERSP>(acc, tg, flag, g);
     }
 }
 
-// ---- fused gradient, phase 2: per-vertex gather over the incident triangles, fixed order ----------------------
-template <typename R, int CT>
+// Small triangles, PIXEL-parallel (coalesced winner-map / grad_out reads, no lanes spent on culled or pixel-less
+// triangles): the FIRST pixel a triangle won, in box order, is its leader; the leader sums the triangle's pixels
+// in box order and writes the records.  Every other lane leaves after the leader test.
+template <typename R, int CT, bool PERSP>
+__global__ __launch_bounds__(256) void k_grad_pix(long long b, long long nv, long long nf, long long h,
+                                                  long long w, bool repeat_f, const R* __restrict__ v,
+                                                  const R* __restrict__ tex, int tex_c, int ch0,
+                                                  const long long* __restrict__ f, const int* __restrict__ win,
+                                                  const R* __restrict__ grad_out, bool want_v,
+                                                  R* __restrict__ tg, unsigned char* __restrict__ flag, R eps) {
+    const long long hw = h * w;
+    const long long g = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (g >= b * hw) return;
+    const int ti = win[g];
+    if (ti < 0) return;
+    const long long s = g / hw, pix = g - s * hw;
+    const int py = (int)(pix / w), px = (int)(pix - (long long)py * w);
+    const R* vs = v + s * nv * 3;
+    const long long* fs = repeat_f ? f : f + s * nf * 3;
+    Tri<R> t;
+    long long i0, i1, i2;
+    load_tri<R>(t, vs, fs, ti, nv, i0, i1, i2);
+    const R praw[9] = {t.p0, t.p1, t.p2, t.p3, t.p4, t.p5, t.p6, t.p7, t.p8};
+    tri_setup<R>(t, h, w, PERSP, eps);
+    if ((long long)(t.x1 - t.x0 + 1) * (t.y1 - t.y0 + 1) > BIG_BOX) return;      // k_grad_big owns it
+    const int* wins = win + s * hw;
+    // which pixels of the box did this triangle win?  All winner-map loads are issued together (a loop that
+    // leaves at the first hit would serialise one memory round trip per pixel).  Bit index = box order.
+    const int bw = t.x1 - t.x0 + 1, bh = t.y1 - t.y0 + 1;
+    unsigned long long mask = 0;
+    if (bw <= 4 && bh <= 4) {
+        int got[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int xx = i & 3, yy = i >> 2;
+            const long long q = (t.x0 + xx) + (long long)(t.y0 + yy) * w;
+            got[i] = (xx < bw && yy < bh && q < hw) ? wins[q] : -1;
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+            if (got[i] == ti) mask |= 1ull << ((i >> 2) * bw + (i & 3));
+    } else {
+        int p = 0;
+        for (int y = t.y0; y <= t.y1; ++y)
+            for (int x = t.x0; x <= t.x1; ++x, ++p) {
+                const long long q = x + (long long)y * w;
+                if (q < hw && wins[q] == ti) mask |= 1ull << p;
+            }
+    }
+    const int self = (py - t.y0) * bw + (px - t.x0);
+    if (mask & ((1ull << self) - 1ull)) return;          // an earlier pixel of the box leads this triangle
+    JacTri<R, PERSP> jt;
+    jt.init(praw, eps);
+    TriAcc<R, CT, PERSP> acc;
+    acc.clear();
+    const bool distinct = want_v && jt.ok && i0 != i1 && i0 != i2 && i1 != i2;
+    const R* tb = tex + s * nv * tex_c;
+    while (mask) {                                        // ascending bit = box order
+        const int p = __ffsll((long long)mask) - 1;
+        mask &= mask - 1ull;
+        const int yy = p / bw;
+        grad_pixel<R, CT, PERSP>(acc, t, jt, distinct, t.x0 + (p - yy * bw), t.y0 + yy, w, hw, h, eps, wins, ti,
+                                 grad_out + s * hw * tex_c, tb + i0 * tex_c, tb + i1 * tex_c, tb + i2 * tex_c, tex_c,
+                                 ch0);
+    }
+    store_row<R, CT, PERSP>(acc, tg, flag, s * nf + ti);
+}
+
+// ---- fused gradient, phase 2: per-vertex sum over its incident corners, in incidence-list order ---------------
+template <typename R, int CT, bool PERSP>
 __global__ __launch_bounds__(256) void k_grad_vert(long long nv, long long nf, const int* __restrict__ adj_off,
                                                    const int* __restrict__ adj, long long off_bstride,
                                                    long long adj_bstride, const R* __restrict__ tg,
                                                    const unsigned char* __restrict__ flag, int tex_c, int ch0,
                                                    R* __restrict__ grad_v, R* __restrict__ grad_tex) {
-    constexpr int ROW = 9 + 3 * CT;
+    using S = RowShape<CT, PERSP>;
     const long long vert = (long long)blockIdx.x * 256 + threadIdx.x;
     const long long s = blockIdx.y;
     if (vert >= nv) return;
     const int* off = adj_off + s * off_bstride;
     const int* ad = adj + s * adj_bstride;
-    R av0 = 0, av1 = 0, av2 = 0;
+    R av[3] = {0, 0, 0};
     R at[CT];
 #pragma unroll
     for (int j = 0; j < CT; ++j) at[j] = 0;
@@ -785,18 +901,17 @@ __global__ __launch_bounds__(256) void k_grad_vert(long long nv, long long nf, c
         const int k = idx / (int)nf;
         const long long row = s * nf + (idx - k * (int)nf);
         if (!flag[row]) continue;
-        const R* r = tg + row * ROW;
-        av0 += r[3 * k];
-        av1 += r[3 * k + 1];
-        av2 += r[3 * k + 2];
+        const R* r = tg + row * S::RS + k * S::CORNER;
 #pragma unroll
-        for (int j = 0; j < CT; ++j) at[j] += r[9 + k * CT + j];
+        for (int j = 0; j < S::NVC; ++j) av[j] += r[j];
+#pragma unroll
+        for (int j = 0; j < CT; ++j) at[j] += r[S::NVC + j];
     }
     if (grad_v && ch0 == 0) {
         R* o = grad_v + (s * nv + vert) * 3;
-        o[0] = av0;
-        o[1] = av1;
-        o[2] = av2;
+        o[0] = av[0];
+        o[1] = av[1];
+        o[2] = av[2];
     }
     if (grad_tex) {
         R* o = grad_tex + (s * nv + vert) * tex_c + ch0;
@@ -809,10 +924,10 @@ __global__ __launch_bounds__(256) void k_grad_vert(long long nv, long long nf, c
 template <typename R>
 int forward_impl(long long b, long long nv, long long nf, long long h, long long w, int repeat_v,
                  int repeat_f, int perspective, const R* v, const long long* tri, long long* index,
-                 R* coeff, R* zbuf, R eps, const R* tex, long long tex_c, R* attr, int* win, void* work,
-                 hipStream_t st) {
+                 R* coeff, R* zbuf, R eps, const R* tex, long long tex_c, R* attr, int* win, int* big,
+                 void* work, hipStream_t st) {
     if (b < 0 || nv < 0 || nf < 0 || h <= 0 || w <= 0) return SR_EINVAL;
-    if (nf >= 0xFFFFFFFELL || (win && nf >= 0x7FFFFFFFLL)) return SR_ERANGE;
+    if (nf >= 0xFFFFFFFELL || (win && nf >= 0x7FFFFFFFLL) || (big && b * nf >= 0x7FFFFFFFLL)) return SR_ERANGE;
     if (b == 0) return SR_OK;
     if (!work || (nf > 0 && (!v || !tri))) return SR_EINVAL;
     if (attr && (!tex || tex_c <= 0)) return SR_EINVAL;
@@ -822,7 +937,7 @@ int forward_impl(long long b, long long nv, long long nf, long long h, long long
     unsigned* tmin = reinterpret_cast<unsigned*>(keys + npix);
     const bool is64 = sizeof(R) == 8;
     hipLaunchKernelGGL(k_fill_u64, dim3(sr_stream_grid(npix, 256)), dim3(256), 0, st, keys,
-                       is64 ? key_init_f64() : key_init_f32(), npix);
+                       is64 ? key_init_f64() : key_init_f32(), npix, big);
     if (is64)
         hipLaunchKernelGGL(k_fill_u32, dim3(sr_stream_grid(npix, 256)), dim3(256), 0, st, tmin,
                            0xFFFFFFFFu, npix);
@@ -831,12 +946,12 @@ int forward_impl(long long b, long long nv, long long nf, long long h, long long
         const unsigned grid = (unsigned)sr_ceil_div(ntri, 256);
         if (!is64) {
             hipLaunchKernelGGL((k_depth_keys<R, 0>), dim3(grid), dim3(256), 0, st, b, nv, nf, h, w,
-                               repeat_v != 0, repeat_f != 0, perspective != 0, v, tri, keys, tmin, eps);
+                               repeat_v != 0, repeat_f != 0, perspective != 0, v, tri, keys, tmin, big, eps);
         } else {
             hipLaunchKernelGGL((k_depth_keys<R, 1>), dim3(grid), dim3(256), 0, st, b, nv, nf, h, w,
-                               repeat_v != 0, repeat_f != 0, perspective != 0, v, tri, keys, tmin, eps);
+                               repeat_v != 0, repeat_f != 0, perspective != 0, v, tri, keys, tmin, big, eps);
             hipLaunchKernelGGL((k_depth_keys<R, 2>), dim3(grid), dim3(256), 0, st, b, nv, nf, h, w,
-                               repeat_v != 0, repeat_f != 0, perspective != 0, v, tri, keys, tmin, eps);
+                               repeat_v != 0, repeat_f != 0, perspective != 0, v, tri, keys, tmin, big, eps);
         }
     }
     hipLaunchKernelGGL((k_resolve<R>), dim3((unsigned)sr_ceil_div(npix, 256)), dim3(256), 0, st, b, nv, nf,
@@ -858,43 +973,53 @@ int backward_impl(long long b, long long n, long long h, long long w, int perspe
     return sr_launch_status();
 }
 
-inline long long grad_row_values(long long tex_c) { return 9 + 3 * (tex_c < 4 ? tex_c : 4); }
+// floats per scratch row for the widest chunk (<= 4 channels) and either projection: 3 * (3 + 4) rounded up to 4
+inline long long grad_row_floats() { return 24; }
 
-template <typename R, int CT>
-void grad_launch(long long b, long long nv, long long nf, long long h, long long w, bool repeat_f,
-                 bool perspective, const R* v, const R* tex, int tex_c, int ch0, const long long* tri,
-                 const int* win, const R* grad_out, const int* adj_off, const int* adj, long long off_bs,
-                 long long adj_bs, R* grad_v, R* grad_tex, R eps, R* tg, unsigned char* flag, hipStream_t st) {
+template <typename R, int CT, bool PERSP>
+void grad_launch(long long b, long long nv, long long nf, long long h, long long w, bool repeat_f, const R* v,
+                 const R* tex, int tex_c, int ch0, const long long* tri, const int* win, const int* big,
+                 const R* grad_out, const int* adj_off, const int* adj, long long off_bs, long long adj_bs,
+                 R* grad_v, R* grad_tex, R eps, R* tg, unsigned char* flag, hipStream_t st) {
     const bool want_v = grad_v != nullptr && ch0 == 0;
-    hipLaunchKernelGGL((k_grad_tri<R, CT>), dim3((unsigned)sr_ceil_div(b * nf, 256)), dim3(256), 0, st, b, nv, nf,
-                       h, w, repeat_f, perspective, v, tex, tex_c, ch0, tri, win, grad_out, want_v, tg, flag, eps);
-    hipLaunchKernelGGL((k_grad_vert<R, CT>), dim3((unsigned)sr_ceil_div(nv, 256), (unsigned)b), dim3(256), 0, st,
-                       nv, nf, adj_off, adj, off_bs, adj_bs, tg, flag, tex_c, ch0, grad_v, grad_tex);
+    (void)hipMemsetAsync(flag, 0, (size_t)(b * nf), st);
+    hipLaunchKernelGGL((k_grad_big<R, CT, PERSP>), dim3(SR_NUM_CU * 2), dim3(256), 0, st, nv, nf, h, w, repeat_f, v,
+                       tex, tex_c, ch0, tri, win, big, grad_out, want_v, tg, flag, eps);
+    hipLaunchKernelGGL((k_grad_pix<R, CT, PERSP>), dim3((unsigned)sr_ceil_div(b * h * w, 256)), dim3(256), 0, st, b,
+                       nv, nf, h, w, repeat_f, v, tex, tex_c, ch0, tri, win, grad_out, want_v, tg, flag, eps);
+    hipLaunchKernelGGL((k_grad_vert<R, CT, PERSP>), dim3((unsigned)sr_ceil_div(nv, 256), (unsigned)b), dim3(256), 0,
+                       st, nv, nf, adj_off, adj, off_bs, adj_bs, tg, flag, tex_c, ch0, grad_v, grad_tex);
 }
 
 template <typename R>
 int grad_impl(long long b, long long nv, long long nf, long long h, long long w, int repeat_f, int perspective,
-              const R* v, const R* tex, long long tex_c, const long long* tri, const int* win,
+              const R* v, const R* tex, long long tex_c, const long long* tri, const int* win, const int* big,
               const R* grad_out, const int* adj_off, const int* adj, long long off_bs, long long adj_bs,
               R* grad_v, R* grad_tex, R eps, void* work, hipStream_t st) {
     if (b < 0 || nv < 0 || nf < 0 || h < 0 || w < 0 || tex_c <= 0) return SR_EINVAL;
     if (b == 0 || nv == 0 || (!grad_v && !grad_tex)) return SR_OK;
     if (b > 65535 || nf >= 0x7FFFFFFFLL / 3 || tex_c > 0x7FFFFFFF) return SR_ERANGE;
-    if (!v || !tex || !grad_out || !adj_off || !work || (nf > 0 && (!tri || !adj || !win))) return SR_EINVAL;
+    if (!v || !tex || !grad_out || !adj_off || !work || (nf > 0 && (!tri || !adj || !win || !big))) return SR_EINVAL;
     if (eps < 0) eps = -eps;
     R* tg = reinterpret_cast<R*>(work);
-    unsigned char* flag = reinterpret_cast<unsigned char*>(tg + b * nf * grad_row_values(tex_c));
+    unsigned char* flag = reinterpret_cast<unsigned char*>(tg + b * nf * grad_row_floats());
     // attribute channels in chunks of <= 4 register accumulators; the vertex gradient rides with chunk 0
     for (long long ch0 = 0; ch0 < (grad_tex ? tex_c : 1); ch0 += 4) {
         const long long ct = tex_c - ch0 < 4 ? tex_c - ch0 : 4;
-#define SR_GRAD_CASE(CT)                                                                                        \
-    grad_launch<R, CT>(b, nv, nf, h, w, repeat_f != 0, perspective != 0, v, tex, (int)tex_c, (int)ch0, tri, win, \
-                       grad_out, adj_off, adj, off_bs, adj_bs, grad_v, grad_tex, eps, tg, flag, st)
+#define SR_GRAD_ARGS                                                                                              \
+    b, nv, nf, h, w, repeat_f != 0, v, tex, (int)tex_c, (int)ch0, tri, win, big, grad_out, adj_off, adj, off_bs, \
+        adj_bs, grad_v, grad_tex, eps, tg, flag, st
+#define SR_GRAD_CASE(CT)                                          \
+    do {                                                          \
+        if (perspective) grad_launch<R, CT, true>(SR_GRAD_ARGS);  \
+        else grad_launch<R, CT, false>(SR_GRAD_ARGS);             \
+    } while (0)
         if (ct == 1) SR_GRAD_CASE(1);
         else if (ct == 2) SR_GRAD_CASE(2);
         else if (ct == 3) SR_GRAD_CASE(3);
         else SR_GRAD_CASE(4);
 #undef SR_GRAD_CASE
+#undef SR_GRAD_ARGS
     }
     return sr_launch_status();
 }
@@ -974,29 +1099,31 @@ extern "C" int64_t sr_rasterize_scratch_bytes(int64_t b, int64_t h, int64_t w, i
     return npix * (is_double ? 12 : 8) + 16;
 }
 extern "C" int64_t sr_rasterize_grad_scratch_bytes(int64_t b, int64_t nf, int64_t tex_c, int is_double) {
+    (void)tex_c;
     const int64_t rows = (b > 0 ? b : 0) * (nf > 0 ? nf : 0);
-    return rows * grad_row_values(tex_c > 0 ? tex_c : 1) * (is_double ? 8 : 4) + rows + 16;
+    return rows * grad_row_floats() * (is_double ? 8 : 4) + rows + 16;
 }
 
 extern "C" int sr_rasterize_forward_f32(int64_t b, int64_t nv, int64_t nf, int64_t h, int64_t w,
                                         int repeat_v, int repeat_f, int perspective, const float* v,
                                         const int64_t* tri, int64_t* index, float* coeff, float* zbuf,
                                         float eps, const float* tex, int64_t tex_c, float* attr,
-                                        int32_t* win, void* work, sr_stream_t stream) {
+                                        int32_t* win, int32_t* big, void* work, sr_stream_t stream) {
     return forward_impl<float>(b, nv, nf, h, w, repeat_v, repeat_f, perspective, v,
                                reinterpret_cast<const long long*>(tri),
                                reinterpret_cast<long long*>(index), coeff, zbuf, eps, tex, tex_c, attr,
-                               win, work, sr_stream(stream));
+                               win, big, work, sr_stream(stream));
 }
 extern "C" int sr_rasterize_forward_f64(int64_t b, int64_t nv, int64_t nf, int64_t h, int64_t w,
                                         int repeat_v, int repeat_f, int perspective, const double* v,
                                         const int64_t* tri, int64_t* index, double* coeff,
                                         double* zbuf, double eps, const double* tex, int64_t tex_c,
-                                        double* attr, int32_t* win, void* work, sr_stream_t stream) {
+                                        double* attr, int32_t* win, int32_t* big, void* work,
+                                        sr_stream_t stream) {
     return forward_impl<double>(b, nv, nf, h, w, repeat_v, repeat_f, perspective, v,
                                 reinterpret_cast<const long long*>(tri),
                                 reinterpret_cast<long long*>(index), coeff, zbuf, eps, tex, tex_c, attr,
-                                win, work, sr_stream(stream));
+                                win, big, work, sr_stream(stream));
 }
 extern "C" int sr_rasterize_backward_f32(int64_t b, int64_t n, int64_t h, int64_t w, int repeat_v,
                                          int perspective, const float* v, const int64_t* index,
@@ -1014,22 +1141,24 @@ extern "C" int sr_rasterize_backward_f64(int64_t b, int64_t n, int64_t h, int64_
 }
 extern "C" int sr_rasterize_grad_f32(int64_t b, int64_t nv, int64_t nf, int64_t h, int64_t w, int repeat_f,
                                      int perspective, const float* v, const float* tex, int64_t tex_c,
-                                     const int64_t* tri, const int32_t* win, const float* grad_out,
+                                     const int64_t* tri, const int32_t* win, const int32_t* big,
+                                     const float* grad_out,
                                      const int32_t* adj_off, const int32_t* adj, int64_t adj_off_bstride,
                                      int64_t adj_bstride, float* grad_v, float* grad_tex, float eps,
                                      void* work, sr_stream_t stream) {
     return grad_impl<float>(b, nv, nf, h, w, repeat_f, perspective, v, tex, tex_c,
-                            reinterpret_cast<const long long*>(tri), win, grad_out, adj_off, adj,
+                            reinterpret_cast<const long long*>(tri), win, big, grad_out, adj_off, adj,
                             adj_off_bstride, adj_bstride, grad_v, grad_tex, eps, work, sr_stream(stream));
 }
 extern "C" int sr_rasterize_grad_f64(int64_t b, int64_t nv, int64_t nf, int64_t h, int64_t w, int repeat_f,
                                      int perspective, const double* v, const double* tex, int64_t tex_c,
-                                     const int64_t* tri, const int32_t* win, const double* grad_out,
+                                     const int64_t* tri, const int32_t* win, const int32_t* big,
+                                     const double* grad_out,
                                      const int32_t* adj_off, const int32_t* adj, int64_t adj_off_bstride,
                                      int64_t adj_bstride, double* grad_v, double* grad_tex, double eps,
                                      void* work, sr_stream_t stream) {
     return grad_impl<double>(b, nv, nf, h, w, repeat_f, perspective, v, tex, tex_c,
-                             reinterpret_cast<const long long*>(tri), win, grad_out, adj_off, adj,
+                             reinterpret_cast<const long long*>(tri), win, big, grad_out, adj_off, adj,
                              adj_off_bstride, adj_bstride, grad_v, grad_tex, eps, work, sr_stream(stream));
 }
 extern "C" int sr_rasterize_forward_cpu_f32(int64_t b, int64_t nv, int64_t nf, int64_t h, int64_t w, int repeat_v,

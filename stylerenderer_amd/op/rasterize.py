@@ -93,6 +93,7 @@ def _forward_impl(vertices, triangles, height, width, perspective, eps, tex=None
     coeff = torch.empty((b, h, w, 3), dtype=dt, device=dev) if want_index else None
     zbuf = torch.empty((b, h, w), dtype=dt, device=dev) if want_z else None
     win = torch.empty((b, h, w), dtype=torch.int32, device=dev) if want_win else None
+    big = torch.empty(1 + b * nf, dtype=torch.int32, device=dev) if want_win else None
     attr, tex_c, tex_flat = None, 0, None
     if tex is not None:
         tex_c = 1 if tex.dim() == vertices.dim() - 1 else int(tex.shape[-1])
@@ -106,14 +107,15 @@ def _forward_impl(vertices, triangles, height, width, perspective, eps, tex=None
         rc = getattr(L, "sr_rasterize_forward_" + suf)(
             b, nv, nf, h, w, int(rv), int(rf), int(bool(perspective)), _lib.ptr(vertices),
             _lib.ptr(triangles), _lib.ptr(index), _lib.ptr(coeff), _lib.ptr(zbuf), abs(float(eps)),
-            _lib.ptr(tex_flat), tex_c, _lib.ptr(attr), _lib.ptr(win), _lib.ptr(work), stream_of(vertices))
+            _lib.ptr(tex_flat), tex_c, _lib.ptr(attr), _lib.ptr(win), _lib.ptr(big), _lib.ptr(work),
+            stream_of(vertices))
     _lib.check(rc, "sr_rasterize_forward")
     if rv and rf:
         index = index[0] if index is not None else None
         coeff = coeff[0] if coeff is not None else None
         zbuf = zbuf[0] if zbuf is not None else None
         attr = attr[0] if attr is not None else None
-    return index, coeff, zbuf, attr, win
+    return index, coeff, zbuf, attr, ((win, big) if want_win else None)
 
 
 def forward(vertices, triangles, height, width, perspective=False, eps=1e-9):
@@ -207,10 +209,11 @@ class Rasterize(Function):
         tri = tri.contiguous()
         on_dev = is_device_tensor(v)
         need_grad = on_dev and (ctx.needs_input_grad[0] or ctx.needs_input_grad[1])
-        ind, coeff, _, out, win = _forward_impl(v, tri, h, w, perspective, eps, tex=tex,
-                                                want_index=not on_dev, want_win=need_grad)
+        ind, coeff, _, out, state = _forward_impl(v, tri, h, w, perspective, eps, tex=tex,
+                                                  want_index=not on_dev, want_win=need_grad)
         if on_dev:
-            ctx.save_for_backward(v, tex, tri, win)
+            win, big = state if state is not None else (None, None)
+            ctx.save_for_backward(v, tex, tri, win, big)
         else:
             ctx.save_for_backward(v, tex, tri, ind, coeff)
         ctx.on_dev = on_dev
@@ -226,7 +229,7 @@ class Rasterize(Function):
             return (None,) * 7
         if not ctx.on_dev:
             return Rasterize._backward_host(ctx, grad_out, need_v, need_t)
-        v, tex, tri, win = ctx.saved_tensors
+        v, tex, tri, win, big = ctx.saved_tensors
         if v.dim() != 3:
             raise RuntimeError("rasterize backward: batched vertices [b, n, 3] required")
         if win is None:
@@ -249,7 +252,7 @@ class Rasterize(Function):
         with on_device_of(v):
             rc = getattr(L, "sr_rasterize_grad_" + suf)(
                 b, nv, nf, h, w, int(tri.dim() == 2), int(bool(ctx.perspective)), _lib.ptr(v), _lib.ptr(tex_c), c,
-                _lib.ptr(tri), _lib.ptr(win), _lib.ptr(go), _lib.ptr(off), _lib.ptr(adj), off_bs, adj_bs,
+                _lib.ptr(tri), _lib.ptr(win), _lib.ptr(big), _lib.ptr(go), _lib.ptr(off), _lib.ptr(adj), off_bs, adj_bs,
                 _lib.ptr(grad_v), _lib.ptr(grad_t), abs(float(ctx.eps)), _lib.ptr(work), stream_of(v))
         _lib.check(rc, "sr_rasterize_grad")
         return grad_v, grad_t, None, None, None, None, None
