@@ -194,11 +194,17 @@ def train_leg(dev, rank, world, iters, batch, size=256):
     import torch
     import torch.distributed as dist
 
-    from stylerenderer_amd import train
+    from stylerenderer_amd import graph_train, train
 
-    tr = train.Trainer(size=size, latent=512, n_mlp=8, channel_multiplier=2, use_mesh=True, device=dev, seed=0)
-    data = train.SyntheticImages(64, size, dev)
     faces = train.SyntheticFaceSource(dev, seed=0)
+    graphs = os.environ.get("SR_TRAIN_GRAPHS", "1") != "0"
+    if graphs:
+        # forward + backward of each phase and the Adam steps replayed from hipGraphs (graph_train.py)
+        tr = graph_train.GraphedTrainer(size=size, latent=512, n_mlp=8, channel_multiplier=2, use_mesh=True,
+                                        device=dev, seed=0, batch=batch, mesh_vertices=faces.model.dim[2] // 3)
+    else:
+        tr = train.Trainer(size=size, latent=512, n_mlp=8, channel_multiplier=2, use_mesh=True, device=dev, seed=0)
+    data = train.SyntheticImages(64, size, dev)
 
     def fence():
         if world > 1:
@@ -229,6 +235,8 @@ def train_leg(dev, rank, world, iters, batch, size=256):
            "ms_per_iter": round(elapsed / iters * 1e3, 3),
            "host_enqueue_ms_per_iter": round(t_enq / iters * 1e3, 3),
            "launch_bound": bool(t_enq > 0.95 * elapsed),
+           "execution": ("hipGraph replay per phase (graph_train.GraphedTrainer); flat-buffer gradient all-reduce "
+                         "between replays" if graphs else "eager launches (train.Trainer, DDP buckets)"),
            "losses_finite": finite, "parallelism": "dp%d" % world}
     if world > 1:
         n = int(G_PARAM_BYTES // 4)

@@ -85,6 +85,24 @@ int sr_noise_bias_act_bwd_dot(float* gx, float* gbias, float* gnoise_w, float* r
                               const float* out, const float* noise, const float* noise_w, const float* bias,
                               float alpha, float scale, int64_t n, int64_t c, int64_t inner,
                               int64_t noise_bstride, float* scratch, sr_stream_t stream);
+/* StyledMapConv tail (reference model.py:49-54: `out * stylemap[:, :1] + stylemap[:, 1:2]`, then
+ * NoiseInjection and FusedLeakyReLU) as one pass and its backward as one pass (+ the fixed-order finish):
+ *   y = lrelu((x * a[b,p] + s[b,p]) + noise_w * noise[b,p] + bias[c]) * scale
+ *   gx = g * a ; gamap[b,p] = sum_c g * x ; gsmap[b,p] = sum_c g ; gbias[c] = sum_{b,p} g ; gnoise_w = sum g * noise
+ * with g = lrelu'(y) * gy * scale.  x / y / gx [n, c, inner]; amap / smap point at [n] planes of `inner` floats
+ * `map_bstride` floats apart (two channels of one rasterised-map tensor); gamap / gsmap [n, inner] contiguous.
+ * inner % 4 == 0 and 16-byte aligned pointers. */
+int sr_noise_bias_act_affine(float* y, const float* x, const float* amap, const float* smap, int64_t map_bstride,
+                             const float* noise, const float* noise_w, const float* bias, float alpha,
+                             float scale, int64_t n, int64_t c, int64_t inner, int64_t noise_bstride,
+                             sr_stream_t stream);
+int64_t sr_noise_bias_act_affine_bwd_scratch_floats(int64_t n, int64_t c, int64_t inner);
+int sr_noise_bias_act_affine_bwd(float* gx, float* gamap, float* gsmap, float* gbias, float* gnoise_w,
+                                 const float* gy, const float* out, const float* x, const float* amap,
+                                 int64_t map_bstride, const float* noise, float alpha, float scale, int64_t n,
+                                 int64_t c, int64_t inner, int64_t noise_bstride, float* scratch,
+                                 sr_stream_t stream);
+
 /* Row-wise dot products of two [rows, inner] tensors, optionally with a scaled copy in the same
  * sweep: dots[r] = sum_i a[r,i]*b[r,i] ; out_scaled[r,i] = b[r,i]*scale[r] (out_scaled may be NULL).
  * These are the style / demodulation gradients of the modulated convolution (sum_p x*dx', sum_p g*y)

@@ -1,0 +1,33 @@
+#!/usr/bin/env python3
+"""GPU box: which operators make up one BASELINE config[2] iteration (eager), by count and device time.
+usage: python scripts/op_census.py [phase]   phase in {all, d, g, path, r1}"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+from torch.profiler import ProfilerActivity, profile  # noqa: E402
+
+from stylerenderer_amd import graph_train, train  # noqa: E402
+
+phase = sys.argv[1] if len(sys.argv) > 1 else "all"
+dev = torch.device("cuda", 0)
+faces = train.SyntheticFaceSource(dev, seed=0)
+tr = graph_train.GraphedTrainer(size=256, latent=512, n_mlp=8, use_mesh=True, device=dev, seed=0, batch=4,
+                                mesh_vertices=faces.model.dim[2] // 3, capture=False)
+data = train.SyntheticImages(16, 256, dev)
+tr.step(data.batch(4), faces=faces, log=False)
+tr._load_inputs(data.batch(4), None, faces)
+bodies = tr._bodies()
+names = {"all": ("d", "d_opt", "g", "g_opt"), "d": ("d",), "g": ("g",), "path": ("path",), "r1": ("r1",)}[phase]
+torch.cuda.synchronize()
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+    for n in names:
+        bodies[n]()
+    torch.cuda.synchronize()
+ka = prof.key_averages()
+rows = sorted(ka, key=lambda e: -e.count)
+print("phase %s: top operators by call count" % phase)
+for e in rows[:70]:
+    print("%6d  %9.1f us dev  %s" % (e.count, e.device_time_total, e.key[:90]))

@@ -9,14 +9,18 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
-from stylerenderer_amd import train  # noqa: E402
+from stylerenderer_amd import graph_train, train  # noqa: E402
 
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 batch = int(sys.argv[2]) if len(sys.argv) > 2 else 4
 dev = torch.device("cuda", 0)
-tr = train.Trainer(size=256, latent=512, n_mlp=8, use_mesh=True, device=dev, seed=0)
-data = train.SyntheticImages(64, 256, dev)
 faces = train.SyntheticFaceSource(dev, seed=0)
+if os.environ.get("SR_TRAIN_GRAPHS", "1") != "0":
+    tr = graph_train.GraphedTrainer(size=256, latent=512, n_mlp=8, use_mesh=True, device=dev, seed=0, batch=batch,
+                                    mesh_vertices=faces.model.dim[2] // 3)
+else:
+    tr = train.Trainer(size=256, latent=512, n_mlp=8, use_mesh=True, device=dev, seed=0)
+data = train.SyntheticImages(64, 256, dev)
 for _ in range(2):
     tr.step(data.batch(batch), faces=faces, log=False)
 tr.iteration = 0

@@ -294,6 +294,187 @@ extern "C" int sr_noise_bias_act_bwd_dot(float* gx, float* gbias, float* gnoise_
     return sr_launch_status();
 }
 
+// ------------------------------------------------------------------------------------------------
+// StyledMapConv tail (reference model.py:49-54): per-pixel affine from the rasterised normal map between the
+// modulated convolution and the noise injection,
+//     y = lrelu( (x * a[b,p] + s[b,p]) + w * noise[b,p] + bias[c] ) * scale
+// as ONE pass (the reference: mul, add, add, bias+act = four).  Backward in one pass as well: lanes own 4 pixels
+// and walk the channels, so the per-pixel sums over channels (gradients of the two maps) stay in registers while
+// the per-channel sums (bias / noise-strength gradients) leave as per-wave partials:
+//     g = lrelu'(y) * gy * scale;  gx = g * a;  ga[b,p] = sum_c g * x;  gs[b,p] = sum_c g;
+//     gbias[c] = sum_{b,p} g;  gw = sum g * noise                      16 B/element instead of ~60.
+namespace {
+
+constexpr int APIX = EB * 4;        // pixels per workgroup of the affine kernels
+
+__global__ __launch_bounds__(EB) void k_nba_aff_fwd(float* __restrict__ y, const float* __restrict__ x,
+                                                    const float* __restrict__ amap, const float* __restrict__ smap,
+                                                    int64_t map_bstride, const float* __restrict__ noise,
+                                                    const float* __restrict__ noise_w,
+                                                    const float* __restrict__ bias, float alpha, float scale, int c,
+                                                    int64_t inner, int64_t noise_bstride, int cgroup) {
+    const int64_t b = blockIdx.y;
+    const int64_t p = (int64_t)blockIdx.x * APIX + threadIdx.x * 4;
+    if (p >= inner) return;
+    const int c0 = blockIdx.z * cgroup, c1 = (c0 + cgroup < c) ? c0 + cgroup : c;
+    const float4 a = *reinterpret_cast<const float4*>(amap + b * map_bstride + p);
+    const float4 sft = *reinterpret_cast<const float4*>(smap + b * map_bstride + p);
+    const float nw = noise ? noise_w[0] : 0.0f;
+    float4 nz = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (noise) nz = *reinterpret_cast<const float4*>(noise + b * noise_bstride + p);
+    nz.x *= nw; nz.y *= nw; nz.z *= nw; nz.w *= nw;
+    for (int ch = c0; ch < c1; ++ch) {
+        const int64_t o = (b * c + ch) * inner + p;
+        float4 v = *reinterpret_cast<const float4*>(x + o);
+        const float bb = bias ? bias[ch] : 0.0f;
+        v.x = v.x * a.x + sft.x; v.y = v.y * a.y + sft.y; v.z = v.z * a.z + sft.z; v.w = v.w * a.w + sft.w;
+        if (noise) { v.x += nz.x; v.y += nz.y; v.z += nz.z; v.w += nz.w; }
+        v.x += bb; v.y += bb; v.z += bb; v.w += bb;
+        float4 r;
+        r.x = ((v.x > 0.0f) ? v.x : v.x * alpha) * scale;
+        r.y = ((v.y > 0.0f) ? v.y : v.y * alpha) * scale;
+        r.z = ((v.z > 0.0f) ? v.z : v.z * alpha) * scale;
+        r.w = ((v.w > 0.0f) ? v.w : v.w * alpha) * scale;
+        *reinterpret_cast<float4*>(y + o) = r;
+    }
+}
+
+// partial layout: [(row * chunks + chunk) * 4 + wave] float2 (bias share, noise share): k_nba_finish sums them
+// with chunks' = 4 * chunks.  Channels are split into grid.z groups (a 256^2 map at batch 4 is only 256
+// pixel-chunk workgroups); each group leaves its per-pixel sums in its own plane and k_plane_sum adds the planes
+// in group order.
+__global__ __launch_bounds__(EB) void k_nba_aff_bwd(float* __restrict__ gx, float* __restrict__ gamap,
+                                                    float* __restrict__ gsmap, float* __restrict__ partial,
+                                                    const float* __restrict__ gy, const float* __restrict__ out,
+                                                    const float* __restrict__ x, const float* __restrict__ amap,
+                                                    int64_t map_bstride, const float* __restrict__ noise,
+                                                    float alpha, float scale, int c, int64_t inner,
+                                                    int64_t noise_bstride, int chunks, int cgroup,
+                                                    int64_t plane) {
+    const int64_t b = blockIdx.y;
+    const int64_t p = (int64_t)blockIdx.x * APIX + threadIdx.x * 4;
+    const bool live = p < inner;
+    const int c0 = blockIdx.z * cgroup, c1 = (c0 + cgroup < c) ? c0 + cgroup : c;
+    gamap += (int64_t)blockIdx.z * plane;
+    gsmap += (int64_t)blockIdx.z * plane;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f), nz = a, ga = a, gs = a;
+    if (live) {
+        a = *reinterpret_cast<const float4*>(amap + b * map_bstride + p);
+        if (noise) nz = *reinterpret_cast<const float4*>(noise + b * noise_bstride + p);
+    }
+    for (int ch = c0; ch < c1; ++ch) {
+        const int64_t row = b * c + ch;
+        float sb = 0.0f, sn = 0.0f;
+        if (live) {
+            const int64_t o = row * inner + p;
+            const float4 g = *reinterpret_cast<const float4*>(gy + o);
+            const float4 yo = *reinterpret_cast<const float4*>(out + o);
+            const float4 xv = *reinterpret_cast<const float4*>(x + o);
+            float4 r;
+            r.x = ((yo.x > 0.0f) ? g.x : g.x * alpha) * scale;
+            r.y = ((yo.y > 0.0f) ? g.y : g.y * alpha) * scale;
+            r.z = ((yo.z > 0.0f) ? g.z : g.z * alpha) * scale;
+            r.w = ((yo.w > 0.0f) ? g.w : g.w * alpha) * scale;
+            *reinterpret_cast<float4*>(gx + o) = make_float4(r.x * a.x, r.y * a.y, r.z * a.z, r.w * a.w);
+            ga.x += r.x * xv.x; ga.y += r.y * xv.y; ga.z += r.z * xv.z; ga.w += r.w * xv.w;
+            gs.x += r.x; gs.y += r.y; gs.z += r.z; gs.w += r.w;
+            sb = (r.x + r.y) + (r.z + r.w);
+            sn = (r.x * nz.x + r.y * nz.y) + (r.z * nz.z + r.w * nz.w);
+        }
+        sb = sr_wave_sum(sb);
+        sn = sr_wave_sum(sn);
+        if (lane == 0)
+            reinterpret_cast<float2*>(partial)[(row * chunks + blockIdx.x) * 4 + wave] = make_float2(sb, sn);
+    }
+    if (live) {
+        *reinterpret_cast<float4*>(gamap + b * inner + p) = ga;
+        *reinterpret_cast<float4*>(gsmap + b * inner + p) = gs;
+    }
+}
+
+// out[i] = sum over g (ascending) of part[g * plane + i]
+__global__ __launch_bounds__(EB) void k_plane_sum(float* __restrict__ out, const float* __restrict__ part,
+                                                  int64_t plane, int groups) {
+    const int64_t i = ((int64_t)blockIdx.x * EB + threadIdx.x) * 4;
+    if (i >= plane) return;
+    float4 acc = *reinterpret_cast<const float4*>(part + i);
+    for (int g = 1; g < groups; ++g) {
+        const float4 v = *reinterpret_cast<const float4*>(part + g * plane + i);
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    *reinterpret_cast<float4*>(out + i) = acc;
+}
+
+// channel groups so that the launch has a few thousand workgroups
+inline int aff_cgroup(int64_t n, int64_t c, int64_t inner) {
+    const int64_t wgs = sr_ceil_div(inner, APIX) * n;
+    int64_t groups = sr_ceil_div(2048, wgs);
+    if (groups > 16) groups = 16;        // k_plane_sum walks the group planes serially
+    if (groups > c) groups = c;
+    if (groups < 1) groups = 1;
+    return (int)sr_ceil_div(c, groups);
+}
+
+}  // namespace
+
+extern "C" int sr_noise_bias_act_affine(float* y, const float* x, const float* amap, const float* smap,
+                                        int64_t map_bstride, const float* noise, const float* noise_w,
+                                        const float* bias, float alpha, float scale, int64_t n, int64_t c,
+                                        int64_t inner, int64_t noise_bstride, sr_stream_t stream) {
+    if (n < 0 || c < 0 || inner < 0) return SR_EINVAL;
+    if (n * c * inner == 0) return SR_OK;
+    if (!y || !x || !amap || !smap || (noise && !noise_w) || n > 65535) return SR_EINVAL;
+    if (!vec_ok(inner, y, x, noise, amap) || ((uintptr_t)smap & 15) || map_bstride % 4 != 0 ||
+        (noise && noise_bstride % 4 != 0))
+        return SR_EINVAL;
+    const int cg = aff_cgroup(n, c, inner);
+    hipLaunchKernelGGL(k_nba_aff_fwd, dim3((unsigned)sr_ceil_div(inner, APIX), (unsigned)n, (unsigned)sr_ceil_div(c, cg)),
+                       dim3(EB), 0, sr_stream(stream), y, x, amap, smap, map_bstride, noise, noise_w, bias, alpha, scale,
+                       (int)c, inner, noise_bstride, cg);
+    return sr_launch_status();
+}
+
+extern "C" int64_t sr_noise_bias_act_affine_bwd_scratch_floats(int64_t n, int64_t c, int64_t inner) {
+    if (n <= 0 || c <= 0 || inner <= 0) return 2;
+    const int64_t groups = sr_ceil_div(c, aff_cgroup(n, c, inner));
+    return 2 * n * c * sr_ceil_div(inner, APIX) * 4 + ((c + 2 + 3) / 4) * 4 + 2 * groups * n * inner;
+}
+
+extern "C" int sr_noise_bias_act_affine_bwd(float* gx, float* gamap, float* gsmap, float* gbias, float* gnoise_w,
+                                            const float* gy, const float* out, const float* x, const float* amap,
+                                            int64_t map_bstride, const float* noise, float alpha, float scale,
+                                            int64_t n, int64_t c, int64_t inner, int64_t noise_bstride,
+                                            float* scratch, sr_stream_t stream) {
+    if (n < 0 || c < 0 || inner < 0) return SR_EINVAL;
+    if (n * c * inner == 0) return SR_OK;
+    if (!gx || !gamap || !gsmap || !gy || !out || !x || !amap || !scratch || n > 65535) return SR_EINVAL;
+    if (!vec_ok(inner, gx, gy, out, x) || !vec_ok(inner, gamap, gsmap, amap, noise) || map_bstride % 4 != 0 ||
+        (noise && noise_bstride % 4 != 0))
+        return SR_EINVAL;
+    const int chunks = (int)sr_ceil_div(inner, APIX);
+    hipStream_t st = sr_stream(stream);
+    const int cg = aff_cgroup(n, c, inner);
+    const int groups = (int)sr_ceil_div(c, cg);
+    const int64_t plane = n * inner;
+    float* chan_nw = scratch + 2 * n * c * (int64_t)chunks * 4;
+    float* ga_part = groups > 1 ? chan_nw + ((c + 2 + 3) / 4) * 4 : gamap;
+    float* gs_part = groups > 1 ? ga_part + groups * plane : gsmap;
+    hipLaunchKernelGGL(k_nba_aff_bwd, dim3((unsigned)chunks, (unsigned)n, (unsigned)groups), dim3(EB), 0, st, gx,
+                       ga_part, gs_part, scratch, gy, out, x, amap, map_bstride, noise, alpha, scale, (int)c, inner,
+                       noise_bstride, chunks, cg, plane);
+    if (groups > 1) {
+        const unsigned g1 = (unsigned)sr_ceil_div(plane, EB * 4);
+        hipLaunchKernelGGL(k_plane_sum, dim3(g1), dim3(EB), 0, st, gamap, ga_part, plane, groups);
+        hipLaunchKernelGGL(k_plane_sum, dim3(g1), dim3(EB), 0, st, gsmap, gs_part, plane, groups);
+    }
+    hipLaunchKernelGGL(k_nba_finish, dim3((unsigned)c), dim3(64), 0, st, gbias, chan_nw, scratch, n, (int)c,
+                       chunks * 4);
+    if (noise && gnoise_w)
+        hipLaunchKernelGGL(k_nba_finish2, dim3(1), dim3(64), 0, st, gnoise_w, chan_nw, (int)c);
+    return sr_launch_status();
+}
+
 extern "C" int64_t sr_rowdot_scratch_floats(int64_t rows, int64_t inner) {
     if (rows <= 0 || inner <= 0) return 1;
     return rows * sr_ceil_div(inner, ECHUNK) + 1;

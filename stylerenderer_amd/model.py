@@ -18,7 +18,7 @@ from torch import nn
 from .layers import (Blur, ConstantInput, ConvLayer, EqualLinear, ModulatedConv2d, NoiseInjection,  # noqa: F401
                      PixelNorm, ResBlock, Upsample)
 from .op import FusedLeakyReLU, rasterize
-from .op.fused_elem import blur_noise_bias_act, noise_bias_act
+from .op.fused_elem import blur_noise_bias_act, noise_bias_act, noise_bias_act_affine
 
 CHANNEL_BASE = {4: 512, 8: 512, 16: 512, 32: 512, 64: 256, 128: 128, 256: 64, 512: 32, 1024: 16}
 
@@ -93,12 +93,13 @@ class StyledMapConv(nn.Module):
 
     def forward(self, input, style, stylemap, noise=None):
         out = self.conv(input, style)
-        out = out * stylemap[:, :1] + stylemap[:, 1:2]
-        if out.device.type == "cuda":
+        if out.device.type == "cuda" and not (noise is not None and noise.requires_grad):
             if noise is None:
                 noise = out.new_empty(out.shape[0], 1, out.shape[2], out.shape[3]).normal_()
-            return noise_bias_act(out, noise, self.noise.weight, self.activate.bias,
-                                  self.activate.negative_slope, self.activate.scale)
+            # per-pixel affine + noise + bias + LeakyReLU in one pass over the activation (and one in backward)
+            return noise_bias_act_affine(out, stylemap[:, :2], noise, self.noise.weight, self.activate.bias,
+                                         self.activate.negative_slope, self.activate.scale)
+        out = out * stylemap[:, :1] + stylemap[:, 1:2]
         out = self.noise(out, noise=noise)
         return self.activate(out)
 
@@ -199,8 +200,15 @@ class Generator(nn.Module):
         else:
             if inject_index is None:
                 inject_index = np.random.choice(self.n_latent - 2) + 1
-            latent = torch.cat([styles[0].unsqueeze(1).repeat(1, inject_index, 1),
-                                styles[1].unsqueeze(1).repeat(1, self.n_latent - inject_index, 1)], 1)
+            if torch.is_tensor(inject_index):
+                # crossover point held on the device (captured training step: the same graph serves every
+                # crossover, incl. inject_index == n_latent, i.e. no mixing): same latent as the cat below
+                layer = torch.arange(self.n_latent, device=styles[0].device).view(1, -1, 1)
+                latent = torch.where(layer < inject_index.view(1, 1, 1), styles[0].unsqueeze(1),
+                                     styles[1].unsqueeze(1))
+            else:
+                latent = torch.cat([styles[0].unsqueeze(1).repeat(1, inject_index, 1),
+                                    styles[1].unsqueeze(1).repeat(1, self.n_latent - inject_index, 1)], 1)
         return latent, noise
 
     def forward(self, styles, return_latents=False, inject_index=None, truncation=1,

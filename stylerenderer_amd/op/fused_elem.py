@@ -101,6 +101,96 @@ def noise_bias_act(x, noise, noise_weight, bias, negative_slope=0.2, scale=2 ** 
     return fused_leaky_relu(x, bias, negative_slope, scale)
 
 
+class _NBAAffineBackward(Function):
+    """First-order backward of `_NBAAffine` as its own node, so that a recorded backward (path-length
+    regulariser) differentiates it through the defining tensor algebra."""
+
+    @staticmethod
+    def forward(ctx, gy, out, x, smap2, noise, slope, scale):
+        n, c, inner = _geometry(out)
+        gy = gy.contiguous()
+        gx = torch.empty_like(out)
+        gmap = torch.empty((2, n) + tuple(out.shape[2:]), dtype=out.dtype, device=out.device)   # [a | s] planes
+        gb = torch.empty(c, dtype=out.dtype, device=out.device)
+        gnw = torch.zeros(1, dtype=out.dtype, device=out.device)
+        L = _lib.lib()
+        scratch = torch.empty(L.sr_noise_bias_act_affine_bwd_scratch_floats(n, c, inner), dtype=out.dtype,
+                              device=out.device)
+        bstride = 0 if noise is None or noise.numel() == inner else inner
+        with on_device_of(out):
+            rc = L.sr_noise_bias_act_affine_bwd(
+                _lib.ptr(gx), gmap.data_ptr(), gmap.data_ptr() + 4 * n * inner, _lib.ptr(gb), _lib.ptr(gnw),
+                _lib.ptr(gy), _lib.ptr(out), _lib.ptr(x), _lib.ptr(smap2), smap2.stride(0), _lib.ptr(noise),
+                float(slope), float(scale), n, c, inner, bstride, _lib.ptr(scratch), stream_of(out))
+        _lib.check(rc, "sr_noise_bias_act_affine_bwd")
+        return gx, gmap.transpose(0, 1), gb, gnw
+
+    @staticmethod
+    def backward(ctx, *grads):
+        raise RuntimeError("_NBAAffineBackward is not differentiable: the recorded-backward path re-derives the "
+                           "VJP from tensor algebra (see _NBAAffine.backward)")
+
+
+class _NBAAffine(Function):
+    """y = lrelu((x * a + s) + noise_w * noise + bias) * scale with a = smap2[:, 0:1], s = smap2[:, 1:2]:
+    the tail of StyledMapConv (reference model.py:49-54) in one pass."""
+
+    @staticmethod
+    def forward(ctx, x, smap2, noise, noise_w, bias, slope, scale):
+        n, c, inner = _geometry(x)
+        y = torch.empty_like(x)
+        bstride = 0 if noise is None or noise.numel() == inner else inner
+        with on_device_of(x):
+            rc = _lib.lib().sr_noise_bias_act_affine(
+                _lib.ptr(y), _lib.ptr(x), smap2.data_ptr(), smap2.data_ptr() + 4 * inner, smap2.stride(0),
+                _lib.ptr(noise), _lib.ptr(noise_w), _lib.ptr(bias), float(slope), float(scale), n, c, inner, bstride,
+                stream_of(x))
+        _lib.check(rc, "sr_noise_bias_act_affine")
+        ctx.save_for_backward(x, smap2, noise, noise_w, bias, y)
+        ctx.cfg = (slope, scale)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, smap2, noise, noise_w, bias, y = ctx.saved_tensors
+        slope, scale = ctx.cfg
+        needs = ctx.needs_input_grad
+        if torch.is_grad_enabled():
+            # recorded backward (create_graph): differentiate the defining composition instead
+            with torch.enable_grad():
+                xa, ma = x.view_as(x), smap2.view_as(smap2)
+                nwa = noise_w.view_as(noise_w) if noise_w is not None else None
+                ba = bias.view_as(bias) if bias is not None else None
+                pre = xa * ma[:, :1] + ma[:, 1:2]
+                if noise is not None:
+                    pre = pre + nwa * noise
+                out = fused_leaky_relu(pre, ba, slope, scale)
+                ins = (xa, ma, None, nwa, ba)
+                sel = [t for t, nd in zip(ins, needs[:5]) if nd and t is not None]
+                got = iter(torch.autograd.grad(out, sel, gy, create_graph=True, allow_unused=True)) if sel else iter(())
+                grads = [next(got) if (nd and t is not None) else None for t, nd in zip(ins, needs[:5])]
+            return tuple(grads) + (None, None)
+        gx, gmap, gb, gnw = _NBAAffineBackward.apply(gy, y, x, smap2, noise, slope, scale)
+        return (gx if needs[0] else None, gmap if needs[1] else None, None,
+                gnw if (noise is not None and needs[3]) else None, gb if needs[4] else None, None, None)
+
+
+def noise_bias_act_affine(x, smap2, noise, noise_weight, bias, negative_slope=0.2, scale=2 ** 0.5):
+    """lrelu((x * smap2[:, :1] + smap2[:, 1:2]) + noise_weight * noise + bias) * scale; `smap2` [B, 2, H, W]
+    (a channel slice of a contiguous map tensor is fine)."""
+    if noise is not None:
+        noise = noise.contiguous()
+    n, c, inner = _geometry(x) if x.dim() >= 3 else (0, 0, 0)
+    ok = (_fusable(x, noise) and x.is_contiguous() and bias is not None and smap2.dim() == 4
+          and tuple(smap2.shape) == (n, 2) + tuple(x.shape[2:]) and smap2.dtype == torch.float32
+          and smap2.stride()[1:] == (inner, x.shape[3], 1) and smap2.stride(0) % 4 == 0
+          and smap2.data_ptr() % 16 == 0 and n <= 65535)
+    if not ok:
+        out = x * smap2[:, :1] + smap2[:, 1:2]
+        return noise_bias_act(out, noise, noise_weight, bias, negative_slope, scale)
+    return _NBAAffine.apply(x, smap2, noise, noise_weight if noise is not None else None, bias, negative_slope, scale)
+
+
 class _BlurNBA(Function):
     """Blur (4x4 FIR, up = down = 1) + noise + bias + LeakyReLU in ONE pass (csrc/upfirdn2d.hip
     k_fir4_tile<true>): the tail of an upsampling StyledConv (reference layers.py:304-311 blur after the

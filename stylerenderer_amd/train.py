@@ -105,7 +105,7 @@ class Trainer:
     def __init__(self, size=256, latent=512, n_mlp=8, channel_multiplier=2, lr=0.002, r1=10.0,
                  path_regularize=2.0, path_batch_shrink=2, d_reg_every=16, g_reg_every=4, mixing=0.9,
                  use_mesh=False, device="cpu", seed=0, augment=False, augment_p=0.0, ada_target=0.6,
-                 ada_length=500 * 1000):
+                 ada_length=500 * 1000, wrap_ddp=True):
         self.args = dict(size=size, latent=latent, r1=r1, path_regularize=path_regularize,
                          path_batch_shrink=path_batch_shrink, d_reg_every=d_reg_every,
                          g_reg_every=g_reg_every, mixing=mixing, augment=augment, augment_p=augment_p,
@@ -133,8 +133,8 @@ class Trainer:
                                   lr=lr * g_ratio, betas=(0 ** g_ratio, 0.99 ** g_ratio))
         self.d_optim = optim.Adam(self.discriminator.parameters(), lr=lr * d_ratio,
                                   betas=(0 ** d_ratio, 0.99 ** d_ratio))
-        self.g_ddp = sr_dist.construct_ddp(self.generator, self.device)
-        self.d_ddp = sr_dist.construct_ddp(self.discriminator, self.device)
+        self.g_ddp = sr_dist.construct_ddp(self.generator, self.device) if wrap_ddp else self.generator
+        self.d_ddp = sr_dist.construct_ddp(self.discriminator, self.device) if wrap_ddp else self.discriminator
         self.mean_path_length = torch.zeros((), device=self.device)
         self.accum = 0.5 ** (32 / (10 * 1000))
         self.np_rng = np.random.RandomState(seed + 17 * rank)
@@ -263,17 +263,19 @@ class Trainer:
 
 class SyntheticImages:
     """In-memory stand-in for the reference's LMDB dataset (reference dataset.py:56-92): float
-    images in [-1, 1], random horizontal flip, sharded by rank."""
+    images in [-1, 1], random horizontal flip, sharded by rank.  Sampling and flipping run on the device
+    (a seeded generator of that device), so fetching a batch never synchronises the host."""
 
     def __init__(self, n, size, device, seed=1234):
         g = torch.Generator(device="cpu").manual_seed(seed + sr_dist.get_rank())
         self.data = (torch.rand(n, 3, size, size, generator=g) * 2 - 1).to(device)
-        self.rng = np.random.RandomState(seed + 1 + sr_dist.get_rank())
+        self.gen = torch.Generator(device=self.data.device).manual_seed(seed + 1 + sr_dist.get_rank())
 
     def batch(self, b):
-        idx = torch.from_numpy(self.rng.randint(0, self.data.shape[0], size=b)).to(self.data.device)
+        dev = self.data.device
+        idx = torch.randint(0, self.data.shape[0], (b,), device=dev, generator=self.gen)
         x = self.data[idx]
-        flip = torch.from_numpy(self.rng.rand(b) < 0.5).to(self.data.device)
+        flip = torch.rand(b, device=dev, generator=self.gen) < 0.5
         return torch.where(flip[:, None, None, None], x.flip(3), x)
 
 

@@ -65,7 +65,8 @@ def random_apply_pose3D(p=[.5, .1, .05, .1, .1, .1, .15], v=None):
     v @ (scale * R) + t (row-vector convention of the reference), or one 3x4 transform when v is None."""
     batch = len(v) if v is not None and v.dim() >= 3 else 1
     if not isinstance(p, torch.Tensor):
-        p = torch.Tensor(p)
+        # sigmas created where the vertices live: the draw below then runs on that device (no host round trip)
+        p = torch.tensor([float(x) for x in p], dtype=torch.float32, device=v.device if v is not None else None)
     p = torch.abs(p.reshape(-1)[:7])
     if len(p) < 7:
         p = torch.cat((p, torch.zeros(7 - len(p), dtype=p.dtype, device=p.device)))

@@ -460,3 +460,48 @@ def test_blur_noise_bias_act_equals_the_two_operators(shape, shared_noise):
     h1 = torch.autograd.grad((g1[0] * g1[0]).sum(), nw)[0]
     h2 = torch.autograd.grad((g2[0] * g2[0]).sum(), ref_in[1])[0]
     assert torch.allclose(h1, h2, rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("shape,shared,cmap", [((2, 6, 8, 8), True, 2), ((3, 5, 16, 12), False, 4), ((4, 128, 32, 32), False, 4)])
+def test_noise_bias_act_affine_matches_unfused_path(shape, shared, cmap):
+    """StyledMapConv tail (reference model.py:49-54) in one pass == mul, add, NoiseInjection, fused_leaky_relu:
+    forward bit for bit; gradients (x, both map channels, noise strength, bias) to fp32 round-off of the channel
+    sums; the recorded backward (path-length regulariser) through the same node."""
+    import stylerenderer_amd.op as op
+    from stylerenderer_amd import synth
+    from stylerenderer_amd.op.fused_elem import noise_bias_act_affine
+
+    b, c, h, w = shape
+    x0 = T(synth.det_normal(shape, 91))
+    m0 = T(synth.det_normal((b, cmap, h, w), 92))
+    noise = T(synth.det_normal((1 if shared else b, 1, h, w), 93))
+    nw0, b0 = T(synth.det_normal((1,), 94)), T(synth.det_normal((c,), 95))
+    gy = T(synth.det_normal(shape, 96))
+    lo = cmap - 2
+
+    def run(fused):
+        x, m, nw, bb = (t.clone().requires_grad_() for t in (x0, m0, nw0, b0))
+        sm = m[:, lo:lo + 2]
+        if fused:
+            y = noise_bias_act_affine(x, sm, noise, nw, bb)
+        else:
+            y = op.fused_leaky_relu(x * sm[:, :1] + sm[:, 1:2] + nw * noise, bb)
+        return (x, m, nw, bb), y
+
+    (ia, ya), (ib, yb) = run(True), run(False)
+    assert bits_equal(ya.detach().cpu().numpy(), yb.detach().cpu().numpy())
+    ga = torch.autograd.grad(ya, ia, gy)
+    gb = torch.autograd.grad(yb, ib, gy)
+    for u, v in zip(ga, gb):
+        assert float((u - v).abs().max()) <= 2e-5 * float(v.abs().max()) + 1e-6
+    # double backward: gradient of |d y / d x|^2-style functional w.r.t. everything
+    def second(inputs, y):
+        (g1, gm) = torch.autograd.grad(y, [inputs[0], inputs[1]], gy, create_graph=True)
+        return torch.autograd.grad((g1 * g1).sum() + (gm * gm).sum(), inputs, allow_unused=True)
+
+    (ia, ya), (ib, yb) = run(True), run(False)
+    for u, v in zip(second(ia, ya), second(ib, yb)):
+        if v is None:
+            assert u is None or float(u.abs().max()) == 0
+            continue
+        assert float((u - v).abs().max()) <= 1e-4 * float(v.abs().max()) + 1e-6
