@@ -148,6 +148,18 @@ def grad_digest(named_grads):
     return names, norms, heads.astype(np.float32)
 
 
+def grad_samples(named_grads, per_tensor=256):
+    """Evenly spaced entries of EVERY gradient tensor (all of it when it has <= per_tensor elements): pins whole
+    tensors, not only their norm and first entries.  Returns (flat values, offsets [n+1]); the test rebuilds the
+    indices with sample_index()."""
+    vals, offs = [], [0]
+    for n in sorted(named_grads):
+        g = named_grads[n].detach().reshape(-1).numpy()
+        vals.append(g[synth.sample_index(g.size, per_tensor)])
+        offs.append(offs[-1] + vals[-1].size)
+    return np.concatenate(vals).astype(np.float32), np.asarray(offs, np.int64)
+
+
 def gold_generator(ns):
     for tag, size, sdim, nmlp, batch in (("s8", 8, 64, 2, 2), ("s64", 64, 512, 8, 1)):
         g = ns.model.Generator(size, sdim, nmlp)
@@ -176,7 +188,9 @@ def gold_generator(ns):
             grads = torch.autograd.grad((img * proj).sum(), list(used.values()), allow_unused=True)
             gd = {n: gr for n, gr in zip(used, grads) if gr is not None}
             names, norms, heads = grad_digest(gd)
+            gs_vals, gs_offs = grad_samples(gd)
             arrays.update({"grad_names": np.array(names), "grad_norms": norms, "grad_heads": heads,
+                           "grad_samples": gs_vals, "grad_sample_offsets": gs_offs,
                            "unused": np.array(sorted(n for n, gr in zip(used, grads) if gr is None))})
             # path-length regulariser (reference train.py:118-134 semantics), double backward
             pl_noise = T(dn(tuple(img.shape), 47)) / np.sqrt(img.shape[2] * img.shape[3])
@@ -192,6 +206,8 @@ def gold_generator(ns):
             penalty.backward()
             gd2 = {n: p.grad for n, p in g.named_parameters() if p.grad is not None}
             names2, norms2, heads2 = grad_digest(gd2)
+            pl_vals, pl_offs = grad_samples(gd2)
+            arrays.update({"pl_grad_samples": pl_vals, "pl_grad_sample_offsets": pl_offs})
             arrays.update({"pl_lengths": path_lengths_ref.detach().numpy(),
                            "pl_lengths_sg2": path_lengths.detach().numpy(),
                            "pl_penalty": penalty.detach().numpy(),
@@ -230,9 +246,88 @@ def gold_discriminator(ns):
     r1.backward()
     gd = {n: p.grad for n, p in d.named_parameters() if p.grad is not None}
     names, norms, heads = grad_digest(gd)
+    r1_vals, r1_offs = grad_samples(gd)
     save("discriminator_s16", x=x.detach().numpy(), y=y.detach().numpy(), gx=gx.detach().numpy(),
          r1=r1.detach().numpy(), r1_grad_names=np.array(names), r1_grad_norms=norms,
-         r1_grad_heads=heads, n_params=np.array(sum(p.numel() for p in d.parameters())))
+         r1_grad_heads=heads, r1_grad_samples=r1_vals, r1_grad_sample_offsets=r1_offs,
+         n_params=np.array(sum(p.numel() for p in d.parameters())))
+
+
+def gold_generator_256(ns):
+    """The exact network bench.py times (Generator(256, 512, 8), BASELINE config[1]) on one latent: image only
+    (0.8 MB).  Pins the 128^2 / 256^2 kernel variants no smaller fixture reaches."""
+    g = ns.model.Generator(256, 512, 8)
+    synth.fill_state_dict(g.state_dict(), salt=41)
+    with torch.no_grad():
+        img, lat = g([T(dn((1, 512), 42))], return_latents=True, noise=_noise_list(g, 4300))
+    save("generator_s256", image=img.numpy(), latent_row=lat[0, 0].numpy(),
+         n_keys=np.array(len(g.state_dict())))
+
+
+def _reference_train_functions():
+    """The loss / regulariser / EMA definitions of the reference's train.py (lines 96-145), exec'ed from where the
+    file lies: the module as a whole does not parse, these top-level defs do."""
+    import re
+
+    text = open(os.path.join(ref_shim.REF, "train.py")).read().replace("\t", "    ")
+    names = ["requires_grad", "accumulate", "d_logistic_loss", "d_r1_loss", "g_nonsaturating_loss",
+             "g_path_regularize", "make_noise", "mixing_noise"]
+    env = {"torch": torch, "np": np, "F": torch.nn.functional, "autograd": torch.autograd, "nn": torch.nn}
+    for n in names:
+        m = re.search(r"^def %s\(.*?(?=^def |^if __name__)" % n, text, flags=re.S | re.M)
+        exec(m.group(0), env)
+    return env
+
+
+def gold_train_step(ns):
+    """Reference train.py:100-134 evaluated on mini networks: D logistic / R1 / G non-saturating losses, the
+    path-length regulariser with two targets and lambda_ weights (incl. the double backward), and the EMA."""
+    fn = _reference_train_functions()
+    g = ns.model.Generator(8, 64, 2)
+    d = ns.model.Discriminator(8)
+    synth.fill_state_dict(g.state_dict(), salt=41)
+    synth.fill_state_dict(d.state_dict(), salt=61)
+    out = {}
+    real = T(dn((4, 3, 8, 8), 81))
+    z = T(dn((4, 64), 82))
+    noise = _noise_list(g, 8300)
+    fake, _ = g([z], noise=noise)
+    real_pred, fake_pred = d(real), d(fake.detach())
+    out["real"], out["fake"] = real.numpy(), fake.detach().numpy()
+    out["real_pred"], out["fake_pred"] = real_pred.detach().numpy(), fake_pred.detach().numpy()
+    out["d_logistic"] = fn["d_logistic_loss"](real_pred, fake_pred).detach().numpy()
+    out["g_nonsat"] = fn["g_nonsaturating_loss"](fake_pred).detach().numpy()
+    # R1 incl. its gradient w.r.t. the discriminator (double backward), the way the step weights it
+    real_req = real.clone().requires_grad_(True)
+    rp = d(real_req)
+    r1 = fn["d_r1_loss"](rp, real_req)
+    d.zero_grad()
+    (10.0 / 2 * r1 * 16 + 0 * rp[0]).backward()
+    out["r1"] = r1.detach().numpy()
+    gd = {n: p.grad.clone() for n, p in d.named_parameters() if p.grad is not None}
+    out["r1_grad_names"] = np.array(sorted(gd))
+    out["r1_grad_samples"], out["r1_grad_sample_offsets"] = grad_samples(gd)
+    # path-length regulariser: targets = [latents, first noise map], lambda_ = [1, .5], running mean 0.3
+    n0 = noise[0].clone().requires_grad_(True)
+    img, lat = g([z[:2]], return_latents=True, noise=[n0] + noise[1:])
+    torch.manual_seed(123)
+    probe = torch.randn_like(img)                     # what g_path_regularize draws next under this seed
+    torch.manual_seed(123)
+    pen, mean, lengths = fn["g_path_regularize"](img, [lat, n0], torch.tensor(0.3), lambda_=[1.0, 0.5])
+    g.zero_grad()
+    (2.0 * 4 * pen + 0 * img[0, 0, 0, 0]).backward()
+    out["pl_probe"], out["pl_penalty"], out["pl_mean"] = probe.numpy(), pen.detach().numpy(), mean.numpy()
+    out["pl_lengths"] = lengths.detach().numpy()
+    gg = {n: p.grad.clone() for n, p in g.named_parameters() if p.grad is not None}
+    out["pl_grad_names"] = np.array(sorted(gg))
+    out["pl_grad_samples"], out["pl_grad_sample_offsets"] = grad_samples(gg)
+    # EMA
+    g2 = ns.model.Generator(8, 64, 2)
+    synth.fill_state_dict(g2.state_dict(), salt=43)
+    fn["accumulate"](g2, g, 0.9)
+    out["ema_conv1"] = dict(g2.named_parameters())["conv1.conv.weight"].detach().numpy()[0, :4, :4]
+    out["ema_style"] = dict(g2.named_parameters())["style.1.bias"].detach().numpy()
+    save("train_step_s8", **out)
 
 
 # ------------------------------------------------------------------------------- rasterizer
@@ -391,10 +486,10 @@ def main():
     os.makedirs(OUT, exist_ok=True)
     ns = ref_shim.load()
     torch.manual_seed(0)
-    which = sys.argv[1:] or ["fused", "ufd", "modconv", "gen", "gwm", "disc", "raster", "mesh"]
+    which = sys.argv[1:] or ["fused", "ufd", "modconv", "gen", "gen256", "gwm", "disc", "train", "raster", "mesh"]
     table = {"fused": gold_fused_act, "ufd": gold_upfirdn2d, "modconv": gold_modconv,
-             "gen": gold_generator, "gwm": gold_generator_with_map, "disc": gold_discriminator,
-             "raster": gold_raster, "mesh": gold_mesh}
+             "gen": gold_generator, "gen256": gold_generator_256, "gwm": gold_generator_with_map,
+             "disc": gold_discriminator, "train": gold_train_step, "raster": gold_raster, "mesh": gold_mesh}
     with torch.no_grad():
         pass
     for k in which:

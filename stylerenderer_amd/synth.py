@@ -102,6 +102,13 @@ def det_normal(shape, key):
     return (acc * np.sqrt(3.0 / 4.0)).astype(np.float32)
 
 
+def sample_index(numel, count=256):
+    """Evenly spaced flat indices (all of them when numel <= count): the gradient samples of the golden fixtures."""
+    if numel <= count:
+        return np.arange(numel, dtype=np.int64)
+    return np.linspace(0, numel - 1, count).astype(np.int64)
+
+
 def name_key(name):
     import zlib
 

@@ -5,7 +5,7 @@ import pytest
 import torch
 
 from stylerenderer_amd import model, synth
-from util import rel_err
+from util import check_grad_samples, rel_err
 
 T = torch.from_numpy
 
@@ -81,6 +81,8 @@ def test_generator_s8_gradients_and_unused_tail(golden, g8):
     unused = sorted(n for n, g in zip(params, grads) if g is None)
     assert unused == list(gold["unused"])                 # the dead half of to_rgbs
     check_grad_digest(got, gold["grad_names"], gold["grad_norms"], gold["grad_heads"], 1e-4)
+    # 256 evenly spaced entries of every gradient tensor (measured 5e-7 of the tensor's scale)
+    check_grad_samples(got, gold["grad_names"], gold["grad_samples"], gold["grad_sample_offsets"], 4e-6)
 
 
 def test_path_length_regulariser_double_backward(golden, g8):
@@ -100,6 +102,7 @@ def test_path_length_regulariser_double_backward(golden, g8):
     penalty.backward()
     got = {n: p.grad for n, p in g8.named_parameters() if p.grad is not None}
     check_grad_digest(got, gold["pl_grad_names"], gold["pl_grad_norms"], gold["pl_grad_heads"], 1e-3)
+    check_grad_samples(got, gold["pl_grad_names"], gold["pl_grad_samples"], gold["pl_grad_sample_offsets"], 4e-5)
     g8.zero_grad()
 
 
@@ -132,3 +135,4 @@ def test_discriminator_s16(golden):
     r1.backward()
     got = {n: p.grad for n, p in d.named_parameters() if p.grad is not None}
     check_grad_digest(got, gold["r1_grad_names"], gold["r1_grad_norms"], gold["r1_grad_heads"], 1e-3)
+    check_grad_samples(got, gold["r1_grad_names"], gold["r1_grad_samples"], gold["r1_grad_sample_offsets"], 4e-6)

@@ -2,15 +2,17 @@
 Tolerance (north_star: "within a stated fp32 tolerance for generator activations"): the modulated
 convolution applies style/demodulation to the operands instead of building per-sample weights, and
 the MFMA accumulates in a different order than oneDNN, so activations agree to fp32 round-off:
-   max |a - b| <= 2e-4 * max |b|      (images, latents, normal maps)
-   gradient digests: norms within 1e-3 relative (first order), 3e-3 (double backward)."""
+   max |a - b| <= 2e-4 * max |b|      (images, latents, normal maps; measured 2e-6 at 256x256)
+   gradients: 256 evenly spaced entries of EVERY gradient tensor against the reference's, relative to the tensor's
+   scale — first order 5e-6 (measured 1.2e-6), path-length double backward 4e-5 (measured 1.5e-6 here, 9e-6 on the CPU path: scalar noise strengths), R1 double
+   backward 5e-5 (measured 1.1e-5) — and FULL tensors against this repo's own CPU formulation."""
 import numpy as np
 import pytest
 import torch
 
 from stylerenderer_amd import model, synth
 from test_model_cpu import check_grad_digest, noise_list
-from util import rel_err
+from util import check_grad_samples, rel_err
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
@@ -57,6 +59,7 @@ def test_generator_s8_gradients(golden, g8):
     got = {n: g for n, g in zip(params, grads) if g is not None}
     assert sorted(n for n, g in zip(params, grads) if g is None) == list(gold["unused"])
     check_grad_digest(got, gold["grad_names"], gold["grad_norms"], gold["grad_heads"], 1e-3)
+    check_grad_samples(got, gold["grad_names"], gold["grad_samples"], gold["grad_sample_offsets"], 5e-6)
 
 
 def test_path_length_regulariser_double_backward(golden, g8):
@@ -74,6 +77,7 @@ def test_path_length_regulariser_double_backward(golden, g8):
     penalty.backward()
     got = {n: p.grad for n, p in g8.named_parameters() if p.grad is not None}
     check_grad_digest(got, gold["pl_grad_names"], gold["pl_grad_norms"], gold["pl_grad_heads"], 3e-3)
+    check_grad_samples(got, gold["pl_grad_names"], gold["pl_grad_samples"], gold["pl_grad_sample_offsets"], 4e-5)
     g8.zero_grad()
 
 
@@ -138,6 +142,79 @@ def test_discriminator_s16(golden):
     r1.backward()
     got = {n: p.grad for n, p in d.named_parameters() if p.grad is not None}
     check_grad_digest(got, gold["r1_grad_names"], gold["r1_grad_norms"], gold["r1_grad_heads"], 3e-3)
+    check_grad_samples(got, gold["r1_grad_names"], gold["r1_grad_samples"], gold["r1_grad_sample_offsets"], 5e-5)
+
+
+def test_generator_256_vs_reference_image(golden):
+    """The network bench.py times (Generator(256, 512, 8)): image of one latent against the reference's
+    (tests/golden/generator_s256.npz).  Reaches the 128^2 / 256^2 Winograd, fused up-sampling and ToRGB variants."""
+    gold = golden("generator_s256")
+    g = model.Generator(256, 512, 8)
+    assert len(g.state_dict()) == int(gold["n_keys"])
+    synth.fill_state_dict(g.state_dict(), salt=41)
+    g = g.to(DEV)
+    with torch.no_grad():
+        img, lat = g([T(synth.det_normal((1, 512), 42))], return_latents=True, noise=dev_noise(g, 4300))
+    assert rel_err(lat[0, 0].cpu().numpy(), gold["latent_row"]) < 1e-5
+    assert rel_err(img.cpu().numpy(), gold["image"]) < 1e-5            # measured 2.4e-6
+
+
+@pytest.mark.parametrize("size,batch,slope,tol", [(16, 3, 1.0, 2e-5), (64, 2, 1.0, 2e-5), (16, 3, 0.2, 2e-2)])
+def test_full_gradient_tensors_gpu_vs_own_cpu_path(size, batch, slope, tol):
+    """Every gradient tensor IN FULL: device tensors (HIP kernels, operand-scaled shared weights) against the same
+    module on CPU tensors (the reference's grouped-convolution formulation, itself pinned to the reference's
+    gradients in tests/test_model_cpu.py).
+    slope = 1.0 makes every LeakyReLU linear: all the operators in between are then compared as exact adjoints at
+    fp32 round-off (2e-5 of each tensor's scale).  With the real slope 0.2 the comparison is dominated by the kink:
+    ONE pre-activation of ~4e5 whose sign differs between the two fp32 forward passes (|value| ~ 1e-7; measured:
+    1 element of convs.3 at 16x16) changes that element's derivative from 1 to 0.2 and perturbs every upstream
+    gradient by ~1e-3 — a property of LeakyReLU under any two fp32 implementations, bounded here at 2e-2."""
+    from stylerenderer_amd.op import FusedLeakyReLU
+
+    g = model.Generator(size, 64, 2)
+    synth.fill_state_dict(g.state_dict(), salt=5)
+    for m in g.modules():
+        if isinstance(m, FusedLeakyReLU):
+            m.negative_slope = slope
+    z = torch.from_numpy(synth.det_normal((batch, 64), 6))
+    noise = noise_list(g, 70)
+    proj = torch.from_numpy(synth.det_normal((batch, 3, size, size), 7))
+
+    def grads(net, dev):
+        img, _ = net([z.to(dev)], noise=[n.to(dev) for n in noise])
+        params = dict(net.named_parameters())
+        out = torch.autograd.grad((img * proj.to(dev)).sum(), list(params.values()), allow_unused=True)
+        return {n: o for n, o in zip(params, out) if o is not None}
+
+    want = grads(g, "cpu")
+    got = grads(g.to(DEV), DEV)
+    assert sorted(got) == sorted(want)
+    for n in want:
+        scale = float(want[n].abs().max())
+        # scalar noise strengths are sums of ~4e5 signed terms: 5x the bar (measured 2.1e-5; all others <= 3.6e-6)
+        t = tol * (5 if want[n].numel() == 1 else 1)
+        assert float((got[n].cpu() - want[n]).abs().max()) <= t * scale + 1e-9, n
+
+
+@pytest.mark.parametrize("tag,kw", [("plain", dict(in_channel=8, out_channel=6, kernel_size=3, style_dim=16)),
+                                    ("up", dict(in_channel=8, out_channel=6, kernel_size=3, style_dim=16, upsample=True)),
+                                    ("rgb", dict(in_channel=8, out_channel=3, kernel_size=1, style_dim=16,
+                                                 demodulate=False))])
+def test_modulated_conv_layer_vs_reference_gradients(golden, tag, kw):
+    """layers.ModulatedConv2d on the HIP path against the reference layer's output and ALL its gradients (input,
+    style, weight, modulation weight / bias), full tensors (tests/golden/modconv.npz).  Measured <= 3.2e-7."""
+    from stylerenderer_amd import layers
+
+    gold = golden("modconv")
+    m = layers.ModulatedConv2d(**kw)
+    synth.fill_state_dict(m.state_dict(), salt=31)
+    m = m.to(DEV)
+    x, s = T(gold[tag + "_x"]).requires_grad_(), T(gold[tag + "_s"]).requires_grad_()
+    y = m(x, s)
+    assert rel_err(y.detach().cpu().numpy(), gold[tag + "_y"]) < 2e-6
+    grads = torch.autograd.grad(y, [x, s, m.weight, m.modulation.weight, m.modulation.bias], T(gold[tag + "_gy"]))
+    for a, k in zip(grads, ("gx", "gs", "gw", "gmw", "gmb")):
+        assert rel_err(a.cpu().numpy(), gold[tag + "_" + k]) < 2e-6, k
 
 
 def test_generator_256_full_size_properties():

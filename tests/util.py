@@ -25,3 +25,22 @@ def rel_err(a, b):
     b = np.asarray(b, np.float64)
     den = max(float(np.abs(b).max()), 1e-30)
     return float(np.abs(a - b).max()) / den
+
+
+def check_grad_samples(named_grads, names, values, offsets, tol):
+    """Sampled entries of every gradient tensor (fixtures written by oracle/make_golden.grad_samples): the error of
+    each tensor's samples relative to that tensor's largest sampled magnitude.  Returns the worst ratio."""
+    from stylerenderer_amd import synth
+
+    assert sorted(named_grads) == list(names)
+    worst = 0.0
+    for i, n in enumerate(names):
+        want = np.asarray(values[offsets[i]:offsets[i + 1]], np.float64)
+        g = named_grads[n].detach().reshape(-1).cpu().numpy().astype(np.float64)
+        got = g[synth.sample_index(g.size, 256)]
+        assert got.shape == want.shape, n
+        scale = max(float(np.abs(want).max()), 1e-12)
+        err = float(np.abs(got - want).max()) / scale
+        assert err <= tol, (n, err)
+        worst = max(worst, err)
+    return worst
