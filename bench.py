@@ -24,7 +24,8 @@ Prints ONE JSON line on rank 0 with the driver's contract fields plus
                 64 timed iterations), images/s, enqueue time, and for N > 1 the measured 125 MB gradient
                 all-reduce against the xGMI ring bound;
   rasterizer    BASELINE config[3]: Mtri/s forward and forward+backward, its own HBM roofline and the
-                single-thread C oracle (the reference's CPU rasterizer restated) beside it.
+                single-thread C oracle (the reference's CPU rasterizer restated) beside it;
+  inversion     BASELINE config[4]: 400-step latent inversion (generator + rasterizer + LPIPS-shaped metric), steps/s.
 """
 import argparse
 import json
@@ -56,6 +57,8 @@ def parse(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-raster", action="store_true", help="skip the rasterizer (BASELINE config[3]) leg")
     ap.add_argument("--no-train", action="store_true", help="skip the full G+D step (BASELINE config[2]) leg")
+    ap.add_argument("--no-inversion", action="store_true", help="skip the latent-inversion (BASELINE config[4]) leg")
+    ap.add_argument("--inversion-steps", type=int, default=400)
     ap.add_argument("--train-iters", type=int, default=64, help="timed iterations of the G+D step leg")
     ap.add_argument("--train-batch", type=int, default=4, help="images per GPU of the G+D step leg")
     ap.add_argument("--cpu-batch", type=int, default=2)
@@ -262,6 +265,53 @@ def train_leg(dev, rank, world, iters, batch, size=256):
 
 
 # ---------------------------------------------------------------------------------------------------
+def inversion_leg(dev, steps=400, size=256):
+    """BASELINE config[4]: 400 Adam steps over the W+ latent and the mesh pose through GeneratorWithMap(256), the
+    rasterizer (forward + deterministic backward) and the LPIPS-shaped VGG16 metric, one hipGraph per iteration
+    (inversion.LatentInverter).  Random-init generator / metric weights (no checkpoints offline); the target is a
+    rendering of a different latent and pose."""
+    import torch
+
+    from stylerenderer_amd import inversion, lpips, model, synth
+
+    torch.manual_seed(0)
+    g = model.GeneratorWithMap(size, 512, 8, channel_multiplier=2).to(dev)
+    net = lpips.PNetLin().to(dev)
+    v0, tri = synth.face_sized_mesh()
+    v = torch.from_numpy(v0[None]).to(dev)
+    nrm = torch.from_numpy(synth.vertex_normals(v0[None], tri)).to(dev)
+    mesh = (v, nrm, torch.from_numpy(tri).to(dev))
+    with torch.no_grad():
+        w_true = g.style(torch.randn(1, 512, device=dev)).unsqueeze(1).repeat(1, g.n_latent, 1)
+        rot = inversion.utils_3d.euler_mat(torch.tensor([[0.3, -0.1, 0.05]], device=dev), "yxz")[0]
+        posed = (torch.matmul(v, rot).contiguous(), torch.matmul(nrm, rot).contiguous(), mesh[2])
+        noise = [n.detach() for n in g.make_noise()]
+        target, _, _ = g([w_true], posed, input_is_latent=True, noise=noise)
+
+    def timed(use_graph, n):
+        inv = inversion.LatentInverter(g, net, target, mesh, noise=noise, use_graph=use_graph)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        hist = inv.run(n)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        h = hist.cpu()
+        return n / dt, float(h[0]), float(h[-1]), bool(torch.isfinite(h).all())
+
+    sps, l0, l1, finite = timed(True, steps)
+    sps_eager, _, _, _ = timed(False, max(8, steps // 10))
+    del g, net
+    torch.cuda.empty_cache()
+    return {"workload": "BASELINE config[4]: latent inversion, %d Adam steps, GeneratorWithMap(%d) + rasterizer "
+                        "(nv=%d nf=%d) + LPIPS-shaped VGG16 metric, batch 1" % (steps, size, v0.shape[0], tri.shape[0]),
+            "value": round(sps, 2), "unit": "steps/s", "steps": steps,
+            "seconds_for_%d_steps" % steps: round(steps / sps, 2),
+            "eager_steps_per_s": round(sps_eager, 2), "execution": "one hipGraph replay per step (capture included "
+            "in the timed run)", "loss_first": round(l0, 5), "loss_last": round(l1, 5), "losses_finite": finite,
+            "weights": "random init (trunk / heads / generator checkpoints are not available offline)"}
+
+
+# ---------------------------------------------------------------------------------------------------
 def plumbing_main(args, rank, world):
     """CPU stand-in used by tests/test_bench_launch.py: same launch / rendezvous / reduction structure as the
     GPU run on the gloo backend with a 8x8 generator; the JSON line says so (`plumbing: true`)."""
@@ -413,6 +463,9 @@ def main():
     raster = None
     if not args.no_raster and rank == 0:
         raster = raster_leg(dev, 1, cpu_baseline=(world == 1 and not args.no_cpu_baseline))
+    inversion_res = None
+    if not args.no_inversion and rank == 0 and world == 1:
+        inversion_res = inversion_leg(dev, args.inversion_steps, args.size)
     result = None
     if rank == 0:
         images = args.batch * world * args.steps
@@ -443,7 +496,7 @@ def main():
                        "step": "zero_grad + forward + backward" + (" + DDP all-reduce (RCCL)" if world > 1 else "")},
             "model_flop_frac_of_mfma_peak": round(value / world * FLOP_PER_IMAGE_FWD_BWD / (FP32_MFMA_PEAK_TFLOPS * 1e12), 4),
             "roofline": roof, "cpu_baseline": cpu, "kernel_breakdown": breakdown,
-            "train_step": train_res, "rasterizer": raster,
+            "train_step": train_res, "rasterizer": raster, "inversion": inversion_res,
         }
     if world > 1:
         dist.barrier()
