@@ -143,10 +143,13 @@ def raster_leg(dev, world, batch=64, res=256, iters=10, cpu_baseline=True):
                         "frac": round(fwd_bytes / ms_api / 1e6 / HBM_PEAK_GBPS, 4), "traffic": None,
                         "bytes_per_launch": fwd_bytes,
                         "note": "setup ALU + 64-bit atomics bound, priced against the HBM roof as SURVEY 8(d) asks"},
-           "roofline_bwd": {"bound": "hbm", "kernel": "sr_rasterize_grad_f32 (k_grad_tri + k_grad_vert)",
+           "roofline_bwd": {"bound": "hbm", "kernel": "sr_rasterize_grad_f32 (k_grad_big + k_grad_pix + k_grad_vert)",
                             "achieved": round(bwd_bytes / ms_b / 1e6, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                             "frac": round(bwd_bytes / ms_b / 1e6 / HBM_PEAK_GBPS, 4), "bytes_per_launch": bwd_bytes},
            "bit_exact_vs_cpu_oracle": "tests/test_ops_gpu.py"}
+    out["roofline"].update(pmc_traffic(["k_fill_u64", "k_depth_keys<float; 0>", "k_resolve<float>"]))
+    out["roofline_bwd"].update(pmc_traffic(["k_grad_big<float; 3; false>", "k_grad_pix<float; 3; false>",
+                                            "k_grad_vert<float; 3; false>"]))
     if cpu_baseline:
         import raster as oracle_raster
 
@@ -165,25 +168,30 @@ def raster_leg(dev, world, batch=64, res=256, iters=10, cpu_baseline=True):
     return out
 
 
-def pmc_traffic(kernel_row):
-    """HBM bytes per launch of `kernel_row` from the newest committed PMC summary (profiles/r*_pmc.csv,
-    written by scripts/profile_round.sh + scripts/pmc_summary.py from separate rocprofv3 --pmc
-    FETCH_SIZE / WRITE_SIZE passes of this same command).  Units are KB; gfx950's FETCH_SIZE reports
-    half of a 16 B/lane streaming read (MI355X_MICROARCH.md, HBM section; confirmed here on k_nba_bwd
-    and k_rowdot, whose read:write byte ratios are known), hence 2*FETCH + WRITE."""
+def pmc_traffic(kernel_rows):
+    """HBM bytes per launch of `kernel_rows` (one name, or several kernels of one operator: summed) from the newest
+    committed PMC summary (profiles/r*_pmc.csv, written by scripts/profile_round.sh + scripts/pmc_summary.py from
+    separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command).  Units are KB; gfx950's
+    FETCH_SIZE reports half of a 16 B/lane streaming read (MI355X_MICROARCH.md, HBM section; confirmed here on
+    k_nba_bwd and k_rowdot, whose read:write byte ratios are known), hence 2*FETCH + WRITE."""
     import csv
     import glob
 
+    if isinstance(kernel_rows, str):
+        kernel_rows = [kernel_rows]
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.csv")))
     if not files:
         return {}
+    total, seen = 0.0, 0
     with open(files[-1]) as f:
         for r in csv.DictReader(l for l in f if not l.startswith("#")):
-            if r["kernel"] == kernel_row and r.get("FETCH_SIZE") and r.get("WRITE_SIZE"):
-                b = (2.0 * float(r["FETCH_SIZE"]) + float(r["WRITE_SIZE"])) * 1024.0
-                return {"traffic": round(b), "traffic_unit": "bytes/launch",
-                        "traffic_source": "profiles/%s (2*FETCH_SIZE+WRITE_SIZE)" % os.path.basename(files[-1])}
-    return {}
+            if r["kernel"] in kernel_rows and r.get("FETCH_SIZE") and r.get("WRITE_SIZE"):
+                total += (2.0 * float(r["FETCH_SIZE"]) + float(r["WRITE_SIZE"])) * 1024.0
+                seen += 1
+    if seen != len(kernel_rows):
+        return {}
+    return {"traffic": round(total), "traffic_unit": "bytes/launch",
+            "traffic_source": "profiles/%s (2*FETCH_SIZE+WRITE_SIZE)" % os.path.basename(files[-1])}
 
 
 # ---------------------------------------------------------------------------------------------------
