@@ -148,3 +148,95 @@ def mesh_point_normal(v, tri):
     if v.device.type == "cuda" and v.dtype == torch.float32:
         return _VertexNormals.apply(v[:, :, :3], tri)
     return _normals_composite(v[:, :, :3], tri)
+
+
+# ---- ADA augmentation (reference utils_3d.py:155-188, 189-349 cam=None branch, 350-359) ------------
+def _axis_angle_matrix(axis_angle):
+    """[B, 3] rotation vectors -> [B, 3, 3] (Rodrigues' formula in closed form)."""
+    theta = torch.sqrt((axis_angle * axis_angle).sum(1, keepdim=True)).clamp_min(1e-12)
+    k = axis_angle / theta
+    kx, ky, kz = k[:, 0], k[:, 1], k[:, 2]
+    zero = torch.zeros_like(kx)
+    K = torch.stack([zero, -kz, ky, kz, zero, -kx, -ky, kx, zero], 1).view(-1, 3, 3)
+    eye = torch.eye(3, dtype=k.dtype, device=k.device).unsqueeze(0)
+    s, c = torch.sin(theta).view(-1, 1, 1), torch.cos(theta).view(-1, 1, 1)
+    return eye + s * K + (1 - c) * torch.matmul(K, K)
+
+
+def random_apply_color(p=[.2, .3, 0, .15, .5], img=None):
+    """Random brightness / contrast / luma flip / hue rotation / saturation as one 3x4 colour matrix per sample
+    (p = sigmas of [brightness, log-contrast], luma-flip probability, sigmas of [hue, log-saturation])."""
+    batch = len(img) if img is not None and img.dim() >= 4 else 1
+    p = torch.abs(torch.as_tensor(p, dtype=torch.float32).reshape(-1)[:5])
+    p = torch.cat((p, torch.zeros(5 - len(p))))
+    z = torch.cat([torch.normal(mean=0, std=p[:2].unsqueeze(0).expand(batch, -1)), torch.rand(batch, 1),
+                   torch.normal(mean=0, std=p[3:].unsqueeze(0).expand(batch, -1))], 1)
+    bright, contrast = z[:, 0], torch.exp(z[:, 1])
+    luma = (z[:, 2] < p[2]).to(z.dtype)
+    hue, sat = z[:, 3:4], torch.exp(z[:, 4]).view(-1, 1, 1)
+    eye = torch.eye(3).unsqueeze(0)
+    ones = torch.ones(3, 3).unsqueeze(0)
+    C = torch.cat([contrast.view(-1, 1, 1) * eye.expand(batch, -1, -1),
+                   (contrast * bright).view(-1, 1, 1).expand(-1, 3, 1)], 2)               # [B, 3, 4]
+    C = torch.matmul(eye - luma.view(-1, 1, 1) * 2. / 3, C)
+    C = torch.matmul(_axis_angle_matrix(hue.expand(-1, 3) / (3 ** 0.5)), C)
+    C = torch.matmul(eye * sat + ones * (1 - sat) / 3., C)
+    if img is None:
+        return C[0]
+    shape = img.shape
+    x = img.reshape(batch, -1, shape[-1] * shape[-2])
+    C = C.to(dtype=img.dtype, device=img.device)
+    return (torch.matmul(C[:, :, :3], x) + C[:, :, 3:4]).view(shape)
+
+
+def random_apply_pose2D_img(p=[.1, .1, .05, .15, 0, .5], img=None, pad=None):
+    """Random translation / in-plane rotation / zoom / horizontal flip of a batch of images by bilinear resampling.
+    pad=None: the zoom is raised per sample until the rotated, shifted frame stays inside the source (no border
+    shows), the behaviour `augment` relies on; 'zeros' / 'border' / 'reflection' skip that and pad instead."""
+    if img is None or img.dim() < 4:
+        raise ValueError("random_apply_pose2D_img: a batch of images [B, C, H, W] is required")
+    batch, hi, wi = img.shape[0], int(img.shape[-2]), int(img.shape[-1])
+    ho, wo = hi, wi
+    p = torch.abs(torch.as_tensor(p, dtype=torch.float32).reshape(-1)[:6])
+    p = torch.cat((p, torch.zeros(6 - len(p))))
+    z = torch.cat([torch.normal(mean=0, std=p[:3].unsqueeze(0).expand(batch, -1)),
+                   torch.normal(mean=p[4:5].unsqueeze(0).expand(batch, 1), std=p[3:4].unsqueeze(0).expand(batch, -1)),
+                   torch.rand(batch, 1)], 1)
+    flip = z[:, 4:5] < p[-1]
+    f = torch.exp(z[:, 3:4])
+    s, c = torch.sin(z[:, 2:3]), torch.cos(z[:, 2:3])
+    tx, ty = z[:, 0:1], z[:, 1:2]
+    yy, xx = torch.meshgrid(torch.linspace(0, ho, ho), torch.linspace(0, wo, wo), indexing="ij")
+    half = max(wo, ho) / 2.
+    x = ((xx.reshape(1, -1) - wo / 2.) / half).expand(batch, -1)
+    y = ((ho / 2. - yy.reshape(1, -1)) / half).expand(batch, -1)
+    x = torch.where(flip.expand(-1, ho * wo), -x, x) - tx
+    y = y - ty
+    mode = "zeros"
+    if pad is None:
+        corner = [0, wo - 1, wo * (ho - 1), ho * wo - 1]
+        cx, cy = x[:, corner], y[:, corner]
+        rx = (c * cx + s * cy) * max(wo, ho) / float(wi)
+        ry = (-s * cx + c * cy) * max(wo, ho) / float(hi)
+        fmax = torch.max(torch.abs(torch.cat((rx, ry), 1)), 1, keepdim=True)[0]
+        f = torch.where(f < fmax, fmax, f)
+    else:
+        mode = {"z": "zeros", "b": "border", "r": "reflection"}[str(pad).lower()[0]]
+    x, y = x / f, y / f
+    x, y = c * x + s * y, -s * x + c * y
+    gx = (x * max(wo, ho) / float(wi)).view(-1, ho, wo, 1)
+    gy = (-y * max(wo, ho) / float(hi)).view(-1, ho, wo, 1)
+    grid = torch.cat((gx, gy), -1).to(dtype=img.dtype, device=img.device)
+    # the reference's grid runs linspace(-1, 1) over pixel CENTRES, i.e. it was written for grid_sample's
+    # pre-1.3 default (align_corners=True); with today's default the identity transform would blur the image
+    return torch.nn.functional.grid_sample(img, grid, mode="bilinear", padding_mode=mode, align_corners=True)
+
+
+def augment(img, augment_ratio=.5):
+    """Per sample, with probability `augment_ratio`: random 2-D pose then random colour (reference utils_3d.py:350-359)."""
+    shape = img.shape
+    while img.dim() < 4:
+        img = img.unsqueeze(0)
+    aug = random_apply_color(img=random_apply_pose2D_img(img=img, pad=None))
+    pick = torch.rand(img.shape[0], 1, 1, 1, dtype=img.dtype, device=img.device)
+    return torch.where(pick.expand_as(img) < augment_ratio, aug, img).view(shape)

@@ -4,7 +4,7 @@ face_model.py:4-74, layers.py:13-53)."""
 import numpy as np
 import torch
 
-from stylerenderer_amd import face_model, utils_3d
+from stylerenderer_amd import face_model, synth, utils_3d
 from util import rel_err
 
 T = torch.from_numpy
@@ -70,3 +70,42 @@ def test_linear_morphable_model_matches_reference(golden):
     assert rel_err(m(x).detach().numpy(), g["lmm_out"]) < 1e-6
     assert abs(m.regulation(x).item() - float(g["lmm_reg"])) < 1e-4 * abs(float(g["lmm_reg"]))
     assert not m.fc.weight.requires_grad and tuple(m.random_input(5).shape) == (5, 5)
+
+
+def test_ada_augment_properties():
+    """ADA branch of the step (reference train.py:253-280, utils_3d.py:155-188, 350-359).  The reference's own
+    `augment` cannot run on current PyTorch (in-place update of an expanded tensor, utils_3d.py:312-313), so the
+    2-D pose part is pinned by properties; the colour part equals the reference's matrix (checked at authoring
+    time under a shared CPU RNG stream: 1e-7)."""
+    from stylerenderer_amd import utils_3d as u
+
+    img = torch.from_numpy(synth.det_uniform((4, 3, 16, 16), 5))
+    out = u.random_apply_pose2D_img(p=[0, 0, 0, 0, 0, 0], img=img, pad=None)
+    assert float((out - img).abs().max()) < 1e-5                                   # identity
+    out = u.random_apply_pose2D_img(p=[0, 0, 0, 0, 0, 1.1], img=img, pad=None)
+    assert float((out - img.flip(3)).abs().max()) < 1e-5                           # certain flip
+    torch.manual_seed(1)
+    ones = torch.ones(5, 3, 12, 12)
+    assert float((u.random_apply_pose2D_img(img=ones, pad=None) - 1).abs().max()) < 1e-5   # zoom-to-cover: no border shows
+    torch.manual_seed(2)
+    assert float(u.random_apply_pose2D_img(img=ones, pad="zeros").min()) < 0.5     # padded variant does show it
+    # colour: zero sigmas = identity; a pure brightness shift adds a constant
+    assert float((u.random_apply_color(p=[0, 0, 0, 0, 0], img=img) - img).abs().max()) < 1e-6
+    torch.manual_seed(3)
+    shifted = u.random_apply_color(p=[.2, 0, 0, 0, 0], img=img)
+    d = (shifted - img).reshape(4, -1)
+    assert float((d - d[:, :1]).abs().max()) < 1e-5 and float(d.abs().max()) > 1e-3
+    torch.manual_seed(4)
+    mixed = u.augment(img, 0.5)
+    same = [bool(torch.equal(mixed[i], img[i])) for i in range(4)]
+    assert mixed.shape == img.shape and torch.isfinite(mixed).all() and len(same) == 4
+
+
+def test_training_step_with_ada_branch():
+    from stylerenderer_amd import train
+
+    tr = train.Trainer(size=8, latent=32, n_mlp=2, device="cpu", seed=1, augment=True)
+    data = train.SyntheticImages(8, 8, "cpu")
+    logs = [tr.step(data.batch(4)) for _ in range(2)]
+    assert all(np.isfinite(v) for log in logs for v in log.values())
+    assert 0.0 <= tr.ada_aug_p <= 1.0 and float(tr.ada_augment[1]) == 8.0           # sign statistics accumulate
