@@ -22,12 +22,15 @@ tr._load_inputs(data.batch(4), None, faces)
 bodies = tr._bodies()
 names = {"all": ("d", "d_opt", "g", "g_opt"), "d": ("d",), "g": ("g",), "path": ("path",), "r1": ("r1",)}[phase]
 torch.cuda.synchronize()
-with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True) as prof:
     for n in names:
         bodies[n]()
     torch.cuda.synchronize()
-ka = prof.key_averages()
-rows = sorted(ka, key=lambda e: -e.count)
-print("phase %s: top operators by call count" % phase)
-for e in rows[:70]:
-    print("%6d  %9.1f us dev  %s" % (e.count, e.device_time_total, e.key[:90]))
+ka = prof.key_averages(group_by_input_shape=True)
+rows = [e for e in ka if e.key.startswith("aten::") and e.device_time_total > 0]
+rows = sorted(rows, key=lambda e: -e.device_time_total)
+print("phase %s: aten operators with device time, by (op, input shapes)" % phase)
+tot = sum(e.device_time_total for e in rows)
+print("total aten device time %.1f us in %d calls" % (tot, sum(e.count for e in rows)))
+for e in rows[:48]:
+    print("%5d  %8.1f us  %-22s %s" % (e.count, e.device_time_total, e.key, str(e.input_shapes)[:110]))

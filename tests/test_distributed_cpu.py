@@ -48,6 +48,42 @@ def g_loss_grads(g_net, d_net, z, noise):
     return loss.detach()
 
 
+def bucket_launch_order(rank):
+    """Gradient buckets of the eager DDP path are reduced WHILE the backward is still running — also in the
+    path-length iteration, whose backward is a double backward with its own gradient arrival order.  A comm hook
+    stamps every bucket launch; a tensor hook stamps the moment the LAST gradient of the backward (first mapping
+    layer) is produced.  Returns, per kind of iteration, (number of buckets, buckets launched before that moment)."""
+    import time
+
+    from torch.distributed.algorithms.ddp_comm_hooks import default_hooks
+
+    g, _ = build_models()
+    ddp = torch.nn.parallel.DistributedDataParallel(g, broadcast_buffers=False, bucket_cap_mb=1,
+                                                    gradient_as_bucket_view=True)
+    stamps = {"buckets": [], "last": None}
+
+    def hook(state, bucket):
+        stamps["buckets"].append(time.perf_counter())
+        return default_hooks.allreduce_hook(state, bucket)
+
+    ddp.register_comm_hook(None, hook)
+    g.style[1].weight.register_hook(lambda grad: stamps.__setitem__("last", time.perf_counter()))
+    z, noise = fixed_inputs()
+    out = {}
+    for kind in ("plain", "plain", "path", "path"):          # DDP rebuilds its buckets in arrival order after pass 1
+        stamps["buckets"], stamps["last"] = [], None
+        g.zero_grad(set_to_none=True)
+        if kind == "plain":
+            img, _ = ddp([z[rank::2]], noise=noise)
+            img.square().mean().backward()
+        else:
+            img, lat = ddp([z[rank::2]], noise=noise, return_latents=True)
+            pen, _, _ = train.g_path_regularize(img, lat, torch.zeros(()), noise=torch.ones_like(img))
+            (pen + 0 * img[0, 0, 0, 0]).backward()
+        out[kind] = (len(stamps["buckets"]), sum(t < stamps["last"] for t in stamps["buckets"]))
+    return out
+
+
 def worker(rank, world, port, outdir):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK=str(rank))
@@ -74,7 +110,8 @@ def worker(rank, world, port, outdir):
     logs = [tr.step(data.batch(4)) for _ in range(2)]
     checksum = torch.stack([p.detach().double().sum() for p in tr.generator.parameters()]
                            + [p.detach().double().sum() for p in tr.discriminator.parameters()])
-    torch.save({"grads": grads, "red": red, "logs": logs, "checksum": checksum, "loss": loss,
+    overlap = bucket_launch_order(rank)
+    torch.save({"grads": grads, "red": red, "logs": logs, "checksum": checksum, "loss": loss, "overlap": overlap,
                 "init_sum": init_sum, "z_probe": z_probe},
                os.path.join(outdir, "rank%d.pt" % rank))
     sr_dist.synchronize()
@@ -127,6 +164,15 @@ def test_ranks_share_weights_but_not_sample_streams(two_rank_run):
     assert torch.equal(r0["init_sum"], r1["init_sum"])
     assert not torch.equal(r0["z_probe"], r1["z_probe"])
     assert float((r0["z_probe"] - r1["z_probe"]).abs().mean()) > 0.5
+
+
+def test_buckets_launch_during_backward_including_the_double_backward(two_rank_run):
+    for r in two_rank_run:
+        for kind in ("plain", "path"):
+            n_buckets, early = r["overlap"][kind]
+            assert n_buckets >= 4, (kind, n_buckets)
+            # all but the bucket that holds the last-produced gradients are in flight before the backward ends
+            assert early >= n_buckets - 2, (kind, n_buckets, early)
 
 
 def test_single_process_training_step_updates_parameters():
