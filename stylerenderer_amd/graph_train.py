@@ -207,10 +207,13 @@ class GraphedTrainer(Trainer):
             self._draw_inject(k)
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
+        reduce_after = {"d": self.flat_d, "r1": self.flat_d, "g": self.flat_g, "path": self.flat_g}
         with torch.cuda.stream(side):
             for _ in range(warmup):
                 for name in ("d", "d_opt", "r1", "d_opt", "g", "g_opt", "path", "g_opt"):
                     bodies[name]()
+                    if name in reduce_after:
+                        self._reduce(reduce_after[name])       # replicas stay in step during the warm-up too
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         if not self.capture:
