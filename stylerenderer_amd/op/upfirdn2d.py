@@ -54,7 +54,7 @@ class UpFirDn2dBackward(Function):
         up_x, up_y = up
         down_x, down_y = down
         g_pad_x0, g_pad_x1, g_pad_y0, g_pad_y1 = g_pad
-        grad_output = grad_output.reshape(-1, out_size[0], out_size[1], 1)
+        grad_output = grad_output.reshape(in_size[0] * in_size[1], out_size[0], out_size[1], 1)
         grad_input = upfirdn2d_op(grad_output, grad_kernel, down_x, down_y, up_x, up_y,
                                   g_pad_x0, g_pad_x1, g_pad_y0, g_pad_y1)
         grad_input = grad_input.view(in_size[0], in_size[1], in_size[2], in_size[3])
@@ -66,7 +66,7 @@ class UpFirDn2dBackward(Function):
     @staticmethod
     def backward(ctx, gradgrad_input):
         (kernel,) = ctx.saved_tensors
-        gg = gradgrad_input.reshape(-1, ctx.in_size[2], ctx.in_size[3], 1)
+        gg = gradgrad_input.reshape(ctx.in_size[0] * ctx.in_size[1], ctx.in_size[2], ctx.in_size[3], 1)
         out = upfirdn2d_op(gg, kernel, ctx.up[0], ctx.up[1], ctx.down[0], ctx.down[1], *ctx.pad)
         out = out.view(ctx.in_size[0], ctx.in_size[1], ctx.out_size[0], ctx.out_size[1])
         return out, None, None, None, None, None, None, None, None
@@ -79,7 +79,7 @@ class UpFirDn2d(Function):
         down_x, down_y = down
         pad_x0, pad_x1, pad_y0, pad_y1 = pad
         kernel_h, kernel_w = kernel.shape
-        _, channel, in_h, in_w = input.shape
+        batch, channel, in_h, in_w = input.shape
         ctx.in_size = input.shape
         out_h = _out_size(in_h, up_y, down_y, pad_y0, pad_y1, kernel_h)
         out_w = _out_size(in_w, up_x, down_x, pad_x0, pad_x1, kernel_w)
@@ -90,9 +90,11 @@ class UpFirDn2d(Function):
                      kernel_h - pad_y0 - 1,
                      in_h * up_y - out_h * down_y + pad_y0 - up_y + 1)
         ctx.save_for_backward(kernel, torch.flip(kernel, [0, 1]))
-        out = upfirdn2d_op(input.reshape(-1, in_h, in_w, 1), kernel, up_x, up_y, down_x, down_y,
+        # explicit plane count: `-1` is ambiguous for zero-size batches / channel counts (the reference's
+        # view(-1, channel, ...) raises there, op/upfirdn2d.py:125)
+        out = upfirdn2d_op(input.reshape(batch * channel, in_h, in_w, 1), kernel, up_x, up_y, down_x, down_y,
                            pad_x0, pad_x1, pad_y0, pad_y1)
-        return out.view(-1, channel, out_h, out_w)
+        return out.view(batch, channel, out_h, out_w)
 
     @staticmethod
     def backward(ctx, grad_output):

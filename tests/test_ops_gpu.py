@@ -505,3 +505,37 @@ def test_noise_bias_act_affine_matches_unfused_path(shape, shared, cmap):
             assert u is None or float(u.abs().max()) == 0
             continue
         assert float((u - v).abs().max()) <= 1e-4 * float(v.abs().max()) + 1e-6
+
+
+def test_empty_and_degenerate_inputs_on_device():
+    """Zero-size tensors and degenerate geometry through every operator of the boundary: no launch, no crash,
+    shapes and gradients as torch would produce them."""
+    import stylerenderer_amd.op as op
+    from stylerenderer_amd.op.fused_elem import noise_bias_act
+    R = importlib.import_module("stylerenderer_amd.op.rasterize")
+
+    bias = torch.zeros(4, device=DEV, requires_grad=True)
+    x = torch.zeros(0, 4, 3, 3, device=DEV, requires_grad=True)
+    y = op.fused_leaky_relu(x, bias)
+    assert y.shape == (0, 4, 3, 3)
+    y.sum().backward()
+    assert bias.grad is not None and float(bias.grad.abs().max()) == 0.0
+    k = torch.ones(4, 4, device=DEV) / 16
+    assert op.upfirdn2d(torch.zeros(0, 3, 8, 8, device=DEV), k, pad=(1, 1)).shape == (0, 3, 7, 7)
+    assert op.upfirdn2d(torch.zeros(2, 0, 8, 8, device=DEV), k, up=2, pad=(2, 1)).shape == (2, 0, 16, 16)
+    one = op.upfirdn2d(torch.ones(1, 1, 1, 1, device=DEV), k, pad=(2, 1))            # 1x1 image, kernel larger than it
+    assert one.shape == (1, 1, 1, 1) and abs(float(one) - 1 / 16) < 1e-7
+    assert noise_bias_act(torch.zeros(0, 4, 8, 8, device=DEV), None, None, bias.detach()).shape == (0, 4, 8, 8)
+    # rasterizer: empty batch, no triangles, a single vertex referenced three times, 1x1 target
+    v = torch.zeros(2, 3, 3, device=DEV)
+    tri0 = torch.zeros(0, 3, dtype=torch.int64, device=DEV)
+    out = op.rasterize(v.clone().requires_grad_(), torch.ones(2, 3, 2, device=DEV).requires_grad_(), tri0, 4)
+    assert out.shape == (2, 4, 4, 2) and not out.any()
+    gv, gt = torch.autograd.grad(out.sum(), [n for n in (out.grad_fn.next_functions[0][0].variable,
+                                                         out.grad_fn.next_functions[1][0].variable)])
+    assert not gv.any() and not gt.any()
+    idx, coeff = R.forward(torch.zeros(0, 3, 3, device=DEV), tri0, 4, 4)
+    assert idx.shape == (0, 4, 4, 3) and coeff.shape == (0, 4, 4, 3)
+    same = torch.zeros(1, 3, dtype=torch.int64, device=DEV)                          # ids (0, 0, 0): a point
+    idx, coeff = R.forward(v, same, 1, 1)
+    assert idx.shape == (2, 1, 1, 3) and torch.isfinite(coeff).all()
