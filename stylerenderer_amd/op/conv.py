@@ -318,7 +318,7 @@ def _nba_bwd_dot(gy, out, noise, noise_w, abias, slope, gain):
     inner = h * w
     L = _lib.lib()
     g = torch.empty_like(out)
-    gb = torch.empty(n, dtype=out.dtype, device=out.device)
+    gb = (torch.zeros if out.numel() == 0 else torch.empty)(n, dtype=out.dtype, device=out.device)
     gnw = torch.zeros(1, dtype=out.dtype, device=out.device)
     rdot = torch.empty((b, n), dtype=out.dtype, device=out.device)
     scratch = torch.empty(L.sr_noise_bias_act_bwd_dot_scratch_floats(b, n, inner), dtype=out.dtype, device=out.device)

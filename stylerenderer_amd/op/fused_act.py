@@ -61,7 +61,8 @@ def _act_backward(grad_output, out, negative_slope, scale):
     for i in range(2, o.dim()):
         inner *= o.size(i)
     gx = torch.empty_like(o)
-    gb = torch.empty(c, dtype=o.dtype, device=o.device)
+    # an empty input launches nothing: its bias gradient is the empty sum, not uninitialised memory
+    gb = (torch.zeros if o.numel() == 0 else torch.empty)(c, dtype=o.dtype, device=o.device)
     L = _lib.lib()
     scratch = torch.empty(L.sr_fused_act_bwd_scratch_floats(n, c, inner), dtype=o.dtype, device=o.device)
     with on_device_of(o):

@@ -52,7 +52,7 @@ class _NBABackward(Function):
         n, c, inner = _geometry(out)
         gy = gy.contiguous()
         gx = torch.empty_like(out)
-        gb = torch.empty(c, dtype=out.dtype, device=out.device)
+        gb = (torch.zeros if out.numel() == 0 else torch.empty)(c, dtype=out.dtype, device=out.device)
         gnw = torch.zeros(1, dtype=out.dtype, device=out.device)
         L = _lib.lib()
         scratch = torch.empty(L.sr_noise_bias_act_bwd_scratch_floats(n, c, inner), dtype=out.dtype,
@@ -111,7 +111,7 @@ class _NBAAffineBackward(Function):
         gy = gy.contiguous()
         gx = torch.empty_like(out)
         gmap = torch.empty((2, n) + tuple(out.shape[2:]), dtype=out.dtype, device=out.device)   # [a | s] planes
-        gb = torch.empty(c, dtype=out.dtype, device=out.device)
+        gb = (torch.zeros if out.numel() == 0 else torch.empty)(c, dtype=out.dtype, device=out.device)
         gnw = torch.zeros(1, dtype=out.dtype, device=out.device)
         L = _lib.lib()
         scratch = torch.empty(L.sr_noise_bias_act_affine_bwd_scratch_floats(n, c, inner), dtype=out.dtype,
