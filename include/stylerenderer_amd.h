@@ -103,6 +103,14 @@ int sr_noise_bias_act_affine_bwd(float* gx, float* gamap, float* gsmap, float* g
                                  int64_t c, int64_t inner, int64_t noise_bstride, float* scratch,
                                  sr_stream_t stream);
 
+/* Adam step over ONE flat fp32 parameter buffer (the optimiser of reference train.py:529-536: torch.optim.Adam with
+ * the lazy-regularisation corrected lr / betas, no weight decay) in a single pass over p, g, m, v (28 B/parameter):
+ *   m += (g - m)(1 - beta1);  v = beta2 v + (1 - beta2) g^2;  p -= lr / (1 - beta1^t) * m / (sqrt(v) / sqrt(1 - beta2^t) + eps)
+ * `step` points at the device scalar t (a float the caller increments before the call), so the launch can be
+ * captured in a hipGraph.  All four buffers 16-byte aligned. */
+int sr_adam_flat(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                 float eps, const float* step, sr_stream_t stream);
+
 /* Row-wise dot products of two [rows, inner] tensors, optionally with a scaled copy in the same
  * sweep: dots[r] = sum_i a[r,i]*b[r,i] ; out_scaled[r,i] = b[r,i]*scale[r] (out_scaled may be NULL).
  * These are the style / demodulation gradients of the modulated convolution (sum_p x*dx', sum_p g*y)

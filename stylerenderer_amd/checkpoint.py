@@ -65,8 +65,11 @@ def trainer_state(trainer):
     """The reference's checkpoint dict for a train.Trainer."""
     g = trainer.generator
     used = [n for n, _ in g.named_parameters() if n not in trainer.frozen]
+    def own(module):          # parameters may be views of a flat optimiser buffer: save compact copies
+        return {k: v.detach().clone() for k, v in module.state_dict().items()}
+
     out = {
-        "g": g.state_dict(), "d": trainer.discriminator.state_dict(), "g_ema": trainer.g_ema.state_dict(),
+        "g": own(g), "d": own(trainer.discriminator), "g_ema": own(trainer.g_ema),
         "g_optim": _full_optim_state(trainer.g_optim, g, used),
         "d_optim": trainer.d_optim.state_dict(),
         "args": dict(trainer.args), "ada_aug_p": float(trainer.ada_aug_p),

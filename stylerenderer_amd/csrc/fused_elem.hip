@@ -716,3 +716,62 @@ extern "C" int sr_smallconv_dw(float* dws, const float* g, const float* x, int64
                        (int)N, chunks, B * C);
     return sr_launch_status();
 }
+
+// ------------------------------------------------------------------------------------------------
+// Adam over one flat parameter buffer (the optimiser of reference train.py:529-536) as ONE pass: p, g, m, v are
+// read once and p, m, v written once (28 B per parameter) instead of the ~10 multi-tensor passes of the foreach
+// implementation.  Same update as torch.optim.Adam (no weight decay, no amsgrad):
+//     m = m + (g - m) * (1 - b1);  v = b2 * v + (1 - b2) * g * g;
+//     p = p - (lr / (1 - b1^t)) * m / (sqrt(v) / sqrt(1 - b2^t) + eps)
+// `step` is a device scalar holding t (already incremented by the caller), so the launch is graph-capturable.
+namespace {
+
+__global__ __launch_bounds__(EB) void k_adam_flat(float* __restrict__ p, const float* __restrict__ g,
+                                                  float* __restrict__ m, float* __restrict__ v, int64_t n4,
+                                                  int64_t n, float lr, float b1, float b2, float eps,
+                                                  const float* __restrict__ step) {
+    const float t = step[0];
+    const float bc1 = 1.0f - powf(b1, t);
+    const float bc2s = sqrtf(1.0f - powf(b2, t));
+    const float step_size = lr / bc1;
+    const float om1 = 1.0f - b1, om2 = 1.0f - b2;
+    const int64_t stride = (int64_t)gridDim.x * EB;
+    for (int64_t i = (int64_t)blockIdx.x * EB + threadIdx.x; i < n4; i += stride) {
+        const float4 gv = reinterpret_cast<const float4*>(g)[i];
+        float4 mv = reinterpret_cast<float4*>(m)[i], vv = reinterpret_cast<float4*>(v)[i];
+        float4 pv = reinterpret_cast<float4*>(p)[i];
+#define SR_ADAM1(c)                                                   \
+        mv.c = mv.c + (gv.c - mv.c) * om1;                            \
+        vv.c = b2 * vv.c + om2 * gv.c * gv.c;                         \
+        pv.c = pv.c - step_size * (mv.c / (sqrtf(vv.c) / bc2s + eps));
+        SR_ADAM1(x) SR_ADAM1(y) SR_ADAM1(z) SR_ADAM1(w)
+#undef SR_ADAM1
+        reinterpret_cast<float4*>(m)[i] = mv;
+        reinterpret_cast<float4*>(v)[i] = vv;
+        reinterpret_cast<float4*>(p)[i] = pv;
+    }
+    // tail (n % 4 elements)
+    if (blockIdx.x == 0 && threadIdx.x < n - 4 * n4) {
+        const int64_t i = 4 * n4 + threadIdx.x;
+        const float gs = g[i];
+        const float ms = m[i] + (gs - m[i]) * om1;
+        const float vs = b2 * v[i] + om2 * gs * gs;
+        m[i] = ms;
+        v[i] = vs;
+        p[i] = p[i] - step_size * (ms / (sqrtf(vs) / bc2s + eps));
+    }
+}
+
+}  // namespace
+
+extern "C" int sr_adam_flat(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
+                            float beta2, float eps, const float* step, sr_stream_t stream) {
+    if (n < 0) return SR_EINVAL;
+    if (n == 0) return SR_OK;
+    if (!p || !g || !m || !v || !step) return SR_EINVAL;
+    if (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) return SR_EINVAL;
+    const int64_t n4 = n / 4;
+    hipLaunchKernelGGL(k_adam_flat, dim3(sr_stream_grid(n4 > 0 ? n4 : 1, EB)), dim3(EB), 0, sr_stream(stream), p, g, m, v,
+                       n4, n, lr, beta1, beta2, eps, step);
+    return sr_launch_status();
+}

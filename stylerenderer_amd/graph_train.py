@@ -27,13 +27,14 @@ What has to be static for capture, and how:
   * each phase starts with `.grad = None` (autograd then ASSIGNS gradients: no zero fill, no accumulate kernel per
     parameter) and ends with one multi-tensor copy of the phase's gradients into views of a flat buffer per
     network — the buffer the all-reduce and the captured Adam step read;
-  * Adam runs with capturable=True; the lazy-regularisation cadence is host control flow between replays;
+  * Adam is one captured launch over flat parameter / gradient / moment buffers (optim.FlatAdam, csrc sr_adam_flat);
+    the lazy-regularisation cadence is host control flow between replays;
   * loss scalars land in a fixed tensor; nothing is read back unless `log=True`.
 """
 import torch
-from torch import optim
 
 from . import distributed as sr_dist
+from .optim import FlatAdam, flat_layout, flat_views
 from .train import (Trainer, accumulate, d_logistic_loss, d_r1_loss, g_nonsaturating_loss, g_path_regularize,
                     requires_grad)
 
@@ -66,10 +67,9 @@ class GraphedTrainer(Trainer):
             p.grad = v
         g_ratio = a["g_reg_every"] / (a["g_reg_every"] + 1)
         d_ratio = a["d_reg_every"] / (a["d_reg_every"] + 1)
-        self.g_optim = optim.Adam(self.g_params, lr=a["lr"] * g_ratio, betas=(0 ** g_ratio, 0.99 ** g_ratio),
-                                  capturable=True, foreach=True)
-        self.d_optim = optim.Adam(self.d_params, lr=a["lr"] * d_ratio, betas=(0 ** d_ratio, 0.99 ** d_ratio),
-                                  capturable=True, foreach=True)
+        # one-launch Adam over flat parameter / gradient / moment buffers (optim.FlatAdam)
+        self.g_optim = FlatAdam(self.g_params, self.flat_g, lr=a["lr"] * g_ratio, betas=(0 ** g_ratio, 0.99 ** g_ratio))
+        self.d_optim = FlatAdam(self.d_params, self.flat_d, lr=a["lr"] * d_ratio, betas=(0 ** d_ratio, 0.99 ** d_ratio))
         size = a["size"]
         self.s_real = torch.zeros(batch, 3, size, size, device=dev)
         self.s_inject = {k: torch.zeros((), dtype=torch.int64, device=dev) for k in ("d", "g", "path")}
@@ -86,12 +86,9 @@ class GraphedTrainer(Trainer):
     # ---- static state -----------------------------------------------------------------------------
     @staticmethod
     def _flatten_grads(params):
-        flat = torch.zeros(sum(p.numel() for p in params), device=params[0].device, dtype=params[0].dtype)
-        views, off = [], 0
-        for p in params:
-            views.append(flat[off:off + p.numel()].view_as(p))
-            off += p.numel()
-        return flat, views
+        offs, total = flat_layout(params)                      # 256-byte aligned slots, shared with FlatAdam
+        flat = torch.zeros(total, device=params[0].device, dtype=params[0].dtype)
+        return flat, flat_views(flat, params, offs)
 
     @staticmethod
     def _clear(params):

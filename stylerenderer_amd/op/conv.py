@@ -319,7 +319,8 @@ def _nba_bwd_dot(gy, out, noise, noise_w, abias, slope, gain):
     L = _lib.lib()
     g = torch.empty_like(out)
     gb = (torch.zeros if out.numel() == 0 else torch.empty)(n, dtype=out.dtype, device=out.device)
-    gnw = torch.zeros(1, dtype=out.dtype, device=out.device)
+    # written by the finish kernel whenever there is noise; a fill launch only for the cases that need the zero
+    gnw = (torch.empty if (noise is not None and out.numel() > 0) else torch.zeros)(1, dtype=out.dtype, device=out.device)
     rdot = torch.empty((b, n), dtype=out.dtype, device=out.device)
     scratch = torch.empty(L.sr_noise_bias_act_bwd_dot_scratch_floats(b, n, inner), dtype=out.dtype, device=out.device)
     bstride = 0 if noise is None or noise.numel() == inner else inner
@@ -360,7 +361,7 @@ class UpConvNBAFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gy):
         from .fused_elem import _BlurNBA
-        from .upfirdn2d import upfirdn2d_op
+        from .upfirdn2d import flipped, upfirdn2d_op
 
         x, wt, iscale, oscale, kernel, noise, noise_w, abias, out = ctx.saved_tensors
         pad, slope, gain, shape257 = ctx.cfg
@@ -378,7 +379,7 @@ class UpConvNBAFn(torch.autograd.Function):
         g, gb, gnw, rdot = _nba_bwd_dot(gy, out, noise, noise_w, abias, slope, gain)
         p0 = pad[0]
         oh, ow = out.shape[2], out.shape[3]
-        g257 = upfirdn2d_op(g.reshape(-1, oh, ow, 1), torch.flip(kernel, [0, 1]), 1, 1, 1, 1, 3 - p0,
+        g257 = upfirdn2d_op(g.reshape(-1, oh, ow, 1), flipped(kernel), 1, 1, 1, 1, 3 - p0,
                             shape257[3] - ow + p0, 3 - p0, shape257[2] - oh + p0).view(shape257)
         gx = gw = gis = gos = None
         if needs[0] or needs[2]:

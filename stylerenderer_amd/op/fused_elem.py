@@ -53,7 +53,8 @@ class _NBABackward(Function):
         gy = gy.contiguous()
         gx = torch.empty_like(out)
         gb = (torch.zeros if out.numel() == 0 else torch.empty)(c, dtype=out.dtype, device=out.device)
-        gnw = torch.zeros(1, dtype=out.dtype, device=out.device)
+        gnw = (torch.empty if (noise is not None and out.numel() > 0) else torch.zeros)(1, dtype=out.dtype,
+                                                                                            device=out.device)
         L = _lib.lib()
         scratch = torch.empty(L.sr_noise_bias_act_bwd_scratch_floats(n, c, inner), dtype=out.dtype,
                               device=out.device)
@@ -112,7 +113,8 @@ class _NBAAffineBackward(Function):
         gx = torch.empty_like(out)
         gmap = torch.empty((2, n) + tuple(out.shape[2:]), dtype=out.dtype, device=out.device)   # [a | s] planes
         gb = (torch.zeros if out.numel() == 0 else torch.empty)(c, dtype=out.dtype, device=out.device)
-        gnw = torch.zeros(1, dtype=out.dtype, device=out.device)
+        gnw = (torch.empty if (noise is not None and out.numel() > 0) else torch.zeros)(1, dtype=out.dtype,
+                                                                                            device=out.device)
         L = _lib.lib()
         scratch = torch.empty(L.sr_noise_bias_act_affine_bwd_scratch_floats(n, c, inner), dtype=out.dtype,
                               device=out.device)
@@ -217,13 +219,13 @@ class _BlurNBA(Function):
 
     @staticmethod
     def backward(ctx, gy):
-        from .upfirdn2d import UpFirDn2dBackward
+        from .upfirdn2d import UpFirDn2dBackward, flipped
 
         y, noise, kernel = ctx.saved_tensors
         slope, scale, p0, p1, in_size, out_size = ctx.cfg
         gpre, gb, gnw = _NBABackward.apply(gy, y, noise, slope, scale)
         g_pad = (3 - p0, in_size[3] - out_size[1] + p0, 3 - p0, in_size[2] - out_size[0] + p0)
-        gx = UpFirDn2dBackward.apply(gpre, kernel, torch.flip(kernel, [0, 1]), (1, 1), (1, 1), (p0, p1, p0, p1),
+        gx = UpFirDn2dBackward.apply(gpre, kernel, flipped(kernel), (1, 1), (1, 1), (p0, p1, p0, p1),
                                      g_pad, in_size, out_size)
         return gx, None, None, None, (gnw if noise is not None else None), gb, None, None
 

@@ -48,6 +48,22 @@ def upfirdn2d_op(input, kernel, up_x, up_y, down_x, down_y, pad_x0, pad_x1, pad_
     return out
 
 
+_FLIP_CACHE = {}
+
+
+def flipped(kernel):
+    """torch.flip(kernel, [0, 1]), cached per tensor (address, version): the FIR kernels are module buffers that
+    never change, and the gradient of every blur / resampling call needs the flipped taps (one launch each)."""
+    key = (kernel.data_ptr(), kernel._version, tuple(kernel.shape), str(kernel.device), kernel.dtype)
+    hit = _FLIP_CACHE.get(key)
+    if hit is None:
+        if len(_FLIP_CACHE) > 64:
+            _FLIP_CACHE.clear()
+        hit = (torch.flip(kernel.detach(), [0, 1]).contiguous(), kernel)      # holds `kernel`: the key is its address
+        _FLIP_CACHE[key] = hit
+    return hit[0]
+
+
 class UpFirDn2dBackward(Function):
     @staticmethod
     def forward(ctx, grad_output, kernel, grad_kernel, up, down, pad, g_pad, in_size, out_size):
@@ -89,7 +105,7 @@ class UpFirDn2d(Function):
                      in_w * up_x - out_w * down_x + pad_x0 - up_x + 1,
                      kernel_h - pad_y0 - 1,
                      in_h * up_y - out_h * down_y + pad_y0 - up_y + 1)
-        ctx.save_for_backward(kernel, torch.flip(kernel, [0, 1]))
+        ctx.save_for_backward(kernel, flipped(kernel))
         # explicit plane count: `-1` is ambiguous for zero-size batches / channel counts (the reference's
         # view(-1, channel, ...) raises there, op/upfirdn2d.py:125)
         out = upfirdn2d_op(input.reshape(batch * channel, in_h, in_w, 1), kernel, up_x, up_y, down_x, down_y,

@@ -1,0 +1,90 @@
+"""Adam over flat buffers (the optimiser of reference train.py:529-536, `optim.Adam(..., lr * ratio, betas = (0 ** ratio,
+0.99 ** ratio))`) for the graph-replayed training iteration.
+
+`FlatAdam` moves its parameters into ONE contiguous fp32 buffer (each parameter becomes a 256-byte aligned view of it,
+so every kernel that consumes a weight still sees an aligned tensor) and keeps the gradients, first and second
+moments in buffers of the same layout; a step is one launch of `sr_adam_flat` (28 B per parameter) instead of the
+~10 multi-tensor passes of torch's foreach Adam.  `state_dict()` / `load_state_dict()` speak torch.optim.Adam's format
+(per-parameter `step`, `exp_avg`, `exp_avg_sq`), so checkpoints move between the two.
+"""
+import torch
+
+from . import _lib
+
+ALIGN = 64          # floats: 256-byte aligned views
+
+
+def flat_layout(params):
+    offs, off = [], 0
+    for p in params:
+        offs.append(off)
+        off += (p.numel() + ALIGN - 1) // ALIGN * ALIGN
+    return offs, off
+
+
+def flat_views(flat, params, offs):
+    return [flat[o:o + p.numel()].view_as(p) for p, o in zip(params, offs)]
+
+
+class FlatAdam:
+    def __init__(self, params, flat_grad, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+        self.params = list(params)
+        p0 = self.params[0]
+        if p0.device.type != "cuda" or any(p.dtype != torch.float32 for p in self.params):
+            raise RuntimeError("FlatAdam: float32 parameters on a GPU required")
+        self.offs, self.total = flat_layout(self.params)
+        if flat_grad.numel() != self.total:
+            raise RuntimeError("FlatAdam: gradient buffer does not follow flat_layout(params)")
+        self.flat_g = flat_grad
+        self.flat_p = torch.zeros(self.total, device=p0.device)
+        self.m = torch.zeros_like(self.flat_p)
+        self.v = torch.zeros_like(self.flat_p)
+        self.step_t = torch.zeros((), device=p0.device)
+        with torch.no_grad():
+            for p, view in zip(self.params, flat_views(self.flat_p, self.params, self.offs)):
+                view.copy_(p)
+                p.data = view                      # the module now reads its weights out of the flat buffer
+        self.param_groups = [{"params": self.params, "lr": float(lr), "betas": (float(betas[0]), float(betas[1])),
+                              "eps": float(eps), "weight_decay": 0, "amsgrad": False}]
+
+    def step(self):
+        g = self.param_groups[0]
+        self.step_t.add_(1.0)
+        rc = _lib.lib().sr_adam_flat(self.flat_p.data_ptr(), self.flat_g.data_ptr(), self.m.data_ptr(),
+                                     self.v.data_ptr(), self.total, g["lr"], g["betas"][0], g["betas"][1], g["eps"],
+                                     self.step_t.data_ptr(), _lib.current_stream(self.flat_p.device))
+        _lib.check(rc, "sr_adam_flat")
+
+    def zero_grad(self, set_to_none=False):
+        self.flat_g.zero_()
+
+    # ---- torch.optim.Adam's checkpoint format ---------------------------------------------------------
+    def state_dict(self):
+        state = {}
+        if float(self.step_t) > 0:
+            for i, (m, v) in enumerate(zip(flat_views(self.m, self.params, self.offs),
+                                           flat_views(self.v, self.params, self.offs))):
+                state[i] = {"step": self.step_t.detach().clone(), "exp_avg": m.detach().clone(),
+                            "exp_avg_sq": v.detach().clone()}
+        group = {k: v for k, v in self.param_groups[0].items() if k != "params"}
+        group["params"] = list(range(len(self.params)))
+        return {"state": state, "param_groups": [group]}
+
+    def load_state_dict(self, sd):
+        group = sd["param_groups"][0]
+        if len(group["params"]) != len(self.params):
+            raise ValueError("FlatAdam.load_state_dict: parameter count mismatch")
+        for k in ("lr", "betas", "eps"):
+            if k in group:
+                self.param_groups[0][k] = tuple(float(b) for b in group[k]) if k == "betas" else float(group[k])
+        step = 0.0
+        with torch.no_grad():
+            self.m.zero_()
+            self.v.zero_()
+            mv = flat_views(self.m, self.params, self.offs)
+            vv = flat_views(self.v, self.params, self.offs)
+            for i, st in sd["state"].items():
+                mv[int(i)].copy_(st["exp_avg"])
+                vv[int(i)].copy_(st["exp_avg_sq"])
+                step = max(step, float(st["step"]))
+            self.step_t.fill_(step)

@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 import torch
 
-from stylerenderer_amd import train
+from stylerenderer_amd import synth, train
 
 pytestmark = pytest.mark.gpu
 
@@ -127,3 +127,39 @@ def test_train_functions_on_hip_path_match_reference_definitions():
 
     gold = np.load(os.path.join(os.path.dirname(__file__), "golden", "train_step_s8.npz"))
     tp.run_all(gold, "cuda", 2e-5, 2e-4, 4e-4)
+
+
+def test_flat_adam_matches_torch_adam_and_speaks_its_checkpoint_format():
+    """optim.FlatAdam (one sr_adam_flat launch over flat buffers) against torch.optim.Adam on the same gradients,
+    with the lazy-regularisation hyper-parameters of the G optimiser (beta1 = 0), incl. a state_dict round trip."""
+    from stylerenderer_amd import optim as sr_optim
+
+    dev = torch.device("cuda")
+    shapes = [(7, 5, 3, 3), (130,), (1,), (64, 33)]
+    ref = [torch.from_numpy(synth.det_normal(s, 11 + i)).to(dev).requires_grad_() for i, s in enumerate(shapes)]
+    mine = [p.detach().clone().requires_grad_() for p in ref]
+    offs, total = sr_optim.flat_layout(mine)
+    flat_g = torch.zeros(total, device=dev)
+    lr, betas = 0.002 * 0.8, (0.0, 0.99 ** 0.8)
+    a = torch.optim.Adam(ref, lr=lr, betas=betas)
+    b = sr_optim.FlatAdam(mine, flat_g, lr=lr, betas=betas)
+    assert all(p.data_ptr() % 256 == 0 for p in mine)
+    gviews = sr_optim.flat_views(flat_g, mine, offs)
+    for step in range(5):
+        if step == 3:                                   # checkpoint round trip through torch's format
+            sd = b.state_dict()
+            assert set(sd["state"][0]) == {"step", "exp_avg", "exp_avg_sq"} and float(sd["state"][0]["step"]) == 3
+            b2 = sr_optim.FlatAdam([p.detach().clone().requires_grad_() for p in mine], torch.zeros_like(flat_g),
+                                   lr=lr, betas=betas)
+            b2.load_state_dict(sd)
+            assert torch.equal(b2.m, b.m) and torch.equal(b2.v, b.v) and float(b2.step_t) == 3
+            c = torch.optim.Adam([p.detach().clone().requires_grad_() for p in ref], lr=lr, betas=betas)
+            c.load_state_dict(a.state_dict())           # the reverse direction: torch loads what torch wrote
+        for i, (p, q) in enumerate(zip(ref, mine)):
+            g = torch.from_numpy(synth.det_normal(shapes[i], 100 * step + i)).to(dev) * (0.1 + step)
+            p.grad = g.clone()
+            gviews[i].copy_(g)
+        a.step()
+        b.step()
+        for p, q in zip(ref, mine):
+            assert float((p - q).abs().max()) <= 2e-6 * float(p.abs().max()) + 1e-7, step
