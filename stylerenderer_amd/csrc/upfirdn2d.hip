@@ -196,6 +196,82 @@ __global__ __launch_bounds__(256) void k_fir4_tile(float* __restrict__ out,
     }
 }
 
+// ------------------------------------------------------------------------------ 4x4 taps, up = 2 or down = 2
+// The two resampling shapes of the networks: down = 2 (the blur in front of ResBlock.skip's 1x1 stride-2
+// convolution evaluated only at the pixels that convolution reads, and the gradient of the ToRGB skip
+// up-sampling) and up = 2 (the ToRGB skip up-sampling and the gradient of the former).  Same scheme as
+// k_fir4_tile: the input window of a 32 x 32 output tile is staged once in LDS with coalesced row loads, each
+// lane produces four consecutive outputs of one row.  Taps are visited ky-major then kx, multiply and add
+// separate (-ffp-contract=off), inserted zeros are skipped (not multiplied): the order of k_upfirdn_generic and
+// of the numpy oracle, so all three agree bit for bit.
+constexpr int R_OH = 32, R_OW = 32;
+
+template <int UP, int DOWN>
+__global__ __launch_bounds__(256) void k_fir4_resample(float* __restrict__ out, const float* __restrict__ x,
+                                                       const float* __restrict__ k, int in_h, int in_w,
+                                                       int out_h, int out_w, int pad_x0, int pad_y0,
+                                                       int tiles_x, int tiles_y) {
+    static_assert((UP == 1 && DOWN == 2) || (UP == 2 && DOWN == 1), "one of the two resampling shapes");
+    // input rows / columns a tile can touch: (R - 1) * DOWN + 4 taps, every UP-th of them holds data
+    constexpr int SPAN_H = ((R_OH - 1) * DOWN + 4 + UP - 1) / UP + 1;
+    constexpr int SPAN_W = ((R_OW - 1) * DOWN + 4 + UP - 1) / UP + 1;
+    constexpr int LDW = SPAN_W | 1;                                   // odd pitch: rows on different banks
+    __shared__ float s_in[SPAN_H * LDW];
+    __shared__ float s_k[16];
+    int bid = blockIdx.x;
+    const int tx_i = bid % tiles_x;
+    bid /= tiles_x;
+    const int ty_i = bid % tiles_y;
+    const int64_t plane = bid / tiles_y;
+    const int oy0 = ty_i * R_OH, ox0 = tx_i * R_OW;
+    // first upsampled coordinate of the tile, and the first input row / column at or after it
+    const int my0 = oy0 * DOWN - pad_y0, mx0 = ox0 * DOWN - pad_x0;
+    const int iy_lo = floor_div(my0 + UP - 1, UP), ix_lo = floor_div(mx0 + UP - 1, UP);
+    const float* src = x + plane * (int64_t)in_h * in_w;
+    if (threadIdx.x < 16) {
+        const int ky = threadIdx.x >> 2, kx = threadIdx.x & 3;
+        s_k[threadIdx.x] = k[(3 - ky) * 4 + (3 - kx)];
+    }
+    for (int i = threadIdx.x; i < SPAN_H * SPAN_W; i += 256) {
+        const int r = i / SPAN_W, c = i - r * SPAN_W;
+        const int gy = iy_lo + r, gx = ix_lo + c;
+        const bool ok = gy >= 0 && gy < in_h && gx >= 0 && gx < in_w;
+        s_in[r * LDW + c] = ok ? src[(int64_t)gy * in_w + gx] : 0.0f;
+    }
+    __syncthreads();
+    float kf[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) kf[i] = s_k[i];
+    const int ly = threadIdx.x >> 3, lx = (threadIdx.x & 7) * 4;
+    const int oy = oy0 + ly;
+    if (oy >= out_h) return;
+    const int my = oy * DOWN - pad_y0;
+    float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int ky = 0; ky < 4; ++ky) {
+        const int m = my + ky;
+        if (UP == 2 && (m & 1)) continue;                               // an inserted zero row
+        const int iy = (UP == 2 ? (m >> 1) : m);                        // arithmetic shift: exact for even m
+        if (iy < 0 || iy >= in_h) continue;
+        const float* row = s_in + (iy - iy_lo) * LDW;
+#pragma unroll
+        for (int kx = 0; kx < 4; ++kx)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int mxc = (ox0 + lx + c) * DOWN - pad_x0 + kx;
+                if (UP == 2 && (mxc & 1)) continue;
+                const int ix = (UP == 2 ? (mxc >> 1) : mxc);
+                if (ix < 0 || ix >= in_w) continue;
+                const float prod = row[ix - ix_lo] * kf[ky * 4 + kx];
+                acc[c] = acc[c] + prod;
+            }
+    }
+    float* q = out + plane * (int64_t)out_h * out_w + (int64_t)oy * out_w + ox0 + lx;
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+        if (ox0 + lx + c < out_w) q[c] = acc[c];
+}
+
 }  // namespace
 
 extern "C" int sr_upfirdn2d(float* out, const float* x, const float* k, int64_t major, int in_h,
@@ -219,6 +295,20 @@ extern "C" int sr_upfirdn2d(float* out, const float* x, const float* k, int64_t 
         if (blocks < 0x7FFFFFFFLL) {
             hipLaunchKernelGGL(k_fir4_tile<false>, dim3((unsigned)blocks), dim3(256), 0, st, out, x, k, in_h, in_w,
                                out_h, out_w, pad_x0, pad_y0, tiles_x, tiles_y, FirNba{});
+            return sr_launch_status();
+        }
+    }
+    if (kh == 4 && kw == 4 && up_x == up_y && down_x == down_y &&
+        ((up_x == 1 && down_x == 2) || (up_x == 2 && down_x == 1))) {
+        const int tiles_x = (out_w + R_OW - 1) / R_OW, tiles_y = (out_h + R_OH - 1) / R_OH;
+        const int64_t blocks = (int64_t)tiles_x * tiles_y * major;
+        if (blocks < 0x7FFFFFFFLL) {
+            if (down_x == 2)
+                hipLaunchKernelGGL((k_fir4_resample<1, 2>), dim3((unsigned)blocks), dim3(256), 0, st, out, x, k, in_h,
+                                   in_w, out_h, out_w, pad_x0, pad_y0, tiles_x, tiles_y);
+            else
+                hipLaunchKernelGGL((k_fir4_resample<2, 1>), dim3((unsigned)blocks), dim3(256), 0, st, out, x, k, in_h,
+                                   in_w, out_h, out_w, pad_x0, pad_y0, tiles_x, tiles_y);
             return sr_launch_status();
         }
     }

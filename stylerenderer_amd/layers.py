@@ -102,13 +102,19 @@ class EqualConv2d(nn.Module):
         return {(3, 1, 1): "c3", (3, 2, 0): "c3s2", (1, 1, 0): "c1", (1, 2, 0): "c1s2"}.get(
             (k, self.stride, self.padding))
 
-    def forward(self, input):
+    def forward(self, input, with_bias=True):
         geom = self._geom()
+        bias = self.bias if with_bias else None
         if input.device.type == "cuda" and geom is not None:
             wt, _ = _weight_prep(self.weight, self.scale)
-            return _conv.conv2d(input, wt, None, None, self.bias, geom)
-        return F.conv2d(input, self.weight * self.scale, bias=self.bias, stride=self.stride,
+            return _conv.conv2d(input, wt, None, None, bias, geom)
+        return F.conv2d(input, self.weight * self.scale, bias=bias, stride=self.stride,
                         padding=self.padding)
+
+    def forward_stride1(self, input):
+        """The 1x1 convolution applied to an input that is already decimated (see ConvLayer.forward)."""
+        wt, _ = _weight_prep(self.weight, self.scale)
+        return _conv.conv2d(input, wt, None, None, self.bias, "c1")
 
     def __repr__(self):
         return "%s(%d, %d, %d, stride=%d, padding=%d)" % (
@@ -308,7 +314,15 @@ class ConstantInput(nn.Module):
 class ConvLayer(nn.Sequential):
     """[Blur] -> EqualConv2d -> [FusedLeakyReLU | ScaledLeakyReLU] (reference layers.py:341-378).
     `activate` is 'lrelu' or anything else for "no activation"; the reference passes False from
-    ResBlock.skip, which its own code cannot digest — accepted here."""
+    ResBlock.skip, which its own code cannot digest — accepted here.
+    Same sub-modules and state_dict keys as the reference; on device tensors `forward` runs two algebraically
+    identical shortcuts instead of the module chain:
+      * 1x1 stride-2 convolution after the blur (ResBlock.skip): a 1x1 stride-2 convolution only reads every second
+        blurred pixel, so the blur is evaluated AT those pixels (upfirdn2d with down = 2: a quarter of the FIR
+        work, and its gradient is one zero-insert + FIR pass instead of zero-fill, strided copy and a full blur);
+      * the convolution's own bias and the FusedLeakyReLU bias (the reference has both) are added as one vector
+        in the activation kernel: their gradients are the same sum, computed once in the activation backward
+        instead of a second full-tensor reduction."""
 
     def __init__(self, in_channel, out_channel, kernel_size, downsample=False,
                  blur_kernel=[1, 3, 3, 1], bias=True, activate="lrelu"):
@@ -326,6 +340,32 @@ class ConvLayer(nn.Sequential):
         if activate == "lrelu":
             layers.append(FusedLeakyReLU(out_channel) if bias else ScaledLeakyReLU(0.2))
         super().__init__(*layers)
+
+    def forward(self, input):
+        if input.device.type != "cuda" or input.dtype != torch.float32:
+            return super().forward(input)
+        mods = list(self)
+        x = input
+        if isinstance(mods[0], Blur):
+            blur, conv = mods[0], mods[1]
+            if conv.weight.shape[2] == 1 and conv.stride == 2 and conv.padding == 0:
+                x = upfirdn2d(x, blur.kernel, down=2, pad=blur.pad)        # blur evaluated at the kept pixels only
+                x = conv.forward_stride1(x)
+                mods = mods[2:]
+            else:
+                x = blur(x)
+                mods = mods[1:]
+        if mods and isinstance(mods[0], EqualConv2d):
+            conv = mods[0]
+            act = mods[1] if len(mods) > 1 and isinstance(mods[1], FusedLeakyReLU) else None
+            if act is not None and conv.bias is not None and conv._geom() is not None:
+                x = conv(x, with_bias=False)
+                return fused_leaky_relu(x, conv.bias + act.bias, act.negative_slope, act.scale)
+            x = conv(x)
+            mods = mods[1:]
+        for m in mods:
+            x = m(x)
+        return x
 
 
 class ResBlock(nn.Module):

@@ -539,3 +539,27 @@ def test_empty_and_degenerate_inputs_on_device():
     same = torch.zeros(1, 3, dtype=torch.int64, device=DEV)                          # ids (0, 0, 0): a point
     idx, coeff = R.forward(v, same, 1, 1)
     assert idx.shape == (2, 1, 1, 3) and torch.isfinite(coeff).all()
+
+
+@pytest.mark.parametrize("up,down,pad", [(1, 2, (1, 1)), (1, 2, (2, 2)), (2, 1, (2, 1)), (2, 1, (1, 1)), (1, 2, (-1, 3))])
+@pytest.mark.parametrize("shape", [(2, 3, 70, 45), (1, 2, 33, 129), (1, 1, 5, 3)])
+def test_upfirdn2d_resampling_tiles_vs_oracle(up, down, pad, shape):
+    """The LDS-tiled 4x4 resampling kernels (k_fir4_resample: down = 2 and up = 2) over several tiles, odd sizes,
+    crops: bitwise equal to the numpy oracle, and gradients bitwise equal to the oracle applied to the adjoint
+    parameters (the other resampling kernel)."""
+    import stylerenderer_amd.op as op
+    from stylerenderer_amd import synth
+
+    x = synth.det_normal(shape, 201)
+    k = ops_np.make_blur_kernel((1, 3, 3, 1), float(up * up))
+    xt = T(x).requires_grad_()
+    y = op.upfirdn2d(xt, T(k), up=up, down=down, pad=pad)
+    want = ops_np.upfirdn2d(x, k, up, down, pad)
+    assert bits_equal(y.detach().cpu().numpy(), want)
+    gy = synth.det_normal(tuple(y.shape), 202)
+    (gx,) = torch.autograd.grad(y, xt, T(gy))
+    in_h, in_w = shape[2], shape[3]
+    gx0, gx1 = 4 - pad[0] - 1, in_w * up - y.shape[3] * down + pad[0] - up + 1
+    gy0, gy1 = 4 - pad[0] - 1, in_h * up - y.shape[2] * down + pad[0] - up + 1
+    want_gx = ops_np.upfirdn2d_full(gy, k[::-1, ::-1].copy(), down, down, up, up, gx0, gx1, gy0, gy1)
+    assert bits_equal(gx.cpu().numpy(), want_gx)
