@@ -112,3 +112,22 @@ def test_multi_resolution_store_roundtrip(tmp_path):
     batch = next(dataset.sample_data(loader))
     assert batch.shape == (2, 3, 16, 16) and torch.isfinite(batch).all()
     assert os.path.isfile(os.path.join(d, "length"))
+
+
+def test_generate_cli_writes_images_from_a_checkpoint(tmp_path):
+    """reference generate.py:14-75: load 'g_ema', optional truncation, %06d.png files."""
+    from stylerenderer_amd import generate
+
+    g = model.Generator(8, 512, 8)
+    path = str(tmp_path / "000010.pt")
+    torch.save({"g_ema": g.state_dict()}, path)
+    out = str(tmp_path / "sample")
+    n = generate.main(["--size", "8", "--pics", "2", "--sample", "3", "--truncation", "0.7", "--truncation_mean", "16",
+                       "--ckpt", path, "--output", out, "--seed", "1", "--gpu", "-1"])
+    assert n == 2 and sorted(os.listdir(out)) == ["000000.png", "000001.png"]
+    from PIL import Image
+
+    im = np.asarray(Image.open(os.path.join(out, "000000.png")))
+    assert im.shape == (3 * (8 + 2) + 2, 8 + 2 + 2, 3)                     # three samples, one per row, 2 px padding
+    grid = generate.to_uint8_grid(torch.tensor([[[[-1.0, 1.0]], [[0.0, 0.0]], [[3.0, -3.0]]]]), padding=0)
+    assert grid.tolist() == [[[0, 128, 255], [255, 128, 0]]]
