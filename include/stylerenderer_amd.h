@@ -195,6 +195,13 @@ int sr_upfirdn2d(float* out, const float* x, const float* k, int64_t major, int 
                  int out_h, int out_w, int kh, int kw, int up_x, int up_y, int down_x, int down_y,
                  int pad_x0, int pad_x1, int pad_y0, int pad_y1, sr_stream_t stream);
 
+/* ToRGB skip connection (reference model.py:66-68: `out + self.upsample(skip)`, Upsample = upfirdn2d with up = 2 and the
+ * 4x4 kernel, layers.py:170-181) in one pass: out = upfirdn2d(x, k, up = 2, pad = (pad0, pad1)) + addend.
+ * x [major, in_h, in_w]; out / addend [major, out_h, out_w], out_h = 2 in_h + pad0 + pad1 - 3.  Same arithmetic
+ * as sr_upfirdn2d followed by an addition (IEEE addition commutes), bit for bit. */
+int sr_upsample2_add(float* out, const float* x, const float* k, const float* addend, int64_t major, int in_h,
+                     int in_w, int out_h, int out_w, int pad0, int pad1, sr_stream_t stream);
+
 /* Blur (4x4 FIR, up = down = 1, pad (pad0, pad1) on both axes: reference layers.py:194-203 after the
  * stride-2 transposed convolution) with the StyledConv tail fused into its store (reference
  * model.py:26-32): y = lrelu((fir(x) + noise_w[0]*noise[b, p]) + bias[ch], alpha) * gain.

@@ -210,7 +210,8 @@ template <int UP, int DOWN>
 __global__ __launch_bounds__(256) void k_fir4_resample(float* __restrict__ out, const float* __restrict__ x,
                                                        const float* __restrict__ k, int in_h, int in_w,
                                                        int out_h, int out_w, int pad_x0, int pad_y0,
-                                                       int tiles_x, int tiles_y) {
+                                                       int tiles_x, int tiles_y,
+                                                       const float* __restrict__ addend) {
     static_assert((UP == 1 && DOWN == 2) || (UP == 2 && DOWN == 1), "one of the two resampling shapes");
     // input rows / columns a tile can touch: (R - 1) * DOWN + 4 taps, every UP-th of them holds data
     constexpr int SPAN_H = ((R_OH - 1) * DOWN + 4 + UP - 1) / UP + 1;
@@ -266,10 +267,12 @@ __global__ __launch_bounds__(256) void k_fir4_resample(float* __restrict__ out, 
                 acc[c] = acc[c] + prod;
             }
     }
-    float* q = out + plane * (int64_t)out_h * out_w + (int64_t)oy * out_w + ox0 + lx;
+    const int64_t o = plane * (int64_t)out_h * out_w + (int64_t)oy * out_w + ox0 + lx;
+    float* q = out + o;
+    // optional second operand of a following addition (ToRGB: rgb + upsample(skip), reference model.py:66-68)
 #pragma unroll
     for (int c = 0; c < 4; ++c)
-        if (ox0 + lx + c < out_w) q[c] = acc[c];
+        if (ox0 + lx + c < out_w) q[c] = addend ? acc[c] + addend[o + c] : acc[c];
 }
 
 }  // namespace
@@ -305,10 +308,10 @@ extern "C" int sr_upfirdn2d(float* out, const float* x, const float* k, int64_t 
         if (blocks < 0x7FFFFFFFLL) {
             if (down_x == 2)
                 hipLaunchKernelGGL((k_fir4_resample<1, 2>), dim3((unsigned)blocks), dim3(256), 0, st, out, x, k, in_h,
-                                   in_w, out_h, out_w, pad_x0, pad_y0, tiles_x, tiles_y);
+                                   in_w, out_h, out_w, pad_x0, pad_y0, tiles_x, tiles_y, (const float*)nullptr);
             else
                 hipLaunchKernelGGL((k_fir4_resample<2, 1>), dim3((unsigned)blocks), dim3(256), 0, st, out, x, k, in_h,
-                                   in_w, out_h, out_w, pad_x0, pad_y0, tiles_x, tiles_y);
+                                   in_w, out_h, out_w, pad_x0, pad_y0, tiles_x, tiles_y, (const float*)nullptr);
             return sr_launch_status();
         }
     }
@@ -316,6 +319,20 @@ extern "C" int sr_upfirdn2d(float* out, const float* x, const float* k, int64_t 
     const int64_t total = major * (int64_t)out_h * out_w;
     hipLaunchKernelGGL(k_upfirdn_generic, dim3(sr_stream_grid(total, 256)), dim3(256),
                        (size_t)kh * kw * sizeof(float), st, out, x, k, p, total);
+    return sr_launch_status();
+}
+
+extern "C" int sr_upsample2_add(float* out, const float* x, const float* k, const float* addend, int64_t major,
+                                int in_h, int in_w, int out_h, int out_w, int pad0, int pad1, sr_stream_t stream) {
+    if (major < 0 || in_h < 0 || in_w < 0) return SR_EINVAL;
+    if (in_h * 2 + pad0 + pad1 - 4 + 1 != out_h || in_w * 2 + pad0 + pad1 - 4 + 1 != out_w) return SR_EINVAL;
+    if (major == 0 || out_h <= 0 || out_w <= 0) return SR_OK;
+    if (!out || !x || !k || !addend) return SR_EINVAL;
+    const int tiles_x = (out_w + R_OW - 1) / R_OW, tiles_y = (out_h + R_OH - 1) / R_OH;
+    const int64_t blocks = (int64_t)tiles_x * tiles_y * major;
+    if (blocks >= 0x7FFFFFFFLL) return SR_ERANGE;
+    hipLaunchKernelGGL((k_fir4_resample<2, 1>), dim3((unsigned)blocks), dim3(256), 0, sr_stream(stream), out, x, k, in_h,
+                       in_w, out_h, out_w, pad0, pad0, tiles_x, tiles_y, addend);
     return sr_launch_status();
 }
 

@@ -18,7 +18,9 @@ from torch import nn
 from .layers import (Blur, ConstantInput, ConvLayer, EqualLinear, ModulatedConv2d, NoiseInjection,  # noqa: F401
                      PixelNorm, ResBlock, Upsample)
 from .op import FusedLeakyReLU, rasterize
+from .op import smallconv as _smallconv
 from .op.fused_elem import blur_noise_bias_act, noise_bias_act, noise_bias_act_affine
+from .op.upfirdn2d import upsample2_add
 
 CHANNEL_BASE = {4: 512, 8: 512, 16: 512, 32: 512, 64: 256, 128: 128, 256: 64, 512: 32, 1024: 16}
 
@@ -113,6 +115,15 @@ class ToRGB(nn.Module):
         self.bias = nn.Parameter(torch.zeros(1, 3, 1, 1))
 
     def forward(self, input, style, skip=None):
+        conv = self.conv
+        if _smallconv.supported(input, conv.out_channel):
+            # device tensors: the bias rides in the streaming 1x1 kernel and the skip addition in the up-sampling
+            # kernel's store — two launches for conv + bias + upsample + add (reference model.py:63-69)
+            out = _smallconv.modulated_conv1x1_small(input, conv.weight[0, :, :, 0, 0] * conv.scale,
+                                                     conv.modulation(style), self.bias.view(-1))
+            if skip is not None:
+                out = upsample2_add(skip, self.upsample.kernel, self.upsample.pad, out)
+            return out
         out = self.conv(input, style) + self.bias
         if skip is not None:
             out = out + self.upsample(skip)

@@ -18,13 +18,14 @@ def supported(x, n_out):
             and (x.size(2) * x.size(3)) % 4 == 0 and x.size(0) * x.size(1) <= 65535 and x.size(1) <= 4096)
 
 
-def _fwd(x, ws):
+def _fwd(x, ws, bias=None):
     x, ws = x.contiguous(), ws.contiguous()
     b, c, h, w = x.shape
     n = ws.size(1)
     out = torch.empty((b, n, h, w), dtype=x.dtype, device=x.device)
     with on_device_of(x):
-        rc = _lib.lib().sr_smallconv_fwd(_lib.ptr(out), _lib.ptr(x), _lib.ptr(ws), None, b, c, n, h * w,
+        rc = _lib.lib().sr_smallconv_fwd(_lib.ptr(out), _lib.ptr(x), _lib.ptr(ws),
+                                         _lib.ptr(bias.contiguous()) if bias is not None else None, b, c, n, h * w,
                                          stream_of(x))
     _lib.check(rc, "sr_smallconv_fwd")
     return out
@@ -57,16 +58,17 @@ def _dw(g, x):
 
 class SmallConvFwd(Function):
     @staticmethod
-    def forward(ctx, x, ws):
+    def forward(ctx, x, ws, bias=None):
         ctx.save_for_backward(x, ws)
-        return _fwd(x, ws)
+        return _fwd(x, ws, bias)
 
     @staticmethod
     def backward(ctx, g):
         x, ws = ctx.saved_tensors
         gx = SmallConvDx.apply(g, ws) if ctx.needs_input_grad[0] else None
         gw = SmallConvDw.apply(g, x) if ctx.needs_input_grad[1] else None
-        return gx, gw
+        gb = g.sum((0, 2, 3)) if len(ctx.needs_input_grad) > 2 and ctx.needs_input_grad[2] else None
+        return gx, gw, gb
 
 
 class SmallConvDx(Function):
@@ -97,7 +99,7 @@ class SmallConvDw(Function):
         return d_g, d_x
 
 
-def modulated_conv1x1_small(x, weight_jc, style):
-    """weight_jc [N, C] (already scaled), style [B, C] -> [B, N, H, W]."""
+def modulated_conv1x1_small(x, weight_jc, style, bias=None):
+    """weight_jc [N, C] (already scaled), style [B, C], optional bias [N] -> [B, N, H, W]."""
     ws = weight_jc[None, :, :] * style[:, None, :]
-    return SmallConvFwd.apply(x, ws)
+    return SmallConvFwd.apply(x, ws, bias)

@@ -137,6 +137,51 @@ def _upfirdn2d_cpu(input, kernel, up, down, pad):
     return y.reshape(n, c, y.shape[2], y.shape[3])
 
 
+class UpsampleAdd(Function):
+    """upfirdn2d(skip, kernel, up = 2, pad) + addend in one kernel (ToRGB's skip connection, reference model.py:66-68).
+    Linear in both inputs: the gradient of `skip` is the existing differentiable down-sampling operator, the gradient
+    of `addend` is the incoming gradient itself, so gradients of any order stay on the same kernels."""
+
+    @staticmethod
+    def forward(ctx, skip, kernel, addend, pad):
+        b, c, ih, iw = skip.shape
+        p0, p1 = pad
+        oh, ow = 2 * ih + p0 + p1 - 3, 2 * iw + p0 + p1 - 3
+        x, a, k = skip.contiguous(), addend.contiguous(), kernel.contiguous()
+        out = torch.empty((b, c, oh, ow), dtype=x.dtype, device=x.device)
+        with on_device_of(x):
+            rc = _lib.lib().sr_upsample2_add(_lib.ptr(out), _lib.ptr(x), _lib.ptr(k), _lib.ptr(a), b * c, ih, iw, oh,
+                                             ow, p0, p1, stream_of(x))
+        _lib.check(rc, "sr_upsample2_add")
+        ctx.save_for_backward(kernel)
+        ctx.cfg = (p0, p1, tuple(skip.shape), (oh, ow))
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (kernel,) = ctx.saved_tensors
+        p0, p1, in_size, out_size = ctx.cfg
+        g_skip = None
+        if ctx.needs_input_grad[0]:
+            g_pad = (4 - p0 - 1, in_size[3] * 2 - out_size[1] + p0 - 2 + 1, 4 - p0 - 1,
+                     in_size[2] * 2 - out_size[0] + p0 - 2 + 1)
+            g_skip = UpFirDn2dBackward.apply(g, kernel, flipped(kernel), (2, 2), (1, 1), (p0, p1, p0, p1), g_pad,
+                                             in_size, out_size)
+        return g_skip, None, (g if ctx.needs_input_grad[2] else None), None
+
+
+def upsample2_add(skip, kernel, pad, addend):
+    """addend + upfirdn2d(skip, kernel, up=2, pad=pad); one launch on device tensors with the 4x4 kernel."""
+    ok = (is_device_tensor(skip) and skip.dtype == torch.float32 and addend.dtype == torch.float32 and skip.dim() == 4
+          and tuple(kernel.shape) == (4, 4) and skip.numel() > 0
+          and tuple(addend.shape) == (skip.shape[0], skip.shape[1], 2 * skip.shape[2] + pad[0] + pad[1] - 3,
+                                      2 * skip.shape[3] + pad[0] + pad[1] - 3))
+    if not ok:
+        return addend + upfirdn2d(skip, kernel, up=2, down=1, pad=pad)
+    k = kernel if kernel.device == skip.device else kernel.to(skip.device)
+    return UpsampleAdd.apply(skip, k, addend, tuple(pad))
+
+
 def upfirdn2d(input, kernel, up=1, down=1, pad=(0, 0)):
     if not is_device_tensor(input):
         return _upfirdn2d_cpu(input, kernel, up, down, pad)

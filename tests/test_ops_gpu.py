@@ -563,3 +563,39 @@ def test_upfirdn2d_resampling_tiles_vs_oracle(up, down, pad, shape):
     gy0, gy1 = 4 - pad[0] - 1, in_h * up - y.shape[2] * down + pad[0] - up + 1
     want_gx = ops_np.upfirdn2d_full(gy, k[::-1, ::-1].copy(), down, down, up, up, gx0, gx1, gy0, gy1)
     assert bits_equal(gx.cpu().numpy(), want_gx)
+
+
+def test_torgb_fused_bias_and_skip_add_equal_the_separate_operators():
+    """ToRGB on device tensors = streaming 1x1 kernel with the bias + up-sampling kernel with the skip addition
+    (two launches) against conv, + bias, upsample, + (reference model.py:63-69): outputs bit for bit, gradients and
+    the double backward to round-off."""
+    import stylerenderer_amd.op as op
+    from stylerenderer_amd import model, synth
+
+    rgb = model.ToRGB(16, 32).to(DEV)
+    synth.fill_state_dict(rgb.state_dict(), salt=71)
+    x0, s0 = T(synth.det_normal((2, 16, 12, 20), 72)), T(synth.det_normal((2, 32), 73))
+    k0 = T(synth.det_normal((2, 3, 6, 10), 74))
+    proj = T(synth.det_normal((2, 3, 12, 20), 75))
+
+    def run(fused):
+        x, s, k = (t.clone().requires_grad_() for t in (x0, s0, k0))
+        if fused:
+            y = rgb(x, s, k)
+        else:
+            y = rgb.conv(x, s) + rgb.bias
+            y = y + op.upfirdn2d(k, rgb.upsample.kernel, up=2, pad=rgb.upsample.pad)
+        params = [x, s, k, rgb.bias, rgb.conv.weight]
+        g1 = torch.autograd.grad((y * proj).sum(), params, create_graph=True)
+        g2 = torch.autograd.grad((g1[0] * g1[0]).sum() + (g1[2] * g1[2]).sum(), [s, rgb.conv.weight], allow_unused=True)
+        return y.detach(), [g.detach() for g in g1], g2
+
+    ya, ga, ha = run(True)
+    yb, gb, hb = run(False)
+    assert torch.equal(ya, yb)
+    for u, v in zip(ga, gb):
+        assert float((u - v).abs().max()) <= 1e-6 * float(v.abs().max()) + 1e-9
+    for u, v in zip(ha, hb):
+        assert (u is None) == (v is None)
+        if v is not None:
+            assert float((u - v).abs().max()) <= 1e-5 * float(v.abs().max()) + 1e-9
