@@ -322,7 +322,9 @@ class ConvLayer(nn.Sequential):
         work, and its gradient is one zero-insert + FIR pass instead of zero-fill, strided copy and a full blur);
       * the convolution's own bias and the FusedLeakyReLU bias (the reference has both) are added as one vector
         in the activation kernel: their gradients are the same sum, computed once in the activation backward
-        instead of a second full-tensor reduction."""
+        instead of a second full-tensor reduction;
+      * stride-1 3x3 layers on Winograd-eligible maps apply that bias + LeakyReLU in the convolution's store
+        (op.conv.ConvNBAFn, the node StyledConv uses, without noise or modulation)."""
 
     def __init__(self, in_channel, out_channel, kernel_size, downsample=False,
                  blur_kernel=[1, 3, 3, 1], bias=True, activate="lrelu"):
@@ -359,8 +361,16 @@ class ConvLayer(nn.Sequential):
             conv = mods[0]
             act = mods[1] if len(mods) > 1 and isinstance(mods[1], FusedLeakyReLU) else None
             if act is not None and conv.bias is not None and conv._geom() is not None:
+                bias = conv.bias + act.bias
+                if conv._geom() == "c3" and _fused_tails():
+                    # stride-1 3x3 layers of 32^2 .. 256^2 maps: bias + LeakyReLU in the Winograd kernel's store
+                    # (the pre-activation tensor is never written or kept for backward)
+                    xc = x.contiguous()
+                    wt, _ = _weight_prep(conv.weight, conv.scale)
+                    if _conv.conv_nba_supported(xc, wt, None):
+                        return _conv.conv2d_nba(xc, wt, None, None, None, None, bias, act.negative_slope, act.scale)
                 x = conv(x, with_bias=False)
-                return fused_leaky_relu(x, conv.bias + act.bias, act.negative_slope, act.scale)
+                return fused_leaky_relu(x, bias, act.negative_slope, act.scale)
             x = conv(x)
             mods = mods[1:]
         for m in mods:

@@ -443,3 +443,31 @@ def test_fused_styledconv_nodes_second_order_with_linked_inputs(up):
     gs_u, g2_u = run(False)
     assert rel_err_t(gs_f, gs_u) < 1e-5
     assert rel_err_t(g2_f, g2_u) < 1e-4
+
+
+def test_convlayer_shortcuts_equal_the_module_chain(monkeypatch):
+    """layers.ConvLayer on device tensors (bias + LeakyReLU in the Winograd store; both biases added once; the skip
+    branch's blur evaluated at the kept pixels) against the plain chain Blur -> EqualConv2d(+bias) -> FusedLeakyReLU."""
+    from stylerenderer_amd import layers, synth
+
+    cases = [dict(in_channel=16, out_channel=64, kernel_size=3),                      # Winograd + fused tail
+             dict(in_channel=16, out_channel=24, kernel_size=3),                      # direct kernel, biases merged
+             dict(in_channel=16, out_channel=32, kernel_size=1, downsample=True, activate=False, bias=False),
+             dict(in_channel=16, out_channel=32, kernel_size=3, downsample=True)]
+    for i, kw in enumerate(cases):
+        m = layers.ConvLayer(**kw).to(DEV)
+        synth.fill_state_dict(m.state_dict(), salt=300 + i)
+        x0 = torch.from_numpy(synth.det_normal((2, 16, 32, 32), 310 + i)).to(DEV)
+
+        def run(chain):
+            x = x0.clone().requires_grad_()
+            y = torch.nn.Sequential.forward(m, x) if chain else m(x)
+            proj = torch.from_numpy(synth.det_normal(tuple(y.shape), 320 + i)).to(DEV)
+            grads = torch.autograd.grad((y * proj).sum(), [x] + list(m.parameters()))
+            return y.detach(), grads
+
+        ya, ga = run(False)
+        yb, gb = run(True)
+        assert rel_err_t(ya, yb) < 2e-6, kw
+        for u, v in zip(ga, gb):
+            assert rel_err_t(u, v) < 2e-5, kw
