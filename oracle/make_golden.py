@@ -475,7 +475,21 @@ def gold_mesh(ns):
     wex = dn((nv * 3, de), 76)                                  # transposed layout on purpose
     m = ref_fm.LinearMorphableModel(nv, ds, de, mean, wsh, wex, sigma_shape=[1.5, 2.0], sigma_expression=.25)
     x = T(dn((4, ds + de), 77))
-    save("mesh_frontend", v=v, tri=tri.astype(np.int32), normals=n.detach().numpy(), grad_v=gv.numpy(),
+    # load_bfm on a synthetic .mat-shaped dict (the licensed file is absent): pins the key contract and scaling
+    nvb, dsb, deb = 6, 3, 2
+    cell = np.empty((1, 1), dtype=object)
+    cell[0, 0] = np.array([[1, 2, 3], [3, 4, 5], [4, 5, 6], [1, 3, 6]], np.float64).T        # 1-based, [3, nf]
+    bfm = {"v": dn((3, nvb), 81).astype(np.float64) * 1e5, "w_shape": dn((3 * nvb, dsb), 82).astype(np.float64) * 1e5,
+           "w_exp": dn((3 * nvb, deb), 83).astype(np.float64) * 1e5, "sigma_shape": np.array([[2.0], [0.5], [1.5]]),
+           "sigma_exp": np.array([[0.3, 0.7]]), "tri": cell}
+    np.random.seed(0)
+    bm, btri = ref_fm.load_bfm(dict(bfm))
+    bx = T(dn((2, dsb + deb), 84))
+    bfm_arrays = {"bfm_v": bfm["v"], "bfm_w_shape": bfm["w_shape"], "bfm_w_exp": bfm["w_exp"],
+                  "bfm_sigma_shape": bfm["sigma_shape"], "bfm_sigma_exp": bfm["sigma_exp"], "bfm_tri_cell": cell[0, 0],
+                  "bfm_x": bx.numpy(), "bfm_out": bm(bx).detach().numpy(), "bfm_tri": btri.numpy(),
+                  "bfm_sigma": bm.sigma.detach().numpy()}
+    save("mesh_frontend", v=v, tri=tri.astype(np.int32), **bfm_arrays, normals=n.detach().numpy(), grad_v=gv.numpy(),
          euler_in=ang.numpy(), euler_yxz=R.numpy(), euler_zyx_single=R2.numpy(), normalize_out=nrm.numpy(),
          lmm_mean=mean, lmm_wsh=wsh, lmm_wex=wex, lmm_x=x.numpy(), lmm_out=m(x).detach().numpy(),
          lmm_sigma=m.sigma.detach().numpy(), lmm_reg=np.array(m.regulation(x).item()),

@@ -69,3 +69,30 @@ class LinearMorphableModel(nn.Module):
 
     def regulation(self, x):
         return ((x / self.sigma[np.newaxis, :]) ** 2).sum()
+
+
+def load_bfm(file_name="/data/BaselFaceModel.mat"):
+    """Basel Face Model -> (LinearMorphableModel, tri int64 [nf, 3]) with the reference's `.mat` contract
+    (reference face_model.py:342-362): keys `v` [3, nv] (mean shape), `w_shape` [3 nv, ds], `w_exp` [3 nv, de],
+    optional `sigma_shape` / `sigma_exp` (folded into the bases), `tri` as a 1x1 MATLAB cell of 1-based indices.
+    Coordinates are centred and scaled by 1e-5 like the reference.  `file_name` may be the path of the (licensed,
+    not distributed) file or an already loaded dict."""
+    if isinstance(file_name, str):
+        import scipy.io as sio
+
+        data = sio.loadmat(file_name)
+    else:
+        data = file_name
+    v = (data["v"] - data["v"].mean(1).reshape(-1, 1)).T * 1e-5
+    w_shape = data["w_shape"] * 1e-5
+    w_exp = data["w_exp"] * 1e-5
+    if "sigma_shape" in data.keys():
+        w_shape = w_shape.dot(np.diag(np.reshape(data["sigma_shape"], -1)))
+    if "sigma_exp" in data.keys():
+        w_exp = w_exp.dot(np.diag(np.reshape(data["sigma_exp"], -1)))
+    tri = np.asarray(data["tri"][0, 0]).astype(np.int64)
+    tri = tri - tri.min()
+    if tri.shape[0] == 3 and tri.shape[1] != 3:
+        tri = tri.T
+    model = LinearMorphableModel(len(v), w_shape.shape[1], w_exp.shape[1], v, w_shape, w_exp)
+    return model, torch.from_numpy(np.ascontiguousarray(tri))

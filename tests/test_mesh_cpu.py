@@ -109,3 +109,19 @@ def test_training_step_with_ada_branch():
     logs = [tr.step(data.batch(4)) for _ in range(2)]
     assert all(np.isfinite(v) for log in logs for v in log.values())
     assert 0.0 <= tr.ada_aug_p <= 1.0 and float(tr.ada_augment[1]) == 8.0           # sign statistics accumulate
+
+
+def test_load_bfm_contract(golden):
+    """face_model.load_bfm (reference face_model.py:342-362) on the .mat-shaped dict the fixture was generated from:
+    centring, 1e-5 scaling, sigma folding, 1-based MATLAB cell of triangles."""
+    g = golden("mesh_frontend")
+    cell = np.empty((1, 1), dtype=object)
+    cell[0, 0] = g["bfm_tri_cell"]
+    data = {"v": g["bfm_v"], "w_shape": g["bfm_w_shape"], "w_exp": g["bfm_w_exp"],
+            "sigma_shape": g["bfm_sigma_shape"], "sigma_exp": g["bfm_sigma_exp"], "tri": cell}
+    np.random.seed(0)
+    m, tri = face_model.load_bfm(data)
+    assert tri.dtype == torch.int64 and np.array_equal(tri.numpy(), g["bfm_tri"]) and int(tri.min()) == 0
+    out = m(torch.from_numpy(g["bfm_x"]))
+    assert rel_err(out.detach().numpy(), g["bfm_out"]) < 1e-6
+    assert np.allclose(m.sigma.detach().numpy(), g["bfm_sigma"])
