@@ -61,8 +61,8 @@ class GraphedTrainer(Trainer):
                 torch.distributed.broadcast(p.data, 0)
         self.g_params = [p for n, p in g.named_parameters() if n not in self.frozen]
         self.d_params = list(d.parameters())
-        self.flat_g, self.views_g = self._flatten_grads(self.g_params)
-        self.flat_d, self.views_d = self._flatten_grads(self.d_params)
+        self.flat_g, self.views_g = self._flatten_grads(self.g_params, self.world)
+        self.flat_d, self.views_d = self._flatten_grads(self.d_params, self.world)
         for p, v in zip(self.g_params + self.d_params, self.views_g + self.views_d):
             p.grad = v
         g_ratio = a["g_reg_every"] / (a["g_reg_every"] + 1)
@@ -74,6 +74,10 @@ class GraphedTrainer(Trainer):
         self.s_real = torch.zeros(batch, 3, size, size, device=dev)
         self.s_inject = {k: torch.zeros((), dtype=torch.int64, device=dev) for k in ("d", "g", "path")}
         self.s_loss = {k: torch.zeros((), device=dev) for k in LOSS_SLOTS}
+        # gradient averaging between the replays: all-reduce or in-place reduce-scatter + all-gather, whichever
+        # this node's RCCL runs faster on the real buffers (distributed.FlatGradReducer)
+        self.reduce_g = sr_dist.FlatGradReducer(self.flat_g, self.world)
+        self.reduce_d = sr_dist.FlatGradReducer(self.flat_d, self.world)
         self.s_mesh = None
         if self.use_mesh:
             if mesh_vertices is None:
@@ -85,8 +89,8 @@ class GraphedTrainer(Trainer):
 
     # ---- static state -----------------------------------------------------------------------------
     @staticmethod
-    def _flatten_grads(params):
-        offs, total = flat_layout(params)                      # 256-byte aligned slots, shared with FlatAdam
+    def _flatten_grads(params, world=1):
+        offs, total = flat_layout(params, world)               # 256-byte aligned slots, shared with FlatAdam
         flat = torch.zeros(total, device=params[0].device, dtype=params[0].dtype)
         return flat, flat_views(flat, params, offs)
 
@@ -215,9 +219,12 @@ class GraphedTrainer(Trainer):
         torch.cuda.synchronize()
         if not self.capture:
             return
+        # thread_local: only THIS thread's calls are policed during capture.  Under the default (global) mode the
+        # RCCL watchdog thread's routine hipEventQuery on an earlier collective (the warm-up reductions, a DDP leg
+        # that ran before) aborts the process with "operation not permitted when stream is capturing".
         for name in ("d", "r1", "g", "path", "d_opt", "g_opt"):
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
+            with torch.cuda.graph(graph, capture_error_mode="thread_local"):
                 bodies[name]()
             self.graphs[name] = graph
         torch.cuda.synchronize()
@@ -230,8 +237,7 @@ class GraphedTrainer(Trainer):
 
     def _reduce(self, flat):
         if self.world > 1:
-            torch.distributed.all_reduce(flat, op=torch.distributed.ReduceOp.SUM)
-            flat.div_(self.world)
+            (self.reduce_g if flat is self.flat_g else self.reduce_d)()
 
     # ---- one iteration -------------------------------------------------------------------------------
     def step(self, real_img, mesh=None, faces=None, log=True):

@@ -92,7 +92,7 @@ class LatentInverter:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):     # see graph_train.build_graphs
             self._iteration()
         return warmup
 

@@ -14,12 +14,15 @@ from . import _lib
 ALIGN = 64          # floats: 256-byte aligned views
 
 
-def flat_layout(params):
+def flat_layout(params, multiple_of=1):
+    """Offsets of 256-byte aligned slots and the total length, rounded up to `multiple_of` * ALIGN floats (so the
+    buffer splits evenly over the ranks of a reduce-scatter)."""
     offs, off = [], 0
     for p in params:
         offs.append(off)
         off += (p.numel() + ALIGN - 1) // ALIGN * ALIGN
-    return offs, off
+    step = ALIGN * max(1, int(multiple_of))
+    return offs, (off + step - 1) // step * step
 
 
 def flat_views(flat, params, offs):
@@ -32,8 +35,9 @@ class FlatAdam:
         p0 = self.params[0]
         if p0.device.type != "cuda" or any(p.dtype != torch.float32 for p in self.params):
             raise RuntimeError("FlatAdam: float32 parameters on a GPU required")
-        self.offs, self.total = flat_layout(self.params)
-        if flat_grad.numel() != self.total:
+        self.offs, _ = flat_layout(self.params)
+        self.total = flat_grad.numel()                 # may carry tail padding (rank-divisible length)
+        if self.total < self.offs[-1] + self.params[-1].numel():
             raise RuntimeError("FlatAdam: gradient buffer does not follow flat_layout(params)")
         self.flat_g = flat_grad
         self.flat_p = torch.zeros(self.total, device=p0.device)

@@ -111,6 +111,11 @@ def worker(rank, world, port, outdir):
     checksum = torch.stack([p.detach().double().sum() for p in tr.generator.parameters()]
                            + [p.detach().double().sum() for p in tr.discriminator.parameters()])
     overlap = bucket_launch_order(rank)
+    # flat-buffer gradient averaging of the graph-replayed trainer (all-reduce form; gloo has no reduce-scatter)
+    flat = torch.arange(8, dtype=torch.float32) * (rank + 1)
+    red_flat = sr_dist.FlatGradReducer(flat)
+    red_flat()
+    red["flat_mode"], red["flat_mean"] = red_flat.mode, flat.tolist()
     torch.save({"grads": grads, "red": red, "logs": logs, "checksum": checksum, "loss": loss, "overlap": overlap,
                 "init_sum": init_sum, "z_probe": z_probe},
                os.path.join(outdir, "rank%d.pt" % rank))
@@ -138,6 +143,12 @@ def test_ddp_gradients_equal_full_batch(two_rank_run):
         scale = float(ref.abs().max()) + 1e-12
         assert float((r0["grads"][n] - ref).abs().max()) <= 2e-5 * scale, n
         assert torch.equal(r0["grads"][n], r1["grads"][n]), n      # replicas hold the same gradient
+
+
+def test_flat_gradient_reducer(two_rank_run):
+    for r in two_rank_run:
+        assert r["red"].pop("flat_mode") == "allreduce"
+        assert r["red"].pop("flat_mean") == [1.5 * i for i in range(8)]          # mean of x and 2x
 
 
 def test_packed_scalar_reduction(two_rank_run):
