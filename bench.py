@@ -238,6 +238,10 @@ def train_leg(dev, rank, world, iters, batch, size=256):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, t_enq = float(t[0]), float(t[1])
     finite = all(bool(torch.isfinite(v)) for v in last.values())
+    collective = None
+    if graphs and world > 1:
+        collective = {"generator_grads": tr.reduce_g.mode, "discriminator_grads": tr.reduce_d.mode,
+                      **{"g_" + k: round(v, 3) if isinstance(v, float) else v for k, v in tr.reduce_g.timings.items()}}
     out = {"workload": "BASELINE config[2]: GeneratorWithMap(%d) + Discriminator(%d) full G+D step, %d img/GPU "
                        "(global %d), d_reg_every 16, g_reg_every 4, path batch %d, synthetic images + mesh "
                        "nv=%d nf=%d" % (size, size, batch, batch * world, max(1, batch // 2),
@@ -248,7 +252,7 @@ def train_leg(dev, rank, world, iters, batch, size=256):
            "launch_bound": bool(t_enq > 0.95 * elapsed),
            "execution": ("hipGraph replay per phase (graph_train.GraphedTrainer); flat-buffer gradient all-reduce "
                          "between replays" if graphs else "eager launches (train.Trainer, DDP buckets)"),
-           "losses_finite": finite, "parallelism": "dp%d" % world}
+           "losses_finite": finite, "parallelism": "dp%d" % world, "gradient_collective": collective}
     if world > 1:
         n = int(G_PARAM_BYTES // 4)
         buf = torch.zeros(n, device=dev)

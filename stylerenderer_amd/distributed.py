@@ -139,7 +139,11 @@ class FlatGradReducer:
         if pin in ("allreduce", "rsag"):
             self.mode = pin if (pin == "allreduce" or self.shardable) else "allreduce"
         elif self.shardable and flat.is_cuda:
-            self.mode = self._autotune()
+            try:
+                self.mode = self._autotune()
+            except RuntimeError as e:              # a backend without in-place reduce-scatter: every rank lands here
+                self.timings = {"autotune_error": str(e)[:200]}
+                self.mode = "allreduce"
 
     def _shard(self):
         n = self.flat.numel() // self.world
