@@ -163,3 +163,41 @@ def test_flat_adam_matches_torch_adam_and_speaks_its_checkpoint_format():
         b.step()
         for p, q in zip(ref, mine):
             assert float((p - q).abs().max()) <= 2e-6 * float(p.abs().max()) + 1e-7, step
+
+
+def test_checkpoint_moves_between_graphed_and_eager_trainers(tmp_path):
+    """The reference's checkpoint dict written by the graph-replayed trainer (flat-buffer Adam) resumes in the eager
+    trainer (torch.optim.Adam) and the other way round: weights, EMA, both optimisers' moments, iteration."""
+    from stylerenderer_amd import checkpoint, graph_train
+
+    dev = torch.device("cuda")
+    kw = dict(size=16, latent=32, n_mlp=2, device=dev, seed=4)
+    a = graph_train.GraphedTrainer(batch=4, **kw)
+    data = train.SyntheticImages(8, 16, dev)
+    for _ in range(3):
+        a.step(data.batch(4))
+    path = checkpoint.save_checkpoint(str(tmp_path / checkpoint.checkpoint_name(3)), a)
+    ck = torch.load(path, weights_only=False)
+    assert set(checkpoint.CKPT_KEYS) <= set(ck) and ck["iteration"] == 3
+    n_all = sum(1 for _ in a.generator.parameters())
+    assert len(ck["g_optim"]["param_groups"][0]["params"]) == n_all              # reference indexing
+    b = train.Trainer(**kw)
+    checkpoint.load_checkpoint(path, b, map_location=dev)
+    assert b.iteration == 3
+    for (n, p), (_, q) in zip(a.generator.named_parameters(), b.generator.named_parameters()):
+        assert torch.equal(p, q), n
+    used = [n for n, _ in a.generator.named_parameters() if n not in a.frozen]
+    sb = b.g_optim.state_dict()["state"]
+    sa = a.g_optim.state_dict()["state"]
+    assert len(sb) == len(sa) == len(used)
+    for i in range(len(used)):
+        assert torch.equal(sb[i]["exp_avg_sq"], sa[i]["exp_avg_sq"]) and float(sb[i]["step"]) == float(sa[i]["step"])
+    b.step(data.batch(4))                                                        # the eager trainer continues
+    path2 = checkpoint.save_checkpoint(str(tmp_path / checkpoint.checkpoint_name(4)), b)
+    c = graph_train.GraphedTrainer(batch=4, **kw)
+    checkpoint.load_checkpoint(path2, c, map_location=dev)
+    assert c.iteration == 4 and float(c.g_optim.step_t) == float(b.g_optim.state_dict()["state"][0]["step"])
+    for (n, p), (_, q) in zip(b.discriminator.named_parameters(), c.discriminator.named_parameters()):
+        assert torch.equal(p, q), n
+    log = c.step(data.batch(4))
+    assert all(np.isfinite(v) for v in log.values())
