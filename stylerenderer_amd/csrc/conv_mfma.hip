@@ -80,15 +80,23 @@ struct ConvParams {
 // are padded to a multiple of 4 floats, and the whole image moves with 16-byte DMAs (a 4-byte DMA
 // costs the same issue slot for a quarter of the data: measured ~3x fewer DMA instructions per
 // chunk).  Needs IW % 4 == 0, a 16-byte aligned input and stride 1; otherwise the 4-byte form.
+// V4 with IS == 2 ("rotating lead", ROT): the stride-2 data gradient of the up-sampling layers reads (2^k+1)-wide
+// maps whose rows are NOT 16-byte aligned — but with IW = 1 and IH*IW = 1 (mod 4) the alignment of a window row is
+// (channel + row + column) mod 4, so every LDS row is filled from the aligned address at or below its window start
+// (lead = 0..3 floats, different per row and channel) and the operand fetch adds that lead back: its value for
+// k-step (channel pair cp, tap row ty) is (L0 + 2 cp + ty) mod 4 with a per-lane constant L0 — four precomputed
+// offsets, selected at compile time in the unrolled loop.  Same 16-byte DMA count as the aligned stride-1 form.
 template <int IS, int TY, int TX, int PW, int PH, int PB, bool V4>
 struct Geo {
+    static constexpr bool ROT = V4 && IS == 2;
     static constexpr int NT = TY * TX;
     // channels per K chunk: ~32-36 k-steps of MFMA work per barrier whatever the window
     static constexpr int KC = NT >= 9 ? 4 : (NT >= 4 ? 8 : 16);
     static constexpr int EH = (PH - 1) * IS + TY;
     static constexpr int EW = (PW - 1) * IS + TX;
-    static constexpr int LEAD = V4 ? (TX > 1 ? 3 : 0) : 0;
-    static constexpr int EWP = V4 ? (LEAD + EW + 3) / 4 * 4 : EW + ((EW % 2 == 0) ? 1 : 0);
+    static constexpr int LEAD = (V4 && !ROT) ? (TX > 1 ? 3 : 0) : 0;
+    static constexpr int EWP = ROT ? (EW + 3 + 3) / 4 * 4
+                                   : (V4 ? (LEAD + EW + 3) / 4 * 4 : EW + ((EW % 2 == 0) ? 1 : 0));
     static constexpr int PLANE = PB * EH * EWP;                  // one channel of the chunk
     static constexpr int W_FLOATS = NT * KC * BN;                // [tap][c][128]
     static constexpr int W_INSTR = W_FLOATS / 256;               // 1 KiB (2 rows) per wave instruction
@@ -143,6 +151,7 @@ __global__ __launch_bounds__(256) void k_conv_mfma(const ConvParams p) {
 
     // ---- per-lane LDS offsets of the MFMA operands (inside one buffer)
     int a_off[2], b_off[2], s_off[2];
+    int b_rot[2][4];               // ROT: b_off plus the lead of k-step class (2 cp + ty) mod 4
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
         a_off[t] = half * BN + wco * 64 + t * 32 + l31;
@@ -150,6 +159,9 @@ __global__ __launch_bounds__(256) void k_conv_mfma(const ConvParams p) {
         const int px = m % PW, py = (m / PW) % PH, pb = m / (PW * PH);
         b_off[t] = G::W_FLOATS + half * G::PLANE + (pb * G::EH + py * IS) * G::EWP + px * IS + G::LEAD;
         s_off[t] = G::S_BASE + pb * G::KC + half;                        // style of (sample, channel)
+        const int l0 = half + iy0 + py * IS + ix0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) b_rot[t][k] = b_off[t] + ((l0 + k) & 3);
     }
 
     // ---- DMA descriptors (chunk-invariant part), a few registers per lane
@@ -185,9 +197,17 @@ __global__ __launch_bounds__(256) void k_conv_mfma(const ConvParams p) {
                 const int q = f % G::PLANE;
                 const int cola = q % G::EWP, r = (q / G::EWP) % G::EH;
                 pb = q / (G::EWP * G::EH);
-                const int gy = iy0 + r, gx = ix0 - G::LEAD + cola;
-                if (gy >= 0 && gy < p.IH && gx >= 0 && gx + 3 < p.IW && b0 + pb < p.B)
-                    src = (pb * p.C + c) * p.IH * p.IW + gy * p.IW + gx;
+                const int gy = iy0 + r;
+                int gx = ix0 - G::LEAD + cola;
+                bool ok = gy >= 0 && gy < p.IH && b0 + pb < p.B;
+                if (G::ROT) {
+                    // aligned group at or below the window start of this (channel, row); it may run into the
+                    // neighbouring row — those columns are never fetched as operands
+                    gx = ix0 - ((c * (p.IH * p.IW) + gy * p.IW + ix0) & 3) + cola;
+                } else {
+                    ok = ok && gx >= 0 && gx + 3 < p.IW;
+                }
+                if (ok) src = (pb * p.C + c) * p.IH * p.IW + gy * p.IW + gx;
             } else if (j >= G::IMG_INSTR && j < G::IN_INSTR) {
                 const int e = (j - G::IMG_INSTR) * 64 + lane;
                 if (e < G::KC * PB) {
@@ -331,8 +351,8 @@ __global__ __launch_bounds__(256) void k_conv_mfma(const ConvParams p) {
                     const int i_tap = (2 * cp) * G::PLANE + ty * G::EWP + tx;
                     float a0 = sb[w_tap + a_off[0]];
                     float a1 = sb[w_tap + a_off[1]];
-                    float x0 = sb[i_tap + b_off[0]];
-                    float x1 = sb[i_tap + b_off[1]];
+                    float x0 = sb[i_tap + (G::ROT ? b_rot[0][(2 * cp + ty) & 3] : b_off[0])];
+                    float x1 = sb[i_tap + (G::ROT ? b_rot[1][(2 * cp + ty) & 3] : b_off[1])];
                     if (PB == 1) { a0 *= sc0; a1 *= sc0; }
                     else { x0 *= sc0; x1 *= sc1; }
                     acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, x0, acc[0][0], 0, 0, 0);
@@ -669,6 +689,12 @@ bool wino_enabled() {
     return !(e && e[0] == '0');
 }
 
+// SR_CONV_ROT=0 keeps the 4-byte halo DMA of the stride-2 kernels (A/B measurements)
+bool rot_enabled() {
+    const char* e = std::getenv("SR_CONV_ROT");
+    return !(e && e[0] == '0');
+}
+
 template <int IS, int TY, int TX>
 int launch_by_patch(ConvParams& p, hipStream_t st) {
     int pw, ph, pb;
@@ -693,10 +719,18 @@ int launch_by_patch(ConvParams& p, hipStream_t st) {
     // 16-byte halo DMAs: stride 1, one sample per tile, aligned rows, window origin dx0 = -(TX > 1)
     const bool v4 = IS == 1 && pb == 1 && p.IW % 4 == 0 && (reinterpret_cast<uintptr_t>(p.in) & 15) == 0 &&
                     p.gx_base % 4 == 0 && p.dx0 == (TX > 1 ? -1 : 0);
+    // rotating-lead 16-byte DMAs for stride 2 (see Geo): (2^k+1)-sized maps, window inside the image, whole tiles
+    const bool rot = IS == 2 && pb == 1 && (p.IW & 3) == 1 && ((p.IH * p.IW) & 3) == 1 && p.C % 4 == 0 &&
+                     (reinterpret_cast<uintptr_t>(p.in) & 15) == 0 && p.dx0 >= 0 && p.dy0 >= 0 && p.gx_base == 0 &&
+                     p.gy_base == 0 && (p.GW - 1) * 2 + p.dx0 + TX <= p.IW && (p.GH - 1) * 2 + p.dy0 + TY <= p.IH &&
+                     ext_w % pw == 0 && ext_h % ph == 0 && rot_enabled();
     int rc;
     if (IS == 1 && v4) {
         if (pw == 32) rc = launch_one<1, TY, TX, 32, 4, 1, true>(p, grid, st);
         else rc = launch_one<1, TY, TX, 16, 8, 1, true>(p, grid, st);
+    } else if (IS == 2 && rot && TY == 3 && TX == 3) {
+        if (pw == 32) rc = launch_one<2, 3, 3, 32, 4, 1, true>(p, grid, st);
+        else rc = launch_one<2, 3, 3, 16, 8, 1, true>(p, grid, st);
     } else if (pw == 32) rc = launch_one<IS, TY, TX, 32, 4, 1, false>(p, grid, st);
     else if (pw == 16) rc = launch_one<IS, TY, TX, 16, 8, 1, false>(p, grid, st);
     else if (pw == 8) rc = launch_one<IS, TY, TX, 8, 8, 2, false>(p, grid, st);

@@ -47,6 +47,9 @@ CASES = [
     (2, 8, 6, 9, 9, 3, 2, 0, False),
     (2, 10, 5, 33, 33, 3, 2, 0, False),
     (1, 7, 3, 65, 65, 3, 2, 0, False),
+    (2, 8, 6, 65, 65, 3, 2, 0, False),           # rotating-lead 16-byte halo DMA, 32 x 4 patches
+    (1, 12, 130, 33, 33, 3, 2, 0, False),        # same, 16 x 8 patches, two channel tiles, channel tail (12 = 3 x 4)
+    (2, 16, 64, 129, 129, 3, 2, 0, False),       # same, several tiles per row, split over more chunks
     (2, 8, 6, 4, 4, 3, 2, 0, True),
     (2, 8, 6, 8, 8, 3, 2, 0, True),
     (1, 11, 9, 16, 16, 3, 2, 0, True),
@@ -57,6 +60,23 @@ CASES = [
     (2, 16, 5, 32, 32, 1, 1, 0, False),
     (2, 6, 4, 9, 9, 1, 2, 0, False),
 ]
+
+
+def test_stride2_rotating_lead_dma_equals_dword_dma(monkeypatch):
+    """The 16-byte rotating-lead halo DMA of the stride-2 data-gradient kernel stages the same operands as the
+    4-byte form (SR_CONV_ROT=0): outputs are bit-identical (same MFMA chain, same k order)."""
+    from stylerenderer_amd.op.conv import conv2d_mfma
+
+    g = torch.Generator().manual_seed(5)
+    for b, c, n, hw in ((2, 16, 64, 129), (1, 64, 128, 257), (3, 8, 6, 33)):
+        x = torch.randn(b, c, hw, hw, generator=g).to(DEV)
+        wt = torch.randn(9, c, n, generator=g).to(DEV)
+        isc, osc = torch.randn(b, c, generator=g).to(DEV), torch.randn(b, n, generator=g).to(DEV)
+        monkeypatch.setenv("SR_CONV_ROT", "1")
+        a = conv2d_mfma(x, wt, isc, osc, None, 3, 2, 0, False)
+        monkeypatch.setenv("SR_CONV_ROT", "0")
+        d = conv2d_mfma(x, wt, isc, osc, None, 3, 2, 0, False)
+        assert torch.equal(a, d), (b, c, n, hw)
 
 
 @pytest.mark.parametrize("case", CASES)
