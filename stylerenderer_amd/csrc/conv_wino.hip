@@ -25,6 +25,7 @@
 //     128 contiguous bytes of an output row).
 // LDS: 2 x (U 32 KB + V 32 KB + d 13 KB) + style = 156 KB of the CU's 160 KB; one workgroup per CU
 // (the 256 accumulators allow one wave per SIMD anyway).
+#include <type_traits>
 #include "common.h"
 #include "conv_wino.h"
 
@@ -43,6 +44,14 @@ constexpr int LEAD = 3;                   // halo columns start at x0 - 4 (16-by
 constexpr int EWP = 40;                   // LEAD + 2*TW + 2 = 37 -> row pitch 40 floats
 constexpr int PLANE = EH * EWP;           // 400 floats per channel
 
+#ifdef WINO_TIMING
+// debug build only (scripts/build_variant.sh): per-workgroup time stamps of wave 0
+__device__ long long g_wino_stamps[8 * 16384];
+#define WINO_STAMP(i) do { if (tid == 0) { g_wino_stamps[(blockIdx.x & 16383) * 8 + (i)] = wall_clock64(); } } while (0)
+#else
+#define WINO_STAMP(i)
+#endif
+
 template <int KC>
 struct WG {
     static constexpr int CQ = KC / 4;                       // channel quads per chunk
@@ -59,6 +68,7 @@ struct WG {
 
 template <int KC>
 __global__ __launch_bounds__(256) void k_conv_wino(const WinoParams p) {
+#if __HIP_DEVICE_COMPILE__   // the buffer-resource builtins exist in the device pass only; the host pass needs the stub
     using G = WG<KC>;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* const ubuf = smem;
@@ -86,40 +96,51 @@ __global__ __launch_bounds__(256) void k_conv_wino(const WinoParams p) {
     const int half = lane >> 5, l31 = lane & 31;
     const int wn = wave & 1, wt = wave >> 1;
     const int nchunks = p.C / KC;
+    WINO_STAMP(0);
+#ifdef WINO_TIMING
+    if (tid == 0) {
+        g_wino_stamps[(blockIdx.x & 16383) * 8 + 6] = __builtin_amdgcn_s_getreg((31 << 11) | 4);
+        g_wino_stamps[(blockIdx.x & 16383) * 8 + 7] = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+    }
+#endif
 
     // style row of this sample (ones when absent), consumed by the input transform
     for (int c = tid; c < p.C; c += 256) sty[c] = p.iscale ? p.iscale[(int64_t)b * p.C + c] : 1.0f;
 
-    // ---- DMA descriptors of the halo patch (chunk 0); -1 = zero line (outside the image)
-    int d_src[G::D_PER_WAVE];
+    // ---- DMA descriptors of the halo patch: byte offset of this lane's 16-byte line inside the sample (chunk 0);
+    // lines outside the image get an offset beyond the buffer's range: a buffer load returns zeros for them.
+    // Buffer addressing keeps the per-chunk part of every address in SGPRs (soffset): no VALU work per DMA.
+    int d_off[G::D_PER_WAVE];
 #pragma unroll
     for (int i = 0; i < G::D_PER_WAVE; ++i) {
         const int j = wave + 4 * i;
         const int f = (j * 64 + lane) * 4;
-        int src = -1;
+        int off = 0x7FFFFFF0;
         if (j < G::D_INSTR && f < G::D_FLOATS) {
             const int c = f / PLANE, q = f % PLANE;
             const int r = q / EWP, cola = q % EWP;
             const int gy = oy0 - 1 + r, gx = ox0 - 4 + cola;
-            if (gy >= 0 && gy < p.H && gx >= 0 && gx + 3 < p.W) src = (c * p.H + gy) * p.W + gx;
+            if (gy >= 0 && gy < p.H && gx >= 0 && gx + 3 < p.W) off = ((c * p.H + gy) * p.W + gx) * 4;
         }
-        d_src[i] = src;
+        d_off[i] = off;
     }
-    const float* in_b = p.in + (int64_t)b * p.C * p.H * p.W;
-    const int chunk_in = KC * p.H * p.W;
-    const float* u_n = p.u + (int64_t)n_t * nchunks * G::UV + lane * 4;
+    const int chunk_in_bytes = KC * p.H * p.W * 4;
+    const __amdgpu_buffer_rsrc_t r_in = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.in + (int64_t)b * p.C * p.H * p.W), 0, p.C * p.H * p.W * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_u = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.u + (int64_t)n_t * nchunks * G::UV), 0, nchunks * G::UV * 4, 0x00020000);
+    const int u_voff = lane * 16;
 
     // one DMA instruction each (all waves issue the same number; surplus ones land in the pad zone)
     auto dma_d1 = [&](int k, int buf, int i) {
         const int j = wave + 4 * i;
         float* dst = j < G::D_INSTR ? dbuf + buf * G::D_BUF + j * 256 : smem + G::PAD + (wave - 1) * 256;
-        const float* src = d_src[i] >= 0 ? in_b + (int64_t)k * chunk_in + d_src[i] : g_wino_zero;
-        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)dst, 16, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(r_in, (lptr_t)dst, 16, d_off[i], k * chunk_in_bytes, 0, 0);
     };
     auto dma_u1 = [&](int k, int buf, int i) {
         const int j = wave + 4 * i;
-        __builtin_amdgcn_global_load_lds((gptr_t)(u_n + (int64_t)k * G::UV + j * 256),
-                                         (lptr_t)(ubuf + buf * G::UV + j * 256), 16, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(r_u, (lptr_t)(ubuf + buf * G::UV + j * 256), 16, u_voff,
+                                                 (k * G::UV + j * 256) * 4, 0, 0);
     };
     auto dma_d = [&](int k, int buf) {
 #pragma unroll
@@ -213,19 +234,28 @@ __global__ __launch_bounds__(256) void k_conv_wino(const WinoParams p) {
     if (nchunks > 1) dma_d(1, 1);
     __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): this wave's DMAs have landed
     __syncthreads();
+    WINO_STAMP(1);
     transform(0, 0, 0);
+    WINO_STAMP(2);
 
     static_assert(KC == 8, "the slot schedule below is written for two channel quads per chunk");
-    for (int k = 0; k < nchunks; ++k) {
-        // V[k] complete, d[k+1] / U[k] landed (every wave drained its own DMAs), iteration k-1's buffers free
+    // Operand registers of the two channel quads.  The MFMA stream runs HALF A CHUNK behind the operand fetch:
+    // body k issues the second quad of chunk k-1 (registers loaded in body k-1) in slots 0-7 while it fetches the
+    // first quad of chunk k, then the first quad of chunk k in slots 8-15 while it fetches the second one.  No
+    // MFMA waits on an LDS read issued after the barrier (measured before: a 16-read round trip, ~500 cycles of
+    // idle matrix pipe per chunk).
+    float ax[2][16], ay[2][16], xx[2][16], xy[2][16];
+    auto body = [&](int k, auto first_tag) {
+        constexpr bool FIRST = decltype(first_tag)::value;
+        // V[k] complete, d[k+1] / U[k] landed (every wave drained its own DMAs), body k-1's buffers free
         __builtin_amdgcn_s_waitcnt(0x0F70);
         __syncthreads();
-        // chunks fetched during this iteration (clamped at the end: a redundant fetch into a free buffer
-        // keeps the loop body branch-free): d[k+2] -> dbuf[k & 1], U[k+1] -> ubuf[(k+1) & 1]
+        // chunks fetched during this body (clamped at the end: a redundant fetch into a free buffer keeps the
+        // body branch-free): d[k+2] -> dbuf[k & 1], U[k+1] -> ubuf[(k+1) & 1]
         const int kd = min(k + 2, nchunks - 1), ku = min(k + 1, nchunks - 1);
         const float* ub = ubuf + (k & 1) * G::UV + a_off;
         const float* vb_ = vbuf + (k & 1) * G::UV + b_off;
-        // transform of chunk k+1 (garbage in, unused out on the last iteration: no branch in this block)
+        // transform of chunk k+1 (garbage in, unused out in the last body: no branch in this block)
         const int kn = (k + 1 < nchunks) ? k + 1 : k;
         const float* d0 = dbuf + ((k + 1) & 1) * G::D_BUF + t_rd;
         float* vout = vbuf + ((k + 1) & 1) * G::UV + t_wr;
@@ -233,64 +263,92 @@ __global__ __launch_bounds__(256) void k_conv_wino(const WinoParams p) {
         sab.x = sty[kn * KC + t_ca];
         sab.y = sty[kn * KC + t_ca + 2];
         f2 dd[16], vv[16];                                       // (channel a, channel b) pairs: packed VALU ops
-        float ax[2][16], ay[2][16], xx[2][16], xy[2][16];       // operand sets of the two channel quads
+#ifdef WINO_SCALAR_XFORM
+        float da[16], db[16], va[16], vb2[16];
+#endif
         auto load_ops = [&](int cq, int pos) {
             ax[cq][pos] = ub[pos * G::PS + cq * 256];
             ay[cq][pos] = ub[pos * G::PS + cq * 256 + 1];
             xx[cq][pos] = vb_[pos * G::PS + cq * 256];
             xy[cq][pos] = vb_[pos * G::PS + cq * 256 + 1];
         };
-#pragma unroll
-        for (int pos = 0; pos < 16; ++pos) load_ops(0, pos);
-        // 16 slots of 4 MFMAs; the VALU / LDS work of the next chunk's input transform and the operand
-        // fetch of the second quad are pinned between them (sched_barrier: nothing crosses a slot edge)
+        // 16 slots of 4 MFMAs; the LDS / VALU / DMA work is pinned between them (sched_barrier: nothing crosses
+        // a slot edge)
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
-            const int cq = s >> 3, j = s & 7;
+            const int cq = (s < 8) ? 1 : 0, j = s & 7;
+            if (!(FIRST && s < 8)) {
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int m = 4 * j + u, pos = m & 15;
-                if (m < 16) acc[pos] = __builtin_amdgcn_mfma_f32_32x32x2f32(ax[cq][pos], xx[cq][pos], acc[pos], 0, 0, 0);
-                else acc[pos] = __builtin_amdgcn_mfma_f32_32x32x2f32(ay[cq][pos], xy[cq][pos], acc[pos], 0, 0, 0);
+                for (int u = 0; u < 4; ++u) {
+                    const int m = 4 * j + u, pos = m & 15;
+                    if (m < 16) acc[pos] = __builtin_amdgcn_mfma_f32_32x32x2f32(ax[cq][pos], xx[cq][pos], acc[pos], 0, 0, 0);
+                    else acc[pos] = __builtin_amdgcn_mfma_f32_32x32x2f32(ay[cq][pos], xy[cq][pos], acc[pos], 0, 0, 0);
+                }
+            }
+            if (s < 4) {                         // operands of the first quad of chunk k: 4 positions per slot
+#pragma unroll
+                for (int e = 0; e < 4; ++e) load_ops(0, 4 * s + e);
+            }
+            if (s >= 8 && s < 12) {              // operands of the second quad (consumed by the next body)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) load_ops(1, 4 * (s - 8) + e);
             }
 #ifndef WINO_NO_DMA
-            // two DMA instructions per slot in the first six slots, under the MFMAs (8 weight + 4 halo
-            // instructions per wave): everything is in flight ~10 slots (~1.1 us) before the next barrier
-            if (s < 4) { dma_u1(ku, (k + 1) & 1, 2 * s); dma_u1(ku, (k + 1) & 1, 2 * s + 1); }
-            else if (s < 6) { dma_d1(kd, k & 1, 2 * (s - 4)); dma_d1(kd, k & 1, 2 * (s - 4) + 1); }
+            // two DMA instructions per slot (4 halo + 8 weight instructions per wave): the halo patch is in flight
+            // ~11 slots before the next barrier, the (L2-resident) weights at least 6
+            if (s >= 4 && s < 6) { dma_d1(kd, k & 1, 2 * (s - 4)); dma_d1(kd, k & 1, 2 * (s - 4) + 1); }
+            else if (s >= 6 && s < 10) { dma_u1(ku, (k + 1) & 1, 2 * (s - 6)); dma_u1(ku, (k + 1) & 1, 2 * (s - 6) + 1); }
 #endif
 #ifndef WINO_NO_XFORM
             if (s < 4) {                         // halo reads: 4 positions of both channels per slot
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int idx = 4 * s + e, r = idx >> 2, jj = idx & 3;
+#ifdef WINO_SCALAR_XFORM
+                    da[idx] = d0[r * EWP + jj];
+                    db[idx] = d0[2 * PLANE + r * EWP + jj];
+#else
                     dd[idx].x = d0[r * EWP + jj];
                     dd[idx].y = d0[2 * PLANE + r * EWP + jj];
+#endif
                 }
             }
+#ifdef WINO_SCALAR_XFORM
+            if (s >= 4 && s < 8) { bt_row(da, va, s - 4, sab.x); bt_row(db, vb2, s - 4, sab.y); }
+#else
+            if (s >= 4 && s < 8) bt_row2(dd, vv, s - 4, sab);
 #endif
-            if (s >= 2 && s < 6) {               // operands of the second quad: 4 positions per slot
-#pragma unroll
-                for (int e = 0; e < 4; ++e) load_ops(1, 4 * (s - 2) + e);
-            }
-#ifndef WINO_NO_XFORM
-            if (s >= 6 && s < 10) bt_row2(dd, vv, s - 6, sab);
             if (s >= 12) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int pos = 4 * (s - 12) + e;
+#ifdef WINO_SCALAR_XFORM
+                    vout[pos * G::PS] = va[pos];
+                    vout[pos * G::PS + 1] = vb2[pos];
+#else
                     vout[pos * G::PS] = vv[pos].x;
                     vout[pos * G::PS + 1] = vv[pos].y;
+#endif
                 }
             }
 #endif
             __builtin_amdgcn_sched_barrier(0);
         }
+    };
+    body(0, std::true_type{});
+    for (int k = 1; k < nchunks; ++k) body(k, std::false_type{});
+    // second quad of the last chunk
+#pragma unroll
+    for (int m = 0; m < 32; ++m) {
+        const int pos = m & 15;
+        if (m < 16) acc[pos] = __builtin_amdgcn_mfma_f32_32x32x2f32(ax[1][pos], xx[1][pos], acc[pos], 0, 0, 0);
+        else acc[pos] = __builtin_amdgcn_mfma_f32_32x32x2f32(ay[1][pos], xy[1][pos], acc[pos], 0, 0, 0);
     }
 
     // the clamped fetches of the last iteration are still landing in this workgroup's LDS: drain them
     // before the wave can retire
     __builtin_amdgcn_s_waitcnt(0x0F70);
+    WINO_STAMP(3);
 
     // ---- epilogue: Y = A^T M A per (tile, channel); C/D layout: column (tile) = lane & 31,
     // row (channel) = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
@@ -341,6 +399,8 @@ __global__ __launch_bounds__(256) void k_conv_wino(const WinoParams p) {
             *reinterpret_cast<float2*>(o + a * p.W) = make_float2(v0, v1);
         }
     }
+    WINO_STAMP(4);
+#endif
 }
 
 // U[pos][c][n] = (G g G^T)[pos], written in the chunk order the kernel DMAs:
@@ -394,11 +454,18 @@ int launch(const WinoParams& p, float* u, const float* wt, int ldw, hipStream_t 
 
 }  // namespace
 
+#ifdef WINO_TIMING
+extern "C" int sr_debug_wino_stamps(long long* host, int n) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_wino_stamps), (size_t)n * sizeof(long long));
+}
+#endif
+
 bool sr_wino_eligible(int64_t B, int64_t C, int64_t N, int64_t H, int64_t W, const void* in, const void* out) {
     if (B <= 0 || C % 8 != 0 || N % 64 != 0 || H % 8 != 0 || W % 32 != 0) return false;
     // LDS: 157 KB of buffers + the style row (C floats) must fit the 160 KB of a CU
     if (C > 512 || B * ((W / 32) * (H / 8)) * (N / 64) > 0x7FFFFFFFLL) return false;
-    if (C * H * W >= (1LL << 31)) return false;
+    // buffer addressing: byte offsets inside one sample / one output-channel tile of U stay below 2^31 - 16
+    if (C * H * W >= (1LL << 29) - 4 || 16 * C * 64 >= (1LL << 29)) return false;
     return ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out)) & 15) == 0;
 }
 
