@@ -32,6 +32,8 @@ for (b, c, n, res) in ((16, 128, 128, 256), (16, 256, 256, 128), (16, 512, 512, 
         np.median(ph[:, 2]) / 1e3, ph[:, 2].mean() / 1e3, np.median(ph[:, 3]) / 1e3, ph[:, 3].mean() / 1e3,
         (t[:, 4] - t[:, 0]).mean() / 1e3))
     print("  loop per chunk %.3f us" % (np.median(ph[:, 2]) / 1e3 / (c // 8)))
+    mhz = s[:, 5].astype(np.float64) / ((t[:, 4] - t[:, 0]) / 1e3)
+    print("  s_memtime ticks per us (shader clock under this load, MHz): median %.0f" % np.median(mhz))
     gaps = []
     for k in np.unique(key):
         sel = np.where(key == k)[0]

@@ -55,8 +55,8 @@ __device__ long long g_wino_stamps[8 * 16384];
 template <int KC>
 struct WG {
     static constexpr int CQ = KC / 4;                       // channel quads per chunk
-    static constexpr int PS = CQ * 256;                     // position stride in a U / V buffer
-    static constexpr int UV = 16 * PS;                      // floats per U (or V) chunk: [pos][cq][h][64][2]
+    static constexpr int PPS = CQ * 512;                    // position-pair stride in a U / V buffer
+    static constexpr int UV = 8 * PPS;                      // floats per U (or V) chunk: [pos / 2][cq][e][h][64][pos % 2]
     static constexpr int U_INSTR = UV / 256;                // 16-byte DMA wave-instructions per U chunk
     static constexpr int D_FLOATS = KC * PLANE;
     static constexpr int D_INSTR = (D_FLOATS / 4 + 63) / 64;
@@ -73,7 +73,7 @@ __global__ __launch_bounds__(256) void k_conv_wino(const WinoParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* const ubuf = smem;
     float* const vbuf = smem + 2 * G::UV;
-    float* const dbuf = smem + 4 * G::UV;
+    float* const dbuf = smem + 4 * G::UV + 1;               // + 1: see the input transform
     float* const sty = smem + G::STY;
 
     // ---- tile decode (XCD-chunked: consecutive ids = same input patch / neighbouring patches on one L2)
@@ -98,14 +98,12 @@ __global__ __launch_bounds__(256) void k_conv_wino(const WinoParams p) {
     const int nchunks = p.C / KC;
     WINO_STAMP(0);
 #ifdef WINO_TIMING
+    const long long wino_c0 = clock64();
     if (tid == 0) {
         g_wino_stamps[(blockIdx.x & 16383) * 8 + 6] = __builtin_amdgcn_s_getreg((31 << 11) | 4);
         g_wino_stamps[(blockIdx.x & 16383) * 8 + 7] = __builtin_amdgcn_s_getreg((31 << 11) | 20);
     }
 #endif
-
-    // style row of this sample (ones when absent), consumed by the input transform
-    for (int c = tid; c < p.C; c += 256) sty[c] = p.iscale ? p.iscale[(int64_t)b * p.C + c] : 1.0f;
 
     // ---- DMA descriptors of the halo patch: byte offset of this lane's 16-byte line inside the sample (chunk 0);
     // lines outside the image get an offset beyond the buffer's range: a buffer load returns zeros for them.
@@ -151,72 +149,127 @@ __global__ __launch_bounds__(256) void k_conv_wino(const WinoParams p) {
         for (int i = 0; i < G::U_INSTR / 4; ++i) dma_u1(k, buf, i);
     };
 
-    // ---- input transform item of this thread: tile = lane, channels (ca, ca + 2) of the chunk
-    const int t_cq = (G::CQ > 1) ? (wave & 1) : 0;
-    const int t_h = (G::CQ > 1) ? (wave >> 1) : (wave & 1);
-    const bool t_on = (G::CQ > 1) || wave < 2;
+    // ---- input transform item of this thread: tile = lane, channels (ca, ca + 2) of the chunk (quad t_cq, half
+    // t_h, k-steps e = 0 / 1).  dbuf is shifted by one float so that column x0 - 1 of a tile sits on an even index:
+    // a row of the 4x4 patch is two aligned float pairs, and the whole transform runs on (column j, column j + 1)
+    // pairs with packed ops — no register shuffles between the LDS reads, the arithmetic and the LDS writes.
+    static_assert(KC == 8, "two channel quads per chunk");
+    const int t_cq = wave & 1, t_h = wave >> 1;
     const int t_ca = 4 * t_cq + t_h;
     const int t_rd = t_ca * PLANE + (2 * (lane >> 4)) * EWP + LEAD + 2 * (lane & 15);
-    const int t_wr = t_cq * 256 + t_h * 128 + lane * 2;
+    const int t_wr = t_cq * 512 + t_h * 128 + lane * 2;
 
     typedef float f2 __attribute__((ext_vector_type(2)));
-    // the same on (channel a, channel b) pairs: v_pk_add_f32 / v_pk_mul_f32, half the VALU issue slots
-    // (explicit v_pk_*_f32: the compiler scalarises ext_vector arithmetic here; a non-MFMA instruction costs the
-    // matrix pipe an issue slot)
-    auto pk_add = [](f2 a, f2 b) { f2 r; asm("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; };
-    auto pk_sub = [](f2 a, f2 b) {
+    auto ld2 = [](const float* q) { return *reinterpret_cast<const f2*>(q); };
+    auto st2 = [](float* q, f2 v) { *reinterpret_cast<f2*>(q) = v; };
+    // explicit v_pk_*_f32 (the compiler scalarises ext_vector arithmetic here).  `ch` picks the style of channel a
+    // (low half of s) or b (high half), broadcast to both lanes of the pair by op_sel.
+    auto pk_add = [](f2 x, f2 y) { f2 r; asm("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y)); return r; };
+    auto pk_sub = [](f2 x, f2 y) {
         f2 r;
-        asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+        asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(x), "v"(y));
         return r;
     };
-    auto pk_mul = [](f2 a, f2 b) { f2 r; asm("v_pk_mul_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; };
-    auto bt_row2 = [&](const f2 (&d)[16], f2 (&o)[16], int q, f2 s) {
-        f2 t[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-            t[j] = q == 0 ? pk_sub(d[j], d[8 + j]) : q == 1 ? pk_add(d[4 + j], d[8 + j]) : q == 2 ? pk_sub(d[8 + j], d[4 + j])
-                                                                                    : pk_sub(d[4 + j], d[12 + j]);
-        o[4 * q + 0] = pk_mul(pk_sub(t[0], t[2]), s);
-        o[4 * q + 1] = pk_mul(pk_add(t[1], t[2]), s);
-        o[4 * q + 2] = pk_mul(pk_sub(t[2], t[1]), s);
-        o[4 * q + 3] = pk_mul(pk_sub(t[1], t[3]), s);
+    auto pk_mul_s = [](f2 x, f2 sv, int ch) {                     // x * s
+        f2 r;
+        if (ch == 0) asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,0]" : "=v"(r) : "v"(x), "v"(sv));
+        else asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(r) : "v"(x), "v"(sv));
+        return r;
     };
-    // B^T d B of one channel, row q of the 4x4 result (12 VALU ops), style multiplied in
-    auto bt_row = [](const float (&d)[16], float (&o)[16], int q, float s) {
-        float t[4];
+    auto pk_fms_s = [](f2 x, f2 sv, f2 y, int ch) {               // x * s - y
+        f2 r;
+        if (ch == 0)
+            asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,1] neg_lo:[0,0,1] neg_hi:[0,0,1]"
+                : "=v"(r) : "v"(x), "v"(sv), "v"(y));
+        else
+            asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,1,1] neg_lo:[0,0,1] neg_hi:[0,0,1]"
+                : "=v"(r) : "v"(x), "v"(sv), "v"(y));
+        return r;
+    };
+    auto pk_fnma_s = [](f2 x, f2 sv, f2 y, int ch) {              // y - x * s
+        f2 r;
+        if (ch == 0)
+            asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0] neg_hi:[1,0,0]"
+                : "=v"(r) : "v"(x), "v"(sv), "v"(y));
+        else
+            asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]"
+                : "=v"(r) : "v"(x), "v"(sv), "v"(y));
+        return r;
+    };
+    // column stage on t = (t0, t1 | t2, t3): (t0 - t2, t1 + t2) and (t2 - t1, t1 - t3)
+    auto col01 = [](f2 tp, f2 tq) {
+        f2 r;
+        asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,0]" : "=v"(r) : "v"(tp), "v"(tq));
+        return r;
+    };
+    auto col23 = [](f2 tp, f2 tq) {
+        f2 r;
+        asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[1,0]" : "=v"(r) : "v"(tq), "v"(tp));
+        return r;
+    };
+    // B^T d B of the two channels in four steps (the loop pins one step per MFMA slot).  Row stage with the style
+    // folded in: s*d0 - s*d2, s*d1 + s*d2, s*d2 - s*d1, s*d1 - s*d3 (20 packed ops per channel pair of columns).
+    struct XF {
+        f2 P[2][4], Q[2][4];          // halo rows: columns (0,1), (2,3) of channel a / b
+        f2 sp[2][2], sq[2][2];        // s * rows 1, 2
+        f2 tp[2][4], tq[2][4];        // after the row stage
+        f2 o01[2][4], o23[2][4];      // result rows q: positions (4q, 4q+1), (4q+2, 4q+3)
+    };
+    auto xf_read = [&](XF& x, const float* d0, int r) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-            t[j] = q == 0 ? d[j] - d[8 + j] : q == 1 ? d[4 + j] + d[8 + j] : q == 2 ? d[8 + j] - d[4 + j]
-                                                                          : d[4 + j] - d[12 + j];
-        o[4 * q + 0] = (t[0] - t[2]) * s;
-        o[4 * q + 1] = (t[1] + t[2]) * s;
-        o[4 * q + 2] = (t[2] - t[1]) * s;
-        o[4 * q + 3] = (t[1] - t[3]) * s;
+        for (int ch = 0; ch < 2; ++ch) {
+            x.P[ch][r] = ld2(d0 + ch * 2 * PLANE + r * EWP);
+            x.Q[ch][r] = ld2(d0 + ch * 2 * PLANE + r * EWP + 2);
+        }
+    };
+    auto xf_step = [&](XF& x, int step, f2 sv) {
+#pragma unroll
+        for (int ch = 0; ch < 2; ++ch) {
+            if (step == 0) {
+                x.sp[ch][0] = pk_mul_s(x.P[ch][1], sv, ch);
+                x.sp[ch][1] = pk_mul_s(x.P[ch][2], sv, ch);
+                x.sq[ch][0] = pk_mul_s(x.Q[ch][1], sv, ch);
+                x.sq[ch][1] = pk_mul_s(x.Q[ch][2], sv, ch);
+                x.tp[ch][0] = pk_fms_s(x.P[ch][0], sv, x.sp[ch][1], ch);
+                x.tq[ch][0] = pk_fms_s(x.Q[ch][0], sv, x.sq[ch][1], ch);
+            } else if (step == 1) {
+                x.tp[ch][1] = pk_add(x.sp[ch][0], x.sp[ch][1]);
+                x.tq[ch][1] = pk_add(x.sq[ch][0], x.sq[ch][1]);
+                x.tp[ch][2] = pk_sub(x.sp[ch][1], x.sp[ch][0]);
+                x.tq[ch][2] = pk_sub(x.sq[ch][1], x.sq[ch][0]);
+                x.tp[ch][3] = pk_fnma_s(x.P[ch][3], sv, x.sp[ch][0], ch);
+                x.tq[ch][3] = pk_fnma_s(x.Q[ch][3], sv, x.sq[ch][0], ch);
+            } else {
+#pragma unroll
+                for (int q = 2 * (step - 2); q < 2 * (step - 2) + 2; ++q) {
+                    x.o01[ch][q] = col01(x.tp[ch][q], x.tq[ch][q]);
+                    x.o23[ch][q] = col23(x.tp[ch][q], x.tq[ch][q]);
+                }
+            }
+        }
+    };
+    // V layout (and U, see k_wino_weights): [position pair 8][quad 2][k-step 2][half 2][64][position parity 2]
+    auto xf_write = [&](const XF& x, float* vout, int q) {
+#pragma unroll
+        for (int ch = 0; ch < 2; ++ch) {
+            st2(vout + (2 * q) * G::PPS + ch * 256, x.o01[ch][q]);
+            st2(vout + (2 * q + 1) * G::PPS + ch * 256, x.o23[ch][q]);
+        }
     };
     // whole transform of chunk k (prologue only; inside the loop it is sliced between the MFMAs)
     auto transform = [&](int k, int dsel, int vsel) {
-        if (!t_on) return;
         const float* d0 = dbuf + dsel * G::D_BUF + t_rd;
         float* v = vbuf + vsel * G::UV + t_wr;
-        const float sa = sty[k * KC + t_ca], sb = sty[k * KC + t_ca + 2];
-        float da[16], db[16], va[16], vb[16];
+        f2 sv;
+        sv.x = sty[k * KC + t_ca];
+        sv.y = sty[k * KC + t_ca + 2];
+        XF x;
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
+        for (int r = 0; r < 4; ++r) xf_read(x, d0, r);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                da[4 * r + j] = d0[r * EWP + j];
-                db[4 * r + j] = d0[2 * PLANE + r * EWP + j];
-            }
+        for (int st = 0; st < 4; ++st) xf_step(x, st, sv);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            bt_row(da, va, q, sa);
-            bt_row(db, vb, q, sb);
-        }
-#pragma unroll
-        for (int pos = 0; pos < 16; ++pos) {
-            v[pos * G::PS] = va[pos];
-            v[pos * G::PS + 1] = vb[pos];
-        }
+        for (int q = 0; q < 4; ++q) xf_write(x, v, q);
     };
 
     f32x16 acc[16];
@@ -232,6 +285,9 @@ __global__ __launch_bounds__(256) void k_conv_wino(const WinoParams p) {
     dma_d(0, 0);
     dma_u(0, 0);
     if (nchunks > 1) dma_d(1, 1);
+    // style row of this sample (ones when absent), consumed by the input transform: fetched behind the DMAs, so
+    // its round trip overlaps theirs
+    for (int c = tid; c < p.C; c += 256) sty[c] = p.iscale ? p.iscale[(int64_t)b * p.C + c] : 1.0f;
     __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): this wave's DMAs have landed
     __syncthreads();
     WINO_STAMP(1);
@@ -244,7 +300,12 @@ __global__ __launch_bounds__(256) void k_conv_wino(const WinoParams p) {
     // first quad of chunk k, then the first quad of chunk k in slots 8-15 while it fetches the second one.  No
     // MFMA waits on an LDS read issued after the barrier (measured before: a 16-read round trip, ~500 cycles of
     // idle matrix pipe per chunk).
-    float ax[2][16], ay[2][16], xx[2][16], xy[2][16];
+    f2 au[2][2][8], bv[2][2][8];                                   // [quad][k-step][position pair]
+    auto mfma_step = [&](int cq, int m) {
+        const int e = m >> 4, pos = m & 15, pp = pos >> 1;
+        if (pos & 1) acc[pos] = __builtin_amdgcn_mfma_f32_32x32x2f32(au[cq][e][pp].y, bv[cq][e][pp].y, acc[pos], 0, 0, 0);
+        else acc[pos] = __builtin_amdgcn_mfma_f32_32x32x2f32(au[cq][e][pp].x, bv[cq][e][pp].x, acc[pos], 0, 0, 0);
+    };
     auto body = [&](int k, auto first_tag) {
         constexpr bool FIRST = decltype(first_tag)::value;
         // V[k] complete, d[k+1] / U[k] landed (every wave drained its own DMAs), body k-1's buffers free
@@ -262,15 +323,13 @@ __global__ __launch_bounds__(256) void k_conv_wino(const WinoParams p) {
         f2 sab;
         sab.x = sty[kn * KC + t_ca];
         sab.y = sty[kn * KC + t_ca + 2];
-        f2 dd[16], vv[16];                                       // (channel a, channel b) pairs: packed VALU ops
-#ifdef WINO_SCALAR_XFORM
-        float da[16], db[16], va[16], vb2[16];
-#endif
-        auto load_ops = [&](int cq, int pos) {
-            ax[cq][pos] = ub[pos * G::PS + cq * 256];
-            ay[cq][pos] = ub[pos * G::PS + cq * 256 + 1];
-            xx[cq][pos] = vb_[pos * G::PS + cq * 256];
-            xy[cq][pos] = vb_[pos * G::PS + cq * 256 + 1];
+        XF x;
+        auto load_ops = [&](int cq, int pp) {
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                au[cq][e][pp] = ld2(ub + pp * G::PPS + cq * 512 + e * 256);
+                bv[cq][e][pp] = ld2(vb_ + pp * G::PPS + cq * 512 + e * 256);
+            }
         };
         // 16 slots of 4 MFMAs; the LDS / VALU / DMA work is pinned between them (sched_barrier: nothing crosses
         // a slot edge)
@@ -279,58 +338,21 @@ __global__ __launch_bounds__(256) void k_conv_wino(const WinoParams p) {
             const int cq = (s < 8) ? 1 : 0, j = s & 7;
             if (!(FIRST && s < 8)) {
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int m = 4 * j + u, pos = m & 15;
-                    if (m < 16) acc[pos] = __builtin_amdgcn_mfma_f32_32x32x2f32(ax[cq][pos], xx[cq][pos], acc[pos], 0, 0, 0);
-                    else acc[pos] = __builtin_amdgcn_mfma_f32_32x32x2f32(ay[cq][pos], xy[cq][pos], acc[pos], 0, 0, 0);
-                }
+                for (int u = 0; u < 4; ++u) mfma_step(cq, 4 * j + u);
             }
-            if (s < 4) {                         // operands of the first quad of chunk k: 4 positions per slot
-#pragma unroll
-                for (int e = 0; e < 4; ++e) load_ops(0, 4 * s + e);
-            }
-            if (s >= 8 && s < 12) {              // operands of the second quad (consumed by the next body)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) load_ops(1, 4 * (s - 8) + e);
-            }
+            if (s < 4) { load_ops(0, 2 * s); load_ops(0, 2 * s + 1); }                     // first quad of chunk k
+            if (s >= 8 && s < 12) { load_ops(1, 2 * (s - 8)); load_ops(1, 2 * (s - 8) + 1); }  // second quad (next body)
 #ifndef WINO_NO_DMA
-            // two DMA instructions per slot (4 halo + 8 weight instructions per wave): the halo patch is in flight
-            // ~11 slots before the next barrier, the (L2-resident) weights at least 6
-            if (s >= 4 && s < 6) { dma_d1(kd, k & 1, 2 * (s - 4)); dma_d1(kd, k & 1, 2 * (s - 4) + 1); }
-            else if (s >= 6 && s < 10) { dma_u1(ku, (k + 1) & 1, 2 * (s - 6)); dma_u1(ku, (k + 1) & 1, 2 * (s - 6) + 1); }
+            // two DMA instructions per slot (4 halo + 8 weight instructions per wave): the halo patch (HBM for the
+            // first output-channel tile that touches it) is in flight 15 slots before the next barrier, the
+            // (L2-resident) weights at least 8
+            if (s < 2) { dma_d1(kd, k & 1, 2 * s); dma_d1(kd, k & 1, 2 * s + 1); }
+            else if (s >= 4 && s < 8) { dma_u1(ku, (k + 1) & 1, 2 * (s - 4)); dma_u1(ku, (k + 1) & 1, 2 * (s - 4) + 1); }
 #endif
 #ifndef WINO_NO_XFORM
-            if (s < 4) {                         // halo reads: 4 positions of both channels per slot
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int idx = 4 * s + e, r = idx >> 2, jj = idx & 3;
-#ifdef WINO_SCALAR_XFORM
-                    da[idx] = d0[r * EWP + jj];
-                    db[idx] = d0[2 * PLANE + r * EWP + jj];
-#else
-                    dd[idx].x = d0[r * EWP + jj];
-                    dd[idx].y = d0[2 * PLANE + r * EWP + jj];
-#endif
-                }
-            }
-#ifdef WINO_SCALAR_XFORM
-            if (s >= 4 && s < 8) { bt_row(da, va, s - 4, sab.x); bt_row(db, vb2, s - 4, sab.y); }
-#else
-            if (s >= 4 && s < 8) bt_row2(dd, vv, s - 4, sab);
-#endif
-            if (s >= 12) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int pos = 4 * (s - 12) + e;
-#ifdef WINO_SCALAR_XFORM
-                    vout[pos * G::PS] = va[pos];
-                    vout[pos * G::PS + 1] = vb2[pos];
-#else
-                    vout[pos * G::PS] = vv[pos].x;
-                    vout[pos * G::PS + 1] = vv[pos].y;
-#endif
-                }
-            }
+            if (s < 4) xf_read(x, d0, s);
+            if (s >= 4 && s < 8) xf_step(x, s - 4, sab);
+            if (s >= 12) xf_write(x, vout, s - 12);
 #endif
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -339,11 +361,7 @@ __global__ __launch_bounds__(256) void k_conv_wino(const WinoParams p) {
     for (int k = 1; k < nchunks; ++k) body(k, std::false_type{});
     // second quad of the last chunk
 #pragma unroll
-    for (int m = 0; m < 32; ++m) {
-        const int pos = m & 15;
-        if (m < 16) acc[pos] = __builtin_amdgcn_mfma_f32_32x32x2f32(ax[1][pos], xx[1][pos], acc[pos], 0, 0, 0);
-        else acc[pos] = __builtin_amdgcn_mfma_f32_32x32x2f32(ay[1][pos], xy[1][pos], acc[pos], 0, 0, 0);
-    }
+    for (int m = 0; m < 32; ++m) mfma_step(1, m);
 
     // the clamped fetches of the last iteration are still landing in this workgroup's LDS: drain them
     // before the wave can retire
@@ -381,6 +399,7 @@ __global__ __launch_bounds__(256) void k_conv_wino(const WinoParams p) {
         const float ob = p.obias ? p.obias[n] : 0.0f;
         float* o = p.out + ((int64_t)b * p.N + n) * plane + (int64_t)oy * p.W + ox;
         const float ab = (p.nba && p.abias) ? p.abias[n] : 0.0f;
+        float y[2][2];
 #pragma unroll
         for (int a = 0; a < 2; ++a) {
             const float y0 = (s[a][0] + s[a][1]) + s[a][2];
@@ -396,15 +415,22 @@ __global__ __launch_bounds__(256) void k_conv_wino(const WinoParams p) {
                 v0 = ((v0 > 0.0f) ? v0 : v0 * p.alpha) * p.gain;
                 v1 = ((v1 > 0.0f) ? v1 : v1 * p.alpha) * p.gain;
             }
-            *reinterpret_cast<float2*>(o + a * p.W) = make_float2(v0, v1);
+            y[a][0] = v0;
+            y[a][1] = v1;
         }
+        // (one 16-byte store per lane pair-row via a DPP swap measured 0.2 us slower than these two)
+        *reinterpret_cast<float2*>(o) = make_float2(y[0][0], y[0][1]);
+        *reinterpret_cast<float2*>(o + p.W) = make_float2(y[1][0], y[1][1]);
     }
     WINO_STAMP(4);
+#ifdef WINO_TIMING
+    if (tid == 0) g_wino_stamps[(blockIdx.x & 16383) * 8 + 5] = clock64() - wino_c0;
+#endif
 #endif
 }
 
 // U[pos][c][n] = (G g G^T)[pos], written in the chunk order the kernel DMAs:
-//   [n / 64][c / KC][pos][cq][h][n % 64][e],  chunk-local channel = 4 cq + 2 e + h
+//   [n / 64][c / KC][pos / 2][cq][e][h][n % 64][pos % 2],  chunk-local channel = 4 cq + 2 e + h
 template <int KC>
 __global__ __launch_bounds__(64) void k_wino_weights(float* __restrict__ u, const float* __restrict__ wt, int C,
                                                      int N, int ldw) {
@@ -422,13 +448,11 @@ __global__ __launch_bounds__(64) void k_wino_weights(float* __restrict__ u, cons
         h[3][j] = g[2][j];
     }
     const int cl = c % KC, cq = cl / 4, e = (cl % 4) / 2, hh = cl % 2;
-    float* dst = u + ((int64_t)blockIdx.x * (C / KC) + c / KC) * G::UV + cq * 256 + hh * 128 + threadIdx.x * 2 + e;
+    float* dst = u + ((int64_t)blockIdx.x * (C / KC) + c / KC) * G::UV + cq * 512 + e * 256 + hh * 128 + threadIdx.x * 2;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        dst[(4 * i + 0) * G::PS] = h[i][0];
-        dst[(4 * i + 1) * G::PS] = 0.5f * ((h[i][0] + h[i][2]) + h[i][1]);
-        dst[(4 * i + 2) * G::PS] = 0.5f * ((h[i][0] + h[i][2]) - h[i][1]);
-        dst[(4 * i + 3) * G::PS] = h[i][2];
+        *reinterpret_cast<float2*>(dst + (2 * i) * G::PPS) = make_float2(h[i][0], 0.5f * ((h[i][0] + h[i][2]) + h[i][1]));
+        *reinterpret_cast<float2*>(dst + (2 * i + 1) * G::PPS) = make_float2(0.5f * ((h[i][0] + h[i][2]) - h[i][1]), h[i][2]);
     }
 }
 
