@@ -418,6 +418,17 @@ int launch_one(const ConvParams& p, dim3 grid, hipStream_t st) {
     return launch_fast<IS, TY, TX, PW, PH, PB, V4, false>(p, grid, st);
 }
 
+#if __HIP_DEVICE_COMPILE__
+// Buffer resource over [base, base + bytes): every input goes through readfirstlane so that the descriptor
+// provably lives in SGPRs (a descriptor the compiler believes divergent turns each buffer op into a waterfall loop).
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t uniform_rsrc(const float* base, int bytes) {
+    const uint64_t a = reinterpret_cast<uint64_t>(base);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)a), hi = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
+    return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((uint64_t)hi << 32) | lo), 0,
+                                             __builtin_amdgcn_readfirstlane(bytes), 0x00020000);
+}
+#endif
+
 // ------------------------------------------------------------------------------------------------
 // Stride-2 transposed 3x3 convolution, all four output phases in ONE workgroup (interior of the map).
 //
@@ -448,6 +459,7 @@ struct TFused {
 };
 
 __global__ __launch_bounds__(256) void k_convt_fused(const ConvParams p) {
+#if __HIP_DEVICE_COMPILE__   // buffer-resource builtins: device pass only (the host pass needs just the stub)
     using G = TFused;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* const sty = smem + G::STY;
@@ -471,52 +483,54 @@ __global__ __launch_bounds__(256) void k_convt_fused(const ConvParams p) {
     const int half = lane >> 5, l31 = lane & 31;
     const int wco = wave & 1, wpx = wave >> 1;
 
-    for (int c = tid; c < p.C; c += 256) sty[c] = p.iscale ? p.iscale[(int64_t)b * p.C + c] : 1.0f;
-
-    // ---- DMA descriptors (chunk 0)
-    int w_src[G::W_PER_WAVE];
+    // ---- DMA descriptors: byte offsets inside the weight tensor / this sample for chunk 0; lanes with nothing to
+    // fetch (outside the image, surplus instructions) point beyond the buffer and receive zeros.  The chunk part of
+    // every address is the scalar soffset of the buffer load: no vector ALU work per DMA instruction.
+    constexpr int OOB = 0x7FFFFFF0;
+    int w_off[G::W_PER_WAVE];
 #pragma unroll
     for (int i = 0; i < G::W_PER_WAVE; ++i) {
         const int j = wave + 4 * i;
         const int row = 2 * j + half;                       // [tap * KC + c]
         const int t = row / G::KC, c = row % G::KC;
         const int col = min(n0 + l31 * 4, p.ldw - 4);
-        w_src[i] = j < G::W_INSTR ? (t * p.C + c) * p.ldw + col : 0;
+        w_off[i] = j < G::W_INSTR ? ((t * p.C + c) * p.ldw + col) * 4 : OOB;
     }
-    int i_src[G::I_PER_WAVE];                               // -1: outside the image (zero line)
+    int i_off[G::I_PER_WAVE];
 #pragma unroll
     for (int i = 0; i < G::I_PER_WAVE; ++i) {
         const int j = wave + 4 * i;
         const int f = (j * 64 + lane) * 4;
-        int src = j < G::I_INSTR ? -1 : 0;                  // surplus instruction: any valid address
+        int off = OOB;
         if (j < G::I_INSTR && f < G::KC * G::PLANE) {
             const int c = f / G::PLANE, q = f % G::PLANE;
             const int r = q / G::EWP, cola = q % G::EWP;
             const int gy = j0 - 1 + r, gx = i0 - 4 + cola;
-            if (gy >= 0 && gy < p.IH && gx >= 0 && gx + 3 < p.IW) src = (c * p.IH + gy) * p.IW + gx;
+            if (gy >= 0 && gy < p.IH && gx >= 0 && gx + 3 < p.IW) off = ((c * p.IH + gy) * p.IW + gx) * 4;
         }
-        i_src[i] = src;
+        i_off[i] = off;
     }
-    const float* in_b = p.in + (int64_t)b * p.C * p.IH * p.IW;
     const int plane_in = p.IH * p.IW;
+    const __amdgpu_buffer_rsrc_t r_w = uniform_rsrc(p.wt, 9 * p.C * p.ldw * 4);
+    const __amdgpu_buffer_rsrc_t r_in = uniform_rsrc(p.in + (int64_t)b * p.C * plane_in, p.C * plane_in * 4);
+    const int nchunks = p.C / G::KC;
 
-    auto dma = [&](int c0, int buf) {
-        float* dst = smem + buf * G::BUF;
-#pragma unroll
-        for (int i = 0; i < G::W_PER_WAVE; ++i) {
+    // DMA instruction i (0 .. 10) of chunk k (clamped to the last chunk: a surplus fetch lands in a free buffer)
+    auto dma1 = [&](int k, int i) {
+        const int kc = min(k, nchunks - 1), c0 = kc * G::KC;
+        float* dst = smem + (k & 1) * G::BUF;
+        if (i < G::I_PER_WAVE) {                             // the halo patch first: it may come from HBM
             const int j = wave + 4 * i;
-            __builtin_amdgcn_global_load_lds((gptr_t)(p.wt + w_src[i] + (int64_t)c0 * p.ldw),
-                                             (lptr_t)(j < G::W_INSTR ? dst + j * 256 : smem + G::PAD + wave * 256), 16,
-                                             0, 0);
-        }
-#pragma unroll
-        for (int i = 0; i < G::I_PER_WAVE; ++i) {
-            const int j = wave + 4 * i;
-            const float* src = i_src[i] >= 0 ? in_b + i_src[i] + (int64_t)c0 * plane_in : g_zero_line;
-            __builtin_amdgcn_global_load_lds(
-                (gptr_t)src, (lptr_t)(j < G::I_INSTR ? dst + G::W_FLOATS + j * 256 : smem + G::PAD + wave * 256), 16, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                r_in, (lptr_t)(j < G::I_INSTR ? dst + G::W_FLOATS + j * 256 : smem + G::PAD + wave * 256), 16, i_off[i],
+                c0 * plane_in * 4, 0, 0);
+        } else {                                             // then the (L2-resident) weights
+            const int ii = i - G::I_PER_WAVE, j = wave + 4 * ii;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(r_w, (lptr_t)(j < G::W_INSTR ? dst + j * 256 : smem + G::PAD + wave * 256),
+                                                     16, w_off[ii], c0 * p.ldw * 4, 0, 0);
         }
     };
+    constexpr int N_DMA = G::W_PER_WAVE + G::I_PER_WAVE;    // 11 per wave and chunk
 
     // accumulators: [phase py*2+px][channel tile][pixel tile]
     f32x16 acc[4][2][2];
@@ -537,38 +551,55 @@ __global__ __launch_bounds__(256) void k_convt_fused(const ConvParams p) {
         b_off[t] = G::W_FLOATS + half * G::PLANE + (py + 1) * G::EWP + l31 + G::LEAD + 1;
     }
 
-    dma(0, 0);
-    int buf = 0;
-    for (int c0 = 0; c0 < p.C; c0 += G::KC) {
-        __builtin_amdgcn_s_waitcnt(0x0F70);
-        __syncthreads();
-        if (c0 + G::KC < p.C) dma(c0 + G::KC, buf ^ 1);
-        const float* sb = smem + buf * G::BUF;
-        // One wave per SIMD: nobody else hides LDS latency, so the 26 operands of k-step s+1 are fetched
-        // (and style-scaled) under the 36 MFMAs of k-step s; only the first k-step of a chunk waits.
-        float A[2][9][2], X[2][4][2];                        // [set][tap][channel tile], [set][dy*2+dx][pixel tile]
-        auto load_set = [&](int cp, int set) {
+    // ---- pipeline.  One wave per SIMD: nobody else hides LDS latency or DMA issue, so
+    //  * the 26 operands of k-step g + 1 are fetched (and the 8 input operands style-scaled) under the 36 MFMAs
+    //    of k-step g — across chunk boundaries too: the chunk barrier sits in front of the LAST k-step of a
+    //    chunk, whose operands are already in registers, and the first k-step of the next chunk is fetched
+    //    under it (no MFMA ever waits for an LDS round trip behind a barrier);
+    //  * the 11 DMA instructions of a chunk are spread over three k-steps, one per 8 MFMAs.
+    // Chunk k + 1 is complete at the barrier of chunk k (issued a whole chunk earlier); chunk k + 2 then goes
+    // into the buffer of chunk k, which nobody reads any more.
 #pragma unroll
-            for (int sh = 0; sh < 4; ++sh)
+    for (int i = 0; i < N_DMA; ++i) dma1(0, i);
 #pragma unroll
-                for (int t = 0; t < 2; ++t)
-                    X[set][sh][t] = sb[(2 * cp) * G::PLANE + b_off[t] - (sh >> 1) * G::EWP - (sh & 1)];
+    for (int i = 0; i < 4; ++i) dma1(1, i);
+    for (int c = tid; c < p.C; c += 256) sty[c] = p.iscale ? p.iscale[(int64_t)b * p.C + c] : 1.0f;
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    __syncthreads();
+
+    float A[2][9][2], X[2][4][2];                        // [set][tap][channel tile], [set][dy*2+dx][pixel tile]
+    float sc_next;
+    auto load_set = [&](const float* sb, int c0, int cp, int set) {
 #pragma unroll
-            for (int tap = 0; tap < 9; ++tap)
+        for (int sh = 0; sh < 4; ++sh)
 #pragma unroll
-                for (int t = 0; t < 2; ++t) A[set][tap][t] = sb[(tap * G::KC + 2 * cp) * BN + a_off[t]];
-        };
-        auto scale_set = [&](int cp, int set) {              // style onto the 8 input operands (not the 18 weights)
-            const float sc = sty[c0 + 2 * cp + half];
+            for (int t = 0; t < 2; ++t)
+                X[set][sh][t] = sb[(2 * cp) * G::PLANE + b_off[t] - (sh >> 1) * G::EWP - (sh & 1)];
 #pragma unroll
-            for (int sh = 0; sh < 4; ++sh) { X[set][sh][0] *= sc; X[set][sh][1] *= sc; }
-        };
-        load_set(0, 0);
-        scale_set(0, 0);
+        for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) A[set][tap][t] = sb[(tap * G::KC + 2 * cp) * BN + a_off[t]];
+        sc_next = sty[c0 + 2 * cp + half];
+    };
+    load_set(smem, 0, 0, 0);
+#pragma unroll
+    for (int sh = 0; sh < 4; ++sh) { X[0][sh][0] *= sc_next; X[0][sh][1] *= sc_next; }
+
+    for (int k = 0; k < nchunks; ++k) {
+        const float* sb = smem + (k & 1) * G::BUF;
+        const float* sbn = smem + ((k + 1) & 1) * G::BUF;
+        const int c0 = k * G::KC, c0n = min(k + 1, nchunks - 1) * G::KC;
 #pragma unroll
         for (int cp = 0; cp < G::KC / 2; ++cp) {
-            const int cur = cp & 1;
-            if (cp + 1 < G::KC / 2) load_set(cp + 1, cur ^ 1);
+            const int cur = cp & 1, nxt = cur ^ 1;
+            if (cp == G::KC / 2 - 1) {
+                // chunk k + 1 landed (every wave drained its own DMAs), all reads of chunk k retired
+                __builtin_amdgcn_s_waitcnt(0x0F70);
+                __syncthreads();
+                load_set(sbn, c0n, 0, nxt);
+            } else {
+                load_set(sb, c0, cp + 1, nxt);
+            }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int ky = 0; ky < 3; ++ky)
@@ -579,20 +610,21 @@ __global__ __launch_bounds__(256) void k_convt_fused(const ConvParams p) {
                     acc[ph][0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[cur][tap][0], X[cur][sh][1], acc[ph][0][1], 0, 0, 0);
                     acc[ph][1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[cur][tap][1], X[cur][sh][0], acc[ph][1][0], 0, 0, 0);
                     acc[ph][1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[cur][tap][1], X[cur][sh][1], acc[ph][1][1], 0, 0, 0);
+                    // style onto the 8 input operands of the next k-step (not its 18 weights): one multiply per
+                    // tap from the second tap on (eight MFMAs cover the LDS latency of the fetch above)
+                    if (tap >= 1) X[nxt][(tap - 1) >> 1][(tap - 1) & 1] *= sc_next;
+                    // DMA: chunk k + 2 starts behind the barrier (4 instructions), the rest of chunk k + 1 follows in
+                    // the first two k-steps of the next iteration... seen from this iteration: cp 0 / 1 finish
+                    // chunk k + 1, the last k-step starts chunk k + 2
+                    if ((tap & 1) == 1) {
+                        const int u = tap >> 1;                               // 0 .. 3
+                        if (cp == 0) dma1(k + 1, 4 + u);
+                        else if (cp == 1 && 8 + u < N_DMA) dma1(k + 1, 8 + u);
+                        else if (cp == G::KC / 2 - 1) dma1(k + 2, u);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
                 }
-            if (cp + 1 < G::KC / 2) {
-                scale_set(cp + 1, cur ^ 1);
-                // four MFMAs cover the LDS latency, then one scale multiply per four MFMAs
-                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);
         }
-        buf ^= 1;
     }
     __builtin_amdgcn_s_waitcnt(0x0F70);
 
@@ -618,9 +650,12 @@ __global__ __launch_bounds__(256) void k_convt_fused(const ConvParams p) {
                 }
             }
     }
+#endif
 }
 
 bool convt_fused_eligible(const ConvParams& p) {
+    // buffer addressing: byte offsets inside one sample / the weight tensor below 2^31 - 16
+    if ((int64_t)p.C * p.IH * p.IW >= (1LL << 29) - 4 || 9LL * p.C * p.ldw >= (1LL << 29) - 4) return false;
     return p.IH % TFused::PH == 0 && p.IW % TFused::PW == 0 && p.C % TFused::KC == 0 && p.C <= 2048 &&
            (reinterpret_cast<uintptr_t>(p.in) & 15) == 0;
 }
