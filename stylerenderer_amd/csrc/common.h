@@ -35,3 +35,16 @@ __device__ __forceinline__ float sr_wave_sum(float x) {
     for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, SR_WAVE);
     return x;
 }
+
+#if __HIP_DEVICE_COMPILE__
+// Buffer resource over [base, base + bytes) for raw buffer loads / LDS-DMA.  Every input goes through readfirstlane
+// so that the descriptor provably lives in SGPRs: a descriptor the compiler believes divergent turns each buffer
+// operation into a waterfall loop.  The builtins exist in the device pass only, hence the guard (kernels that use
+// them keep their bodies under the same guard; the host pass needs just the launch stub).
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t uniform_rsrc(const float* base, int bytes) {
+    const unsigned long long a = reinterpret_cast<unsigned long long>(base);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+    return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo), 0,
+                                             __builtin_amdgcn_readfirstlane(bytes), 0x00020000);
+}
+#endif

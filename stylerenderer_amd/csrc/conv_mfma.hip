@@ -418,17 +418,6 @@ int launch_one(const ConvParams& p, dim3 grid, hipStream_t st) {
     return launch_fast<IS, TY, TX, PW, PH, PB, V4, false>(p, grid, st);
 }
 
-#if __HIP_DEVICE_COMPILE__
-// Buffer resource over [base, base + bytes): every input goes through readfirstlane so that the descriptor
-// provably lives in SGPRs (a descriptor the compiler believes divergent turns each buffer op into a waterfall loop).
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t uniform_rsrc(const float* base, int bytes) {
-    const uint64_t a = reinterpret_cast<uint64_t>(base);
-    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)a), hi = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
-    return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((uint64_t)hi << 32) | lo), 0,
-                                             __builtin_amdgcn_readfirstlane(bytes), 0x00020000);
-}
-#endif
-
 // ------------------------------------------------------------------------------------------------
 // Stride-2 transposed 3x3 convolution, all four output phases in ONE workgroup (interior of the map).
 //

@@ -12,41 +12,52 @@
 // range (all tiles of all samples) is split over workgroups; partial dU slabs are summed in a fixed
 // order and pulled back to 3x3 by k_wgrad_wino_finish (deterministic, no atomics).
 //
-// K loop in chunks of 8 tiles (a 16x2 pixel strip):
-//   * the strip's x halo (64 channels x 4 rows x 24 columns, 16-byte aligned window) and gy pixels
-//     (64 channels x 2 rows x 16 columns) arrive by LDS-DMA, four chunks deep; every channel occupies
-//     25 (resp. 9) float4 slots = 24 (8) payload + 1 hole, so that the 32 lanes of a half-wave, which
-//     own 32 different channels, hit different bank groups with ds_read_b128 / ds_read_b64;
-//   * BOTH transforms run in registers, directly into the MFMA operands: lane (channel = l & 31,
-//     k = l >> 5) computes B^T d B of its own (channel, tile) — 8 ds_read_b128 + 32 VALU ops per
-//     k-step (packed fp32 where the data allows) — and A dY A^T of its own (output channel, tile) —
-//     2 ds_read_b64 + 12 VALU ops.  No transformed operand ever touches LDS.  The transforms of k-step
-//     s+1 (and the chunk's 10 DMA instructions) are pinned into the four 4-MFMA slots of k-step s.
-//   * k-step s pairs tiles (t, t + 2) on the two k-lanes so both halves read with the same
-//     compile-time element pattern (tile columns 3 + 2t .. 6 + 2t of the aligned window).
+// K loop in strips of 8 tiles (16 x 2 pixels), two sub-chunks of 4 tiles each:
+//   * the strip's x halo (64 channels x 4 rows x 24 columns, 16-byte aligned window) and gy pixels (64 channels
+//     x 2 rows x 16 columns) arrive by buffer-addressed LDS-DMA, double buffered, a strip and a half ahead; every
+//     channel occupies 25 (resp. 9) float4 slots = 24 (8) payload + 1 hole, so that 16 lanes that own 16 different
+//     channels hit different banks.  The x image is shifted by one float: column x0 - 1 of the first tile sits on
+//     an even index, so a tile row is two aligned float pairs wherever the tile is.
+//   * each (channel, tile) pair is transformed ONCE per workgroup — thread (tile = wave, channel = lane) computes
+//     B^T d B of an input tile (20 packed ops on (column, column+1) pairs, style folded into the row stage) and
+//     A dY A^T of an output-gradient tile (12 packed ops) — and written to LDS in MFMA operand layout
+//     [position pair][k pair][k parity][64 channels][2]; the operands of a sub-chunk are 2 x 16 KB.
+//   * the waves fetch their operands with one ds_read_b64 per two MFMAs; the MFMA stream runs one sub-chunk behind
+//     the fetch (each slot of four MFMAs refills the registers it has just read), so no MFMA ever waits for an
+//     LDS round trip behind the (one per sub-chunk) barrier.  Body j: MFMAs of sub-chunk j-1 | fetch sub-chunk j | transform sub-chunk j+1
+//     | (odd j) DMA of strip (j+1)/2 + 1.
+#include <type_traits>
 #include "common.h"
 #include "conv_wino.h"
 
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef const void __attribute__((address_space(1)))* gptr_t;
 typedef void __attribute__((address_space(3)))* lptr_t;
-
-__device__ __attribute__((aligned(16))) const float g_wgw_zero[4] = {0.f, 0.f, 0.f, 0.f};
 
 constexpr int XS = 25;                      // float4 slots per channel of the x strip (4 rows x 6 + hole)
 constexpr int GS = 9;                       // float4 slots per channel of the gy strip (2 rows x 4 + hole)
 constexpr int X_INSTR = 64 * XS / 64;       // 25 wave-instructions
 constexpr int G_INSTR = 64 * GS / 64;       // 9
-constexpr int X_FLOATS = X_INSTR * 256;     // 6400
+constexpr int X_FLOATS = X_INSTR * 256 + 4; // 6404: the image starts one float in (see above)
 constexpr int G_FLOATS = G_INSTR * 256;     // 2304
-constexpr int BUF = X_FLOATS + G_FLOATS;    // 8704 floats = 34 KB per chunk
-constexpr int NBUF = 4;
+constexpr int RAW = X_FLOATS + G_FLOATS;    // 8708 floats = 34 KB per strip
+constexpr int OB = 4096;                    // floats of one operand (V or Z) of a sub-chunk: [8][2][2][64][2]
+constexpr int OBUF = 2 * OB;                // V then Z
 constexpr int PAD = 4 * 256;                // landing zone of the surplus DMA instructions (never read)
 constexpr int X_PER_WAVE = (X_INSTR + 3) / 4;   // 7
 constexpr int G_PER_WAVE = (G_INSTR + 3) / 4;   // 3
+constexpr int N_DMA = X_PER_WAVE + G_PER_WAVE;  // 10 per wave and strip
 constexpr int MAX_B = 32;                   // scale tables [B][64] x 2 in LDS
+constexpr int OOB = 0x7FFFFFF0;             // buffer offset beyond every tensor: the load returns zeros
+
+#ifdef WGW_TIMING
+// debug build only (scripts/build_variant.sh): per-workgroup time stamps of wave 0
+__device__ long long g_wgw_stamps[8 * 16384];
+#define WGW_STAMP(i) do { if (threadIdx.x == 0) { g_wgw_stamps[(blockIdx.x & 16383) * 8 + (i)] = wall_clock64(); } } while (0)
+#else
+#define WGW_STAMP(i)
+#endif
 
 struct WgWinoParams {
     const float* x;
@@ -56,24 +67,15 @@ struct WgWinoParams {
     float* partial;          // [slices][16][C][N]
     int B, C, N, H, W;
     int tiles_c, tiles_n, slices, chunks_per_slice, chunks_total;
-    int cty, ctx;            // chunk grid per sample: H/2 x W/16
+    int cty, ctx;            // strip grid per sample: H/2 x W/16
 };
 
-__device__ __forceinline__ void bt_row4(const float (&d)[16], float (&o)[16], int q, float s) {
-    float t[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-        t[j] = q == 0 ? d[j] - d[8 + j] : q == 1 ? d[4 + j] + d[8 + j] : q == 2 ? d[8 + j] - d[4 + j]
-                                                                      : d[4 + j] - d[12 + j];
-    o[4 * q + 0] = (t[0] - t[2]) * s;
-    o[4 * q + 1] = (t[1] + t[2]) * s;
-    o[4 * q + 2] = (t[2] - t[1]) * s;
-    o[4 * q + 3] = (t[1] - t[3]) * s;
-}
-
 __global__ __launch_bounds__(256) void k_wgrad_wino(const WgWinoParams p) {
+#if __HIP_DEVICE_COMPILE__   // buffer-resource builtins: device pass only (the host pass needs just the stub)
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* const pad = smem + NBUF * BUF;
+    float* const raw = smem;                          // [2][RAW]
+    float* const obuf = smem + 2 * RAW;               // [2][OBUF]
+    float* const pad = obuf + 2 * OBUF;
     float* const tabx = pad + PAD;                    // [B][64] style of this channel block
     float* const tabg = tabx + MAX_B * 64;            // [B][64] demodulation of this output block
 
@@ -90,76 +92,76 @@ __global__ __launch_bounds__(256) void k_wgrad_wino(const WgWinoParams p) {
     const int c0 = c_t * 64, n0 = n_t * 64;
     const int k_beg = slice * p.chunks_per_slice;
     const int k_end = min(p.chunks_total, k_beg + p.chunks_per_slice);
+    const int nstrips = k_end - k_beg;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = lane >> 5, l31 = lane & 31;
     const int wc = wave >> 1, wn = wave & 1;
-
-    for (int i = tid; i < p.B * 64; i += 256) {
-        const int b = i >> 6, ch = i & 63;
-        tabx[i] = p.xscale ? p.xscale[(int64_t)b * p.C + c0 + ch] : 1.0f;
-        tabg[i] = p.gscale ? p.gscale[(int64_t)b * p.N + n0 + ch] : 1.0f;
+    WGW_STAMP(0);
+#ifdef WGW_TIMING
+    const long long wgw_c0 = clock64();
+    if (tid == 0) {
+        g_wgw_stamps[(blockIdx.x & 16383) * 8 + 6] = __builtin_amdgcn_s_getreg((31 << 11) | 4);
+        g_wgw_stamps[(blockIdx.x & 16383) * 8 + 7] = __builtin_amdgcn_s_getreg((31 << 11) | 20);
     }
+#endif
 
-    // ---- DMA descriptors.  Slot s = 64 j + lane of the chunk image; every wave issues the same number
-    // of instructions (the surplus ones land in a pad region nobody reads).  Holes and pad slots may
-    // hold anything, only out-of-image halo elements need the zero line: flag bits 1 top row, 2 bottom
-    // row, 4 left column group, 8 right column group are matched against the strip's position.
-    int xd_off[X_PER_WAVE], xd_flag[X_PER_WAVE];
+    // ---- DMA descriptors.  Slot s = 64 j + lane of the strip image; every wave issues the same number of
+    // instructions (the surplus ones land in a pad region nobody reads).  Byte offsets are relative to the strip
+    // origin (row y0 - 1, column x0 - 4 of channel c0); holes, pad slots and halo elements outside the image get
+    // an out-of-range offset and receive zeros: flag bits 1 top row, 2 bottom row, 4 left column group, 8 right
+    // column group (kept in the low bits of the offset, a multiple of 16) are matched against the strip's position.
+    int xd[X_PER_WAVE];                      // byte offset (a multiple of 16) | flags
 #pragma unroll
     for (int i = 0; i < X_PER_WAVE; ++i) {
         const int s = 64 * (wave + 4 * i) + lane;
         const int c = s / XS, rem = s % XS;
         const int r = rem / 6, q = rem % 6;
         const bool payload = wave + 4 * i < X_INSTR && rem < XS - 1;
-        xd_off[i] = payload ? (c * p.H + (r - 1)) * p.W + 4 * q - 4 : 0;
-        xd_flag[i] = payload ? (r == 0 ? 1 : 0) | (r == 3 ? 2 : 0) | (q == 0 ? 4 : 0) | (q == 5 ? 8 : 0) : 0;
+        xd[i] = payload ? (((c * p.H + r) * p.W + 4 * q) * 4) | (r == 0 ? 1 : 0) | (r == 3 ? 2 : 0) | (q == 0 ? 4 : 0) | (q == 5 ? 8 : 0)
+                        : OOB;
     }
     int gd_off[G_PER_WAVE];
 #pragma unroll
     for (int i = 0; i < G_PER_WAVE; ++i) {
         const int s = 64 * (wave + 4 * i) + lane;
         const int n = s / GS, rem = s % GS;
-        gd_off[i] = (wave + 4 * i < G_INSTR && rem < GS - 1) ? (n * p.H + rem / 4) * p.W + 4 * (rem % 4) : 0;
+        gd_off[i] = (wave + 4 * i < G_INSTR && rem < GS - 1) ? ((n * p.H + rem / 4) * p.W + 4 * (rem % 4)) * 4 : OOB;
     }
-    const int64_t plane = (int64_t)p.H * p.W;
+    const int plane = p.H * p.W;
+    // x descriptor starts W + 4 floats in front of the tensor: strip offsets stay non-negative
+    const __amdgpu_buffer_rsrc_t r_x = uniform_rsrc(p.x - (p.W + 4), (p.B * p.C * plane + p.W + 4) * 4);
+    const __amdgpu_buffer_rsrc_t r_g = uniform_rsrc(p.gy, p.B * p.N * plane * 4);
 
-    // strip coordinates of the chunk the next fetch brings in (advanced incrementally, clamped at the last
-    // chunk of the tensor so that a surplus fetch at the end of a slice stays in bounds)
+    // strip coordinates of the next fetch (advanced incrementally, clamped at the last strip of the tensor so that a
+    // surplus fetch at the end of a slice stays in bounds)
     int d_txc = k_beg % p.ctx, d_ty = (k_beg / p.ctx) % p.cty, d_b = k_beg / (p.ctx * p.cty);
-    const float* d_xo;
-    const float* d_go;
-    int d_edge;
+    int d_xs, d_gs, d_edge;
     float* d_dst;
-    auto dma_begin = [&](int buf) {          // uniform part of one chunk fetch
+    auto dma_begin = [&](int buf) {          // uniform part of one strip fetch
         const int y0 = 2 * d_ty, x0 = 16 * d_txc;
-        d_xo = p.x + ((int64_t)d_b * p.C + c0) * plane + (int64_t)y0 * p.W + x0;
-        d_go = p.gy + ((int64_t)d_b * p.N + n0) * plane + (int64_t)y0 * p.W + x0;
+        d_xs = ((d_b * p.C + c0) * plane + y0 * p.W + x0) * 4;
+        d_gs = ((d_b * p.N + n0) * plane + y0 * p.W + x0) * 4;
         d_edge = (d_ty == 0 ? 1 : 0) | (d_ty == p.cty - 1 ? 2 : 0) | (d_txc == 0 ? 4 : 0) | (d_txc == p.ctx - 1 ? 8 : 0);
-        d_dst = smem + buf * BUF;
+        d_dst = raw + buf * RAW;
         const bool last = d_txc == p.ctx - 1 && d_ty == p.cty - 1 && d_b == p.B - 1;
         if (!last && ++d_txc == p.ctx) {
             d_txc = 0;
             if (++d_ty == p.cty) { d_ty = 0; ++d_b; }
         }
     };
-    auto dma_x1 = [&](int i) {
-        const float* src = (xd_flag[i] & d_edge) ? g_wgw_zero : d_xo + xd_off[i];
-        __builtin_amdgcn_global_load_lds(
-            (gptr_t)src, (lptr_t)(wave + 4 * i < X_INSTR ? d_dst + (wave + 4 * i) * 256 : pad + wave * 256), 16, 0, 0);
-    };
-    auto dma_g1 = [&](int i) {
-        __builtin_amdgcn_global_load_lds(
-            (gptr_t)(d_go + gd_off[i]),
-            (lptr_t)(wave + 4 * i < G_INSTR ? d_dst + X_FLOATS + (wave + 4 * i) * 256 : pad + wave * 256), 16, 0, 0);
-    };
-    auto dma_next = [&](int buf) {
-        dma_begin(buf);
-#pragma unroll
-        for (int i = 0; i < X_PER_WAVE; ++i) dma_x1(i);
-#pragma unroll
-        for (int i = 0; i < G_PER_WAVE; ++i) dma_g1(i);
+    auto dma1 = [&](int i) {                 // instruction i (0 .. 9) of the strip begun last
+        if (i < X_PER_WAVE) {
+            const int off = (xd[i] & d_edge) ? OOB : (xd[i] & ~15);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                r_x, (lptr_t)(wave + 4 * i < X_INSTR ? d_dst + 1 + (wave + 4 * i) * 256 : pad + wave * 256), 16, off, d_xs, 0, 0);
+        } else {
+            const int g = i - X_PER_WAVE;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                r_g, (lptr_t)(wave + 4 * g < G_INSTR ? d_dst + X_FLOATS + (wave + 4 * g) * 256 : pad + wave * 256), 16,
+                gd_off[g], d_gs, 0, 0);
+        }
     };
 
     f32x16 acc[16];
@@ -168,228 +170,227 @@ __global__ __launch_bounds__(256) void k_wgrad_wino(const WgWinoParams p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[pos][r] = 0.0f;
 
-    // per-lane read bases inside a chunk buffer (floats); k-lane 1 reads one float4 slot further right
-    const int xb = (wc * 32 + l31) * (XS * 4) + half * 4;
-    const int gb = X_FLOATS + (wn * 32 + l31) * (GS * 4) + half * 4;
-    const int tab_c = wc * 32 + l31, tab_n = wn * 32 + l31;
-
-    // k-step ks of a chunk pairs tiles t = (ks & 1) + 4 (ks >> 1) (k-lane 0) and t + 2 (k-lane 1): columns
-    // 3 + 2t .. 6 + 2t of the aligned window = elements 3..6 (even ks) / 1..4 (odd ks) of two float4 slots.
-    // The raw operands are fetched with explicit ds_read_b128 / ds_read_b64 (inline asm: left to itself
-    // the compiler fetches only the 4 live elements per row as ds_read2_b32, which lands the 32 lanes of a
-    // half-wave — 32 channels, 100 floats apart — on 8 banks; whole 16-byte slots at 25-slot pitch are
-    // conflict free).  lds_wait() carries the registers as operands, so every use is ordered behind it.
-    typedef float f4 __attribute__((ext_vector_type(4)));
+    // ---- packed fp32 helpers (explicit v_pk_*: the compiler scalarises ext_vector arithmetic here)
     typedef float f2 __attribute__((ext_vector_type(2)));
-    struct Raw { f4 a[4], b[4]; f2 g0, g1; };
-    auto load_raw = [&](unsigned xaddr, unsigned gaddr, int ks, Raw& R) {
-        const int xo = ((ks >> 1) * 2 + (ks & 1)) * 16, go = ((ks & 1) + 4 * (ks >> 1)) * 8;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(R.a[r]) : "v"(xaddr), "i"(r * 96 + xo));
-            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(R.b[r]) : "v"(xaddr), "i"(r * 96 + xo + 16));
-        }
-        asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(R.g0) : "v"(gaddr), "i"(go));
-        asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(R.g1) : "v"(gaddr), "i"(go + 64));
-    };
-    auto lds_wait = [](Raw& R) {
-        asm volatile("s_waitcnt lgkmcnt(0)"
-                     : "+v"(R.a[0]), "+v"(R.a[1]), "+v"(R.a[2]), "+v"(R.a[3]), "+v"(R.b[0]), "+v"(R.b[1]), "+v"(R.b[2]),
-                       "+v"(R.b[3]), "+v"(R.g0), "+v"(R.g1));
-    };
-    // Transforms with packed fp32 ops where the data allows (a non-MFMA instruction costs the matrix pipe an
-    // issue slot).  B^T d B, row q: t0..t3 scalar (the two operands of each come from
-    // different 16-byte loads), then with P = (t1, t2), Q = (t0, t3):
-    //   (o1, o2) = (P.lo + P.hi, P.hi - P.lo)        (o0, -o3) = (Q.lo - P.hi, Q.hi - P.lo)
-    // one v_pk_add_f32 each (op_sel / neg modifiers), one v_pk_mul_f32 each for the style (the second with
-    // neg_hi to undo the sign).  A dY A^T: both stages packed on the (p, q) / (r, s) pairs as loaded.
+    auto ld2 = [](const float* q) { return *reinterpret_cast<const f2*>(q); };
+    auto st2 = [](float* q, f2 v) { *reinterpret_cast<f2*>(q) = v; };
     auto pk_mul = [](f2 a, f2 b) { f2 r; asm("v_pk_mul_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; };
-    auto pk_mul_pn = [](f2 a, f2 b) {            // (a.lo * b.lo, -(a.hi * b.hi))
-        f2 r;
-        asm("v_pk_mul_f32 %0, %1, %2 neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
-        return r;
-    };
     auto pk_add = [](f2 a, f2 b) { f2 r; asm("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; };
     auto pk_sub = [](f2 a, f2 b) {
         f2 r;
         asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
         return r;
     };
-    auto pk_sum_diff = [](f2 w) {                // (w.lo + w.hi, w.lo - w.hi)
+    auto pk_fms = [](f2 a, f2 b, f2 c) {         // a * b - c
         f2 r;
-        asm("v_pk_add_f32 %0, %1, %1 op_sel:[0,1] op_sel_hi:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(w));
+        asm("v_pk_fma_f32 %0, %1, %2, %3 neg_lo:[0,0,1] neg_hi:[0,0,1]" : "=v"(r) : "v"(a), "v"(b), "v"(c));
         return r;
     };
-    auto pk_nsum_ndiff = [](f2 w) {              // (-w.lo - w.hi, -w.lo + w.hi)
+    auto pk_fnma = [](f2 a, f2 b, f2 c) {        // c - a * b
         f2 r;
-        asm("v_pk_add_f32 %0, %1, %1 op_sel:[0,1] op_sel_hi:[0,1] neg_lo:[1,1] neg_hi:[1,0]" : "=v"(r) : "v"(w));
+        asm("v_pk_fma_f32 %0, %1, %2, %3 neg_lo:[1,0,0] neg_hi:[1,0,0]" : "=v"(r) : "v"(a), "v"(b), "v"(c));
         return r;
     };
-    auto pk_o12 = [](f2 P) {                     // (P.lo + P.hi, P.hi - P.lo)
+    // column stage of B^T d B on t = (t0, t1 | t2, t3): (t0 - t2, t1 + t2) and (t2 - t1, t1 - t3)
+    auto col01 = [](f2 tp, f2 tq) {
         f2 r;
-        asm("v_pk_add_f32 %0, %1, %1 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(P));
+        asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,0]" : "=v"(r) : "v"(tp), "v"(tq));
         return r;
     };
-    auto pk_o03 = [](f2 Q, f2 P) {               // (Q.lo - P.hi, Q.hi - P.lo)
+    auto col23 = [](f2 tp, f2 tq) {
         f2 r;
-        asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(Q), "v"(P));
+        asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[1,0]" : "=v"(r) : "v"(tq), "v"(tp));
         return r;
     };
-    struct ZTmp { f2 w0, w1, w2, w3; };
-    auto unpack_d = [](const Raw& R, int ks, float (&d)[16]) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            if ((ks & 1) == 0) { d[4 * r] = R.a[r].w; d[4 * r + 1] = R.b[r].x; d[4 * r + 2] = R.b[r].y; d[4 * r + 3] = R.b[r].z; }
-            else { d[4 * r] = R.a[r].y; d[4 * r + 1] = R.a[r].z; d[4 * r + 2] = R.a[r].w; d[4 * r + 3] = R.b[r].x; }
-        }
+    // rows of A dY A^T from w = (a, b): (a, a + b | a - b, -b); last row from (r, s): (-r, -r - s | -r + s, s).
+    // c01 = (0, 1), c10 = (1, 0): one fused multiply-add each (a non-finite gradient turns its 0-weighted
+    // neighbour into NaN instead of leaving it finite — such a step is lost either way).
+    auto z_lo = [](f2 w, f2 c01) {               // (a, a + b)
+        f2 r;
+        asm("v_pk_fma_f32 %0, %1, %2, %1 op_sel:[1,0,0] op_sel_hi:[1,1,0]" : "=v"(r) : "v"(w), "v"(c01));
+        return r;
     };
-    auto v_row = [&](const float (&d)[16], int q, f2 s2, float (&V)[16]) {
-        float t[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-            t[j] = q == 0 ? d[j] - d[8 + j] : q == 1 ? d[4 + j] + d[8 + j] : q == 2 ? d[8 + j] - d[4 + j]
-                                                                          : d[4 + j] - d[12 + j];
-        f2 P, Q;
-        P.x = t[1]; P.y = t[2];
-        Q.x = t[0]; Q.y = t[3];
-        const f2 a = pk_mul(pk_o12(P), s2);          // (o1, o2) * s
-        const f2 b = pk_mul_pn(pk_o03(Q, P), s2);    // (o0, o3) * s
-        V[4 * q + 0] = b.x;
-        V[4 * q + 1] = a.x;
-        V[4 * q + 2] = a.y;
-        V[4 * q + 3] = b.y;
+    auto z_hi = [](f2 w, f2 c10) {               // (a - b, -b)
+        f2 r;
+        asm("v_pk_fma_f32 %0, %1, %2, %1 op_sel:[0,0,1] op_sel_hi:[0,1,1] neg_lo:[0,0,1] neg_hi:[0,0,1]"
+            : "=v"(r) : "v"(w), "v"(c10));
+        return r;
     };
-    auto z_begin = [&](const Raw& R, f2 g2, ZTmp& T) {
-        T.w0 = pk_mul(R.g0, g2);                     // (p, q) * sg
-        T.w3 = pk_mul(R.g1, g2);                     // (r, s) * sg   (row 3 is its negative)
-        T.w1 = pk_add(T.w0, T.w3);
-        T.w2 = pk_sub(T.w0, T.w3);
+    auto z3_lo = [](f2 w, f2 c01) {              // (-r, -r - s)
+        f2 r;
+        asm("v_pk_fma_f32 %0, %1, %2, %1 op_sel:[1,0,0] op_sel_hi:[1,1,0] neg_lo:[1,0,1] neg_hi:[1,0,1]"
+            : "=v"(r) : "v"(w), "v"(c01));
+        return r;
     };
-    auto z_row = [&](f2 w, int i, float (&Z)[16]) {  // rows 0..2: (a, a + b, a - b, -b)
-        const f2 sd = pk_sum_diff(w);
-        Z[4 * i + 0] = w.x;
-        Z[4 * i + 1] = sd.x;
-        Z[4 * i + 2] = sd.y;
-        Z[4 * i + 3] = -w.y;
+    auto z3_hi = [](f2 w, f2 c10) {              // (-r + s, s)
+        f2 r;
+        asm("v_pk_fma_f32 %0, %1, %2, %1 op_sel:[0,0,1] op_sel_hi:[0,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]"
+            : "=v"(r) : "v"(w), "v"(c10));
+        return r;
     };
-    auto z_row3 = [&](f2 w, float (&Z)[16]) {        // row 3 from (r, s): (-r, -r - s, -r + s, s)
-        const f2 nd = pk_nsum_ndiff(w);
-        Z[12] = -w.x;
-        Z[13] = nd.x;
-        Z[14] = nd.y;
-        Z[15] = w.y;
-    };
-    // piece i (0..3) of the transforms of one k-step: pinned into the four MFMA slots of the previous one
-    auto transform_piece = [&](const float (&d)[16], const Raw& R, ZTmp& T, int i, f2 s2, f2 g2, float (&V)[16],
-                               float (&Z)[16]) {
-        v_row(d, i, s2, V);
-        if (i == 0) z_begin(R, g2, T);
-        if (i == 1) { z_row(T.w0, 0, Z); z_row(T.w1, 1, Z); }
-        if (i == 2) { z_row(T.w2, 2, Z); z_row3(T.w3, Z); }
-    };
-    auto transform = [&](const Raw& R, int ks, float sx, float sg, float (&V)[16], float (&Z)[16]) {
-        float d[16];
-        unpack_d(R, ks, d);
-        f2 s2, g2;
-        s2.x = s2.y = sx;
-        g2.x = g2.y = sg;
-        ZTmp T;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) transform_piece(d, R, T, i, s2, g2, V, Z);
-    };
+    f2 c01, c10;
+    c01.x = 0.0f; c01.y = 1.0f;
+    c10.x = 1.0f; c10.y = 0.0f;
 
-    // ---- pipeline.  Four chunk buffers; at the top of iteration kk chunks kk and kk+1 are complete in
-    // LDS (every wave drained its own DMAs of them before the barrier), chunk kk+2 is in flight and chunk
-    // kk+3 is issued into the buffer of chunk kk-1.  The operands of k-step 0 of chunk kk+1 are produced
-    // under the MFMAs of the last k-step of chunk kk, so the matrix pipe never waits for a transform.
-    // Raw s_barrier, not __syncthreads: the release fence of the latter drains vmcnt to 0 and with it the
-    // chunks that are meant to stay in flight.  Cross-wave data is DMA-written only: "my DMAs landed"
-    // (vmcnt) + "my LDS reads retired" (lgkmcnt) before the barrier is the whole protocol; the asm memory
-    // clobbers keep the compiler from moving LDS accesses across it.
-    const unsigned lds0 = (unsigned)(__SIZE_TYPE__)(lptr_t)smem;       // LDS byte address of the buffers
-    const int per_sample = p.ctx * p.cty;
-    int c_left = per_sample - (k_beg % per_sample), c_b = k_beg / per_sample;   // sample of the chunk being fetched
-    auto scales_next = [&](float& sx, float& sg) {       // scales of the next chunk whose operands are built
-        const int b = min(c_b, p.B - 1);
-        sx = tabx[b * 64 + tab_c];
-        sg = tabg[b * 64 + tab_n];
-        if (--c_left == 0) { c_left = per_sample; ++c_b; }
+    // ---- transform item of this thread in a sub-chunk: tile = wave (k pair wave >> 1, k parity wave & 1),
+    // channel = lane.  Seven steps, pinned one per MFMA slot inside the loop.
+    struct XF {
+        f2 P[4], Q[4], g0, g1;            // raw: tile rows (columns 0,1 | 2,3), gradient rows
+        f2 sp1, sp2, sq1, sq2;            // s * rows 1, 2
+        f2 tp[4], tq[4];                  // after the row stage
+        f2 o01[4], o23[4];                // B^T d B rows: positions (4q, 4q+1), (4q+2, 4q+3)
+        f2 w0, w1, w2, w3;
+        f2 z01[4], z23[4];
+        f2 sv, gv;                        // style / demodulation of this (sample, channel), both halves
     };
-    float V[2][16], Z[2][16];
-    Raw R;
-    float sx, sg;
-    dma_next(0);
-    dma_next(1);
-    dma_next(2);
-    asm volatile("s_waitcnt vmcnt(20) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    scales_next(sx, sg);
-#ifdef WGW_NO_XFORM
+    const int t_wr = (wave >> 1) * 256 + (wave & 1) * 128 + lane * 2;
+    auto xf_step = [&](XF& x, int step, const float* rw, int hsel, int b_smp, float* ob) {
+        // rw: strip image; hsel: which half of the strip (tiles 4 hsel + wave); ob: operand buffer written
+        const float* xr = rw + 1 + lane * (XS * 4) + 3 + 2 * (4 * hsel + wave);
+        const float* gr = rw + X_FLOATS + lane * (GS * 4) + 2 * (4 * hsel + wave);
+        if (step == 0) {
+            x.P[0] = ld2(xr); x.Q[0] = ld2(xr + 2);
+            x.P[1] = ld2(xr + 24); x.Q[1] = ld2(xr + 26);
+            const float sx = tabx[b_smp * 64 + lane], sg = tabg[b_smp * 64 + lane];
+            x.sv.x = x.sv.y = sx;
+            x.gv.x = x.gv.y = sg;
+        } else if (step == 1) {
+            x.P[2] = ld2(xr + 48); x.Q[2] = ld2(xr + 50);
+            x.P[3] = ld2(xr + 72); x.Q[3] = ld2(xr + 74);
+            x.g0 = ld2(gr);
+            x.g1 = ld2(gr + 16);
+        } else if (step == 2) {
+            x.sp1 = pk_mul(x.P[1], x.sv); x.sp2 = pk_mul(x.P[2], x.sv);
+            x.sq1 = pk_mul(x.Q[1], x.sv); x.sq2 = pk_mul(x.Q[2], x.sv);
+            x.tp[0] = pk_fms(x.P[0], x.sv, x.sp2); x.tq[0] = pk_fms(x.Q[0], x.sv, x.sq2);
+        } else if (step == 3) {
+            x.tp[1] = pk_add(x.sp1, x.sp2); x.tq[1] = pk_add(x.sq1, x.sq2);
+            x.tp[2] = pk_sub(x.sp2, x.sp1); x.tq[2] = pk_sub(x.sq2, x.sq1);
+            x.tp[3] = pk_fnma(x.P[3], x.sv, x.sp1); x.tq[3] = pk_fnma(x.Q[3], x.sv, x.sq1);
+        } else if (step == 4) {
+            x.o01[0] = col01(x.tp[0], x.tq[0]); x.o23[0] = col23(x.tp[0], x.tq[0]);
+            x.o01[1] = col01(x.tp[1], x.tq[1]); x.o23[1] = col23(x.tp[1], x.tq[1]);
+            x.w0 = pk_mul(x.g0, x.gv); x.w3 = pk_mul(x.g1, x.gv);
+            x.w1 = pk_add(x.w0, x.w3); x.w2 = pk_sub(x.w0, x.w3);
+        } else if (step == 5) {
+            x.o01[2] = col01(x.tp[2], x.tq[2]); x.o23[2] = col23(x.tp[2], x.tq[2]);
+            x.o01[3] = col01(x.tp[3], x.tq[3]); x.o23[3] = col23(x.tp[3], x.tq[3]);
 #pragma unroll
-    for (int i = 0; i < 16; ++i) { V[0][i] = V[1][i] = sx + i; Z[0][i] = Z[1][i] = sg - i; }
-#else
-    load_raw(lds0 + (unsigned)xb * 4u, lds0 + (unsigned)gb * 4u, 0, R);
-    lds_wait(R);
-    transform(R, 0, sx, sg, V[0], Z[0]);
-#endif
-    int cur = 0;
-    for (int kk = k_beg; kk < k_end; ++kk) {
-        asm volatile("s_waitcnt vmcnt(10) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        // chunk kk+3 (a surplus fetch past the slice lands in a free buffer): its 10 DMA instructions are
-        // spread over the four k-steps below, under the MFMAs; no branch in the loop body
-        dma_begin((cur + 3) & 3);
-        const unsigned xaddr = lds0 + (unsigned)(cur * BUF + xb) * 4u, gaddr = lds0 + (unsigned)(cur * BUF + gb) * 4u;
-        const int nxt = (cur + 1) & 3;
-        const unsigned xaddr_n = lds0 + (unsigned)(nxt * BUF + xb) * 4u, gaddr_n = lds0 + (unsigned)(nxt * BUF + gb) * 4u;
-        float sxn, sgn;
-        scales_next(sxn, sgn);
+            for (int q = 0; q < 2; ++q) {
+                st2(ob + t_wr + (2 * q) * 512, x.o01[q]);
+                st2(ob + t_wr + (2 * q + 1) * 512, x.o23[q]);
+            }
+        } else if (step == 6) {
+            x.z01[0] = z_lo(x.w0, c01); x.z23[0] = z_hi(x.w0, c10);
+            x.z01[1] = z_lo(x.w1, c01); x.z23[1] = z_hi(x.w1, c10);
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-#ifndef WGW_NO_XFORM
-            // LDS reads of the next k-step (of the next chunk after the last one) in flight under the MFMAs
-            if (ks + 1 < 4) load_raw(xaddr, gaddr, ks + 1, R);
-            else load_raw(xaddr_n, gaddr_n, 0, R);
-#endif
-            __builtin_amdgcn_sched_barrier(0);
-            // two MFMAs cover the LDS latency of the reads above, then the wait; after that four slots of
-            // MFMAs, each with one piece of the next k-step's transforms (and its share of the DMA issue)
-            // pinned into it
+            for (int q = 2; q < 4; ++q) {
+                st2(ob + t_wr + (2 * q) * 512, x.o01[q]);
+                st2(ob + t_wr + (2 * q + 1) * 512, x.o23[q]);
+            }
+        } else {
+            x.z01[2] = z_lo(x.w2, c01); x.z23[2] = z_hi(x.w2, c10);
+            x.z01[3] = z3_lo(x.w3, c01); x.z23[3] = z3_hi(x.w3, c10);
 #pragma unroll
-            for (int pos = 0; pos < 2; ++pos)
-                acc[pos] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[ks & 1][pos], Z[ks & 1][pos], acc[pos], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-#ifndef WGW_NO_XFORM
-            lds_wait(R);
-            float dn[16];
-            unpack_d(R, ks + 1 < 4 ? ks + 1 : 0, dn);
-            f2 s2, g2;
-            s2.x = s2.y = (ks + 1 < 4) ? sx : sxn;
-            g2.x = g2.y = (ks + 1 < 4) ? sg : sgn;
-            ZTmp T;
-#endif
-#pragma unroll
-            for (int slot = 0; slot < 4; ++slot) {
-#pragma unroll
-                for (int pos = (slot == 0 ? 2 : 4 * slot); pos < 4 * slot + 4; ++pos)
-                    acc[pos] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[ks & 1][pos], Z[ks & 1][pos], acc[pos], 0, 0, 0);
-#ifndef WGW_NO_XFORM
-                transform_piece(dn, R, T, slot, s2, g2, V[(ks + 1) & 1], Z[(ks + 1) & 1]);
-#endif
-#ifndef WGW_NO_DMA
-                if (slot > 0) {
-                    const int i = 3 * ks + slot - 1;             // 10 DMA instructions over ks 0..3, slots 1..3
-                    if (i < X_PER_WAVE) dma_x1(i);
-                    else if (i < X_PER_WAVE + G_PER_WAVE) dma_g1(i - X_PER_WAVE);
-                }
-#endif
-                __builtin_amdgcn_sched_barrier(0);
+            for (int q = 0; q < 4; ++q) {
+                st2(ob + OB + t_wr + (2 * q) * 512, x.z01[q]);
+                st2(ob + OB + t_wr + (2 * q + 1) * 512, x.z23[q]);
             }
         }
-        sx = sxn;
-        sg = sgn;
-        cur = nxt;
+    };
+
+    // ---- operand registers [k pair][position pair]: ONE set.  Slot s of a body issues the four MFMAs that read
+    // av / bz [s >> 2][2 (s & 3) .. + 1] and then refills exactly those registers with the next sub-chunk's values
+    // (consumed in the same slot of the next body, a whole body later).
+    f2 av[2][8], bz[2][8];
+    const int a_rd = half * 128 + (wc * 32 + l31) * 2;
+    const int b_rd = OB + half * 128 + (wn * 32 + l31) * 2;
+    auto mfma_step = [&](int m) {
+        const int kp = m >> 4, pos = m & 15, pp = pos >> 1;
+        if (pos & 1) acc[pos] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kp][pp].y, bz[kp][pp].y, acc[pos], 0, 0, 0);
+        else acc[pos] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kp][pp].x, bz[kp][pp].x, acc[pos], 0, 0, 0);
+    };
+
+    // sample of the strip whose tiles are being transformed (advanced once per strip)
+    const int per_sample = p.ctx * p.cty;
+    int c_left = per_sample - (k_beg % per_sample), c_b = k_beg / per_sample;
+    auto next_strip_sample = [&]() {
+        if (--c_left == 0) { c_left = per_sample; ++c_b; }
+    };
+
+    // ---- prologue: strips 0 and 1 in flight, scale tables, operands of sub-chunk 0
+    dma_begin(0);
+#pragma unroll
+    for (int i = 0; i < N_DMA; ++i) dma1(i);
+    dma_begin(1);
+#pragma unroll
+    for (int i = 0; i < N_DMA; ++i) dma1(i);
+    for (int i = tid; i < p.B * 64; i += 256) {
+        const int b = i >> 6, ch = i & 63;
+        tabx[i] = p.xscale ? p.xscale[(int64_t)b * p.C + c0 + ch] : 1.0f;
+        tabg[i] = p.gscale ? p.gscale[(int64_t)b * p.N + n0 + ch] : 1.0f;
     }
+    // the table loads were issued after the DMAs: vmcnt(10) = "strip 0 landed" cannot be told apart from them,
+    // so drain everything once here
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    {
+        XF x;
+#pragma unroll
+        for (int st = 0; st < 8; ++st) xf_step(x, st, raw, 0, min(c_b, p.B - 1), obuf);
+    }
+
+    // Raw s_barrier, not __syncthreads: the release fence of the latter drains vmcnt to 0 and with it the strip
+    // that is meant to stay in flight.  "My DMAs landed" (vmcnt) + "my LDS accesses retired" (lgkmcnt) before
+    // the barrier is the whole protocol; the asm memory clobbers keep the compiler from moving LDS accesses
+    // across it.
+    auto body = [&](auto j_tag, int strip_par, auto first_tag) {
+        // body j (parity j_par, compile time) of strip s = j >> 1 (parity strip_par, run time)
+        constexpr int j_par = decltype(j_tag)::value;
+        constexpr bool FIRST = decltype(first_tag)::value;
+        if (j_par == 0) asm volatile("s_waitcnt vmcnt(10) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        // even body: transforms the second half of the current strip; odd body: the first half of the next one
+        // (sample advanced) and starts the fetch of the strip after that into the buffer of the current one
+        if (j_par == 1) { next_strip_sample(); dma_begin(strip_par); }
+        const float* rw = raw + (j_par == 0 ? strip_par : strip_par ^ 1) * RAW;
+        const int b_smp = min(c_b, p.B - 1);
+        const float* ob_rd = obuf + j_par * OBUF;
+        float* ob_wr = obuf + (j_par ^ 1) * OBUF;
+        XF x;
+        auto load_ops = [&](int kp, int pp) {
+            av[kp][pp] = ld2(ob_rd + a_rd + pp * 512 + kp * 256);
+            bz[kp][pp] = ld2(ob_rd + b_rd + pp * 512 + kp * 256);
+        };
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            if (!FIRST) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) mfma_step(4 * s + u);
+            }
+            load_ops(s >> 2, 2 * (s & 3));
+            load_ops(s >> 2, 2 * (s & 3) + 1);
+#ifndef WGW_NO_DMA
+            if (j_par == 1 && s < 5) { dma1(2 * s); dma1(2 * s + 1); }
+#endif
+#ifndef WGW_NO_XFORM
+            xf_step(x, s, rw, j_par == 0 ? 1 : 0, b_smp, ob_wr);
+#endif
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    WGW_STAMP(1);
+    body(std::integral_constant<int, 0>{}, 0, std::true_type{});
+    body(std::integral_constant<int, 1>{}, 0, std::false_type{});
+    for (int s = 1; s < nstrips; ++s) {      // straight-line loop body: the strip parity is a run-time LDS offset
+        body(std::integral_constant<int, 0>{}, s & 1, std::false_type{});
+        body(std::integral_constant<int, 1>{}, s & 1, std::false_type{});
+    }
+    // MFMAs of the last sub-chunk
+#pragma unroll
+    for (int m = 0; m < 32; ++m) mfma_step(m);
     // surplus fetches are still landing in this workgroup's LDS: drain them before the wave can retire
     __builtin_amdgcn_s_waitcnt(0x0F70);
+    WGW_STAMP(2);
 
     // ---- partial dU slab of this slice: rows = channels (r & 3) + 8 (r >> 2) + 4 half, cols = l31
     float* out = p.partial + (int64_t)slice * 16 * p.C * p.N;
@@ -400,6 +401,11 @@ __global__ __launch_bounds__(256) void k_wgrad_wino(const WgWinoParams p) {
             const int c = c0 + wc * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
             out[((int64_t)pos * p.C + c) * p.N + n0 + wn * 32 + l31] = acc[pos][r];
         }
+    WGW_STAMP(3);
+#ifdef WGW_TIMING
+    if (tid == 0) g_wgw_stamps[(blockIdx.x & 16383) * 8 + 5] = clock64() - wgw_c0;
+#endif
+#endif
 }
 
 // dwt[tap][c][n] = (G^T dU G)[tap], dU = sum over slices (fixed order).  A workgroup covers 64 (c, n)
@@ -454,9 +460,16 @@ void plan(int64_t B, int64_t C, int64_t N, int64_t H, int64_t W, int& slices, in
 
 }  // namespace
 
+#ifdef WGW_TIMING
+extern "C" int sr_debug_wgw_stamps(long long* host, int n) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_wgw_stamps), (size_t)n * sizeof(long long));
+}
+#endif
+
 bool sr_wgrad_wino_eligible(int64_t B, int64_t C, int64_t N, int64_t H, int64_t W, const void* x, const void* gy) {
     if (B <= 0 || B > MAX_B || C % 64 != 0 || N % 64 != 0 || H % 2 != 0 || W % 16 != 0) return false;
-    if (B * C * H * W >= (1LL << 31) || B * N * H * W >= (1LL << 31)) return false;
+    // buffer addressing: byte offsets inside x / gy stay below 2^31 - 16
+    if (B * C * H * W + W + 4 >= (1LL << 29) - 4 || B * N * H * W >= (1LL << 29) - 4) return false;
     return ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(gy)) & 15) == 0;
 }
 
@@ -474,7 +487,7 @@ int sr_wgrad_wino_3x3(float* dwt, const float* x, const float* gy, const float* 
     p.tiles_c = (int)(C / 64); p.tiles_n = (int)(N / 64);
     p.cty = (int)(H / 2); p.ctx = (int)(W / 16);
     plan(B, C, N, H, W, p.slices, p.chunks_per_slice, p.chunks_total);
-    const int lds = (NBUF * BUF + PAD + 2 * MAX_B * 64) * 4;
+    const int lds = (2 * RAW + 2 * OBUF + PAD + 2 * MAX_B * 64) * 4;
     static bool configured = false;
     if (!configured) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_wgrad_wino), hipFuncAttributeMaxDynamicSharedMemorySize,
