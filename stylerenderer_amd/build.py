@@ -19,11 +19,16 @@ ARCH = "gfx950"
 COMMON = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result",
           "-fhip-fp32-correctly-rounded-divide-sqrt"]
 EXACT = ["-ffp-contract=off"]
+# no SLP packing (v_pk_mul / v_pk_add on neighbouring accumulators) for the FIR kernels: it costs the plain blur 73
+# register shuffles and 121 instead of 64 registers (four instead of eight waves per SIMD; 3.1 -> 3.8-4.2 TB/s
+# without it).  The arithmetic is the same IEEE operations either way.  Measured on the other streaming files too:
+# k_smallconv_dw +8 %, k_smallconv_fwd / dx at 64^2 -20..30 %, whole step slower — left alone there.
+NOSLP = ["-fno-slp-vectorize"]
 
 SOURCES = [
     ("capi.hip", EXACT),
     ("fused_bias_act.hip", EXACT),
-    ("upfirdn2d.hip", EXACT),
+    ("upfirdn2d.hip", EXACT + NOSLP),
     ("rasterize.hip", EXACT),
     ("fused_elem.hip", EXACT),
     ("weight_prep.hip", EXACT),
