@@ -331,7 +331,9 @@ def test_demod_scale_forward_backward(b, ci, co):
 # Stated tolerance: |err| <= 4e-6 * sum|a*b| (the transforms add a few fp32 roundings on sums of up to
 # 4 inputs / 3 weights; measured 5e-7), against 2e-6 for the exact-fma-chain direct kernel.
 @pytest.mark.parametrize("b,c,n,h,w,scales", [(2, 24, 64, 16, 32, True), (1, 16, 128, 8, 64, False),
-                                               (3, 40, 64, 24, 32, True)])
+                                               (3, 40, 64, 24, 32, True),
+                                               (1, 8, 64, 8, 32, True),        # one chunk: first body + tail only
+                                               (2, 512, 64, 8, 32, False)])    # 64 chunks, the largest style row
 def test_winograd_conv_vs_float64_and_direct(b, c, n, h, w, scales, monkeypatch):
     from stylerenderer_amd.op.conv import conv2d_mfma
 
@@ -358,7 +360,11 @@ def test_winograd_conv_vs_float64_and_direct(b, c, n, h, w, scales, monkeypatch)
 # Winograd F(3x3,2x2) weight gradient (csrc/conv_wgrad_wino.hip) vs float64 and vs the direct kernel.
 # Stated tolerance 4e-6 * sum|a*b| (measured 3e-7), direct kernel 2e-6.
 @pytest.mark.parametrize("b,c,n,h,w,scales", [(3, 64, 128, 8, 32, True), (2, 128, 64, 16, 16, False),
-                                               (5, 64, 64, 6, 48, True)])
+                                               (5, 64, 64, 6, 48, True),
+                                               (1, 64, 64, 2, 16, True),       # one strip: prologue + tail only
+                                               (3, 64, 64, 2, 16, True),       # odd strip count, a sample per strip
+                                               (2, 64, 64, 2, 48, False),      # a slice that crosses the sample boundary
+                                               (32, 64, 64, 4, 16, True)])     # full scale tables (B = 32), four slices
 def test_winograd_wgrad_vs_float64_and_direct(b, c, n, h, w, scales, monkeypatch):
     from stylerenderer_amd.op.conv import conv2d_wgrad_mfma
 
