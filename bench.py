@@ -232,13 +232,16 @@ def train_leg(dev, rank, world, iters, batch, size=256):
         last = tr.step(data.batch(batch), faces=faces, log=False)
     fence()
     elapsed = time.perf_counter() - t0
-    # host cost of enqueueing an iteration, measured on an EMPTY queue (inside the long loop the host is throttled by
-    # the runtime's limit on launches in flight, so its loop time equals the GPU time whatever bounds the step)
-    t1 = time.perf_counter()
-    for _ in range(2):
+    # host cost of enqueueing ONE iteration on an idle GPU (inside the long loop the host is throttled — a graph is not
+    # re-launched while its previous launch runs — so its loop time equals the GPU time whatever bounds the step)
+    enq = []
+    for _ in range(3):
+        fence()
+        t1 = time.perf_counter()
         last = tr.step(data.batch(batch), faces=faces, log=False)
-    t_enq = (time.perf_counter() - t1) / 2 * iters
+        enq.append(time.perf_counter() - t1)
     fence()
+    t_enq = sorted(enq)[1] * iters
     if world > 1:
         t = torch.tensor([elapsed, t_enq], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
