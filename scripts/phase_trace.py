@@ -19,6 +19,8 @@ tr = graph_train.GraphedTrainer(size=256, latent=512, n_mlp=8, use_mesh=True, de
 data = train.SyntheticImages(64, 256, dev)
 tr.step(data.batch(4), faces=faces, log=False)
 torch.cuda.synchronize()
+import time  # noqa: E402
+time.sleep(1.0)                      # a gap in the trace: scripts/trace_summary.py --after-gap keeps what follows
 for _ in range(n):
     tr.graphs[name].replay()
 torch.cuda.synchronize()

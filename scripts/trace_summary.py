@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Per-iteration summary of a rocprofv3 kernel trace CSV: GPU busy / idle and time by kernel family.
-usage: scripts/trace_summary.py <kernel_trace.csv> <iterations in trace> [skip_fraction_at_start]"""
+usage: scripts/trace_summary.py <kernel_trace.csv> <iterations in trace> [skip_fraction_at_start | --after-gap]
+--after-gap: keep only the kernels behind the longest idle gap of the trace (scripts/phase_trace.py sleeps there)"""
 import collections
 import csv
 import re
@@ -8,9 +9,13 @@ import sys
 
 rows = list(csv.DictReader(open(sys.argv[1])))
 iters = float(sys.argv[2])
-skip = float(sys.argv[3]) if len(sys.argv) > 3 else 0.0
+after_gap = len(sys.argv) > 3 and sys.argv[3] == "--after-gap"
+skip = float(sys.argv[3]) if len(sys.argv) > 3 and not after_gap else 0.0
 ev = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in rows)
 ev = ev[int(len(ev) * skip):]
+if after_gap:
+    gaps = [(ev[i + 1][0] - ev[i][1], i) for i in range(len(ev) - 1)]
+    ev = ev[max(gaps)[1] + 1:]
 wall = ev[-1][1] - ev[0][0]
 busy, cur = 0, ev[0][0]
 for s, e, _ in ev:

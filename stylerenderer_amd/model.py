@@ -119,7 +119,7 @@ class ToRGB(nn.Module):
         if _smallconv.supported(input, conv.out_channel):
             # device tensors: the bias rides in the streaming 1x1 kernel and the skip addition in the up-sampling
             # kernel's store — two launches for conv + bias + upsample + add (reference model.py:63-69)
-            out = _smallconv.modulated_conv1x1_small(input, conv.weight[0, :, :, 0, 0] * conv.scale,
+            out = _smallconv.modulated_conv1x1_small(input, conv.weight.view(conv.out_channel, conv.in_channel) * conv.scale,
                                                      conv.modulation(style), self.bias.view(-1))
             if skip is not None:
                 out = upsample2_add(skip, self.upsample.kernel, self.upsample.pad, out)
