@@ -356,27 +356,37 @@ def main():
     ap.add_argument("--ada_length", type=int, default=500 * 1000)
     ap.add_argument("--ckpt", type=str, default=None, help="checkpoint to resume from (reference layout)")
     ap.add_argument("--save", type=str, default=None, help="write a checkpoint here after the last iteration")
+    ap.add_argument("--graphs", action="store_true",
+                    help="replay every phase from a hipGraph (graph_train.GraphedTrainer: GPU only, no --augment)")
+    ap.add_argument("--log_every", type=int, default=1, help="print (and read back) the losses every N iterations")
     args = ap.parse_args()
     rank, _, world, device = sr_dist.initialize(seed=args.seed)
-    tr = Trainer(args.size, args.latent, args.n_mlp, args.channel_multiplier, args.lr, args.r1,
-                 args.path_regularize, args.path_batch_shrink, args.d_reg_every, args.g_reg_every,
-                 args.mixing, args.mesh, device, args.seed, args.augment, args.augment_p, args.ada_target,
-                 args.ada_length)
+    targs = (args.size, args.latent, args.n_mlp, args.channel_multiplier, args.lr, args.r1, args.path_regularize,
+             args.path_batch_shrink, args.d_reg_every, args.g_reg_every, args.mixing, args.mesh, device, args.seed,
+             args.augment, args.augment_p, args.ada_target, args.ada_length)
+    faces = SyntheticFaceSource(device, seed=args.seed) if args.mesh else None
+    if args.graphs:
+        from . import graph_train
+
+        tr = graph_train.GraphedTrainer(*targs, batch=args.batch,
+                                        mesh_vertices=faces.model.dim[2] // 3 if faces is not None else None)
+    else:
+        tr = Trainer(*targs)
     if args.ckpt:
         from . import checkpoint
 
         checkpoint.load_checkpoint(args.ckpt, tr, map_location=device)
     data = SyntheticImages(max(64, args.batch * 4), args.size, device)
-    faces = SyntheticFaceSource(device, seed=args.seed) if args.mesh else None
     t0 = None
     for it in range(args.iter):
         if it == 1:
             if device.type == "cuda":
                 torch.cuda.synchronize()
             t0 = time.perf_counter()
-        out = tr.step(data.batch(args.batch), faces=faces)
-        if rank == 0:
-            print("iter %d  " % it + "  ".join("%s %.4f" % kv for kv in sorted(out.items())), flush=True)
+        log = it % max(1, args.log_every) == 0 or it == args.iter - 1
+        out = tr.step(data.batch(args.batch), faces=faces, log=log)
+        if rank == 0 and log:
+            print("iter %d  " % it + "  ".join("%s %.4f" % (k, float(v)) for k, v in sorted(out.items())), flush=True)
     if device.type == "cuda":
         torch.cuda.synchronize()
     if rank == 0 and t0 is not None and args.iter > 1:
