@@ -447,9 +447,21 @@ struct TFused {
     static constexpr int STY = PAD + 4 * 256;
 };
 
+#ifdef CONVT_TIMING
+// debug build only (scripts/build_variant.sh): per-workgroup time stamps of wave 0
+__device__ long long g_convt_stamps[8 * 16384];
+#define CONVT_STAMP(i) do { if (threadIdx.x == 0) { g_convt_stamps[(blockIdx.x & 16383) * 8 + (i)] = wall_clock64(); } } while (0)
+#else
+#define CONVT_STAMP(i)
+#endif
+
 __global__ __launch_bounds__(256) void k_convt_fused(const ConvParams p) {
 #if __HIP_DEVICE_COMPILE__   // buffer-resource builtins: device pass only (the host pass needs just the stub)
     using G = TFused;
+    CONVT_STAMP(0);
+#ifdef CONVT_TIMING
+    const long long convt_c0 = clock64();
+#endif
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* const sty = smem + G::STY;
 
@@ -573,6 +585,7 @@ __global__ __launch_bounds__(256) void k_convt_fused(const ConvParams p) {
     load_set(smem, 0, 0, 0);
 #pragma unroll
     for (int sh = 0; sh < 4; ++sh) { X[0][sh][0] *= sc_next; X[0][sh][1] *= sc_next; }
+    CONVT_STAMP(1);
 
     for (int k = 0; k < nchunks; ++k) {
         const float* sb = smem + (k & 1) * G::BUF;
@@ -616,6 +629,7 @@ __global__ __launch_bounds__(256) void k_convt_fused(const ConvParams p) {
         }
     }
     __builtin_amdgcn_s_waitcnt(0x0F70);
+    CONVT_STAMP(2);
 
     // ---- epilogue: lane = input column i, registers = channels; phases (py, 0) and (py, 1) are the
     // neighbouring output columns 2i, 2i + 1 of output row 2j + py
@@ -639,8 +653,18 @@ __global__ __launch_bounds__(256) void k_convt_fused(const ConvParams p) {
                 }
             }
     }
+    CONVT_STAMP(3);
+#ifdef CONVT_TIMING
+    if (threadIdx.x == 0) g_convt_stamps[(blockIdx.x & 16383) * 8 + 5] = clock64() - convt_c0;
+#endif
 #endif
 }
+
+#ifdef CONVT_TIMING
+extern "C" int sr_debug_convt_stamps(long long* host, int n) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_convt_stamps), (size_t)n * sizeof(long long));
+}
+#endif
 
 bool convt_fused_eligible(const ConvParams& p) {
     // buffer addressing: byte offsets inside one sample / the weight tensor below 2^31 - 16
