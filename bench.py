@@ -182,16 +182,24 @@ def pmc_traffic(kernel_rows):
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.csv")))
     if not files:
         return {}
-    total, seen = 0.0, 0
+    total, seen, busy = 0.0, 0, None
     with open(files[-1]) as f:
         for r in csv.DictReader(l for l in f if not l.startswith("#")):
             if r["kernel"] in kernel_rows and r.get("FETCH_SIZE") and r.get("WRITE_SIZE"):
                 total += (2.0 * float(r["FETCH_SIZE"]) + float(r["WRITE_SIZE"])) * 1024.0
                 seen += 1
+                if r.get("SQ_VALU_MFMA_BUSY_CYCLES") and r.get("GRBM_GUI_ACTIVE") and float(r["GRBM_GUI_ACTIVE"]) > 0:
+                    busy = float(r["SQ_VALU_MFMA_BUSY_CYCLES"]) / (float(r["GRBM_GUI_ACTIVE"]) / 8.0 * 1024.0)
     if seen != len(kernel_rows):
         return {}
-    return {"traffic": round(total), "traffic_unit": "bytes/launch",
-            "traffic_source": "profiles/%s (2*FETCH_SIZE+WRITE_SIZE)" % os.path.basename(files[-1])}
+    out = {"traffic": round(total), "traffic_unit": "bytes/launch",
+           "traffic_source": "profiles/%s (2*FETCH_SIZE+WRITE_SIZE)" % os.path.basename(files[-1])}
+    if len(kernel_rows) == 1 and busy is not None:
+        # fraction of the kernel's cycles in which the matrix pipe was busy (same PMC file, separate pass):
+        # SQ_VALU_MFMA_BUSY_CYCLES over GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs — independent of the clock the
+        # roof is quoted at (under these kernels the shader clock is 1.8-2.1 GHz)
+        out["mfma_pipe_busy"] = round(busy, 3)
+    return out
 
 
 # ---------------------------------------------------------------------------------------------------
