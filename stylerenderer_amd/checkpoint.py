@@ -114,7 +114,13 @@ def load_checkpoint(path, trainer, map_location="cpu", strict=True):
     trainer.ada_aug_p = float(ckpt.get("ada_aug_p", trainer.ada_aug_p))
     trainer.iteration = int(ckpt.get("iteration", start_iter_from_name(path)))
     if "mean_path_length" in ckpt:
-        trainer.mean_path_length = torch.tensor(float(ckpt["mean_path_length"]), device=trainer.device)
+        # in place: graph_train's path-length graph was captured on this very tensor
+        with torch.no_grad():
+            trainer.mean_path_length.fill_(float(ckpt["mean_path_length"]))
+    if getattr(trainer, "graphs", None):
+        # captured graphs bake the optimiser's lr / betas and the Adam step counter's address: re-capture on the next
+        # step() (build_graphs restores the loaded state after its warm-up iterations)
+        trainer.graphs = {}
     return ckpt
 
 

@@ -1,24 +1,31 @@
-"""LPIPS-shaped perceptual distance on the MI355X-native operators (SURVEY.md N3 / BASELINE config[4]).
+"""LPIPS perceptual distance (VGG16, version 0.1) on the MI355X-native operators (SURVEY.md N3 / BASELINE config[4]).
 
-Structure of the reference's lpips/networks_basic.py:27-92 (`PNetLin`, pnet_type='vgg', version 0.1) with the
-trunk of lpips/pretrained_networks.py:97-135:
+Mirrors the reference's lpips/networks_basic.py:27-112 (`PNetLin(pnet_type='vgg')`, `ScalingLayer`, `NetLinLayer`)
+on the trunk slicing of lpips/pretrained_networks.py:97-135, with the SAME module / state_dict names, so the
+reference's own files load unchanged:
 
-    ScalingLayer      (x - shift) / scale                                   networks_basic.py:94-101
-    vgg16 trunk       13 x [conv3x3 + bias + ReLU], max-pool before slices 2-5; taps relu1_2, relu2_2,
-                      relu3_3, relu4_3, relu5_3 (64, 128, 256, 512, 512 channels)
-    normalize_tensor  x / (sqrt(sum_c x^2) + 1e-10)                          lpips/__init__.py
-    lin_k             1x1 convolution, no bias, one output channel           networks_basic.py:103-112
-    distance          sum_k spatial_mean( lin_k( (f0_k - f1_k)^2 ) )
+    scaling_layer            (x - shift) / scale                                   networks_basic.py:94-101
+    net.slice1 .. slice5     torchvision vgg16().features[0:4], [4:9], [9:16], [16:23], [23:30]: 13 x
+                             [conv3x3 + bias + ReLU], a 2x2 max-pool in front of slices 2-5; taps relu1_2, relu2_2,
+                             relu3_3, relu4_3, relu5_3 (64, 128, 256, 512, 512 channels); keys `net.slice1.0.weight` ...
+    normalize_tensor         x / (sqrt(sum_c x^2) + 1e-10)                          lpips/__init__.py:42-44
+    lin0 .. lin4             Dropout (identity in eval) + 1x1 convolution, no bias, one output channel; keys
+                             `lin0.model.1.weight` ... as in lpips/weights/v0.1/vgg.pth   networks_basic.py:103-112
+    distance                 sum_k spatial_mean( lin_k( (f0_k - f1_k)^2 ) )          networks_basic.py:62-85
 
 On device tensors every 3x3 convolution runs on the MFMA kernels (op.conv.conv2d, Winograd where eligible) and
 bias + ReLU is the fused activation kernel (negative_slope = 0, scale = 1); CPU tensors use torch's own ops.
 
-WEIGHTS: the reference takes the trunk from torchvision's pretrained VGG16 and the five linear heads from
-lpips/weights/v0.1/vgg.pth.  Neither torchvision nor a network is available here, so the default construction
-fills both with a deterministic He-style initialisation (non-negative heads, like the learned ones): the loss has
-LPIPS's architecture and cost, not its calibration.  `load_trunk_state_dict` / `load_lin_state_dict` accept the
-real tensors (torchvision `features.N.*` keys, LPIPS `linK.model.1.weight` keys) when a deployment has them.
+WEIGHTS.  The five learned heads ARE the reference's (`lpips/weights/v0.1/vgg.pth`, 1 472 floats, BSD-2 LICENSE-LPIPS;
+shipped as data in `lpips_heads_v0_1.npz`, written by oracle/make_golden.py) and are loaded by default.  The trunk
+is torchvision's ImageNet-pretrained VGG16 in the reference; neither torchvision nor a network exists here, so the
+default trunk is a deterministic He-style fill (`synthetic_trunk_state`): the loss has LPIPS's architecture, heads
+and cost, not its ImageNet calibration.  `load_trunk_state_dict` takes `torchvision.models.vgg16().features
+.state_dict()` when a deployment has it.  tests/golden/lpips_vgg.npz pins this module to the reference's classes
+(same trunk fill + real heads): distance, per-layer terms and the input gradient.
 """
+import os
+
 import numpy as np
 import torch
 from torch import nn
@@ -32,6 +39,19 @@ from .op.weight_prep import weight_prep as _weight_prep
 VGG_CFG = ((64, 64), (128, 128), (256, 256, 256), (512, 512, 512), (512, 512, 512))
 # index of each conv inside torchvision's vgg16().features, slice by slice
 VGG_FEATURE_INDEX = ((0, 2), (5, 7), (10, 12, 14), (17, 19, 21), (24, 26, 28))
+HEADS_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lpips_heads_v0_1.npz")
+
+
+def synthetic_trunk_state():
+    """torchvision-keyed ('0.weight', '0.bias', '2.weight', ...) deterministic stand-in for the pretrained trunk."""
+    state, cin, key = {}, 3, 7000
+    for widths, idxs in zip(VGG_CFG, VGG_FEATURE_INDEX):
+        for cout, i in zip(widths, idxs):
+            w = synth.det_normal((cout, cin, 3, 3), key) * np.float32(np.sqrt(2.0 / (cin * 9)))
+            state["%d.weight" % i] = torch.from_numpy(w)
+            state["%d.bias" % i] = torch.from_numpy(synth.det_normal((cout,), key + 1) * np.float32(0.05))
+            cin, key = cout, key + 2
+    return state
 
 
 class ScalingLayer(nn.Module):
@@ -53,12 +73,12 @@ def spatial_average(x, keepdim=True):
 
 
 class _Conv3x3ReLU(nn.Module):
-    def __init__(self, cin, cout, key):
+    """features[i] (Conv2d 3x3 pad 1) fused with features[i+1] (ReLU)."""
+
+    def __init__(self, cin, cout):
         super().__init__()
-        w = synth.det_normal((cout, cin, 3, 3), key) * np.float32(np.sqrt(2.0 / (cin * 9)))
-        self.weight = nn.Parameter(torch.from_numpy(w), requires_grad=False)
-        self.bias = nn.Parameter(torch.from_numpy(synth.det_normal((cout,), key + 1) * np.float32(0.05)),
-                                 requires_grad=False)
+        self.weight = nn.Parameter(torch.zeros(cout, cin, 3, 3), requires_grad=False)
+        self.bias = nn.Parameter(torch.zeros(cout), requires_grad=False)
         self._prepared = None
 
     def forward(self, x):
@@ -73,27 +93,44 @@ class _Conv3x3ReLU(nn.Module):
         return F.relu(F.conv2d(x, self.weight, self.bias, padding=1))
 
 
+class _Slice(nn.ModuleDict):
+    """One `sliceN` of pretrained_networks.vgg16: children keyed by their torchvision feature index."""
+
+    def __init__(self, pool, convs):
+        super().__init__(convs)
+        self.pool = pool
+
+    def forward(self, x):
+        if self.pool:
+            x = F.max_pool2d(x, 2, 2)
+        for layer in self.values():
+            x = layer(x)
+        return x
+
+
 class VGG16Trunk(nn.Module):
     """The five feature slices of torchvision's VGG16 (reference lpips/pretrained_networks.py:97-135)."""
 
     def __init__(self):
         super().__init__()
-        self.slices = nn.ModuleList()
-        cin, key = 3, 7000
-        for widths in VGG_CFG:
-            layers = []
-            for cout in widths:
-                layers.append(_Conv3x3ReLU(cin, cout, key))
-                cin, key = cout, key + 2
-            self.slices.append(nn.ModuleList(layers))
+        cin = 3
+        for s, (widths, idxs) in enumerate(zip(VGG_CFG, VGG_FEATURE_INDEX)):
+            convs = {}
+            for cout, i in zip(widths, idxs):
+                convs[str(i)] = _Conv3x3ReLU(cin, cout)
+                cin = cout
+            setattr(self, "slice%d" % (s + 1), _Slice(s > 0, convs))
+        self.N_slices = 5
+        self.load_trunk_state_dict(synthetic_trunk_state())
+
+    @property
+    def slices(self):
+        return [list(getattr(self, "slice%d" % (s + 1)).values()) for s in range(self.N_slices)]
 
     def forward(self, x):
         feats = []
-        for i, layers in enumerate(self.slices):
-            if i > 0:
-                x = F.max_pool2d(x, 2, 2)
-            for layer in layers:
-                x = layer(x)
+        for s in range(self.N_slices):
+            x = getattr(self, "slice%d" % (s + 1))(x)
             feats.append(x)
         return feats
 
@@ -107,37 +144,72 @@ class VGG16Trunk(nn.Module):
                     layer._prepared = None
 
 
-class PNetLin(nn.Module):
-    """d(in0, in1) -> [B, 1, 1, 1]; inputs in [-1, 1], like the reference's (version 0.1, lpips=True)."""
+class NetLinLayer(nn.Module):
+    """networks_basic.py:103-112: `model` = [Dropout, Conv2d(chn_in, 1, 1, bias=False)] — key `model.1.weight`."""
 
-    def __init__(self):
+    def __init__(self, chn_in, chn_out=1, use_dropout=True):
+        super().__init__()
+        layers = [nn.Dropout()] if use_dropout else []
+        layers += [nn.Conv2d(chn_in, chn_out, 1, stride=1, padding=0, bias=False)]
+        self.model = nn.Sequential(*layers)
+        self.model[-1].weight.requires_grad_(False)
+
+    @property
+    def weight(self):
+        return self.model[-1].weight
+
+
+class PNetLin(nn.Module):
+    """d(in0, in1) -> [B, 1, 1, 1]; inputs in [-1, 1], like the reference's (version 0.1, lpips=True, eval)."""
+
+    def __init__(self, use_dropout=True, heads="default"):
         super().__init__()
         self.chns = [w[-1] for w in VGG_CFG]
         self.L = len(self.chns)
         self.scaling_layer = ScalingLayer()
         self.net = VGG16Trunk()
-        self.lins = nn.ParameterList()
         for k, c in enumerate(self.chns):
-            w = np.abs(synth.det_normal((1, c, 1, 1), 7100 + k)) / np.float32(c)
-            self.lins.append(nn.Parameter(torch.from_numpy(w.astype(np.float32)), requires_grad=False))
+            setattr(self, "lin%d" % k, NetLinLayer(c, use_dropout=use_dropout))
+        if heads == "default":
+            if not os.path.isfile(HEADS_FILE):
+                raise FileNotFoundError("LPIPS heads %s missing (written by oracle/make_golden.py lpips)" % HEADS_FILE)
+            with np.load(HEADS_FILE) as z:
+                self.load_lin_state_dict({"lin%d.model.1.weight" % k: torch.from_numpy(z["lin%d" % k])
+                                          for k in range(self.L)})
+        elif heads is not None:
+            self.load_lin_state_dict(heads)
+        self.eval()                                     # a metric: dropout is never active
+
+    @property
+    def lins(self):
+        return [getattr(self, "lin%d" % k).weight for k in range(self.L)]
 
     def features(self, x):
         return [normalize_tensor(f) for f in self.net(self.scaling_layer(x))]
 
+    def per_layer(self, feats0, feats1):
+        """[spatial_average(lin_k((f0_k - f1_k)^2))] (networks_basic.py:66-76, spatial=False)."""
+        lins = self.lins
+        return [spatial_average((((feats0[k] - feats1[k]) ** 2) * lins[k]).sum(1, keepdim=True))
+                for k in range(self.L)]
+
     def distance_to(self, feats1, in0):
         """Distance of `in0` to precomputed `features(in1)` (the target of an optimisation is fixed)."""
-        feats0 = self.features(in0)
-        val = 0
-        for k in range(self.L):
-            diff = (feats0[k] - feats1[k]) ** 2
-            val = val + spatial_average((diff * self.lins[k]).sum(1, keepdim=True))
+        res = self.per_layer(self.features(in0), feats1)
+        val = res[0]
+        for r in res[1:]:
+            val = val + r
         return val
 
-    def forward(self, in0, in1):
-        return self.distance_to(self.features(in1), in0)
+    def forward(self, in0, in1, retPerLayer=False):
+        feats1 = self.features(in1)
+        if retPerLayer:
+            res = self.per_layer(self.features(in0), feats1)
+            return sum(res[1:], res[0]), res
+        return self.distance_to(feats1, in0)
 
     def load_lin_state_dict(self, state):
         """LPIPS weights/v0.1/vgg.pth: keys 'lin0.model.1.weight' ... 'lin4.model.1.weight' [1, C, 1, 1]."""
         with torch.no_grad():
             for k in range(self.L):
-                self.lins[k].copy_(state["lin%d.model.1.weight" % k])
+                getattr(self, "lin%d" % k).weight.copy_(state["lin%d.model.1.weight" % k])

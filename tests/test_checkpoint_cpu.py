@@ -89,6 +89,52 @@ def test_reference_style_checkpoint_loads(tmp_path):
     tr.step(train.SyntheticImages(8, SIZE, "cpu").batch(4))                # and training continues
 
 
+def test_reference_checkpoint_built_from_the_contract_fixture_loads_at_256(golden, tmp_path):
+    """The checkpoint is built from the REFERENCE's names / shapes / parameter order (tests/golden/state_dict_contract.npz:
+    model.py:86-123, 188-223, 296-336; optimiser over `generator.parameters()` incl. the dead ToRGB tail, train.py:529-536),
+    not from this repo's classes."""
+    gold = golden("state_dict_contract")
+
+    def shapes(tag):
+        return [tuple(int(x) for x in row[1:1 + int(row[0])]) for row in gold[tag + "_shapes"]]
+
+    def state(tag, base):
+        return {str(n): torch.full(sh, base + 1e-3 * i) for i, (n, sh) in enumerate(zip(gold[tag + "_names"], shapes(tag)))}
+
+    def optim_state(tag, lr):
+        names = [str(n) for n in gold[tag + "_names"]]
+        by_name = dict(zip(names, shapes(tag)))
+        pnames = [str(n) for n in gold[tag + "_param_names"]]
+        st = {i: {"step": torch.tensor(7.0), "exp_avg": torch.full(by_name[n], 1e-4 * (i + 1)),
+                  "exp_avg_sq": torch.full(by_name[n], 1e-6 * (i + 1))} for i, n in enumerate(pnames)}
+        return {"state": st, "param_groups": [{"lr": lr, "betas": (0.0, 0.99), "eps": 1e-8, "weight_decay": 0,
+                                               "amsgrad": False, "params": list(range(len(pnames)))}]}
+
+    path = str(tmp_path / "120000.pt")
+    torch.save({"g": state("gm", 0.5), "d": state("d", -0.5), "g_ema": state("gm", 0.25),
+                "g_optim": optim_state("gm", 0.0016), "d_optim": optim_state("d", 0.0019),
+                "args": {"size": 256}, "ada_aug_p": 0.0}, path)
+    tr = train.Trainer(size=256, use_mesh=True, device="cpu")
+    checkpoint.load_checkpoint(path, tr, strict=True)                       # strict: every key, no extras
+    assert tr.iteration == 120000
+    names = [str(n) for n in gold["gm_names"]]
+    k = names.index("convs.3.conv.weight")
+    assert float(tr.generator.state_dict()["convs.3.conv.weight"].flatten()[0]) == pytest.approx(0.5 + 1e-3 * k)
+    assert float(tr.g_ema.state_dict()["convs.3.conv.weight"].flatten()[0]) == pytest.approx(0.25 + 1e-3 * k)
+    pnames = [str(n) for n in gold["gm_param_names"]]
+    used = [n for n, _ in tr.generator.named_parameters() if n not in tr.frozen]
+    assert len(used) < len(pnames)                                           # the dead tail is not optimised here
+    st = tr.g_optim.state_dict()["state"]
+    for i in (0, len(used) // 2, len(used) - 1):
+        assert float(st[i]["exp_avg"].flatten()[0]) == pytest.approx(1e-4 * (pnames.index(used[i]) + 1)), used[i]
+    # plain Generator checkpoints (generate.py:61-69) load through the same names
+    gpath = str(tmp_path / "g.pt")
+    torch.save({"g_ema": state("g", 0.125)}, gpath)
+    gen = checkpoint.load_generator(gpath, 256)
+    assert float(gen.state_dict()["to_rgbs.11.conv.weight"].flatten()[0]) == pytest.approx(
+        0.125 + 1e-3 * [str(n) for n in gold["g_names"]].index("to_rgbs.11.conv.weight"))
+
+
 def test_multi_resolution_store_roundtrip(tmp_path):
     rng = np.random.RandomState(0)
     imgs = [{16: rng.randint(0, 256, (16, 16, 3)).astype(np.uint8),

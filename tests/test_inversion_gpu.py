@@ -57,3 +57,72 @@ def test_graph_replay_equals_eager_and_is_reproducible():
     assert np.array_equal(runs["graph"][0], runs["graph2"][0])
     assert torch.equal(runs["graph"][1], runs["graph2"][1]) and torch.equal(runs["graph"][2], runs["graph2"][2])
     assert float(runs["graph"][2].abs().max()) > 1e-3
+
+
+def test_lpips_on_device_matches_the_reference_fixture(golden):
+    """tests/golden/lpips_vgg.npz = the reference's PNetLin (networks_basic.py:27-112) with the real v0.1 heads."""
+    gold = golden("lpips_vgg")
+    net = lpips.PNetLin().cuda()
+    in0 = torch.from_numpy(gold["in0"]).cuda().requires_grad_(True)
+    val, res = net(in0, torch.from_numpy(gold["in1"]).cuda(), retPerLayer=True)
+    want = gold["value"]
+    e = float(np.abs(val.detach().cpu().numpy() - want).max() / np.abs(want).max())
+    assert e < 5e-5, e
+    per = np.stack([r.detach().cpu().numpy().reshape(-1) for r in res], 0)
+    e = float(np.abs(per[1:] - gold["per_layer"][1:]).max() / np.abs(gold["per_layer"][1:]).max())
+    assert e < 5e-5, e
+    (g,) = torch.autograd.grad(val.sum(), in0)
+    # 13 ReLU layers: a few pre-activations flip sign between two fp32 evaluation orders; bar on the whole gradient
+    e = float(np.linalg.norm(g.cpu().numpy() - gold["grad_in0"]) / np.linalg.norm(gold["grad_in0"]))
+    assert e < 2e-2, e
+
+
+# ---------------------------------------------------------------------------------------------------
+# BASELINE config[4] at its size: GeneratorWithMap(256, 512, 8) + the 24 962-vertex mesh + LPIPS(VGG16), as bench.py's
+# inversion leg builds it.
+def full_size_setup(use_graph):
+    from stylerenderer_amd import model
+
+    dev = torch.device("cuda")
+    torch.manual_seed(0)
+    g = model.GeneratorWithMap(256, 512, 8, channel_multiplier=2).to(dev)
+    net = lpips.PNetLin().to(dev)
+    v0, tri = synth.face_sized_mesh()
+    v = torch.from_numpy(v0[None]).to(dev)
+    nrm = torch.from_numpy(synth.vertex_normals(v0[None], tri)).to(dev)
+    mesh = (v, nrm, torch.from_numpy(tri).to(dev))
+    with torch.no_grad():
+        w_true = g.style(torch.randn(1, 512, device=dev)).unsqueeze(1).repeat(1, g.n_latent, 1)
+        rot = inversion.utils_3d.euler_mat(torch.tensor([[0.3, -0.1, 0.05]], device=dev), "yxz")[0]
+        posed = (torch.matmul(v, rot).contiguous(), torch.matmul(nrm, rot).contiguous(), mesh[2])
+        noise = [n.detach() for n in g.make_noise()]
+        target, _, _ = g([w_true], posed, input_is_latent=True, noise=noise)
+    torch.manual_seed(5)                                      # mean_latent draws
+    return inversion.LatentInverter(g, net, target, mesh, noise=noise, use_graph=use_graph)
+
+
+def test_config4_full_size_graph_equals_eager_is_reproducible_and_converges():
+    steps = 12
+    runs = {}
+    for key, use_graph in (("eager", False), ("graph", True), ("graph2", True)):
+        inv = full_size_setup(use_graph)
+        hist = inv.run(steps)
+        runs[key] = (hist.cpu().numpy(), inv.w.detach().cpu().clone(), inv.pose.detach().cpu().clone())
+        if key == "graph":
+            assert inv.graph is not None
+            # the pose gradient exists only through sr_rasterize_grad (the vertices reach the image through the
+            # rasterised normal maps alone)
+            assert inv.pose.grad is not None and float(inv.pose.grad.abs().max()) > 0
+            assert torch.isfinite(inv.pose.grad).all() and torch.isfinite(inv.w.grad).all()
+            more = inv.run(50).cpu().numpy()                  # steps 13..62 of the same trajectory
+            assert np.isfinite(more).all()
+            assert more[-1] < 0.8 * runs[key][0][0], (runs[key][0][0], more[-1])
+        del inv
+        torch.cuda.empty_cache()
+    for h, _, _ in runs.values():
+        assert np.isfinite(h).all()
+    err = np.abs(runs["graph"][0] - runs["eager"][0]) / np.abs(runs["eager"][0])
+    assert err.max() <= 1e-4, err
+    assert np.array_equal(runs["graph"][0], runs["graph2"][0])
+    assert torch.equal(runs["graph"][1], runs["graph2"][1]) and torch.equal(runs["graph"][2], runs["graph2"][2])
+    assert float(runs["graph"][2].abs().max()) > 1e-4        # the pose moved

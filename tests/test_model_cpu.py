@@ -33,6 +33,24 @@ def test_parameter_counts_and_state_dict_keys():
     assert torch.allclose(blur[0], torch.tensor([.0625, .1875, .1875, .0625]))
 
 
+def test_state_dict_contract_names_shapes_and_order(golden):
+    """tests/golden/state_dict_contract.npz: ordered (name, shape) of the reference's Generator / GeneratorWithMap /
+    Discriminator at 256^2 (reference model.py:86-123 with the duplicated to_rgbs tail, :188-223, :296-336) — what a
+    checkpoint written by reference train.py:411-420 contains, in the order `load_state_dict(strict=True)` and
+    optimizer-state indexing rely on."""
+    gold = golden("state_dict_contract")
+    for tag, net in (("g", model.Generator(256, 512, 8, channel_multiplier=2)),
+                     ("gm", model.GeneratorWithMap(256, 512, 8, channel_multiplier=2)),
+                     ("d", model.Discriminator(256, channel_multiplier=2))):
+        got = list(net.state_dict().items())
+        names = [str(n) for n in gold[tag + "_names"]]
+        assert [k for k, _ in got] == names, tag
+        for (k, t), row in zip(got, gold[tag + "_shapes"]):
+            assert list(t.shape) == [int(x) for x in row[1:1 + int(row[0])]], (tag, k)
+        assert [n for n, _ in net.named_parameters()] == [str(n) for n in gold[tag + "_param_names"]], tag
+    assert len(gold["g_names"]) == 165
+
+
 @pytest.fixture(scope="module")
 def g8():
     g = model.Generator(8, 64, 2)
