@@ -257,8 +257,10 @@ def train_leg(dev, rank, world, iters, batch, size=256):
     finite = all(bool(torch.isfinite(v)) for v in last.values())
     collective = None
     if graphs and world > 1:
-        collective = {"generator_grads": tr.reduce_g.mode, "discriminator_grads": tr.reduce_d.mode,
-                      **{"g_" + k: round(v, 3) if isinstance(v, float) else v for k, v in tr.reduce_g.timings.items()}}
+        # chosen collective, bucket sizes, and when each bucket's reduction finished relative to the END of the
+        # path-length backward (negative = overlapped with it)
+        collective = {"generator_grads": tr.reduce_g.describe(), "discriminator_grads": tr.reduce_d.describe(),
+                      "overlap_path_phase": tr.measure_overlap("path"), "overlap_d_phase": tr.measure_overlap("d")}
     out = {"workload": "BASELINE config[2]: GeneratorWithMap(%d) + Discriminator(%d) full G+D step, %d img/GPU "
                        "(global %d), d_reg_every 16, g_reg_every 4, path batch %d, synthetic images + mesh "
                        "nv=%d nf=%d" % (size, size, batch, batch * world, max(1, batch // 2),
@@ -267,8 +269,9 @@ def train_leg(dev, rank, world, iters, batch, size=256):
            "ms_per_iter": round(elapsed / iters * 1e3, 3),
            "host_enqueue_ms_per_iter": round(t_enq / iters * 1e3, 3),
            "launch_bound": bool(t_enq > 0.95 * elapsed),
-           "execution": ("hipGraph replay per phase (graph_train.GraphedTrainer); flat-buffer gradient all-reduce "
-                         "between replays" if graphs else "eager launches (train.Trainer, DDP buckets)"),
+           "execution": ("hipGraph replay per phase (graph_train.GraphedTrainer); bucketed all-reduce of the flat "
+                         "gradient buffer on a communication stream, released by event-record nodes inside the "
+                         "replayed backward" if graphs else "eager launches (train.Trainer, DDP buckets)"),
            "losses_finite": finite, "parallelism": "dp%d" % world, "gradient_collective": collective}
     if world > 1:
         n = int(G_PARAM_BYTES // 4)

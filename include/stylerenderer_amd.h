@@ -340,6 +340,18 @@ int sr_conv2d_wgrad_mfma(float* dwt, const float* x, const float* gy, const floa
                          int64_t IW, int64_t OH, int64_t OW, int ksize, int stride, int pad,
                          int transposed, float* scratch, sr_stream_t stream);
 
+/* ---- signalling out of a replayed hipGraph (overlapped gradient all-reduce) -----------------------------------
+ * The reference overlaps the gradient all-reduce with the backward through torch DDP's bucket hooks
+ * (reference distributed.py:98-105, used for the path-length step at train.py:335-352).  This build replays each
+ * training phase as ONE hipGraph; a bucket of the flat gradient buffer that is complete in the middle of that graph
+ * is announced by an event-record node: sr_event_record on a capturing stream adds the node (hipEventRecordExternal),
+ * on an ordinary stream it is a plain record; sr_stream_wait_event on the communication stream, issued after the
+ * graph launch, waits for that node only.  Events are created without timing. */
+int sr_event_create(void** event);
+int sr_event_destroy(void* event);
+int sr_event_record(void* event, sr_stream_t stream);
+int sr_stream_wait_event(sr_stream_t stream, void* event);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,6 +1,7 @@
 """One-rank NCCL (RCCL) run of the hipGraph-replayed training iteration with the gradient all-reduce forced on
-(GraphedTrainer.world = 2 on a 1-rank group): checks that RCCL collectives between graph replays order correctly
-on the stream and that the step still trains.  Also runs the eager DDP Trainer on the same group.
+(force_collectives=True on a 1-rank group): checks that the bucketed RCCL collectives released by the event-record
+nodes inside the replayed graphs order correctly and that the step still trains; prints when each bucket finished
+relative to the end of its phase's replay.  Also runs the eager DDP Trainer on the same group.
 usage (GPU box): python scripts/graph_ddp_single_rank_check.py"""
 import os
 import sys
@@ -34,14 +35,10 @@ for _ in range(3):
 del net, g, img
 faces = train.SyntheticFaceSource(dev, seed=0)
 tr = graph_train.GraphedTrainer(size=256, latent=512, n_mlp=8, use_mesh=True, device=dev, seed=0, batch=4,
-                                mesh_vertices=faces.model.dim[2] // 3)
+                                mesh_vertices=faces.model.dim[2] // 3, force_collectives=True)
 from stylerenderer_amd import distributed as sr_dist  # noqa: E402
 
-tr.world = 2                      # all_reduce(SUM) on one rank, then / 2: the step sees half-size gradients
-os.environ["SR_GRAD_COLLECTIVE"] = "allreduce"
-tr.reduce_g = sr_dist.FlatGradReducer(tr.flat_g, world=2)
-tr.reduce_d = sr_dist.FlatGradReducer(tr.flat_d, world=2)
-assert tr.reduce_g.mode == "allreduce"
+print("reducer:", tr.reduce_g.describe(), tr.reduce_d.describe())
 # the in-place reduce-scatter + all-gather form on the same (one-rank) group: must leave the buffer unchanged
 probe = sr_dist.FlatGradReducer(tr.flat_g, world=1)
 probe.world, probe.mode = 1, "rsag"
@@ -62,6 +59,8 @@ torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / 8
 vals = {k: float(v) for k, v in out.items()}
 assert all(v == v for v in vals.values()), vals
-print("graph replay + RCCL all-reduce between replays: %.1f ms/iter, losses %s" % (dt * 1e3, vals))
+print("graph replay + bucketed RCCL all-reduce released by in-graph events: %.1f ms/iter, losses %s" % (dt * 1e3, vals))
+for name in ("d", "r1", "g", "path"):
+    print(tr.measure_overlap(name))
 dist.barrier()
 dist.destroy_process_group()

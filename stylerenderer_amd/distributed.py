@@ -184,3 +184,195 @@ class FlatGradReducer:
             self._allreduce()
         elif self.mode == "rsag":
             self._rsag()
+
+
+def arrival_order(params, run_backward):
+    """Indices of `params` in the order their gradients are produced by `run_backward()` (a representative
+    forward + backward); parameters it does not reach keep their relative order at the end.  Rank 0's order is
+    broadcast so that every rank derives the same flat layout and buckets (torch DDP does the same when it rebuilds
+    its buckets in arrival order after the first iteration)."""
+    seen = []
+    handles = [p.register_post_accumulate_grad_hook(lambda p, i=i: seen.append(i)) for i, p in enumerate(params)]
+    try:
+        run_backward()
+    finally:
+        for h in handles:
+            h.remove()
+    for p in params:
+        p.grad = None
+    rest = [i for i in range(len(params)) if i not in set(seen)]
+    order = torch.tensor(seen + rest, dtype=torch.int64, device=params[0].device)
+    if get_world_size() > 1:
+        dist.broadcast(order, 0)
+    return [int(i) for i in order.tolist()]
+
+
+class BucketedGradReducer:
+    """Averages a flat gradient buffer over the ranks WHILE the backward that fills it is still running — the
+    overlap of reference distributed.py:98-105 (torch DDP bucket hooks, used for the path-length step at
+    train.py:335-352) for a backward that is replayed as one hipGraph.
+
+    The flat buffer is laid out in gradient ARRIVAL order (`arrival_order`) and cut into `n_buckets` contiguous
+    slices of linearly decreasing size.  A post-accumulate hook per parameter counts arrivals; when the last gradient of a
+    bucket is there, the bucket's gradients are copied into their flat views (one multi-tensor copy) and the bucket
+    is SIGNALLED: `sr_event_record` on the producing stream.  Under stream capture that is an event-record node in the
+    middle of the phase graph (include/stylerenderer_amd.h); after each `graph.replay()` the host calls
+    `issue_all()`: for every bucket, `sr_stream_wait_event(comm, event_k)` + `all_reduce(flat[lo_k:hi_k])` on the
+    communication stream — bucket k is on the xGMI links while the graph is still computing the gradients of
+    bucket k+1.  Eagerly (warm-up, `capture=False`, CPU / gloo) the same hooks issue the collective directly.
+    Buckets are issued in index order on every rank, whatever order they completed in.  `wait()` makes the
+    current stream (CPU: the caller) wait for all reductions — it sits in front of the optimiser step.
+
+    No RCCL call is captured into a graph.  n_buckets = 1 degenerates to "reduce after the backward" and then uses
+    FlatGradReducer (autotuned all-reduce vs reduce-scatter + all-gather); SR_GRAD_OVERLAP=0 selects that."""
+
+    def __init__(self, params, views, offs, flat, world=None, n_buckets=4, force=False):
+        from . import _lib
+
+        self.params, self.views, self.flat = list(params), list(views), flat
+        self.world = world if world is not None else get_world_size()
+        self.enabled = self.world > 1 or bool(force)
+        self.is_cuda = flat.is_cuda
+        layout = sorted(range(len(self.params)), key=lambda i: offs[i])
+        total = sum(self.params[i].numel() for i in layout)
+        k = max(1, min(int(n_buckets), len(layout)))
+        # bucket sizes fall off linearly (k : k-1 : ... : 1, i.e. 40 / 30 / 20 / 10 % for four): what is still on the
+        # wire when the backward ends is the LAST bucket, so it is the smallest
+        cuts = [sum(k - j for j in range(b + 1)) / (k * (k + 1) / 2) for b in range(k)]
+        self.buckets, members, acc = [], [], 0
+        for pos, i in enumerate(layout):
+            members.append(i)
+            acc += self.params[i].numel()
+            if (acc >= total * cuts[len(self.buckets)] and len(self.buckets) < k - 1) or pos == len(layout) - 1:
+                lo = offs[members[0]]
+                hi = offs[layout[pos + 1]] if pos + 1 < len(layout) else flat.numel()
+                self.buckets.append({"lo": lo, "hi": hi, "members": members})
+                members = []
+        self.bucket_of = {i: b for b, bk in enumerate(self.buckets) for i in bk["members"]}
+        self.single = FlatGradReducer(flat, self.world) if (len(self.buckets) == 1 and self.world > 1) else None
+        self.comm = None
+        self.events = []
+        if self.is_cuda and self.enabled:
+            import ctypes
+
+            self._lib = _lib
+            self.comm = torch.cuda.Stream(device=flat.device)
+            for _ in self.buckets:
+                ev = ctypes.c_void_p()
+                _lib.check(_lib.lib().sr_event_create(ctypes.byref(ev)), "sr_event_create")
+                self.events.append(ev)
+        self.active = False
+        self.pending, self.done, self.next_issue = [], [], 0
+        self.works = []
+        self.log = []                    # ("flush" | "issue", bucket, time.perf_counter()) of the last eager pass
+        self.stamp = None                # optional callable -> float (tests); perf_counter by default
+        self._handles = [p.register_post_accumulate_grad_hook(lambda p, i=i: self._arrived(i))
+                         for i, p in enumerate(self.params)]
+
+    # ---- one backward ---------------------------------------------------------------------------------------
+    def begin(self):
+        for p in self.params:
+            p.grad = None                # autograd then ASSIGNS: no zero fill, no accumulate kernel
+        self.pending = [len(b["members"]) for b in self.buckets]
+        self.done = [False] * len(self.buckets)
+        self.next_issue = 0
+        self.works = []
+        self.log = []
+        self.active = True
+
+    def _now(self):
+        import time
+
+        return time.perf_counter()
+
+    def _capturing(self):
+        return self.is_cuda and torch.cuda.is_current_stream_capturing()
+
+    def _arrived(self, i):
+        if not self.active:
+            return
+        b = self.bucket_of[i]
+        self.pending[b] -= 1
+        if self.pending[b] == 0:
+            self._flush(b)
+
+    def _flush(self, b):
+        members = self.buckets[b]["members"]
+        have = [(self.views[i], self.params[i].grad) for i in members if self.params[i].grad is not None]
+        miss = [self.views[i] for i in members if self.params[i].grad is None]
+        with torch.no_grad():
+            if have:
+                torch._foreach_copy_([v for v, _ in have], [g for _, g in have])
+            if miss:
+                torch._foreach_zero_(miss)          # a parameter this phase did not reach
+        for i in members:
+            self.params[i].grad = self.views[i]     # what the optimiser (graph) was built on
+        self.done[b] = True
+        self.log.append(("flush", b, self._now()))
+        if not self.enabled:
+            return
+        if self.is_cuda:
+            self._lib.check(self._lib.lib().sr_event_record(self.events[b], self._lib.current_stream(self.flat.device)),
+                            "sr_event_record")
+            if self._capturing():
+                return                               # issued by issue_all() after every replay
+        self._issue_ready()
+
+    def _issue_ready(self):
+        while self.next_issue < len(self.buckets) and self.done[self.next_issue]:
+            self._issue(self.next_issue)
+            self.next_issue += 1
+
+    def _issue(self, b):
+        bk = self.buckets[b]
+        piece = self.flat[bk["lo"]:bk["hi"]]
+        self.log.append(("issue", b, self._now()))
+        if self.is_cuda:
+            self._lib.check(self._lib.lib().sr_stream_wait_event(self.comm.cuda_stream, self.events[b]),
+                            "sr_stream_wait_event")
+            with torch.cuda.stream(self.comm):
+                if self.single is not None:
+                    self.single()
+                else:
+                    dist.all_reduce(piece, op=dist.ReduceOp.SUM)
+                    piece.div_(self.world)
+        elif self.single is not None:
+            self.single()
+        else:
+            self.works.append((dist.all_reduce(piece, op=dist.ReduceOp.SUM, async_op=True), piece))
+
+    def finish(self):
+        """End of the backward: buckets with parameters the phase did not reach are completed (zeros) and signalled."""
+        for b in range(len(self.buckets)):
+            if not self.done[b]:
+                self._flush(b)
+        self.active = False
+
+    # ---- after a replay / before the optimiser ------------------------------------------------------------------
+    def issue_all(self, stamps=None):
+        """After `graph.replay()` of a captured phase: queue every bucket's wait + collective on the comm stream.
+        `stamps` (a list): a timing event is recorded on the comm stream after every bucket's collective."""
+        if self.enabled:
+            for b in range(len(self.buckets)):
+                self._issue(b)
+                if stamps is not None and self.is_cuda:
+                    ev = torch.cuda.Event(enable_timing=True)
+                    ev.record(self.comm)
+                    stamps.append(ev)
+
+    def wait(self):
+        if not self.enabled:
+            return
+        if self.is_cuda:
+            torch.cuda.current_stream(self.flat.device).wait_stream(self.comm)
+        else:
+            for work, piece in self.works:
+                work.wait()
+                piece.div_(self.world)
+            self.works = []
+
+    def describe(self):
+        mb = [round((b["hi"] - b["lo"]) * 4 / 1e6, 1) for b in self.buckets]
+        mode = "off" if not self.enabled else ("after-backward (%s)" % self.single.mode if self.single is not None
+                                               else "overlapped, %d buckets" % len(self.buckets))
+        return {"mode": mode, "bucket_MB": mb}

@@ -5,8 +5,8 @@ Python + launch overhead (~14 us each, 58 ms) exceeds the GPU time of the kernel
 matrix cores idle.  Every C-ABI entry point of libstylerenderer_hip.so is allocation-free and never synchronises
 the host, so the forward + backward of each phase records into a graph unchanged.
 
-One iteration = up to four phases, each `graph(zero grads -> forward -> backward)`, then — OUTSIDE any graph —
-one all-reduce of the phase's flat gradient buffer over RCCL (world > 1), then `graph(Adam step)`:
+One iteration = up to four phases, each `graph(forward -> backward)`; the phase's flat gradient buffer is averaged over
+the ranks by RCCL collectives that run OUTSIDE the graphs but DURING the replay (below); then `graph(Adam step)`:
 
     D      fake = G(z, mesh) (no grad) ; D(fake | real interleaved) ; logistic loss         train.py:245-268
     R1     every d_reg_every: r1/2 * |grad_x D(real)|^2 * d_reg_every                       train.py:281-289
@@ -14,10 +14,18 @@ one all-reduce of the phase's flat gradient buffer over RCCL (world > 1), then `
     path   every g_reg_every: path-length regulariser on batch // path_batch_shrink         train.py:335-354
     EMA    g_ema <- decay * g_ema + (1 - decay) * g  (two multi-tensor launches, eager)     train.py:358
 
-Keeping the collectives out of the graphs is deliberate: the data path is then exactly "replay, all-reduce one
-contiguous 125 MB / 115 MB buffer, replay" (no NCCL kernels inside captured work, nothing that depends on RCCL's
-capture support), at the cost of not overlapping the reduction with the backward (ring bound ~1.4 ms of a ~20 ms
-phase on 8 x xGMI).  The eager Trainer keeps the overlapped DDP path.
+Gradient reduction overlapped with the backward (reference distributed.py:98-105, train.py:335-352; north_star: "RCCL
+all-reduce over xGMI overlapped with the StyleGAN2 path-length-regulariser backward").  No RCCL call is captured:
+the flat gradient buffer of each network is laid out in gradient ARRIVAL order and cut into SR_GRAD_BUCKETS (4)
+contiguous buckets; the captured backward holds, after the last gradient of each bucket, one multi-tensor copy into the
+bucket's flat views and an EVENT-RECORD NODE (`sr_event_record` on the capturing stream -> hipEventRecordExternal;
+include/stylerenderer_amd.h).  Right after `graph.replay()` the host queues, for every bucket, `hipStreamWaitEvent(comm,
+event_k)` + `all_reduce(flat[lo_k:hi_k])` on a communication stream: bucket k is on the xGMI links while the replay
+is still producing bucket k+1; the optimiser graph waits for the communication stream
+(distributed.BucketedGradReducer).  SR_GRAD_OVERLAP=0: one bucket, reduced after the backward by the autotuned
+all-reduce / reduce-scatter + all-gather of distributed.FlatGradReducer (round 2's mode).  With `capture=False` the
+same phases, hooks and collectives run eagerly — on CPU tensors over gloo too, which is how the world-size-2 tests
+exercise this trainer without a GPU.
 
 What has to be static for capture, and how:
   * inputs live in fixed buffers (`real`, two meshes) refreshed by copies before the replays;
@@ -25,27 +33,31 @@ What has to be static for capture, and how:
     (reference train.py:140-144, model.py:160-171) always draws two latents and takes the crossover index from a
     device scalar — crossover == n_latent reproduces "no mixing" exactly;
   * each phase starts with `.grad = None` (autograd then ASSIGNS gradients: no zero fill, no accumulate kernel per
-    parameter) and ends with one multi-tensor copy of the phase's gradients into views of a flat buffer per
-    network — the buffer the all-reduce and the captured Adam step read;
+    parameter); a completed bucket is moved into views of a flat buffer per network by one multi-tensor copy — the
+    buffer the collectives and the captured Adam step read;
   * Adam is one captured launch over flat parameter / gradient / moment buffers (optim.FlatAdam, csrc sr_adam_flat);
     the lazy-regularisation cadence is host control flow between replays;
   * loss scalars land in a fixed tensor; nothing is read back unless `log=True`.
 """
+import os
+
 import torch
 
 from . import distributed as sr_dist
 from .optim import FlatAdam, flat_layout, flat_views
-from .train import (Trainer, accumulate, d_logistic_loss, d_r1_loss, g_nonsaturating_loss, g_path_regularize,
+from .train import (Trainer, accumulate, d_fake_real, d_logistic_loss, d_r1_loss, g_nonsaturating_loss, g_path_regularize,
                     requires_grad)
 
 LOSS_SLOTS = ("d", "real_score", "fake_score", "r1", "g", "path", "path_length", "mean_path")
 
 
 class GraphedTrainer(Trainer):
-    def __init__(self, *args, batch=4, mesh_vertices=None, capture=True, **kw):
+    def __init__(self, *args, batch=4, mesh_vertices=None, capture=True, n_buckets=None, force_collectives=False, **kw):
         super().__init__(*args, wrap_ddp=False, **kw)
-        if self.device.type != "cuda":
-            raise RuntimeError("GraphedTrainer needs a GPU (hipGraph capture); use train.Trainer on CPU")
+        on_gpu = self.device.type == "cuda"
+        if capture and not on_gpu:
+            raise RuntimeError("GraphedTrainer(capture=True) needs a GPU (hipGraph capture); CPU tensors run the same "
+                               "phases eagerly with capture=False")
         if self.args["augment"]:
             raise RuntimeError("GraphedTrainer: the ADA branch reads statistics on the host; use train.Trainer")
         a = self.args
@@ -53,7 +65,7 @@ class GraphedTrainer(Trainer):
         self.batch = batch
         self.capture = capture
         g, d = self.generator, self.discriminator
-        # plain modules: gradients are reduced explicitly between the replays
+        # plain modules: gradients are reduced explicitly, bucket by bucket, while the phase runs
         self.g_ddp, self.d_ddp = g, d
         self.world = sr_dist.get_world_size()
         if self.world > 1:
@@ -61,56 +73,67 @@ class GraphedTrainer(Trainer):
                 torch.distributed.broadcast(p.data, 0)
         self.g_params = [p for n, p in g.named_parameters() if n not in self.frozen]
         self.d_params = list(d.parameters())
-        self.flat_g, self.views_g = self._flatten_grads(self.g_params, self.world)
-        self.flat_d, self.views_d = self._flatten_grads(self.d_params, self.world)
-        for p, v in zip(self.g_params + self.d_params, self.views_g + self.views_d):
-            p.grad = v
-        g_ratio = a["g_reg_every"] / (a["g_reg_every"] + 1)
-        d_ratio = a["d_reg_every"] / (a["d_reg_every"] + 1)
-        # one-launch Adam over flat parameter / gradient / moment buffers (optim.FlatAdam)
-        self.g_optim = FlatAdam(self.g_params, self.flat_g, lr=a["lr"] * g_ratio, betas=(0 ** g_ratio, 0.99 ** g_ratio))
-        self.d_optim = FlatAdam(self.d_params, self.flat_d, lr=a["lr"] * d_ratio, betas=(0 ** d_ratio, 0.99 ** d_ratio))
         size = a["size"]
-        self.s_real = torch.zeros(batch, 3, size, size, device=dev)
-        self.s_inject = {k: torch.zeros((), dtype=torch.int64, device=dev) for k in ("d", "g", "path")}
-        self.s_loss = {k: torch.zeros((), device=dev) for k in LOSS_SLOTS}
-        # gradient averaging between the replays: all-reduce or in-place reduce-scatter + all-gather, whichever
-        # this node's RCCL runs faster on the real buffers (distributed.FlatGradReducer)
-        self.reduce_g = sr_dist.FlatGradReducer(self.flat_g, self.world)
-        self.reduce_d = sr_dist.FlatGradReducer(self.flat_d, self.world)
         self.s_mesh = None
+        self.tri = None
         if self.use_mesh:
             if mesh_vertices is None:
                 raise ValueError("GraphedTrainer(use_mesh=True) needs mesh_vertices (and set_topology(tri))")
             self.s_mesh = {k: (torch.zeros(batch, mesh_vertices, 3, device=dev),
                                torch.zeros(batch, mesh_vertices, 3, device=dev)) for k in ("d", "g")}
-            self.tri = None
+        overlap = os.environ.get("SR_GRAD_OVERLAP", "1") != "0"
+        if n_buckets is None:
+            n_buckets = int(os.environ.get("SR_GRAD_BUCKETS", "4")) if overlap else 1
+        # flat gradient buffers in gradient-arrival order (one cheap probe backward per network, rank 0's order)
+        order_g = sr_dist.arrival_order(self.g_params, self._probe_g)
+        order_d = sr_dist.arrival_order(self.d_params, self._probe_d)
+        self.flat_g, self.views_g, offs_g = self._flatten_grads(self.g_params, self.world, order_g)
+        self.flat_d, self.views_d, offs_d = self._flatten_grads(self.d_params, self.world, order_d)
+        for p, v in zip(self.g_params + self.d_params, self.views_g + self.views_d):
+            p.grad = v
+        g_ratio = a["g_reg_every"] / (a["g_reg_every"] + 1)
+        d_ratio = a["d_reg_every"] / (a["d_reg_every"] + 1)
+        # one-launch Adam over flat parameter / gradient / moment buffers (optim.FlatAdam)
+        self.g_optim = FlatAdam(self.g_params, self.flat_g, lr=a["lr"] * g_ratio, betas=(0 ** g_ratio, 0.99 ** g_ratio),
+                                offs=offs_g)
+        self.d_optim = FlatAdam(self.d_params, self.flat_d, lr=a["lr"] * d_ratio, betas=(0 ** d_ratio, 0.99 ** d_ratio),
+                                offs=offs_d)
+        self.s_real = torch.zeros(batch, 3, size, size, device=dev)
+        self.s_inject = {k: torch.zeros((), dtype=torch.int64, device=dev) for k in ("d", "g", "path")}
+        self.s_loss = {k: torch.zeros((), device=dev) for k in LOSS_SLOTS}
+        # gradient averaging overlapped with the backward of every phase (distributed.BucketedGradReducer)
+        self.reduce_g = sr_dist.BucketedGradReducer(self.g_params, self.views_g, offs_g, self.flat_g, self.world,
+                                                    n_buckets, force=force_collectives)
+        self.reduce_d = sr_dist.BucketedGradReducer(self.d_params, self.views_d, offs_d, self.flat_d, self.world,
+                                                    n_buckets, force=force_collectives)
         self.graphs = {}
+
+    # ---- gradient-arrival probes (layout of the flat buffers) -------------------------------------------
+    def _probe_g(self):
+        """One batch-1 forward + backward of the generator on a dummy mesh (a single degenerate triangle: the
+        rasterised maps are empty, every layer still takes part in the backward)."""
+        g = self.generator
+        z = [torch.zeros(1, self.args["latent"], device=self.device)]
+        if self.use_mesh:
+            nv = self.s_mesh["g"][0].shape[1]
+            mesh = (torch.zeros(1, nv, 3, device=self.device), torch.zeros(1, nv, 3, device=self.device),
+                    torch.zeros(1, 3, dtype=torch.int64, device=self.device))
+            img = g(z, mesh)[0]
+        else:
+            img = g(z)[0]
+        img.sum().backward()
+
+    def _probe_d(self):
+        d = self.discriminator
+        x = torch.zeros(d.stddev_group, 3, self.args["size"], self.args["size"], device=self.device)
+        d(x).sum().backward()
 
     # ---- static state -----------------------------------------------------------------------------
     @staticmethod
-    def _flatten_grads(params, world=1):
-        offs, total = flat_layout(params, world)               # 256-byte aligned slots, shared with FlatAdam
+    def _flatten_grads(params, world=1, order=None):
+        offs, total = flat_layout(params, world, order)        # 256-byte aligned slots, shared with FlatAdam
         flat = torch.zeros(total, device=params[0].device, dtype=params[0].dtype)
-        return flat, flat_views(flat, params, offs)
-
-    @staticmethod
-    def _clear(params):
-        for p in params:
-            p.grad = None
-
-    @staticmethod
-    def _collect(params, views):
-        """Phase gradients -> flat buffer (one multi-tensor copy); parameters a phase did not reach get zeros.
-        Afterwards `.grad` IS the flat view, which is what the optimiser graph was captured on."""
-        have = [(v, p.grad) for p, v in zip(params, views) if p.grad is not None]
-        miss = [v for p, v in zip(params, views) if p.grad is None]
-        if have:
-            torch._foreach_copy_([v for v, _ in have], [g for _, g in have])
-        if miss:
-            torch._foreach_zero_(miss)
-        for p, v in zip(params, views):
-            p.grad = v
+        return flat, flat_views(flat, params, offs), offs
 
     def set_topology(self, tri):
         self.tri = tri.contiguous()
@@ -139,16 +162,14 @@ class GraphedTrainer(Trainer):
     def _phase_d(self):
         g, d = self.generator, self.discriminator
         requires_grad(d, True)
-        self._clear(self.d_params)
+        self.reduce_d.begin()
         with torch.no_grad():
             fake, _, _ = self._generate(g, self._latents(self.batch), self._mesh_tuple("d"),
                                         inject_index=self.s_inject["d"])
-        both = torch.stack([fake, self.s_real], 1).reshape(2 * self.batch, *self.s_real.shape[1:])
-        pred = d(both)
-        fake_pred, real_pred = pred[0::2], pred[1::2]
+        fake_pred, real_pred = d_fake_real(d, d, fake, self.s_real)      # one interleaved pass when batch % 4 == 0
         loss = d_logistic_loss(real_pred, fake_pred)
         loss.backward()
-        self._collect(self.d_params, self.views_d)
+        self.reduce_d.finish()
         self.s_loss["d"].copy_(loss.detach())
         self.s_loss["real_score"].copy_(real_pred.detach().mean())
         self.s_loss["fake_score"].copy_(fake_pred.detach().mean())
@@ -156,30 +177,30 @@ class GraphedTrainer(Trainer):
     def _phase_r1(self):
         d = self.discriminator
         requires_grad(d, True)
-        self._clear(self.d_params)
+        self.reduce_d.begin()
         real = self.s_real.detach().clone().requires_grad_(True)
         pred = d(real)
         r1 = d_r1_loss(pred, real)
         (self.args["r1"] / 2 * r1 * self.args["d_reg_every"] + 0 * pred[0]).backward()
-        self._collect(self.d_params, self.views_d)
+        self.reduce_d.finish()
         self.s_loss["r1"].copy_(r1.detach())
 
     def _phase_g(self):
         g, d = self.generator, self.discriminator
         requires_grad(d, False)
-        self._clear(self.g_params)
+        self.reduce_g.begin()
         fake, _, _ = self._generate(g, self._latents(self.batch), self._mesh_tuple("g"),
                                     inject_index=self.s_inject["g"])
         loss = g_nonsaturating_loss(d(fake))
         loss.backward()
-        self._collect(self.g_params, self.views_g)
+        self.reduce_g.finish()
         self.s_loss["g"].copy_(loss.detach())
 
     def _phase_path(self):
         a = self.args
         g = self.generator
         requires_grad(self.discriminator, False)
-        self._clear(self.g_params)
+        self.reduce_g.begin()
         pb = max(1, self.batch // a["path_batch_shrink"]) if a["path_batch_shrink"] else self.batch
         fake, latents, normals = self._generate(g, self._latents(pb), self._mesh_tuple("g", pb), return_latents=True,
                                                 return_normals=True, inject_index=self.s_inject["path"])
@@ -189,7 +210,7 @@ class GraphedTrainer(Trainer):
         if a["path_batch_shrink"]:
             weighted = weighted + 0 * fake[0, 0, 0, 0]
         weighted.backward()
-        self._collect(self.g_params, self.views_g)
+        self.reduce_g.finish()
         self.mean_path_length.copy_(path_mean)
         self.s_loss["path"].copy_(path_loss.detach())
         self.s_loss["path_length"].copy_(path_lengths.detach().mean())
@@ -200,28 +221,56 @@ class GraphedTrainer(Trainer):
         return {"d": self._phase_d, "r1": self._phase_r1, "g": self._phase_g, "path": self._phase_path,
                 "d_opt": self.d_optim.step, "g_opt": self.g_optim.step}
 
+    PHASE_REDUCER = {"d": "reduce_d", "r1": "reduce_d", "g": "reduce_g", "path": "reduce_g"}
+
+    def _snapshot(self):
+        """Everything the warm-up iterations change: parameters, Adam moments / step, the path-length EMA and the
+        random streams.  Restored before capture, so training starts (or resumes) from exactly the loaded state and
+        the lazy-regularisation cadence is not advanced by untracked steps."""
+        snap = {"tensors": [(t, t.detach().clone()) for t in (
+            self.g_optim.flat_p, self.g_optim.m, self.g_optim.v, self.g_optim.step_t, self.d_optim.flat_p,
+            self.d_optim.m, self.d_optim.v, self.d_optim.step_t, self.mean_path_length)],
+            "np": self.np_rng.get_state(), "torch": torch.get_rng_state()}
+        if self.device.type == "cuda":
+            snap["cuda"] = torch.cuda.get_rng_state(self.device)
+        return snap
+
+    def _restore(self, snap):
+        with torch.no_grad():
+            for t, saved in snap["tensors"]:
+                t.copy_(saved)
+        self.np_rng.set_state(snap["np"])
+        torch.set_rng_state(snap["torch"])
+        if "cuda" in snap:
+            torch.cuda.set_rng_state(snap["cuda"], self.device)
+
+    def _eager_phase(self, name):
+        """A phase body run eagerly: the hooks issue the bucket collectives while the backward runs."""
+        self._bodies()[name]()
+        if name in self.PHASE_REDUCER:
+            getattr(self, self.PHASE_REDUCER[name]).wait()
+
     def build_graphs(self, warmup=3):
-        """Eager warm-up of every phase on a side stream (lazy initialisation, Adam state, incidence caches),
-        then one capture per phase.  The warm-up iterations are real optimisation steps."""
-        bodies = self._bodies()
+        """Eager warm-up of every phase on a side stream (lazy initialisation, incidence / tap caches, RCCL
+        communicators), state restored, then one capture per phase."""
+        if not self.capture:
+            return
+        snap = self._snapshot()
         for k in self.s_inject:
             self._draw_inject(k)
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
-        reduce_after = {"d": self.flat_d, "r1": self.flat_d, "g": self.flat_g, "path": self.flat_g}
         with torch.cuda.stream(side):
             for _ in range(warmup):
                 for name in ("d", "d_opt", "r1", "d_opt", "g", "g_opt", "path", "g_opt"):
-                    bodies[name]()
-                    if name in reduce_after:
-                        self._reduce(reduce_after[name])       # replicas stay in step during the warm-up too
+                    self._eager_phase(name)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
-        if not self.capture:
-            return
+        self._restore(snap)
         # thread_local: only THIS thread's calls are policed during capture.  Under the default (global) mode the
         # RCCL watchdog thread's routine hipEventQuery on an earlier collective (the warm-up reductions, a DDP leg
         # that ran before) aborts the process with "operation not permitted when stream is capturing".
+        bodies = self._bodies()
         for name in ("d", "r1", "g", "path", "d_opt", "g_opt"):
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph, capture_error_mode="thread_local"):
@@ -230,14 +279,36 @@ class GraphedTrainer(Trainer):
         torch.cuda.synchronize()
 
     def _run(self, name):
-        if self.capture:
-            self.graphs[name].replay()
-        else:
-            self._bodies()[name]()
+        """One phase (or optimiser step).  Captured: replay, then queue every bucket's wait-for-event + collective on
+        the communication stream (they start as soon as the replay passes the bucket's event-record node); the
+        current stream — hence the optimiser graph replayed next — waits for the communication stream."""
+        if not self.capture:
+            return self._eager_phase(name)
+        self.graphs[name].replay()
+        if name in self.PHASE_REDUCER:
+            red = getattr(self, self.PHASE_REDUCER[name])
+            red.issue_all()
+            red.wait()
 
-    def _reduce(self, flat):
-        if self.world > 1:
-            (self.reduce_g if flat is self.flat_g else self.reduce_d)()
+    def measure_overlap(self, name="path"):
+        """Replays phase `name` once with timing events: returns the replay's duration and, per bucket, when its
+        reduction FINISHED relative to the end of the replay (ms; negative = while the backward was still running).
+        Leaves the flat gradient buffer reduced like a normal `_run(name)` (no optimiser step follows)."""
+        red = getattr(self, self.PHASE_REDUCER[name])
+        if not (self.capture and red.enabled and red.is_cuda):
+            return None
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        self.graphs[name].replay()
+        e1.record()
+        stamps = []
+        red.issue_all(stamps)
+        red.wait()
+        torch.cuda.synchronize()
+        return {"phase": name, "replay_ms": round(e0.elapsed_time(e1), 3),
+                "bucket_done_ms_after_replay_end": [round(e1.elapsed_time(ev), 3) for ev in stamps],
+                **red.describe()}
 
     # ---- one iteration -------------------------------------------------------------------------------
     def step(self, real_img, mesh=None, faces=None, log=True):
@@ -252,20 +323,16 @@ class GraphedTrainer(Trainer):
         for k in self.s_inject:
             self._draw_inject(k)
         self._run("d")
-        self._reduce(self.flat_d)
         self._run("d_opt")
         ran = ["d", "real_score", "fake_score", "g"]
         if i % a["d_reg_every"] == 0:
             self._run("r1")
-            self._reduce(self.flat_d)
             self._run("d_opt")
             ran.append("r1")
         self._run("g")
-        self._reduce(self.flat_g)
         self._run("g_opt")
         if i % a["g_reg_every"] == 0:
             self._run("path")
-            self._reduce(self.flat_g)
             self._run("g_opt")
             ran += ["path", "path_length", "mean_path"]
         accumulate(self.g_ema, self.generator, self.accum)

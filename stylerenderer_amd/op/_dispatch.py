@@ -1,4 +1,5 @@
 """Shared helpers of the operator wrappers."""
+import collections
 import contextlib
 
 import torch
@@ -29,3 +30,48 @@ def on_device_of(t):
 
 def stream_of(t):
     return _lib.current_stream(t.device)
+
+
+def _capturing():
+    return torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()
+
+
+class DerivedCache:
+    """LRU cache of tensors derived from long-lived inputs (flipped FIR taps, per-topology incidence lists), keyed by
+    the source tensor's address / version; the value must hold the source so that its address cannot be reused.
+
+    Entries that are read or created while the current stream is being CAPTURED are pinned for the life of the
+    process: the hipGraph holds their addresses, so evicting (freeing) them would make every later replay read
+    recycled memory.  (Round 2 cleared the whole dict at a size threshold: a later test's modules pushed a live
+    graph's flipped taps out and the replays went NaN.)  Only unpinned entries count against `capacity`."""
+
+    def __init__(self, capacity):
+        self.capacity = int(capacity)
+        self.data = collections.OrderedDict()
+        self.pinned = set()
+
+    def get(self, key):
+        hit = self.data.get(key)
+        if hit is not None:
+            self.data.move_to_end(key)
+            if _capturing():
+                self.pinned.add(key)
+        return hit
+
+    def put(self, key, value):
+        self.data[key] = value
+        if _capturing():
+            self.pinned.add(key)
+        excess = len(self.data) - len(self.pinned) - self.capacity
+        if excess > 0:
+            for k in [k for k in self.data if k not in self.pinned][:excess]:
+                del self.data[k]
+        return value
+
+    def __len__(self):
+        return len(self.data)
+
+    def clear(self):
+        """Drops the unpinned entries (tests)."""
+        for k in [k for k in self.data if k not in self.pinned]:
+            del self.data[k]

@@ -25,7 +25,7 @@ import torch
 from torch.autograd import Function
 
 from .. import _lib
-from ._dispatch import is_device_tensor, on_device_of, stream_of
+from ._dispatch import DerivedCache, is_device_tensor, on_device_of, stream_of
 
 
 def _geometry(vertices, triangles):
@@ -166,7 +166,7 @@ rasterize_op = types.SimpleNamespace(forward=forward, backward=backward)
 
 
 # ---- per-topology incidence list for the gradient gather ------------------------------------------
-_INC_CACHE = {}
+_INC_CACHE = DerivedCache(16)
 
 
 def _incidence_one(tri, nv):
@@ -196,9 +196,7 @@ def incidence(tri, nv):
         off = torch.stack([p[0] for p in parts]).contiguous()
         adj = torch.stack([p[1] for p in parts]).contiguous()
         val = (off, adj, off.shape[1], adj.shape[1], tri)
-    if len(_INC_CACHE) > 16:
-        _INC_CACHE.clear()
-    _INC_CACHE[key] = val                                    # holds `tri`: the key is its address
+    _INC_CACHE.put(key, val)                                 # holds `tri`: the key is its address
     return val[:4]
 
 

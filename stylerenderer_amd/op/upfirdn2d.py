@@ -16,7 +16,7 @@ from torch.autograd import Function
 from torch.nn import functional as F
 
 from .. import _lib
-from ._dispatch import is_device_tensor, on_device_of, require_f32, stream_of
+from ._dispatch import DerivedCache, is_device_tensor, on_device_of, require_f32, stream_of
 
 
 def _out_size(n, up, down, p0, p1, k):
@@ -48,7 +48,7 @@ def upfirdn2d_op(input, kernel, up_x, up_y, down_x, down_y, pad_x0, pad_x1, pad_
     return out
 
 
-_FLIP_CACHE = {}
+_FLIP_CACHE = DerivedCache(64)
 
 
 def flipped(kernel):
@@ -57,10 +57,8 @@ def flipped(kernel):
     key = (kernel.data_ptr(), kernel._version, tuple(kernel.shape), str(kernel.device), kernel.dtype)
     hit = _FLIP_CACHE.get(key)
     if hit is None:
-        if len(_FLIP_CACHE) > 64:
-            _FLIP_CACHE.clear()
-        hit = (torch.flip(kernel.detach(), [0, 1]).contiguous(), kernel)      # holds `kernel`: the key is its address
-        _FLIP_CACHE[key] = hit
+        # holds `kernel`: the key is its address
+        hit = _FLIP_CACHE.put(key, (torch.flip(kernel.detach(), [0, 1]).contiguous(), kernel))
     return hit[0]
 
 

@@ -14,13 +14,15 @@ from . import _lib
 ALIGN = 64          # floats: 256-byte aligned views
 
 
-def flat_layout(params, multiple_of=1):
+def flat_layout(params, multiple_of=1, order=None):
     """Offsets of 256-byte aligned slots and the total length, rounded up to `multiple_of` * ALIGN floats (so the
-    buffer splits evenly over the ranks of a reduce-scatter)."""
-    offs, off = [], 0
-    for p in params:
-        offs.append(off)
-        off += (p.numel() + ALIGN - 1) // ALIGN * ALIGN
+    buffer splits evenly over the ranks of a reduce-scatter).  `order` (a permutation of range(len(params))) places
+    the slots in that order — graph_train lays the buffer out in gradient ARRIVAL order so that contiguous buckets
+    complete one after the other during the backward; `offs[i]` is always the offset of `params[i]`."""
+    offs, off = [0] * len(params), 0
+    for i in (order if order is not None else range(len(params))):
+        offs[i] = off
+        off += (params[i].numel() + ALIGN - 1) // ALIGN * ALIGN
     step = ALIGN * max(1, int(multiple_of))
     return offs, (off + step - 1) // step * step
 
@@ -30,14 +32,14 @@ def flat_views(flat, params, offs):
 
 
 class FlatAdam:
-    def __init__(self, params, flat_grad, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+    def __init__(self, params, flat_grad, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, offs=None):
         self.params = list(params)
         p0 = self.params[0]
-        if p0.device.type != "cuda" or any(p.dtype != torch.float32 for p in self.params):
-            raise RuntimeError("FlatAdam: float32 parameters on a GPU required")
-        self.offs, _ = flat_layout(self.params)
+        if any(p.dtype != torch.float32 for p in self.params):
+            raise RuntimeError("FlatAdam: float32 parameters required")
+        self.offs = list(offs) if offs is not None else flat_layout(self.params)[0]
         self.total = flat_grad.numel()                 # may carry tail padding (rank-divisible length)
-        if self.total < self.offs[-1] + self.params[-1].numel():
+        if self.total < max(o + p.numel() for o, p in zip(self.offs, self.params)):
             raise RuntimeError("FlatAdam: gradient buffer does not follow flat_layout(params)")
         self.flat_g = flat_grad
         self.flat_p = torch.zeros(self.total, device=p0.device)
@@ -54,10 +56,24 @@ class FlatAdam:
     def step(self):
         g = self.param_groups[0]
         self.step_t.add_(1.0)
+        if self.flat_p.device.type != "cuda":
+            return self._step_host(g)
         rc = _lib.lib().sr_adam_flat(self.flat_p.data_ptr(), self.flat_g.data_ptr(), self.m.data_ptr(),
                                      self.v.data_ptr(), self.total, g["lr"], g["betas"][0], g["betas"][1], g["eps"],
                                      self.step_t.data_ptr(), _lib.current_stream(self.flat_p.device))
         _lib.check(rc, "sr_adam_flat")
+
+    @torch.no_grad()
+    def _step_host(self, g):
+        """CPU tensors (gloo tests, plumbing): the arithmetic of k_adam_flat (csrc/fused_elem.hip) in torch ops."""
+        b1, b2 = g["betas"]
+        t = float(self.step_t)
+        bc1 = 1.0 - b1 ** t
+        bc2s = (1.0 - b2 ** t) ** 0.5
+        grad = self.flat_g
+        self.m.add_((grad - self.m) * (1.0 - b1))
+        self.v.mul_(b2).addcmul_(grad, grad, value=1.0 - b2)
+        self.flat_p.sub_((g["lr"] / bc1) * (self.m / (self.v.sqrt() / bc2s + g["eps"])))
 
     def zero_grad(self, set_to_none=False):
         self.flat_g.zero_()

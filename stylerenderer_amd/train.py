@@ -59,6 +59,19 @@ def d_r1_loss(real_pred, real_img):
     return grad_real.pow(2).reshape(grad_real.shape[0], -1).sum(1).mean()
 
 
+def d_fake_real(d_call, d, fake_img, real_img):
+    """D(fake), D(real) (reference train.py:254-255).  When the per-GPU batch is a multiple of the minibatch-stddev
+    group, both halves go through ONE interleaved pass: the layer views the batch as [group, batch // group]
+    (reference model.py:325-332), so sample b of the 2B batch lands in sub-batch b mod (2B / group) — fake and real
+    never share a sub-batch and the statistics equal those of two calls.  Otherwise two calls, like the reference."""
+    batch = real_img.shape[0]
+    if batch == fake_img.shape[0] and batch % d.stddev_group == 0:
+        both = torch.stack([fake_img, real_img], 1).reshape(2 * batch, *real_img.shape[1:])
+        pred = d_call(both)
+        return pred[0::2], pred[1::2]
+    return d_call(fake_img), d_call(real_img)
+
+
 def g_nonsaturating_loss(fake_pred):
     return F.softplus(-fake_pred).mean()
 
@@ -184,13 +197,9 @@ class Trainer:
         # one discriminator pass over both halves.  Interleaving keeps the minibatch-stddev groups of the two
         # separate calls of the reference (model.py:325-332 views the batch as [group, batch // group]: sample b
         # falls into sub-batch b % 2), so fake and real statistics never mix and the outputs are identical
-        if batch == fake_img.shape[0] and batch % min(batch, d.stddev_group) == 0:
-            both = torch.stack([fake_img, real_aug], 1).reshape(2 * batch, *real_aug.shape[1:])
-            pred = self.d_ddp(both)
-            fake_pred, real_pred = pred[0::2], pred[1::2]
-        else:
-            fake_pred = self.d_ddp(fake_img)
-            real_pred = self.d_ddp(real_aug)
+        # — which needs whole groups: batch % stddev_group == 0.  Smaller / ragged batches (the reference then uses
+        # group = min(batch, 4)) take the reference's two calls.
+        fake_pred, real_pred = d_fake_real(self.d_ddp, d, fake_img, real_aug)
         d_loss = d_logistic_loss(real_pred, fake_pred)
         losses["d"] = d_loss
         losses["real_score"] = real_pred.mean()

@@ -16,7 +16,7 @@ import torch
 from torch.autograd import Function
 
 from . import _lib
-from .op._dispatch import on_device_of, stream_of
+from .op._dispatch import DerivedCache, on_device_of, stream_of
 
 
 def normalize(vec, axis=-1, _type="L2", eps=1e-8):
@@ -79,7 +79,7 @@ def random_apply_pose3D(p=[.5, .1, .05, .1, .1, .1, .15], v=None):
 
 
 # ---- vertex normals -------------------------------------------------------------------------------
-_ADJ_CACHE = {}
+_ADJ_CACHE = DerivedCache(16)
 
 
 def incidence_lists(tri, nv):
@@ -96,10 +96,8 @@ def incidence_lists(tri, nv):
     counts = torch.bincount(flat, minlength=nv)
     off = torch.zeros(nv + 1, dtype=torch.int32, device=tri.device)
     off[1:] = torch.cumsum(counts, 0).to(torch.int32)
-    if len(_ADJ_CACHE) > 16:
-        _ADJ_CACHE.clear()
-    _ADJ_CACHE[key] = (off, order.contiguous(), tri)             # keep `tri` alive: the key holds its address
-    return _ADJ_CACHE[key]
+    # keep `tri` alive: the key holds its address
+    return _ADJ_CACHE.put(key, (off, order.contiguous(), tri))
 
 
 def _normals_composite(v, tri):

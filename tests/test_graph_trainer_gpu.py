@@ -1,0 +1,102 @@
+"""GPU: graph_train.GraphedTrainer at BASELINE config[2]'s size, and its overlapped gradient reduction on a ONE-rank
+RCCL group (the only group a 1-GPU box can form): the event-record nodes inside the replayed backward, the
+communication stream and the RCCL calls between replays are exactly what runs at N > 1."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+
+from stylerenderer_amd import graph_train, train
+
+pytestmark = pytest.mark.gpu
+
+
+def full_size_trainer(**kw):
+    dev = torch.device("cuda")
+    faces = train.SyntheticFaceSource(dev, seed=0)
+    tr = graph_train.GraphedTrainer(size=256, latent=512, n_mlp=8, channel_multiplier=2, use_mesh=True, device=dev,
+                                    seed=0, batch=4, mesh_vertices=faces.model.dim[2] // 3, **kw)
+    return tr, faces, train.SyntheticImages(16, 256, dev)
+
+
+def test_full_size_graphed_iteration_256_and_graph_equals_eager_for_every_phase():
+    """BASELINE config[2] on the DEFAULT trainer of bench.py: GeneratorWithMap(256) + Discriminator(256), 4 images,
+    iteration 0 (R1 + path-length double backward on batch 2) and two more; then, phase by phase, the replayed graph
+    leaves the same flat gradient buffer as the same body launched eagerly from the same RNG state."""
+    tr, faces, data = full_size_trainer()
+    g0 = tr.g_optim.flat_p.clone()
+    d0 = tr.d_optim.flat_p.clone()
+    logs = [tr.step(data.batch(4), faces=faces) for _ in range(3)]
+    assert set(tr.graphs) == {"d", "r1", "g", "path", "d_opt", "g_opt"}
+    assert {"d", "g", "r1", "path", "path_length", "mean_path", "real_score", "fake_score"} <= set(logs[0])
+    assert "r1" not in logs[1] and "path" not in logs[1]
+    for log in logs:
+        assert all(np.isfinite(v) for v in log.values()), log
+    assert logs[0]["path_length"] > 0 and float(tr.mean_path_length) > 0
+    assert float(tr.g_optim.step_t) == 4 and float(tr.d_optim.step_t) == 4      # warm-up steps are not counted
+    assert tr.iteration == 3
+    # every trainable parameter of both networks moved
+    names = [n for n, _ in tr.generator.named_parameters() if n not in tr.frozen]
+    for n, p, o in zip(names, tr.g_params, tr.g_optim.offs):
+        assert not torch.equal(p.detach().reshape(-1), g0[o:o + p.numel()]), n
+    for (n, _), p, o in zip(tr.discriminator.named_parameters(), tr.d_params, tr.d_optim.offs):
+        assert not torch.equal(p.detach().reshape(-1), d0[o:o + p.numel()]), n
+    dev = tr.device
+    for name, flat in (("d", tr.flat_d), ("r1", tr.flat_d), ("g", tr.flat_g), ("path", tr.flat_g)):
+        mpl = tr.mean_path_length.clone()
+        state = torch.cuda.get_rng_state(dev)
+        tr._bodies()[name]()
+        eager = flat.clone()
+        tr.mean_path_length.copy_(mpl)
+        torch.cuda.set_rng_state(state, dev)
+        flat.zero_()
+        tr.graphs[name].replay()
+        torch.cuda.synchronize()
+        scale = float(eager.abs().max())
+        err = float((flat - eager).abs().max())
+        assert scale > 0 and err <= 1e-5 * scale, (name, err, scale)
+
+
+@pytest.fixture(scope="module")
+def one_rank_group():
+    import torch.distributed as dist
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    yield dist
+    dist.destroy_process_group()
+
+
+def test_overlapped_reduction_inside_the_replayed_backward(one_rank_group):
+    """force_collectives=True on a one-rank RCCL group: every bucket's all-reduce is issued on the communication
+    stream behind its event-record node.  (1) The trajectory equals the run without collectives bit for bit
+    (all-reduce over one rank is the identity, / world = 1).  (2) Timing events: the first buckets of the
+    path-length phase are reduced BEFORE the replay of that phase's backward has finished."""
+    a, faces, data = full_size_trainer(force_collectives=True)
+    b, _, _ = full_size_trainer()
+    assert a.reduce_g.enabled and not b.reduce_g.enabled
+    assert a.reduce_g.describe()["mode"] == "overlapped, 4 buckets"
+    batches = [data.batch(4) for _ in range(3)]
+    for tr in (a, b):
+        torch.manual_seed(123)
+        tr.np_rng = np.random.RandomState(5)
+        meshes = [tuple(t.clone() for t in faces.sample(4)) for _ in range(3)]
+        torch.manual_seed(321)
+        tr.logs = [tr.step(x, mesh=m) for x, m in zip(batches, meshes)]
+    assert torch.equal(a.g_optim.flat_p, b.g_optim.flat_p) and torch.equal(a.d_optim.flat_p, b.d_optim.flat_p)
+    assert a.logs == b.logs
+    for name in ("path", "d"):
+        ov = a.measure_overlap(name)
+        done = ov["bucket_done_ms_after_replay_end"]
+        assert len(done) == 4 and done == sorted(done), ov
+        # bucket 0 (40 % of the bytes: the gradients of the high-resolution layers for G) is reduced while the
+        # backward is still running; the later buckets complete in the fast low-resolution tail
+        assert done[0] < 0, ov
+        print("overlap", ov)
