@@ -352,6 +352,12 @@ int sr_event_destroy(void* event);
 int sr_event_record(void* event, sr_stream_t stream);
 int sr_stream_wait_event(sr_stream_t stream, void* event);
 
+/* Repairs a captured, not yet instantiated hipGraph_t for the HIP 7.0 runtime PyTorch-ROCm 2.10 bundles: memset nodes
+ * replay a corrupted value from the second launch on (torch's multi-block reductions zero their semaphores that way),
+ * so each memset node is replaced by a fill-kernel node with the same edges.  `replaced` receives the count.  The
+ * reference has no counterpart: it never captures its step (train.py enqueues ~4 000 launches per iteration). */
+int sr_graph_replace_memset_nodes(void* hip_graph, int* replaced);
+
 #ifdef __cplusplus
 }
 #endif

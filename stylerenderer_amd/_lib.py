@@ -71,6 +71,7 @@ SIGNATURES = {
     "sr_event_destroy": (_i, [_p]),
     "sr_event_record": (_i, [_p, _p]),
     "sr_stream_wait_event": (_i, [_p, _p]),
+    "sr_graph_replace_memset_nodes": (_i, [_p, ctypes.POINTER(_i)]),
 }
 
 _lib = None

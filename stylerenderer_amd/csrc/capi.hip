@@ -1,4 +1,6 @@
 // Library-level entry points of libstylerenderer_hip.so (error strings, ABI version).
+#include <vector>
+
 #include "common.h"
 
 extern "C" int sr_abi_version(void) { return 3; }
@@ -45,4 +47,83 @@ extern "C" int sr_event_record(void* event, sr_stream_t stream) {
 extern "C" int sr_stream_wait_event(sr_stream_t stream, void* event) {
     if (!event) return SR_EINVAL;
     return static_cast<int>(hipStreamWaitEvent(sr_stream(stream), static_cast<hipEvent_t>(event), 0));
+}
+
+// ---- hipGraph repair: memset nodes -> kernel nodes -------------------------------------------------------------
+// The HIP runtime bundled with PyTorch 2.10+rocm7.0 (7.0.51831) replays a captured MEMSET node correctly once; from the
+// second launch of the executable graph on the node writes a corrupted value (0x10 bytes instead of 0:
+// scripts/memset_graph_probe_torch.py; the same program on the ROCm 7.2 runtime is fine).  torch's multi-block
+// reductions zero their semaphores with hipMemsetAsync, so every captured `sum` / `mean` that needs more than one
+// workgroup per output returned garbage from the second replay on (scripts/graph_reduce_probe.py) — the path-length
+// phase and the inversion loss among them.  This entry point rewrites a captured graph BEFORE it is instantiated:
+// every memset node becomes a kernel node (k_graph_fill) with the same predecessors and successors.
+namespace {
+
+__global__ __launch_bounds__(256) void k_graph_fill(unsigned char* __restrict__ dst, unsigned value, unsigned elem,
+                                                    unsigned long long row_bytes, unsigned long long height,
+                                                    unsigned long long pitch, int vec16) {
+    const unsigned long long stride = (unsigned long long)gridDim.x * 256;
+    unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
+    if (vec16) {        // one row, 16-byte aligned, a multiple of 16 bytes, value pattern replicated over 32 bits
+        const uint4 v = make_uint4(value, value, value, value);
+        for (const unsigned long long n16 = row_bytes / 16; i < n16; i += stride) reinterpret_cast<uint4*>(dst)[i] = v;
+        return;
+    }
+    for (const unsigned long long total = row_bytes * height; i < total; i += stride) {
+        const unsigned long long row = i / row_bytes, col = i - row * row_bytes;
+        dst[row * pitch + col] = (unsigned char)(value >> (8 * (col % elem)));
+    }
+}
+
+}  // namespace
+
+extern "C" int sr_graph_replace_memset_nodes(void* graph_handle, int* replaced) {
+    if (!graph_handle) return SR_EINVAL;
+    hipGraph_t graph = static_cast<hipGraph_t>(graph_handle);
+    size_t n = 0;
+    hipError_t e = hipGraphGetNodes(graph, nullptr, &n);
+    if (e != hipSuccess) return static_cast<int>(e);
+    std::vector<hipGraphNode_t> nodes(n);
+    if (n && (e = hipGraphGetNodes(graph, nodes.data(), &n)) != hipSuccess) return static_cast<int>(e);
+    int count = 0;
+    for (size_t k = 0; k < n; ++k) {
+        hipGraphNodeType type;
+        if ((e = hipGraphNodeGetType(nodes[k], &type)) != hipSuccess) return static_cast<int>(e);
+        if (type != hipGraphNodeTypeMemset) continue;
+        hipMemsetParams mp;
+        if ((e = hipGraphMemsetNodeGetParams(nodes[k], &mp)) != hipSuccess) return static_cast<int>(e);
+        size_t nd = 0, ns = 0;
+        if ((e = hipGraphNodeGetDependencies(nodes[k], nullptr, &nd)) != hipSuccess) return static_cast<int>(e);
+        std::vector<hipGraphNode_t> deps(nd);
+        if (nd && (e = hipGraphNodeGetDependencies(nodes[k], deps.data(), &nd)) != hipSuccess) return static_cast<int>(e);
+        if ((e = hipGraphNodeGetDependentNodes(nodes[k], nullptr, &ns)) != hipSuccess) return static_cast<int>(e);
+        std::vector<hipGraphNode_t> succ(ns);
+        if (ns && (e = hipGraphNodeGetDependentNodes(nodes[k], succ.data(), &ns)) != hipSuccess) return static_cast<int>(e);
+        unsigned char* dst = static_cast<unsigned char*>(mp.dst);
+        unsigned elem = mp.elementSize ? mp.elementSize : 1;
+        unsigned value = mp.value;
+        if (elem == 1) value = (value & 0xFFu) * 0x01010101u;
+        else if (elem == 2) value = (value & 0xFFFFu) * 0x00010001u;
+        unsigned long long row_bytes = (unsigned long long)mp.width * elem, height = mp.height ? mp.height : 1;
+        unsigned long long pitch = mp.pitch ? mp.pitch : row_bytes;
+        int vec16 = (height == 1 && row_bytes % 16 == 0 && (reinterpret_cast<uintptr_t>(dst) & 15) == 0) ? 1 : 0;
+        const unsigned long long items = vec16 ? row_bytes / 16 : row_bytes * height;
+        void* args[] = {&dst, &value, &elem, &row_bytes, &height, &pitch, &vec16};
+        hipKernelNodeParams kp;
+        kp.func = reinterpret_cast<void*>(k_graph_fill);
+        kp.gridDim = dim3((unsigned)sr_stream_grid((int64_t)(items ? items : 1), 256));
+        kp.blockDim = dim3(256);
+        kp.sharedMemBytes = 0;
+        kp.kernelParams = args;
+        kp.extra = nullptr;
+        hipGraphNode_t fill;
+        if ((e = hipGraphAddKernelNode(&fill, graph, nd ? deps.data() : nullptr, nd, &kp)) != hipSuccess)
+            return static_cast<int>(e);
+        for (size_t j = 0; j < ns; ++j)
+            if ((e = hipGraphAddDependencies(graph, &fill, &succ[j], 1)) != hipSuccess) return static_cast<int>(e);
+        if ((e = hipGraphDestroyNode(nodes[k])) != hipSuccess) return static_cast<int>(e);
+        ++count;
+    }
+    if (replaced) *replaced = count;
+    return SR_OK;
 }

@@ -982,7 +982,10 @@ void grad_launch(long long b, long long nv, long long nf, long long h, long long
                  const R* grad_out, const int* adj_off, const int* adj, long long off_bs, long long adj_bs,
                  R* grad_v, R* grad_tex, R eps, R* tg, unsigned char* flag, hipStream_t st) {
     const bool want_v = grad_v != nullptr && ch0 == 0;
-    (void)hipMemsetAsync(flag, 0, (size_t)(b * nf), st);
+    // (a fill kernel, not hipMemsetAsync: captured memset nodes replay a corrupted value on the HIP 7.0 runtime
+    // torch bundles — csrc/capi.hip sr_graph_replace_memset_nodes; `flag` is 4-byte aligned and padded to 4 bytes)
+    hipLaunchKernelGGL(k_fill_u32, dim3(sr_stream_grid(sr_ceil_div(b * nf, 4), 256)), dim3(256), 0, st,
+                       reinterpret_cast<unsigned*>(flag), 0u, (long long)sr_ceil_div(b * nf, 4));
     hipLaunchKernelGGL((k_grad_big<R, CT, PERSP>), dim3(SR_NUM_CU * 2), dim3(256), 0, st, nv, nf, h, w, repeat_f, v,
                        tex, tex_c, ch0, tri, win, big, grad_out, want_v, tg, flag, eps);
     hipLaunchKernelGGL((k_grad_pix<R, CT, PERSP>), dim3((unsigned)sr_ceil_div(b * h * w, 256)), dim3(256), 0, st, b,

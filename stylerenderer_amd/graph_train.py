@@ -44,6 +44,7 @@ import os
 import torch
 
 from . import distributed as sr_dist
+from . import graphs
 from .optim import FlatAdam, flat_layout, flat_views
 from .train import (Trainer, accumulate, d_fake_real, d_logistic_loss, d_r1_loss, g_nonsaturating_loss, g_path_regularize,
                     requires_grad)
@@ -267,15 +268,9 @@ class GraphedTrainer(Trainer):
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self._restore(snap)
-        # thread_local: only THIS thread's calls are policed during capture.  Under the default (global) mode the
-        # RCCL watchdog thread's routine hipEventQuery on an earlier collective (the warm-up reductions, a DDP leg
-        # that ran before) aborts the process with "operation not permitted when stream is capturing".
         bodies = self._bodies()
         for name in ("d", "r1", "g", "path", "d_opt", "g_opt"):
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph, capture_error_mode="thread_local"):
-                bodies[name]()
-            self.graphs[name] = graph
+            self.graphs[name] = graphs.capture(bodies[name])     # memset nodes repaired: graphs.py
         torch.cuda.synchronize()
 
     def _run(self, name):

@@ -19,7 +19,7 @@ loss history stays on the device until the end.
 import torch
 from torch import optim
 
-from . import utils_3d
+from . import graphs, utils_3d
 
 
 class LatentInverter:
@@ -91,9 +91,7 @@ class LatentInverter:
                 history[k] = self.loss_value
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
-        self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):     # see graph_train.build_graphs
-            self._iteration()
+        self.graph = graphs.capture(self._iteration)      # memset nodes of torch's reductions repaired: graphs.py
         return warmup
 
     def run(self, steps=400):
