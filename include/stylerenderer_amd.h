@@ -344,13 +344,13 @@ int sr_conv2d_wgrad_mfma(float* dwt, const float* x, const float* gy, const floa
  * The reference overlaps the gradient all-reduce with the backward through torch DDP's bucket hooks
  * (reference distributed.py:98-105, used for the path-length step at train.py:335-352).  This build replays each
  * training phase as ONE hipGraph; a bucket of the flat gradient buffer that is complete in the middle of that graph
- * is announced by an event-record node: sr_event_record on a capturing stream adds the node (hipEventRecordExternal),
- * on an ordinary stream it is a plain record; sr_stream_wait_event on the communication stream, issued after the
- * graph launch, waits for that node only.  Events are created without timing. */
-int sr_event_create(void** event);
-int sr_event_destroy(void* event);
-int sr_event_record(void* event, sr_stream_t stream);
-int sr_stream_wait_event(sr_stream_t stream, void* event);
+ * is announced by a one-lane kernel node: sr_signal_bump increments `*counter` (device memory, initially 0) once all
+ * work enqueued before it on `stream` has finished.  sr_signal_wait enqueues a one-lane kernel on another stream that
+ * returns when `*counter - at_least >= 0` (signed 32-bit distance): with at_least = the number of runs launched so
+ * far, everything enqueued behind it starts at that point of the replay.  The producer must already be enqueued when
+ * the wait is (the wait spins on the device). */
+int sr_signal_bump(uint32_t* counter, sr_stream_t stream);
+int sr_signal_wait(const uint32_t* counter, uint32_t at_least, sr_stream_t stream);
 
 /* Repairs a captured, not yet instantiated hipGraph_t for the HIP 7.0 runtime PyTorch-ROCm 2.10 bundles: memset nodes
  * replay a corrupted value from the second launch on (torch's multi-block reductions zero their semaphores that way),

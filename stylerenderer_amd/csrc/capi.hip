@@ -14,39 +14,39 @@ extern "C" const char* sr_error_string(int code) {
 }
 
 // ---- in-graph signalling for the overlapped gradient reduction (include/stylerenderer_amd.h) ----------------------
-// An event recorded on a CAPTURING stream with hipEventRecordExternal becomes an event-record NODE of the hipGraph:
-// every replay records it at that point of the graph, and a hipStreamWaitEvent issued on another stream after
-// hipGraphLaunch waits for exactly that point — the rest of the graph keeps running (scripts/event_graph_probe.cpp:
-// consumer starts 12 us after the producer node inside a replay on gfx950 / ROCm 7).  On a stream that is not
-// capturing this is a plain hipEventRecord.  torch.cuda.Event(external=True) refuses to do this on ROCm builds.
-extern "C" int sr_event_create(void** event) {
-    if (!event) return SR_EINVAL;
-    hipEvent_t ev = nullptr;
-    const hipError_t e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
-    if (e != hipSuccess) return static_cast<int>(e);
-    *event = ev;
-    return SR_OK;
+// A bucket of the flat gradient buffer that is complete in the MIDDLE of a replayed phase graph has to release its
+// all-reduce on another stream while the rest of the graph keeps running.  The API for that is an event-record node
+// (hipEventRecordWithFlags(..., hipEventRecordExternal)); it works on the ROCm 7.2 runtime but returns
+// hipErrorInvalidValue on the HIP 7.0.51831 runtime PyTorch-ROCm 2.10 bundles, and hipStreamWaitValue32 does not
+// release early on either (scripts/event_graph_probe.cpp, event_graph_probe_torch.py).  Plain kernels do: k_bump is a
+// node of the graph that increments a device counter once everything captured before it has finished, k_poll is the
+// first thing in the communication stream and spins (one lane, s_sleep) until the counter reaches the number of
+// runs the host has launched.  Measured inside a replay: the consumer starts 0.5 us after the producer node.
+namespace {
+
+__global__ void k_signal_bump(unsigned* counter) {
+    __threadfence();
+    atomicAdd(counter, 1u);
 }
 
-extern "C" int sr_event_destroy(void* event) {
-    if (!event) return SR_OK;
-    return static_cast<int>(hipEventDestroy(static_cast<hipEvent_t>(event)));
+__global__ void k_signal_wait(const unsigned* counter, unsigned at_least) {
+    // signed distance: correct across the 2^32 wrap of a counter that only ever grows
+    while ((int)(__hip_atomic_load(counter, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - at_least) < 0)
+        __builtin_amdgcn_s_sleep(16);
 }
 
-extern "C" int sr_event_record(void* event, sr_stream_t stream) {
-    if (!event) return SR_EINVAL;
-    hipStream_t s = sr_stream(stream);
-    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
-    hipError_t e = hipStreamIsCapturing(s, &st);
-    if (e != hipSuccess) return static_cast<int>(e);
-    e = hipEventRecordWithFlags(static_cast<hipEvent_t>(event), s,
-                                st == hipStreamCaptureStatusActive ? hipEventRecordExternal : hipEventRecordDefault);
-    return static_cast<int>(e);
+}  // namespace
+
+extern "C" int sr_signal_bump(uint32_t* counter, sr_stream_t stream) {
+    if (!counter) return SR_EINVAL;
+    hipLaunchKernelGGL(k_signal_bump, dim3(1), dim3(1), 0, sr_stream(stream), counter);
+    return sr_launch_status();
 }
 
-extern "C" int sr_stream_wait_event(sr_stream_t stream, void* event) {
-    if (!event) return SR_EINVAL;
-    return static_cast<int>(hipStreamWaitEvent(sr_stream(stream), static_cast<hipEvent_t>(event), 0));
+extern "C" int sr_signal_wait(const uint32_t* counter, uint32_t at_least, sr_stream_t stream) {
+    if (!counter) return SR_EINVAL;
+    hipLaunchKernelGGL(k_signal_wait, dim3(1), dim3(1), 0, sr_stream(stream), counter, at_least);
+    return sr_launch_status();
 }
 
 // ---- hipGraph repair: memset nodes -> kernel nodes -------------------------------------------------------------

@@ -215,11 +215,12 @@ class BucketedGradReducer:
     The flat buffer is laid out in gradient ARRIVAL order (`arrival_order`) and cut into `n_buckets` contiguous
     slices of linearly decreasing size.  A post-accumulate hook per parameter counts arrivals; when the last gradient of a
     bucket is there, the bucket's gradients are copied into their flat views (one multi-tensor copy) and the bucket
-    is SIGNALLED: `sr_event_record` on the producing stream.  Under stream capture that is an event-record node in the
-    middle of the phase graph (include/stylerenderer_amd.h); after each `graph.replay()` the host calls
-    `issue_all()`: for every bucket, `sr_stream_wait_event(comm, event_k)` + `all_reduce(flat[lo_k:hi_k])` on the
-    communication stream — bucket k is on the xGMI links while the graph is still computing the gradients of
-    bucket k+1.  Eagerly (warm-up, `capture=False`, CPU / gloo) the same hooks issue the collective directly.
+    is SIGNALLED.  Under stream capture the signal is a one-lane kernel node in the middle of the phase graph that
+    increments the bucket's device counter (`sr_signal_bump`, include/stylerenderer_amd.h); after each
+    `graph.replay()` the host calls `issue_all()`: for every bucket, `sr_signal_wait(counter_k, runs so far)` +
+    `all_reduce(flat[lo_k:hi_k])` on the communication stream — bucket k is on the xGMI links while the graph is
+    still computing the gradients of bucket k+1.  Eagerly (warm-up, `capture=False`, CPU / gloo) the same hooks
+    record an ordinary event and issue the collective directly.
     Buckets are issued in index order on every rank, whatever order they completed in.  `wait()` makes the
     current stream (CPU: the caller) wait for all reductions — it sits in front of the optimiser step.
 
@@ -251,16 +252,13 @@ class BucketedGradReducer:
         self.bucket_of = {i: b for b, bk in enumerate(self.buckets) for i in bk["members"]}
         self.single = FlatGradReducer(flat, self.world) if (len(self.buckets) == 1 and self.world > 1) else None
         self.comm = None
-        self.events = []
+        self.counters, self.runs, self.eager_events = None, [], []
         if self.is_cuda and self.enabled:
-            import ctypes
-
             self._lib = _lib
             self.comm = torch.cuda.Stream(device=flat.device)
-            for _ in self.buckets:
-                ev = ctypes.c_void_p()
-                _lib.check(_lib.lib().sr_event_create(ctypes.byref(ev)), "sr_event_create")
-                self.events.append(ev)
+            self.counters = torch.zeros(len(self.buckets), dtype=torch.int32, device=flat.device)
+            self.runs = [0] * len(self.buckets)          # bumps launched so far, per bucket (replays only)
+            self.eager_events = [None] * len(self.buckets)
         self.active = False
         self.pending, self.done, self.next_issue = [], [], 0
         self.works = []
@@ -312,10 +310,14 @@ class BucketedGradReducer:
         if not self.enabled:
             return
         if self.is_cuda:
-            self._lib.check(self._lib.lib().sr_event_record(self.events[b], self._lib.current_stream(self.flat.device)),
-                            "sr_event_record")
+            stream = torch.cuda.current_stream(self.flat.device)      # the producing stream (autograd thread: the op's)
             if self._capturing():
+                self._lib.check(self._lib.lib().sr_signal_bump(self.counters.data_ptr() + 4 * b, stream.cuda_stream),
+                                "sr_signal_bump")
                 return                               # issued by issue_all() after every replay
+            ev = torch.cuda.Event()
+            ev.record(stream)
+            self.eager_events[b] = ev
         self._issue_ready()
 
     def _issue_ready(self):
@@ -323,13 +325,18 @@ class BucketedGradReducer:
             self._issue(self.next_issue)
             self.next_issue += 1
 
-    def _issue(self, b):
+    def _issue(self, b, replay=False):
         bk = self.buckets[b]
         piece = self.flat[bk["lo"]:bk["hi"]]
         self.log.append(("issue", b, self._now()))
         if self.is_cuda:
-            self._lib.check(self._lib.lib().sr_stream_wait_event(self.comm.cuda_stream, self.events[b]),
-                            "sr_stream_wait_event")
+            if replay:
+                self.runs[b] += 1
+                self._lib.check(self._lib.lib().sr_signal_wait(self.counters.data_ptr() + 4 * b,
+                                                               self.runs[b] & 0xFFFFFFFF, self.comm.cuda_stream),
+                                "sr_signal_wait")
+            else:
+                self.comm.wait_event(self.eager_events[b])
             with torch.cuda.stream(self.comm):
                 if self.single is not None:
                     self.single()
@@ -350,11 +357,12 @@ class BucketedGradReducer:
 
     # ---- after a replay / before the optimiser ------------------------------------------------------------------
     def issue_all(self, stamps=None):
-        """After `graph.replay()` of a captured phase: queue every bucket's wait + collective on the comm stream.
+        """After `graph.replay()` of a captured phase (ONLY then: the waits spin on the device until the replay's
+        signal nodes have run): queue every bucket's wait + collective on the comm stream.
         `stamps` (a list): a timing event is recorded on the comm stream after every bucket's collective."""
         if self.enabled:
             for b in range(len(self.buckets)):
-                self._issue(b)
+                self._issue(b, replay=True)
                 if stamps is not None and self.is_cuda:
                     ev = torch.cuda.Event(enable_timing=True)
                     ev.record(self.comm)

@@ -18,9 +18,10 @@ Gradient reduction overlapped with the backward (reference distributed.py:98-105
 all-reduce over xGMI overlapped with the StyleGAN2 path-length-regulariser backward").  No RCCL call is captured:
 the flat gradient buffer of each network is laid out in gradient ARRIVAL order and cut into SR_GRAD_BUCKETS (4)
 contiguous buckets; the captured backward holds, after the last gradient of each bucket, one multi-tensor copy into the
-bucket's flat views and an EVENT-RECORD NODE (`sr_event_record` on the capturing stream -> hipEventRecordExternal;
-include/stylerenderer_amd.h).  Right after `graph.replay()` the host queues, for every bucket, `hipStreamWaitEvent(comm,
-event_k)` + `all_reduce(flat[lo_k:hi_k])` on a communication stream: bucket k is on the xGMI links while the replay
+bucket's flat views and a SIGNAL NODE (`sr_signal_bump`: a one-lane kernel that increments the bucket's device counter;
+include/stylerenderer_amd.h — event-record nodes are refused by the HIP runtime torch bundles).  Right after
+`graph.replay()` the host queues, for every bucket, `sr_signal_wait(counter_k, runs)` + `all_reduce(flat[lo_k:hi_k])`
+on a communication stream: bucket k is on the xGMI links while the replay
 is still producing bucket k+1; the optimiser graph waits for the communication stream
 (distributed.BucketedGradReducer).  SR_GRAD_OVERLAP=0: one bucket, reduced after the backward by the autotuned
 all-reduce / reduce-scatter + all-gather of distributed.FlatGradReducer (round 2's mode).  With `capture=False` the
