@@ -421,7 +421,10 @@ def main():
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)
+        # RCCL kernels on high-priority streams: their own hardware queue, never behind the compute stream's kernels
+        # (HIP multiplexes the streams of one priority over GPU_MAX_HW_QUEUES = 4 hardware queues)
+        dist.init_process_group(backend="nccl", device_id=dev,
+                                pg_options=dist.ProcessGroupNCCL.Options(is_high_priority_stream=True))
         assert dist.get_world_size() == world
 
     from stylerenderer_amd import _lib, model

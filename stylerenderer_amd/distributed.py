@@ -83,7 +83,13 @@ def initialize(backend=None, seed=None):
         os.environ.setdefault("MASTER_PORT", "29500")
         backend = backend or ("nccl" if use_gpu else "gloo")
         if backend == "nccl":
-            dist.init_process_group(backend=backend, device_id=device)
+            # RCCL's kernels on a high-priority stream (a hardware queue of their own, see BucketedGradReducer)
+            opts = None
+            try:
+                opts = dist.ProcessGroupNCCL.Options(is_high_priority_stream=True)
+            except Exception:       # a torch build without the option: default streams
+                opts = None
+            dist.init_process_group(backend=backend, device_id=device, pg_options=opts)
         else:
             dist.init_process_group(backend=backend)
         synchronize()
@@ -255,7 +261,11 @@ class BucketedGradReducer:
         self.counters, self.runs, self.eager_events = None, [], []
         if self.is_cuda and self.enabled:
             self._lib = _lib
-            self.comm = torch.cuda.Stream(device=flat.device)
+            # HIGH priority: HIP multiplexes streams of one priority over a few hardware queues (GPU_MAX_HW_QUEUES,
+            # default 4).  A normal-priority communication stream that lands on the hardware queue the graph is replayed
+            # on runs its wait kernel BEHIND the whole replay — correct, but nothing overlaps (seen when earlier streams
+            # of the process had shifted the round-robin).  High-priority streams get queues of their own.
+            self.comm = torch.cuda.Stream(device=flat.device, priority=-1)
             self.counters = torch.zeros(len(self.buckets), dtype=torch.int32, device=flat.device)
             self.runs = [0] * len(self.buckets)          # bumps launched so far, per bucket (replays only)
             self.eager_events = [None] * len(self.buckets)

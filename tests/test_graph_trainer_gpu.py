@@ -69,7 +69,8 @@ def one_rank_group():
     s.close()
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     torch.cuda.set_device(0)
-    dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0),
+                            pg_options=dist.ProcessGroupNCCL.Options(is_high_priority_stream=True))
     yield dist
     dist.destroy_process_group()
 
