@@ -192,13 +192,16 @@ def pmc_traffic(kernel_rows):
                     busy = float(r["SQ_VALU_MFMA_BUSY_CYCLES"]) / (float(r["GRBM_GUI_ACTIVE"]) / 8.0 * 1024.0)
     if seen != len(kernel_rows):
         return {}
-    out = {"traffic": round(total), "traffic_unit": "bytes/launch",
+    # PMC counters need their own rocprofv3 passes: this value is READ from the committed summary of the builder's
+    # profile of this same command, it is not collected inside this run
+    out = {"traffic": round(total), "traffic_unit": "bytes/launch", "traffic_measured_in_this_run": False,
            "traffic_source": "profiles/%s (2*FETCH_SIZE+WRITE_SIZE)" % os.path.basename(files[-1])}
     if len(kernel_rows) == 1 and busy is not None:
         # fraction of the kernel's cycles in which the matrix pipe was busy (same PMC file, separate pass):
         # SQ_VALU_MFMA_BUSY_CYCLES over GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs — independent of the clock the
         # roof is quoted at (under these kernels the shader clock is 1.8-2.1 GHz)
         out["mfma_pipe_busy"] = round(busy, 3)
+        out["mfma_pipe_busy_measured_in_this_run"] = False
     return out
 
 
@@ -316,7 +319,7 @@ def train_leg(dev, rank, world, iters, batch, size=256):
 # ---------------------------------------------------------------------------------------------------
 def inversion_leg(dev, steps=400, size=256):
     """BASELINE config[4]: 400 Adam steps over the W+ latent and the mesh pose through GeneratorWithMap(256), the
-    rasterizer (forward + deterministic backward) and the LPIPS-shaped VGG16 metric, one hipGraph per iteration
+    rasterizer (forward + deterministic backward) and the LPIPS VGG16 metric (lpips.PNetLin, reference heads), one hipGraph per iteration
     (inversion.LatentInverter).  Random-init generator / metric weights (no checkpoints offline); the target is a
     rendering of a different latent and pose."""
     import torch
@@ -357,7 +360,8 @@ def inversion_leg(dev, steps=400, size=256):
             "seconds_for_%d_steps" % steps: round(steps / sps, 2),
             "eager_steps_per_s": round(sps_eager, 2), "execution": "one hipGraph replay per step (capture included "
             "in the timed run)", "loss_first": round(l0, 5), "loss_last": round(l1, 5), "losses_finite": finite,
-            "weights": "random init (trunk / heads / generator checkpoints are not available offline)"}
+            "weights": "generator / VGG16 trunk: random init (no checkpoints offline); LPIPS heads: the reference's "
+                       "lpips/weights/v0.1/vgg.pth"}
 
 
 # ---------------------------------------------------------------------------------------------------

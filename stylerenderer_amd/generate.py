@@ -23,6 +23,10 @@ def to_uint8_grid(images, nrow=1, value_range=(-1, 1), padding=2):
     lo, hi = value_range
     x = ((images.detach().float().cpu().clamp(lo, hi) - lo) / max(hi - lo, 1e-5))
     b, c, h, w = x.shape
+    if b == 1:
+        # make_grid returns a single image unpadded (`if tensor.size(0) == 1: return tensor.squeeze(0)`): the
+        # reference's default --sample 1 writes size x size files
+        return (x[0].mul(255).add_(0.5).clamp_(0, 255).permute(1, 2, 0).to(torch.uint8)).numpy()
     xmaps = min(nrow, b)
     ymaps = int(math.ceil(b / xmaps))
     grid = torch.zeros(c, ymaps * (h + padding) + padding, xmaps * (w + padding) + padding)

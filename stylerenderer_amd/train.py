@@ -334,11 +334,14 @@ class SyntheticFaceSource:
         self.tri = torch.from_numpy(tri.astype(np.int64)).to(device)
         self.device = device
         self._u = utils_3d
+        # pose sigmas (the defaults of reference utils_3d.py:360) resident on the device: sampling a batch then issues
+        # no host-to-device copy at all (coefficients, poses and normals are drawn / computed there)
+        self.pose_sigma = torch.tensor([.5, .1, .05, .1, .1, .1, .15], dtype=torch.float32, device=device)
 
     @torch.no_grad()
     def sample(self, batch):
-        coeff = self.model.random_input(batch).to(self.device)
-        vert = self._u.random_apply_pose3D(v=self.model(coeff))
+        coeff = self.model.random_input(batch)              # torch.normal on the model's device
+        vert = self._u.random_apply_pose3D(p=self.pose_sigma, v=self.model(coeff))
         return vert, self._u.mesh_point_normal(vert, self.tri), self.tri
 
 

@@ -177,3 +177,11 @@ def test_generate_cli_writes_images_from_a_checkpoint(tmp_path):
     assert im.shape == (3 * (8 + 2) + 2, 8 + 2 + 2, 3)                     # three samples, one per row, 2 px padding
     grid = generate.to_uint8_grid(torch.tensor([[[[-1.0, 1.0]], [[0.0, 0.0]], [[3.0, -3.0]]]]), padding=0)
     assert grid.tolist() == [[[0, 128, 255], [255, 128, 0]]]
+
+
+def test_single_image_grid_is_unpadded_like_make_grid():
+    """torchvision.utils.make_grid returns a one-image batch without the 2 px border, so the reference's
+    default `--sample 1` writes size x size files."""
+    one = generate.to_uint8_grid(torch.zeros(1, 3, 8, 8))
+    assert one.shape == (8, 8, 3) and int(one[0, 0, 0]) == 128
+    assert generate.to_uint8_grid(torch.zeros(2, 3, 8, 8)).shape == (2 * (8 + 2) + 2, 8 + 2 + 2, 3)
