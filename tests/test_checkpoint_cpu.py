@@ -182,6 +182,8 @@ def test_generate_cli_writes_images_from_a_checkpoint(tmp_path):
 def test_single_image_grid_is_unpadded_like_make_grid():
     """torchvision.utils.make_grid returns a one-image batch without the 2 px border, so the reference's
     default `--sample 1` writes size x size files."""
+    from stylerenderer_amd import generate
+
     one = generate.to_uint8_grid(torch.zeros(1, 3, 8, 8))
     assert one.shape == (8, 8, 3) and int(one[0, 0, 0]) == 128
     assert generate.to_uint8_grid(torch.zeros(2, 3, 8, 8)).shape == (2 * (8 + 2) + 2, 8 + 2 + 2, 3)
