@@ -222,7 +222,7 @@ int sr_blur_noise_bias_act(float* y, const float* x, const float* k, const float
  *   index int64 [b, h, w, 3]   coeff [b, h, w, 3]       zbuf [b, h, w] or NULL
  * Unlike the reference the outputs need NOT be pre-initialised: every pixel is written
  * (uncovered: index 0, coeff 0, zbuf -MAX).  `work` is caller scratch of
- * sr_rasterize_scratch_bytes(b, h, w, is_double) bytes.
+ * sr_rasterize_scratch_bytes(b, nf, h, w, is_double) bytes.
  * Optional fused attribute interpolation (reference op/rasterize.py:29-37): when `tex` != NULL,
  * attr[b,h,w,c] = sum_k tex[index_k, :] * coeff_k  with tex [b*nv (or nv), c].
  * Optional winner map `win` int32 [b,h,w]: id of the triangle that owns the pixel, -1 where uncovered
@@ -230,7 +230,7 @@ int sr_blur_noise_bias_act(float* y, const float* x, const float* k, const float
  * 16 B per pixel instead of 48).  Triangles whose bounding box exceeds 64 pixels are walked by the whole
  * workgroup (LDS queue) instead of one lane; optional `big` int32 [1 + b*nf] receives their count and the
  * flat ids sample * nf + triangle (any order) for sr_rasterize_grad_*. */
-int64_t sr_rasterize_scratch_bytes(int64_t b, int64_t h, int64_t w, int is_double);
+int64_t sr_rasterize_scratch_bytes(int64_t b, int64_t nf, int64_t h, int64_t w, int is_double);
 int sr_rasterize_forward_f32(int64_t b, int64_t nv, int64_t nf, int64_t h, int64_t w, int repeat_v,
                              int repeat_f, int perspective, const float* v, const int64_t* tri,
                              int64_t* index, float* coeff, float* zbuf, float eps,

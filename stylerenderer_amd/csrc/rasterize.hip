@@ -42,6 +42,7 @@
 // reference's sequential loops (op/rasterize.cpp:21-95) for CPU tensors, which the reference's extension also
 // accepts (op/rasterize.cpp:126-150).  Device tensors never take it.
 #include <float.h>
+#include <stdlib.h>
 
 #include <vector>
 
@@ -469,6 +470,388 @@ __global__ __launch_bounds__(256) void k_resolve(long long b, long long nv, long
             attr[g * tex_c + ch] = s01 + a2;
         }
     }
+}
+
+// ---- fp32 forward with LDS-staged triangle tiles (square images) ------------------------------------------------
+// The global-key path above pays 8 B/pixel of key buffer (fill, atomics in L2, re-read) and walks bounding boxes one
+// lane per triangle (lanes of a wave wait for the largest box).  The tiled path:
+//   k_tile_bin     one lane per (sample, triangle): the SAME load + setup; accepted small triangles (box <= BIG_BOX
+//                  pixels, hence <= 4 tiles) are appended to the list of every 32x32 screen tile their box touches
+//                  (wave-aggregated counter atomics); large boxes, and entries beyond a tile's capacity, go to the
+//                  sample's `wide` list that every tile of the sample scans;
+//   k_tile_raster  one workgroup per (sample, tile): the depth keys of the tile live in LDS (8 KB, ds_max_u64).  List
+//                  entries are set up 256 at a time into LDS records; the (triangle, pixel-of-clipped-box) pairs are
+//                  enumerated by a block prefix sum so that EVERY lane shades one pixel per step whatever the box
+//                  sizes are; then the tile is resolved from LDS and each output is written once.
+// Same `tri_setup` / `shade` device functions, same packed key (max z, ties -> lowest id): same bits as the global
+// path and the CPU loops.  No key buffer, no fill pass, no second kernel for the resolve.
+constexpr int TILE = 32;            // screen tile edge (pixels)
+constexpr int TILE_CAP = 2048;      // list entries per (sample, tile); overflow spills to the sample's wide list
+constexpr int REC_F = 13;           // floats per LDS triangle record: z0 z1 z2, e0..e8, area (+ 4 integer fields)
+
+// The per-triangle work of these kernels is vector-ALU bound (k_depth_keys: ~1 100 VALU instructions, 80 us for 3.2 M
+// lanes), so the tiled kernels use slimmer device-only forms of `tri_setup` — the SAME floating-point expressions in
+// the same order (same bits), without what costs instructions and changes no result:
+//   * float -> int64 conversion with x86 semantics is ~20 instructions of emulation, four times per triangle; the
+//     bounding box only ever meets [0, res - 1], where a SATURATED 32-bit conversion compares identically (NaN and
+//     values >= 2^63 behave as "very negative", like cvttss2si's INT64_MIN);
+//   * the projection mode is a template parameter (no division code in the orthographic kernels);
+//   * indices are 32-bit, the sample comes from blockIdx.y;
+//   * the resolve step needs the edge constants only: no bounding box, no rejection tests.
+__device__ __forceinline__ int sat_i32_x86(float f) {
+    const int i = (int)f;                                   // v_cvt_i32_f32: saturates, NaN -> 0
+    return (f >= 9223372036854775808.0f || f != f) ? (int)0x80000000 : i;
+}
+
+template <bool PERSP>
+__device__ __forceinline__ bool screen3(Tri<float>& t, float fres, float eps) {
+    if (!to_screen<float>(t.p0, t.p1, t.p2, fres, fres, PERSP, eps)) return false;
+    if (!to_screen<float>(t.p3, t.p4, t.p5, fres, fres, PERSP, eps)) return false;
+    return to_screen<float>(t.p6, t.p7, t.p8, fres, fres, PERSP, eps);
+}
+
+__device__ __forceinline__ bool bounds_i32(Tri<float>& t, int res) {
+    float lo_u = t.p0, hi_u = t.p0, lo_v = t.p1, hi_v = t.p1;
+    grow<float>(lo_u, hi_u, t.p3);
+    grow<float>(lo_v, hi_v, t.p4);
+    grow<float>(lo_u, hi_u, t.p6);
+    grow<float>(lo_v, hi_v, t.p7);
+    int x0 = sat_i32_x86(ceilf(lo_u)), x1 = sat_i32_x86(floorf(hi_u));
+    int y0 = sat_i32_x86(ceilf(lo_v)), y1 = sat_i32_x86(floorf(hi_v));
+    x0 = x0 < 0 ? 0 : x0;
+    x1 = x1 > res - 1 ? res - 1 : x1;
+    y0 = y0 < 0 ? 0 : y0;
+    y1 = y1 > res - 1 ? res - 1 : y1;
+    t.x0 = x0; t.x1 = x1; t.y0 = y0; t.y1 = y1;
+    return x1 >= x0 && y1 >= y0;
+}
+
+// e0..e2 and the signed area sum (tri_setup's `det`)
+__device__ __forceinline__ float edge_origin(Tri<float>& t) {
+    float m0 = t.p3 * t.p7, m1 = t.p4 * t.p6;
+    t.e0 = m0 - m1;
+    m0 = t.p1 * t.p6; m1 = t.p0 * t.p7;
+    t.e1 = m0 - m1;
+    m0 = t.p0 * t.p4; m1 = t.p1 * t.p3;
+    t.e2 = m0 - m1;
+    float det = t.e0 + t.e1;
+    det = det + t.e2;
+    return det;
+}
+
+__device__ __forceinline__ void edge_slopes(Tri<float>& t, float det) {
+    t.e3 = t.p4 - t.p7;
+    t.e4 = t.p7 - t.p1;
+    t.e5 = t.p1 - t.p4;
+    t.e6 = t.p6 - t.p3;
+    t.e7 = t.p0 - t.p6;
+    t.e8 = t.p3 - t.p0;
+    if (det < 0) {
+        t.e0 = -t.e0; t.e1 = -t.e1; t.e2 = -t.e2;
+        t.e3 = -t.e3; t.e4 = -t.e4; t.e5 = -t.e5;
+        t.e6 = -t.e6; t.e7 = -t.e7; t.e8 = -t.e8;
+        t.area = -det;
+    } else {
+        t.area = det;
+    }
+}
+
+// accept / reject + bounding box (what the binning needs); on a square image of `res` pixels
+template <bool PERSP>
+__device__ __forceinline__ bool tri_bounds_fast(Tri<float>& t, int res, float eps) {
+    if (!screen3<PERSP>(t, (float)res, eps)) return false;
+    if (!bounds_i32(t, res)) return false;
+    return !(edge_origin(t) > eps);
+}
+
+// the whole of tri_setup for a triangle that is known to be accepted
+template <bool PERSP>
+__device__ __forceinline__ void tri_setup_accepted(Tri<float>& t, int res, float eps, bool want_box) {
+    screen3<PERSP>(t, (float)res, eps);
+    if (want_box) bounds_i32(t, res);
+    edge_slopes(t, edge_origin(t));
+}
+
+__device__ __forceinline__ bool load_tri32(Tri<float>& t, const float* __restrict__ vs,
+                                           const long long* __restrict__ fs, unsigned ti, unsigned nv,
+                                           unsigned& i0, unsigned& i1, unsigned& i2) {
+    const long long a = fs[3 * (size_t)ti], bq = fs[3 * (size_t)ti + 1], c = fs[3 * (size_t)ti + 2];
+    if ((unsigned long long)a >= nv || (unsigned long long)bq >= nv || (unsigned long long)c >= nv) return false;
+    i0 = (unsigned)a; i1 = (unsigned)bq; i2 = (unsigned)c;
+    t.p0 = vs[3 * i0]; t.p1 = vs[3 * i0 + 1]; t.p2 = vs[3 * i0 + 2];
+    t.p3 = vs[3 * i1]; t.p4 = vs[3 * i1 + 1]; t.p5 = vs[3 * i1 + 2];
+    t.p6 = vs[3 * i2]; t.p7 = vs[3 * i2 + 1]; t.p8 = vs[3 * i2 + 2];
+    return true;
+}
+
+__global__ __launch_bounds__(256) void k_tile_zero(unsigned* __restrict__ p, long long n, int* __restrict__ big) {
+    if (big && blockIdx.x == 0 && threadIdx.x == 0) *big = 0;
+    const long long stride = (long long)gridDim.x * 256;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) p[i] = 0u;
+}
+
+// Wave-level aggregation of counter increments, split so that the atomics of several groups are in flight together:
+// `wave_group` only votes (no memory operation): the lanes of `active` that share `idx` form a group; returns the mask
+// of the caller's group.  The lowest lane of a group issues ONE atomicAdd(count of the group) — every group of the wave
+// in the same instruction — and the others fetch the base from it (`wave_slot`).
+__device__ __forceinline__ unsigned long long wave_group(unsigned idx, bool active) {
+    unsigned long long mine = 0;
+    unsigned long long todo = __ballot(active);
+    const int lane = threadIdx.x & 63;
+    while (todo) {
+        const int lead = __ffsll((long long)todo) - 1;
+        const unsigned key = (unsigned)__shfl((int)idx, lead, SR_WAVE);
+        const unsigned long long same = __ballot(active && idx == key) & todo;
+        if ((same >> lane) & 1ull) mine = same;
+        todo &= ~same;
+    }
+    return mine;
+}
+__device__ __forceinline__ unsigned wave_slot(unsigned long long group, unsigned leader_base) {
+    const int lane = threadIdx.x & 63;
+    const int lead = group ? __ffsll((long long)group) - 1 : lane;
+    const unsigned base = (unsigned)__shfl((int)leader_base, lead, SR_WAVE);
+    return base + (unsigned)__popcll(group & ((1ull << lane) - 1ull));
+}
+
+// grid (ceil(nf / 256), b)
+template <bool PERSP>
+__global__ __launch_bounds__(256) void k_tile_bin(unsigned nv, unsigned nf, int res, bool repeat_v, bool repeat_f,
+                                                  const float* __restrict__ v, const long long* __restrict__ f,
+                                                  unsigned* __restrict__ tile_cnt, unsigned* __restrict__ tile_list,
+                                                  unsigned* __restrict__ wide_cnt, unsigned* __restrict__ wide_list,
+                                                  int* __restrict__ big, int ntx, float eps) {
+    const unsigned ti = blockIdx.x * 256 + threadIdx.x;
+    const unsigned s = blockIdx.y;
+    Tri<float> t;
+    bool ok = false;
+    if (ti < nf) {
+        const float* vs = repeat_v ? v : v + (size_t)s * nv * 3;
+        const long long* fs = repeat_f ? f : f + (size_t)s * nf * 3;
+        unsigned i0, i1, i2;
+        ok = load_tri32(t, vs, fs, ti, nv, i0, i1, i2) && tri_bounds_fast<PERSP>(t, res, eps);
+    }
+    bool wide = ok && ((long long)(t.x1 - t.x0 + 1) * (t.y1 - t.y0 + 1) > BIG_BOX);
+    if (wide && big) big[1 + atomicAdd(big, 1)] = (int)(s * nf + ti);   // (gradient pass: one row each, any order)
+    const int ntile = ntx * ntx;
+    const bool small_ok = ok && !wide;
+    const int tx0 = small_ok ? t.x0 / TILE : 0, tx1 = small_ok ? t.x1 / TILE : 0;
+    const int ty0 = small_ok ? t.y0 / TILE : 0, ty1 = small_ok ? t.y1 / TILE : 0;
+    const int lane = threadIdx.x & 63;
+    // a small box (<= 64 pixels) touches <= 4 tiles: 2 x 2, or up to 3 in a row.  The four common steps vote first and
+    // then have their counter atomics in flight together (a returning atomic is a ~microsecond round trip)
+    const bool h00 = small_ok, h01 = small_ok && tx0 + 1 <= tx1, h10 = small_ok && ty0 + 1 <= ty1, h11 = h01 && h10;
+    const unsigned base_tile = s * ntile + ty0 * ntx + tx0;
+    const unsigned t00 = base_tile, t01 = base_tile + 1, t10 = base_tile + ntx, t11 = base_tile + ntx + 1;
+    const unsigned long long g00 = wave_group(t00, h00), g01 = wave_group(t01, h01), g10 = wave_group(t10, h10),
+                             g11 = wave_group(t11, h11);
+    unsigned b00 = 0, b01 = 0, b10 = 0, b11 = 0;
+    if (g00 && lane == __ffsll((long long)g00) - 1) b00 = atomicAdd(&tile_cnt[t00], (unsigned)__popcll(g00));
+    if (g01 && lane == __ffsll((long long)g01) - 1) b01 = atomicAdd(&tile_cnt[t01], (unsigned)__popcll(g01));
+    if (g10 && lane == __ffsll((long long)g10) - 1) b10 = atomicAdd(&tile_cnt[t10], (unsigned)__popcll(g10));
+    if (g11 && lane == __ffsll((long long)g11) - 1) b11 = atomicAdd(&tile_cnt[t11], (unsigned)__popcll(g11));
+    const unsigned s00 = wave_slot(g00, b00), s01 = wave_slot(g01, b01), s10 = wave_slot(g10, b10),
+                   s11 = wave_slot(g11, b11);
+#define SR_TILE_PUT(H, T, S)                                                        \
+    if (H) {                                                                        \
+        if ((S) < (unsigned)TILE_CAP) tile_list[(size_t)(T) * TILE_CAP + (S)] = ti; \
+        else wide = true; /* this tile is full: every tile of the sample scans it */ \
+    }
+    SR_TILE_PUT(h00, t00, s00)
+    SR_TILE_PUT(h01, t01, s01)
+    SR_TILE_PUT(h10, t10, s10)
+    SR_TILE_PUT(h11, t11, s11)
+    // third tile of a 1-pixel-high / -wide strip (rare)
+    const bool h02 = small_ok && tx0 + 2 <= tx1, h20 = small_ok && ty0 + 2 <= ty1;
+    if (__ballot(h02 || h20)) {
+        const unsigned t02 = base_tile + 2, t20 = base_tile + 2 * ntx;
+        const unsigned long long g02 = wave_group(t02, h02), g20 = wave_group(t20, h20);
+        unsigned b02 = 0, b20 = 0;
+        if (g02 && lane == __ffsll((long long)g02) - 1) b02 = atomicAdd(&tile_cnt[t02], (unsigned)__popcll(g02));
+        if (g20 && lane == __ffsll((long long)g20) - 1) b20 = atomicAdd(&tile_cnt[t20], (unsigned)__popcll(g20));
+        const unsigned s02 = wave_slot(g02, b02), s20 = wave_slot(g20, b20);
+        SR_TILE_PUT(h02, t02, s02)
+        SR_TILE_PUT(h20, t20, s20)
+    }
+#undef SR_TILE_PUT
+    if (__ballot(wide)) {
+        const unsigned long long gw = wave_group(s, wide);
+        unsigned bw = 0;
+        if (gw && lane == __ffsll((long long)gw) - 1) bw = atomicAdd(&wide_cnt[s], (unsigned)__popcll(gw));
+        const unsigned slot = wave_slot(gw, bw);
+        if (wide) wide_list[(size_t)s * nf + slot] = ti;
+    }
+}
+
+// Exclusive prefix sum of one int per lane over the 256 lanes; returns the lane's offset, total in `total`.
+__device__ __forceinline__ int block_scan_256(int x, int* s_wave, int& total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int incl = x;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int y = __shfl_up(incl, off, SR_WAVE);
+        if (lane >= off) incl += y;
+    }
+    __syncthreads();                       // (s_wave may still be read from the previous round)
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    const int w0 = s_wave[0], w1 = s_wave[1], w2 = s_wave[2], w3 = s_wave[3];
+    total = w0 + w1 + w2 + w3;
+    const int before = (wave > 0 ? w0 : 0) + (wave > 1 ? w1 : 0) + (wave > 2 ? w2 : 0);
+    return before + incl - x;
+}
+
+template <bool PERSP>
+__global__ __launch_bounds__(256) void k_tile_raster(unsigned b, unsigned nv, unsigned nf, int res, bool repeat_v,
+                                                     bool repeat_f, const float* __restrict__ v,
+                                                     const long long* __restrict__ f,
+                                                     const unsigned* __restrict__ tile_cnt,
+                                                     const unsigned* __restrict__ tile_list,
+                                                     const unsigned* __restrict__ wide_cnt,
+                                                     const unsigned* __restrict__ wide_list, int ntx,
+                                                     long long* __restrict__ index, float* __restrict__ coeff,
+                                                     float* __restrict__ zbuf, const float* __restrict__ tex,
+                                                     int tex_c, float* __restrict__ attr, int* __restrict__ win,
+                                                     float eps) {
+    __shared__ unsigned long long s_key[TILE * TILE];
+    __shared__ float s_rec[REC_F][256];
+    __shared__ int s_box[4][256];          // clipped box x0, y0, width; triangle id
+    __shared__ int s_pre[257];
+    __shared__ int s_wave[4];
+    const unsigned ntile = (unsigned)(ntx * ntx);
+    // all tiles of a sample on one XCD (blockIdx round-robins over the 8 XCDs): its vertices stay in that L2
+    const unsigned nblk = b * ntile;
+    unsigned unit = blockIdx.x;
+    {
+        const unsigned per = nblk / SR_NUM_XCD;
+        if (per * SR_NUM_XCD == nblk) unit = (blockIdx.x % SR_NUM_XCD) * per + blockIdx.x / SR_NUM_XCD;
+    }
+    const unsigned s = unit / ntile;
+    const int tile = (int)(unit - s * ntile);
+    const int ox = (tile % ntx) * TILE, oy = (tile / ntx) * TILE;
+    const float* vs = repeat_v ? v : v + (size_t)s * nv * 3;
+    const long long* fs = repeat_f ? f : f + (size_t)s * nf * 3;
+    for (int i = threadIdx.x; i < TILE * TILE; i += 256) s_key[i] = key_init_f32();
+    __syncthreads();
+    unsigned n_own = tile_cnt[s * ntile + tile];
+    if (n_own > (unsigned)TILE_CAP) n_own = TILE_CAP;
+    const unsigned n_wide = wide_cnt[s];
+    const unsigned* own = tile_list + (size_t)(s * ntile + tile) * TILE_CAP;
+    const unsigned* wl = wide_list + (size_t)s * nf;
+    const unsigned n_all = n_own + n_wide;
+    for (unsigned c0 = 0; c0 < n_all; c0 += 256) {
+        const unsigned e = c0 + threadIdx.x;
+        int npx = 0;
+        if (e < n_all) {
+            const unsigned ti = e < n_own ? own[e] : wl[e - n_own];
+            Tri<float> t;
+            unsigned i0, i1, i2;
+            load_tri32(t, vs, fs, ti, nv, i0, i1, i2);
+            tri_setup_accepted<PERSP>(t, res, eps, true);          // accepted in k_tile_bin: same inputs, same bits
+            const int x0 = t.x0 > ox ? t.x0 : ox, x1 = t.x1 < ox + TILE - 1 ? t.x1 : ox + TILE - 1;
+            const int y0 = t.y0 > oy ? t.y0 : oy, y1 = t.y1 < oy + TILE - 1 ? t.y1 : oy + TILE - 1;
+            if (x1 >= x0 && y1 >= y0) npx = (x1 - x0 + 1) * (y1 - y0 + 1);
+            const int l = threadIdx.x;
+            s_rec[0][l] = t.p2; s_rec[1][l] = t.p5; s_rec[2][l] = t.p8;
+            s_rec[3][l] = t.e0; s_rec[4][l] = t.e1; s_rec[5][l] = t.e2; s_rec[6][l] = t.e3; s_rec[7][l] = t.e4;
+            s_rec[8][l] = t.e5; s_rec[9][l] = t.e6; s_rec[10][l] = t.e7; s_rec[11][l] = t.e8; s_rec[12][l] = t.area;
+            s_box[0][l] = x0; s_box[1][l] = y0; s_box[3][l] = (int)ti;
+            // box width and ceil(2^16 / width): item -> row is a multiply + shift (exact: item < 1024, width <= 32)
+            s_box[2][l] = (x1 - x0 + 1) | ((65536 + (x1 - x0)) / (x1 - x0 + 1)) << 8;
+        }
+        int total;
+        const int before = block_scan_256(npx, s_wave, total);
+        s_pre[threadIdx.x] = before;
+        if (threadIdx.x == 255) s_pre[256] = total;
+        __syncthreads();
+        for (int item = threadIdx.x; item < total; item += 256) {
+            int lo = 0, hi = 256;                       // largest j with s_pre[j] <= item
+#pragma unroll
+            for (int step = 0; step < 8; ++step) {
+                const int mid = (lo + hi) >> 1;
+                if (s_pre[mid] <= item) lo = mid; else hi = mid;
+            }
+            const int j = lo, local = item - s_pre[j];
+            const int bwr = s_box[2][j], bw = bwr & 0xFF;
+            const int yy = (int)(((unsigned)local * (unsigned)(bwr >> 8)) >> 16), xx = local - yy * bw;
+            const int x = s_box[0][j] + xx, y = s_box[1][j] + yy;
+            Tri<float> t;
+            t.p2 = s_rec[0][j]; t.p5 = s_rec[1][j]; t.p8 = s_rec[2][j];
+            t.e0 = s_rec[3][j]; t.e1 = s_rec[4][j]; t.e2 = s_rec[5][j]; t.e3 = s_rec[6][j]; t.e4 = s_rec[7][j];
+            t.e5 = s_rec[8][j]; t.e6 = s_rec[9][j]; t.e7 = s_rec[10][j]; t.e8 = s_rec[11][j]; t.area = s_rec[12][j];
+            t.p0 = t.p1 = t.p3 = t.p4 = t.p6 = t.p7 = 0.0f;
+            if (!(t.area > eps)) {
+                // zero-area triangle (segment / point rules of pixel_weights read the screen-space vertices): rare,
+                // so the record does not carry them — gathered again, same projection, same bits
+                unsigned i0, i1, i2;
+                Tri<float> q;
+                load_tri32(q, vs, fs, (unsigned)s_box[3][j], nv, i0, i1, i2);
+                screen3<PERSP>(q, (float)res, eps);
+                t.p0 = q.p0; t.p1 = q.p1; t.p3 = q.p3; t.p4 = q.p4; t.p6 = q.p6; t.p7 = q.p7;
+            }
+            float c0, c1, c2, z;
+            if (shade<float>(t, x, y, PERSP, eps, c0, c1, c2, z) && z == z) {      // NaN never passes `zB < z`
+                const unsigned long long key =
+                    ((unsigned long long)ord32(z) << 32) | (unsigned long long)(0xFFFFFFFEu - (unsigned)s_box[3][j]);
+                unsigned long long* slot = &s_key[(y - oy) * TILE + (x - ox)];
+                if (key > *slot) atomicMax(slot, key);
+            }
+        }
+        __syncthreads();                                // records / prefix are rewritten by the next chunk
+    }
+    __syncthreads();
+    // ---- resolve the tile from LDS: every pixel written once ----
+    const size_t hw = (size_t)res * res;
+    const long long shift = repeat_v ? 0 : (long long)nv * s;
+    for (int p = threadIdx.x; p < TILE * TILE; p += 256) {
+        const int lx = p & (TILE - 1), ly = p / TILE;
+        const int x = ox + lx, y = oy + ly;
+        if (x >= res || y >= res) continue;
+        const unsigned long long key = s_key[p];
+        int ti = -1;
+        if (key != key_init_f32()) ti = (int)(0xFFFFFFFEu - (unsigned)(key & 0xFFFFFFFFull));
+        unsigned i0 = 0, i1 = 0, i2 = 0;
+        float c0 = 0, c1 = 0, c2 = 0, z = Lim<float>::lowest();
+        long long shf = 0;
+        if (ti >= 0) {
+            Tri<float> t;
+            load_tri32(t, vs, fs, (unsigned)ti, nv, i0, i1, i2);
+            tri_setup_accepted<PERSP>(t, res, eps, false);
+            shade<float>(t, x, y, PERSP, eps, c0, c1, c2, z);
+            shf = shift;
+        }
+        const size_t g = (size_t)s * hw + (size_t)y * res + x;
+        if (index) {
+            index[3 * g] = (long long)i0 + shf;
+            index[3 * g + 1] = (long long)i1 + shf;
+            index[3 * g + 2] = (long long)i2 + shf;
+        }
+        if (coeff) {
+            coeff[3 * g] = c0;
+            coeff[3 * g + 1] = c1;
+            coeff[3 * g + 2] = c2;
+        }
+        if (zbuf) zbuf[g] = z;
+        if (win) win[g] = ti;
+        if (attr) {
+            const size_t r0 = (size_t)((long long)i0 + shf) * tex_c, r1 = (size_t)((long long)i1 + shf) * tex_c,
+                         r2 = (size_t)((long long)i2 + shf) * tex_c;
+            for (int ch = 0; ch < tex_c; ++ch) {
+                const float a0 = tex[r0 + ch] * c0;
+                const float a1 = tex[r1 + ch] * c1;
+                const float a2 = tex[r2 + ch] * c2;
+                const float s01 = a0 + a1;
+                attr[g * tex_c + ch] = s01 + a2;
+            }
+        }
+    }
+}
+
+// scratch layout of the tiled path (all unsigned): tile_cnt [b * ntile] | wide_cnt [b] | tile_list [b * ntile *
+// TILE_CAP] | wide_list [b * nf]
+inline long long tile_scratch_words(long long b, long long nf, long long hres) {
+    const long long ntx = sr_ceil_div(hres, TILE), ntile = ntx * ntx;
+    return b * ntile + b + b * ntile * TILE_CAP + b * nf;
 }
 
 // d(3 weights)/d(3 vertices x xyz) at one pixel (reference op/rasterize.h:169-228).  `g` = 27 values
@@ -921,6 +1304,55 @@ __global__ __launch_bounds__(256) void k_grad_vert(long long nv, long long nf, c
     }
 }
 
+// The tiled path serves fp32 on square images (x and y ranges are swapped by the reference's call sites, SURVEY D8:
+// on a non-square image pixel columns beyond the width alias into the next row, which only a global key buffer
+// reproduces).  SR_RASTER_TILED=0 keeps the global-key path (ablation).
+template <typename R>
+inline bool tiled_ok(long long, long long, long long, long long) { return false; }
+template <>
+inline bool tiled_ok<float>(long long b, long long nf, long long h, long long w) {
+    static const bool enabled = [] {
+        const char* e = getenv("SR_RASTER_TILED");
+        return !(e && e[0] == '0');
+    }();
+    const long long ntx = sr_ceil_div(h, TILE);
+    return enabled && h == w && nf > 0 && h < 0x40000000LL && b <= 65535 && b * ntx * ntx < 0x7FFFFFFFLL &&
+           b * nf < 0x7FFFFFFFLL;
+}
+
+template <typename R>
+int forward_tiled(long long, long long, long long, long long, int, int, int, const R*, const long long*, long long*, R*,
+                  R*, R, const R*, long long, R*, int*, int*, void*, hipStream_t) {
+    return SR_EINVAL;
+}
+template <>
+int forward_tiled<float>(long long b, long long nv, long long nf, long long hres, int repeat_v, int repeat_f,
+                         int perspective, const float* v, const long long* tri, long long* index, float* coeff,
+                         float* zbuf, float eps, const float* tex, long long tex_c, float* attr, int* win, int* big,
+                         void* work, hipStream_t st) {
+    const int ntx = (int)sr_ceil_div(hres, TILE);
+    const long long ntile = (long long)ntx * ntx;
+    unsigned* tile_cnt = reinterpret_cast<unsigned*>(work);
+    unsigned* wide_cnt = tile_cnt + b * ntile;
+    unsigned* tile_list = wide_cnt + b;
+    unsigned* wide_list = tile_list + b * ntile * TILE_CAP;
+    hipLaunchKernelGGL(k_tile_zero, dim3(sr_stream_grid(b * ntile + b, 256)), dim3(256), 0, st, tile_cnt,
+                       b * ntile + b, big);
+    const dim3 bin_grid((unsigned)sr_ceil_div(nf, 256), (unsigned)b);
+#define SR_TILE_LAUNCH(P)                                                                                              \
+    do {                                                                                                               \
+        hipLaunchKernelGGL((k_tile_bin<P>), bin_grid, dim3(256), 0, st, (unsigned)nv, (unsigned)nf, (int)hres,          \
+                           repeat_v != 0, repeat_f != 0, v, tri, tile_cnt, tile_list, wide_cnt, wide_list, big, ntx, eps); \
+        hipLaunchKernelGGL((k_tile_raster<P>), dim3((unsigned)(b * ntile)), dim3(256), 0, st, (unsigned)b, (unsigned)nv, \
+                           (unsigned)nf, (int)hres, repeat_v != 0, repeat_f != 0, v, tri, tile_cnt, tile_list, wide_cnt,  \
+                           wide_list, ntx, index, coeff, zbuf, tex, (int)tex_c, attr, win, eps);                        \
+    } while (0)
+    if (perspective) SR_TILE_LAUNCH(true);
+    else SR_TILE_LAUNCH(false);
+#undef SR_TILE_LAUNCH
+    return sr_launch_status();
+}
+
 template <typename R>
 int forward_impl(long long b, long long nv, long long nf, long long h, long long w, int repeat_v,
                  int repeat_f, int perspective, const R* v, const long long* tri, long long* index,
@@ -933,6 +1365,8 @@ int forward_impl(long long b, long long nv, long long nf, long long h, long long
     if (attr && (!tex || tex_c <= 0)) return SR_EINVAL;
     const long long npix = b * h * w;
     if (eps < 0) eps = -eps;
+    if (tiled_ok<R>(b, nf, h, w)) return forward_tiled(b, nv, nf, h, repeat_v, repeat_f, perspective, v, tri, index, coeff,
+                                                       zbuf, eps, tex, tex_c, attr, win, big, work, st);
     unsigned long long* keys = reinterpret_cast<unsigned long long*>(work);
     unsigned* tmin = reinterpret_cast<unsigned*>(keys + npix);
     const bool is64 = sizeof(R) == 8;
@@ -1097,9 +1531,16 @@ int backward_cpu(long long b, long long n, long long h, long long w, int perspec
 
 }  // namespace
 
-extern "C" int64_t sr_rasterize_scratch_bytes(int64_t b, int64_t h, int64_t w, int is_double) {
-    const int64_t npix = (b > 0 ? b : 0) * (h > 0 ? h : 0) * (w > 0 ? w : 0);
-    return npix * (is_double ? 12 : 8) + 16;
+extern "C" int64_t sr_rasterize_scratch_bytes(int64_t b, int64_t nf, int64_t h, int64_t w, int is_double) {
+    b = b > 0 ? b : 0;
+    nf = nf > 0 ? nf : 0;
+    const int64_t npix = b * (h > 0 ? h : 0) * (w > 0 ? w : 0);
+    int64_t bytes = npix * (is_double ? 12 : 8) + 16;                       // global-key path
+    if (!is_double && h == w && h > 0) {
+        const int64_t tiled = tile_scratch_words(b, nf, h) * 4 + 16;         // tile lists of the LDS-tiled path
+        if (tiled > bytes) bytes = tiled;
+    }
+    return bytes;
 }
 extern "C" int64_t sr_rasterize_grad_scratch_bytes(int64_t b, int64_t nf, int64_t tex_c, int is_double) {
     (void)tex_c;

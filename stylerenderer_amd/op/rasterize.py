@@ -101,7 +101,7 @@ def _forward_impl(vertices, triangles, height, width, perspective, eps, tex=None
         if tex_flat.dtype != dt:
             raise RuntimeError(" type error")
         attr = torch.empty((b, h, w, tex_c), dtype=dt, device=dev)
-    work = torch.empty(L.sr_rasterize_scratch_bytes(b, h, w, int(suf == "f64")), dtype=torch.uint8,
+    work = torch.empty(L.sr_rasterize_scratch_bytes(b, nf, h, w, int(suf == "f64")), dtype=torch.uint8,
                        device=dev)
     with on_device_of(vertices):
         rc = getattr(L, "sr_rasterize_forward_" + suf)(

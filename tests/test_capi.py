@@ -44,7 +44,7 @@ def test_argument_validation_without_gpu():
     assert L.sr_fused_bias_act(None, None, None, None, 3, 0, 0.2, 1.0, 0, 1, 1, 0, 0, None) == 0
     # inconsistent out size
     assert L.sr_upfirdn2d(None, None, None, 1, 8, 8, 9, 9, 4, 4, 1, 1, 1, 1, 1, 1, 1, 1, None) == -1
-    assert L.sr_rasterize_scratch_bytes(2, 4, 4, 0) >= 2 * 16 * 8
+    assert L.sr_rasterize_scratch_bytes(2, 10, 4, 4, 0) >= 2 * 16 * 8
     assert L.sr_rasterize_forward_f32(1, 3, 1, 0, 4, 0, 1, 0, None, None, None, None, None, 1e-6,
                                       None, 0, None, None, None, None, None) == -1
     assert L.sr_rasterize_grad_scratch_bytes(2, 10, 3, 0) >= 2 * 10 * (9 + 9) * 4 + 20
