@@ -138,16 +138,18 @@ def raster_leg(dev, world, batch=64, res=256, iters=10, cpu_baseline=True):
            "fwd_api_ms": round(ms_api, 4),
            "fwd_bwd_mtri_s": round(world * batch * nf / ms_fb / 1e3, 1), "fwd_bwd_ms": round(ms_fb, 4),
            "bwd_ms": round(ms_b, 4),
-           "roofline": {"bound": "hbm", "kernel": "sr_rasterize_forward_f32 (k_fill_u64 + k_depth_keys + k_resolve)",
+           "roofline": {"bound": "hbm", "kernel": "sr_rasterize_forward_f32 (k_tile_zero + k_tile_bin + k_tile_raster: "
+                                                  "LDS-staged 32x32 triangle tiles)",
                         "achieved": round(fwd_bytes / ms_api / 1e6, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                         "frac": round(fwd_bytes / ms_api / 1e6 / HBM_PEAK_GBPS, 4), "traffic": None,
                         "bytes_per_launch": fwd_bytes,
-                        "note": "setup ALU + 64-bit atomics bound, priced against the HBM roof as SURVEY 8(d) asks"},
+                        "note": "per-triangle setup / per-pixel shading (vector ALU) bound, priced against the HBM roof as "
+                                "SURVEY 8(d) asks"},
            "roofline_bwd": {"bound": "hbm", "kernel": "sr_rasterize_grad_f32 (k_grad_big + k_grad_pix + k_grad_vert)",
                             "achieved": round(bwd_bytes / ms_b / 1e6, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                             "frac": round(bwd_bytes / ms_b / 1e6 / HBM_PEAK_GBPS, 4), "bytes_per_launch": bwd_bytes},
            "bit_exact_vs_cpu_oracle": "tests/test_ops_gpu.py"}
-    out["roofline"].update(pmc_traffic(["k_fill_u64", "k_depth_keys<float; 0>", "k_resolve<float>"]))
+    out["roofline"].update(pmc_traffic(["k_tile_zero", "k_tile_bin<false>", "k_tile_raster<false>"]))
     out["roofline_bwd"].update(pmc_traffic(["k_grad_big<float; 3; false>", "k_grad_pix<float; 3; false>",
                                             "k_grad_vert<float; 3; false>"]))
     if cpu_baseline:
@@ -258,6 +260,56 @@ def train_leg(dev, rank, world, iters, batch, size=256):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, t_enq = float(t[0]), float(t[1])
     finite = all(bool(torch.isfinite(v)) for v in last.values())
+    # ---- where the iteration goes: device time per phase (timed replays) and its MFMA-convolution work, counted
+    # by running every phase body once eagerly with the per-launch hook of op.conv (algorithmic = direct-convolution
+    # flops 2*B*H*W*Cin*Cout*k^2 of every convolution / weight-gradient launch; executed = what the matrix cores
+    # issue: 16/36 of that on the Winograd-eligible stride-1 3x3 launches)
+    phases, roof = None, None
+    if graphs and rank == 0:
+        from stylerenderer_amd.op import conv as conv_op
+
+        cadence = {"d": 1.0, "r1": 1.0 / 16, "g": 1.0, "path": 1.0 / 4, "d_opt": 1.0 + 1.0 / 16, "g_opt": 1.0 + 1.0 / 4}
+        phases = {}
+        for name in ("d", "r1", "g", "path", "d_opt", "g_opt"):
+            gr = tr.graphs[name]
+            gr.replay()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(3):
+                gr.replay()
+            e1.record()
+            torch.cuda.synchronize()
+            phases[name] = {"ms_per_replay": round(e0.elapsed_time(e1) / 3, 3), "per_iteration": round(cadence[name], 4)}
+        bodies = tr._bodies()
+        for name in ("d", "r1", "g", "path"):
+            conv_op.PROFILE = []
+            bodies[name]()
+            torch.cuda.synchronize()
+            prof, conv_op.PROFILE = conv_op.PROFILE, None
+            alg = sum(fl for (_k, _g, fl, _a, _b) in prof)
+            exe = 0.0
+            for kind, geom, fl, _a, _b in prof:
+                k, stride, tr_, _b2, c, n, gh, gw = geom
+                wino = (k == 3 and stride == 1 and tr_ == 0 and c % 64 == 0 and n % 64 == 0 and
+                        (gw % 32 == 0 and gh % 8 == 0 if kind == "conv" else gw % 16 == 0 and gh % 2 == 0))
+                exe += fl * (16.0 / 36.0 if wino and os.environ.get("SR_WINOGRAD", "1") != "0" else 1.0)
+            ms = phases[name]["ms_per_replay"]
+            phases[name].update({"mfma_launches": len(prof), "algorithmic_gflop": round(alg / 1e9, 1),
+                                 "executed_gflop": round(exe / 1e9, 1),
+                                 "executed_tflops": round(exe / (ms * 1e-3) / 1e12, 1),
+                                 "frac_of_fp32_mfma_peak": round(exe / (ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 3)})
+        alg_it = sum(phases[n]["algorithmic_gflop"] * cadence[n] for n in ("d", "r1", "g", "path"))
+        exe_it = sum(phases[n]["executed_gflop"] * cadence[n] for n in ("d", "r1", "g", "path"))
+        ms_it = elapsed / iters * 1e3
+        roof = {"bound": "mfma", "kernel": "all MFMA convolution / weight-gradient launches of an average iteration "
+                                          "(k_conv_wino, k_wgrad_wino, k_convt_fused, k_conv_mfma, k_wgrad_mfma)",
+                "achieved": round(exe_it / ms_it, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(exe_it / ms_it / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                "executed_gflop_per_iteration": round(exe_it, 1), "algorithmic_gflop_per_iteration": round(alg_it, 1),
+                "algorithmic_tflops": round(alg_it / ms_it, 2),
+                "note": "whole-iteration rate: executed matrix-core flops of every phase at its cadence / measured "
+                        "ms per iteration (includes all non-MFMA kernels and the optimiser steps in the time)"}
     collective = None
     if graphs and world > 1:
         # chosen collective, bucket sizes, and when each bucket's reduction finished relative to the END of the
@@ -275,7 +327,8 @@ def train_leg(dev, rank, world, iters, batch, size=256):
            "execution": ("hipGraph replay per phase (graph_train.GraphedTrainer); bucketed all-reduce of the flat "
                          "gradient buffer on a communication stream, released by event-record nodes inside the "
                          "replayed backward" if graphs else "eager launches (train.Trainer, DDP buckets)"),
-           "losses_finite": finite, "parallelism": "dp%d" % world, "gradient_collective": collective}
+           "losses_finite": finite, "parallelism": "dp%d" % world, "gradient_collective": collective,
+           "roofline": roof, "phases": phases}
     if world > 1:
         n = int(G_PARAM_BYTES // 4)
         buf = torch.zeros(n, device=dev)
@@ -513,15 +566,26 @@ def main():
     del g
     torch.cuda.empty_cache()
 
+    def leg(fn, *a, **k):
+        """A secondary leg that raises is REPORTED in the line ({"error": ...}), it does not take the headline
+        measurement above down with it.  (Collective legs: every rank runs the same code, so they fail together.)"""
+        try:
+            return fn(*a, **k)
+        except Exception as e:           # noqa: BLE001
+            import traceback
+
+            sys.stderr.write(traceback.format_exc())
+            return {"error": "%s: %s" % (type(e).__name__, str(e)[:400])}
+
     train_res = None
     if not args.no_train:
-        train_res = train_leg(dev, rank, world, args.train_iters, args.train_batch, args.size)
+        train_res = leg(train_leg, dev, rank, world, args.train_iters, args.train_batch, args.size)
     raster = None
     if not args.no_raster and rank == 0:
-        raster = raster_leg(dev, 1, cpu_baseline=(world == 1 and not args.no_cpu_baseline))
+        raster = leg(raster_leg, dev, 1, cpu_baseline=(world == 1 and not args.no_cpu_baseline))
     inversion_res = None
     if not args.no_inversion and rank == 0 and world == 1:
-        inversion_res = inversion_leg(dev, args.inversion_steps, args.size)
+        inversion_res = leg(inversion_leg, dev, args.inversion_steps, args.size)
     result = None
     if rank == 0:
         images = args.batch * world * args.steps
