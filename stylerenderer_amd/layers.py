@@ -23,6 +23,7 @@ from .op import FusedLeakyReLU, fused_leaky_relu, upfirdn2d
 from .op import conv as _conv
 from .op import smallconv as _smallconv
 from .op import style as _style
+from .op.style_bank import StylePack
 from .op.weight_prep import weight_prep as _weight_prep
 
 
@@ -195,12 +196,14 @@ class ModulatedConv2d(nn.Module):
             self.upsample, self.downsample)
 
     # ---- device tensors: shared weights + operand scaling on the MFMA kernels
-    def _forward_mfma(self, input, style, skip_blur=False):
-        s = self.modulation(style)                                       # [B, Ci]
-        if (self.kernel_size == 1 and not self.demodulate and not self.upsample and not self.downsample
-                and _smallconv.supported(input, self.out_channel)):
-            # ToRGB: <= 4 output channels -> streaming kernels instead of 128-wide MFMA tiles
-            return _smallconv.modulated_conv1x1_small(input, self.weight[0, :, :, 0, 0] * self.scale, s)
+    def style_of(self, style):
+        """Modulation vector [B, Ci]: from the latent row, or precomputed for all layers at once (op.style_bank)."""
+        return style.s if isinstance(style, StylePack) else self.modulation(style)
+
+    def _prepared(self, style, s):
+        """(wt, wsq, d): tap-major weights, demodulation matrix and factor — from the StylePack when it carries them."""
+        if isinstance(style, StylePack) and style.wt is not None:
+            return style.wt, style.wsq, style.d
         # one launch: tap-major scaled weights + the demodulation matrix sum_taps (scale*W)^2 [Ci, Co]
         wt, wsq = _weight_prep(self.weight, self.scale, self.demodulate)
         d = None
@@ -209,6 +212,15 @@ class ModulatedConv2d(nn.Module):
                 d = _style.demod_scale(s, wsq, self.eps)                 # [B, Co]
             else:
                 d = torch.rsqrt(torch.matmul(s * s, wsq) + self.eps)
+        return wt, wsq, d
+
+    def _forward_mfma(self, input, style, skip_blur=False):
+        s = self.style_of(style)                                         # [B, Ci]
+        if (self.kernel_size == 1 and not self.demodulate and not self.upsample and not self.downsample
+                and _smallconv.supported(input, self.out_channel)):
+            # ToRGB: <= 4 output channels -> streaming kernels instead of 128-wide MFMA tiles
+            return _smallconv.modulated_conv1x1_small(input, self.weight[0, :, :, 0, 0] * self.scale, s)
+        wt, wsq, d = self._prepared(style, s)
         k = self.kernel_size
         if self.upsample:
             if k != 3:
@@ -236,11 +248,16 @@ class ModulatedConv2d(nn.Module):
         input = input.contiguous()
         if not _conv.conv_nba_shape_ok(input, self.out_channel, noise):
             return None
-        s = self.modulation(style)
-        wt, wsq = _weight_prep(self.weight, self.scale, True)
-        if not (_conv.conv_nba_supported(input, wt, noise) and _style.demod_supported(s, wsq)):
-            return None
-        d = _style.demod_scale(s, wsq, self.eps)
+        s = self.style_of(style)
+        if isinstance(style, StylePack) and style.d is not None:
+            wt, wsq, d = style.wt, style.wsq, style.d
+            if not _conv.conv_nba_supported(input, wt, noise):
+                return None
+        else:
+            wt, wsq = _weight_prep(self.weight, self.scale, True)
+            if not (_conv.conv_nba_supported(input, wt, noise) and _style.demod_supported(s, wsq)):
+                return None
+            d = _style.demod_scale(s, wsq, self.eps)
         return _conv.conv2d_nba(input, wt, s, d, noise, noise_weight, act_bias, negative_slope, act_scale)
 
     def forward_up_noise_bias_act(self, input, style, noise, noise_weight, act_bias, negative_slope, act_scale):
@@ -249,14 +266,19 @@ class ModulatedConv2d(nn.Module):
         if (input.device.type != "cuda" or not self.upsample or self.kernel_size != 3 or not self.demodulate
                 or act_bias is None or not _fused_tails()):
             return None
-        s = self.modulation(style)
-        wt, wsq = _weight_prep(self.weight, self.scale, True)
+        s = self.style_of(style)
         pad = self.blur.pad
         oh = 2 * input.shape[2] + 1 + pad[0] + pad[1] - 3
         ow = 2 * input.shape[3] + 1 + pad[0] + pad[1] - 3
-        if not (_conv.upconv_nba_supported(input, wt, noise, oh, ow) and _style.demod_supported(s, wsq)):
-            return None
-        d = _style.demod_scale(s, wsq, self.eps)
+        if isinstance(style, StylePack) and style.d is not None:
+            wt, wsq, d = style.wt, style.wsq, style.d
+            if not _conv.upconv_nba_supported(input, wt, noise, oh, ow):
+                return None
+        else:
+            wt, wsq = _weight_prep(self.weight, self.scale, True)
+            if not (_conv.upconv_nba_supported(input, wt, noise, oh, ow) and _style.demod_supported(s, wsq)):
+                return None
+            d = _style.demod_scale(s, wsq, self.eps)
         kernel = self.blur.kernel
         return _conv.upconv_nba(input.contiguous(), wt, s, d, kernel, pad, noise, noise_weight, act_bias,
                                 negative_slope, act_scale)
@@ -265,7 +287,7 @@ class ModulatedConv2d(nn.Module):
     def _forward_grouped(self, input, style):
         batch, in_channel, height, width = input.shape
         k = self.kernel_size
-        s = self.modulation(style).view(batch, 1, in_channel, 1, 1)
+        s = self.style_of(style).view(batch, 1, in_channel, 1, 1)
         weight = self.scale * self.weight * s
         if self.demodulate:
             weight = weight * torch.rsqrt(weight.pow(2).sum([2, 3, 4], keepdim=True) + self.eps)

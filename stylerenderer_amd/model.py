@@ -19,6 +19,7 @@ from .layers import (Blur, ConstantInput, ConvLayer, EqualLinear, ModulatedConv2
                      PixelNorm, ResBlock, Upsample)
 from .op import FusedLeakyReLU, rasterize
 from .op import smallconv as _smallconv
+from .op import style_bank as _style_bank
 from .op.fused_elem import blur_noise_bias_act, noise_bias_act, noise_bias_act_affine
 from .op.upfirdn2d import upsample2_add
 
@@ -120,7 +121,7 @@ class ToRGB(nn.Module):
             # device tensors: the bias rides in the streaming 1x1 kernel and the skip addition in the up-sampling
             # kernel's store — two launches for conv + bias + upsample + add (reference model.py:63-69)
             out = _smallconv.modulated_conv1x1_small(input, conv.weight.view(conv.out_channel, conv.in_channel) * conv.scale,
-                                                     conv.modulation(style), self.bias.view(-1))
+                                                     conv.style_of(style), self.bias.view(-1))
             if skip is not None:
                 out = upsample2_add(skip, self.upsample.kernel, self.upsample.pad, out)
             return out
@@ -222,23 +223,42 @@ class Generator(nn.Module):
                                     styles[1].unsqueeze(1).repeat(1, self.n_latent - inject_index, 1)], 1)
         return latent, noise
 
+    def _style_layers(self):
+        """[(ModulatedConv2d, latent index)] in the order forward() calls them (reference model.py:172-186: conv1 0,
+        to_rgb1 1, then per resolution conv_up i, conv i + 1, to_rgb i + 2 with i = 1, 3, 5, ...)."""
+        seq = [(self.conv1.conv, 0), (self.to_rgb1.conv, 1)]
+        i = 1
+        for conv_up, conv, to_rgb in zip(self.convs[::2], self.convs[1::2], self.to_rgbs):
+            seq += [(conv_up.conv, i), (conv.conv, i + 1), (to_rgb.conv, i + 2)]
+            i += 2
+        return seq
+
+    def _layer_styles(self, latent):
+        """What each modulated layer receives as `style`, in call order: its latent row, or — device tensors — a
+        StylePack from the batched evaluation of every modulation / demodulation of the pass (op.style_bank)."""
+        seq = self._style_layers()
+        if latent.device.type == "cuda" and latent.dtype == torch.float32 and _style_bank.enabled():
+            return _style_bank.build(seq, latent)
+        # one unbind (its backward is one stack) instead of a select per layer, whose backward would
+        # materialise and add a zero-filled [B, n_latent, D] tensor 2 * n_latent times
+        rows = latent.unbind(1)
+        return [rows[li] for _, li in seq]
+
     def forward(self, styles, return_latents=False, inject_index=None, truncation=1,
                 truncation_latent=None, input_is_latent=False, noise=None, randomize_noise=True):
         latent, noise = self._latents(styles, inject_index, truncation, truncation_latent,
                                       input_is_latent, noise, randomize_noise)
         out = self.input(latent)
-        # one unbind (its backward is one stack) instead of a select per layer, whose backward would
-        # materialise and add a zero-filled [B, n_latent, D] tensor 2 * n_latent times
-        w = latent.unbind(1)
-        out = self.conv1(out, w[0], noise=noise[0])
-        skip = self.to_rgb1(out, w[1])
-        i = 1
+        st = self._layer_styles(latent)
+        out = self.conv1(out, st[0], noise=noise[0])
+        skip = self.to_rgb1(out, st[1])
+        k = 2
         for conv_up, conv, n_up, n_conv, to_rgb in zip(self.convs[::2], self.convs[1::2],
                                                        noise[1::2], noise[2::2], self.to_rgbs):
-            out = conv_up(out, w[i], noise=n_up)
-            out = conv(out, w[i + 1], noise=n_conv)
-            skip = to_rgb(out, w[i + 2], skip)
-            i += 2
+            out = conv_up(out, st[k], noise=n_up)
+            out = conv(out, st[k + 1], noise=n_conv)
+            skip = to_rgb(out, st[k + 2], skip)
+            k += 3
         return skip, (latent if return_latents else None)
 
 
@@ -269,11 +289,11 @@ class GeneratorWithMap(Generator):
         out = self.input(latent)
         norm_maps = [rasterize(vert, attr, tri, int(out.shape[2]), int(out.shape[3])).permute(0, 3, 1, 2)]
         maps = self.norm1(norm_maps[-1])
-        w = latent.unbind(1)
-        out = self.conv1(out, w[0], maps, noise=noise[0])
-        skip = self.to_rgb1(out, w[1])
+        st = self._layer_styles(latent)
+        out = self.conv1(out, st[0], maps, noise=noise[0])
+        skip = self.to_rgb1(out, st[1])
         two_stage = len(self.convs) == len(self.norm_to_style)
-        i = 1
+        i, k = 1, 2
         for conv_up, conv, n_up, n_conv, to_rgb in zip(self.convs[::2], self.convs[1::2],
                                                        noise[1::2], noise[2::2], self.to_rgbs):
             norm_maps.append(rasterize(vert, attr, tri, 2 * int(out.shape[2]),
@@ -282,10 +302,11 @@ class GeneratorWithMap(Generator):
                 maps = self.norm_to_style[i](self.norm_to_style[i - 1](norm_maps[-1]))
             else:
                 maps = self.norm_to_style[i // 2](norm_maps[-1])
-            out = conv_up(out, w[i], maps[:, :2], noise=n_up)
-            out = conv(out, w[i + 1], maps[:, 2:], noise=n_conv)
-            skip = to_rgb(out, w[i + 2], skip)
+            out = conv_up(out, st[k], maps[:, :2], noise=n_up)
+            out = conv(out, st[k + 1], maps[:, 2:], noise=n_conv)
+            skip = to_rgb(out, st[k + 2], skip)
             i += 2
+            k += 3
         return skip, (latent if return_latents else None), (norm_maps if return_normals else None)
 
 
