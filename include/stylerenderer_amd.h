@@ -102,6 +102,18 @@ int sr_noise_bias_act_affine_bwd(float* gx, float* gamap, float* gsmap, float* g
                                  int64_t map_bstride, const float* noise, float alpha, float scale, int64_t n,
                                  int64_t c, int64_t inner, int64_t noise_bstride, float* scratch,
                                  sr_stream_t stream);
+/* Second-order pass of the same tail (path-length regulariser: the backward above is itself differentiated, reference
+ * train.py:118-134).  Cotangents of the first-order outputs: Gx [n, c, inner] | NULL, Gmap = (Ga, Gs) planes at
+ * Gmap + b * gmap_bstride (+ inner) | NULL, Gb [c] | NULL, Gnw [1] | NULL.  Writes d_gy, d_x [n, c, inner] and the
+ * gradient of the scale plane d_amap[b * d_amap_bstride + p] = sum_c (gy * m) * Gx (nothing flows to the shift
+ * plane, the bias or the noise weight: the activation mask is piecewise constant).  scratch:
+ * sr_noise_bias_act_affine_bwd2_scratch_floats(n, c, inner) floats. */
+int64_t sr_noise_bias_act_affine_bwd2_scratch_floats(int64_t n, int64_t c, int64_t inner);
+int sr_noise_bias_act_affine_bwd2(float* d_gy, float* d_x, float* d_amap, int64_t d_amap_bstride, const float* Gx,
+                                  const float* Gmap, int64_t gmap_bstride, const float* Gb, const float* Gnw,
+                                  const float* gy, const float* out, const float* x, const float* amap,
+                                  int64_t map_bstride, const float* noise, float alpha, float scale, int64_t n,
+                                  int64_t c, int64_t inner, int64_t noise_bstride, float* scratch, sr_stream_t stream);
 
 /* Adam step over ONE flat fp32 parameter buffer (the optimiser of reference train.py:529-536: torch.optim.Adam with
  * the lazy-regularisation corrected lr / betas, no weight decay) in a single pass over p, g, m, v (28 B/parameter):

@@ -34,3 +34,11 @@ tot = sum(e.device_time_total for e in rows)
 print("total aten device time %.1f us in %d calls" % (tot, sum(e.count for e in rows)))
 for e in rows[:48]:
     print("%5d  %8.1f us  %-22s %s" % (e.count, e.device_time_total, e.key, str(e.input_shapes)[:110]))
+by_name = {}
+for e in rows:
+    a = by_name.setdefault(e.key, [0, 0.0])
+    a[0] += e.count
+    a[1] += e.device_time_total
+print("by operator:")
+for k, (c, t) in sorted(by_name.items(), key=lambda kv: -kv[1][1])[:40]:
+    print("%5d  %8.1f us  %s" % (c, t, k))

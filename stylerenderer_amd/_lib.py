@@ -32,6 +32,8 @@ SIGNATURES = {
     "sr_noise_bias_act_affine": (_i, [_p] * 4 + [_l] + [_p] * 3 + [_f, _f] + [_l] * 4 + [_p]),
     "sr_noise_bias_act_affine_bwd_scratch_floats": (_l, [_l, _l, _l]),
     "sr_noise_bias_act_affine_bwd": (_i, [_p] * 9 + [_l, _p, _f, _f] + [_l] * 4 + [_p, _p]),
+    "sr_noise_bias_act_affine_bwd2_scratch_floats": (_l, [_l, _l, _l]),
+    "sr_noise_bias_act_affine_bwd2": (_i, [_p, _p, _p, _l, _p, _p, _l] + [_p] * 6 + [_l, _p, _f, _f] + [_l] * 4 + [_p, _p]),
     "sr_adam_flat": (_i, [_p] * 4 + [_l] + [_f] * 4 + [_p, _p]),
     "sr_rowdot_scratch_floats": (_l, [_l, _l]),
     "sr_rowdot": (_i, [_p] * 5 + [_l, _l, _p, _p]),

@@ -475,6 +475,116 @@ extern "C" int sr_noise_bias_act_affine_bwd(float* gx, float* gamap, float* gsma
     return sr_launch_status();
 }
 
+// ---- second-order pass of the StyledMapConv tail (path-length regulariser, reference train.py:118-134) --------------
+// First order (k_nba_aff_bwd): r = gy * m (m = LeakyReLU slope of the output sign, times gain);
+//   gx = r * a,  ga[b,p] = sum_c r * x,  gs[b,p] = sum_c r,  gb[c] = sum_{b,p} r,  gnw = sum r * noise.
+// Given the cotangents (Gx, Ga, Gs, Gb, Gnw) of those outputs, the gradients w.r.t. the first-order INPUTS are
+//   d gy = m * (Gx * a + Ga * x + Gs + Gb[c] + Gnw * noise),   d x = r * Ga,   d a[b,p] = sum_c r * Gx
+// (the mask is piecewise constant: nothing flows to the activation output, the shift plane, bias or noise weight).
+// One pass over the activation (reads gy, out, x, Gx; writes d gy, d x) with the per-pixel channel sum kept in
+// registers, channel groups like k_nba_aff_bwd.  Replaces ~45 tensor-algebra launches per layer of the recorded
+// backward and its differentiation.
+namespace {
+
+__global__ __launch_bounds__(EB) void k_nba_aff_bwd2(float* __restrict__ d_gy, float* __restrict__ d_x,
+                                                     float* __restrict__ d_amap, const float* __restrict__ Gx,
+                                                     const float* __restrict__ Gmap, int64_t gmap_bstride,
+                                                     const float* __restrict__ Gb, const float* __restrict__ Gnw,
+                                                     const float* __restrict__ gy, const float* __restrict__ out,
+                                                     const float* __restrict__ x, const float* __restrict__ amap,
+                                                     int64_t map_bstride, const float* __restrict__ noise,
+                                                     float alpha, float scale, int c, int64_t inner,
+                                                     int64_t noise_bstride, int cgroup, int64_t plane) {
+    const int64_t b = blockIdx.y;
+    const int64_t p = (int64_t)blockIdx.x * APIX + threadIdx.x * 4;
+    if (p >= inner) return;
+    const int c0 = blockIdx.z * cgroup, c1 = (c0 + cgroup < c) ? c0 + cgroup : c;
+    d_amap += (int64_t)blockIdx.z * plane;
+    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 a = *reinterpret_cast<const float4*>(amap + b * map_bstride + p);
+    const float4 Ga = Gmap ? *reinterpret_cast<const float4*>(Gmap + b * gmap_bstride + p) : zero;
+    const float4 Gs = Gmap ? *reinterpret_cast<const float4*>(Gmap + b * gmap_bstride + inner + p) : zero;
+    float4 base = Gs;                    // the channel-independent part of T: Gs + Gnw * noise
+    if (noise && Gnw) {
+        const float4 nz = *reinterpret_cast<const float4*>(noise + b * noise_bstride + p);
+        const float w = Gnw[0];
+        base.x += w * nz.x; base.y += w * nz.y; base.z += w * nz.z; base.w += w * nz.w;
+    }
+    float4 da = zero;
+    for (int ch = c0; ch < c1; ++ch) {
+        const int64_t o = (b * c + ch) * inner + p;
+        const float4 g = *reinterpret_cast<const float4*>(gy + o);
+        const float4 yo = *reinterpret_cast<const float4*>(out + o);
+        const float4 xv = *reinterpret_cast<const float4*>(x + o);
+        const float4 gxv = Gx ? *reinterpret_cast<const float4*>(Gx + o) : zero;
+        const float gb = Gb ? Gb[ch] : 0.0f;
+        float4 m, r, t;
+        m.x = ((yo.x > 0.0f) ? 1.0f : alpha) * scale;
+        m.y = ((yo.y > 0.0f) ? 1.0f : alpha) * scale;
+        m.z = ((yo.z > 0.0f) ? 1.0f : alpha) * scale;
+        m.w = ((yo.w > 0.0f) ? 1.0f : alpha) * scale;
+        r.x = g.x * m.x; r.y = g.y * m.y; r.z = g.z * m.z; r.w = g.w * m.w;
+        t.x = ((gxv.x * a.x + Ga.x * xv.x) + base.x) + gb;
+        t.y = ((gxv.y * a.y + Ga.y * xv.y) + base.y) + gb;
+        t.z = ((gxv.z * a.z + Ga.z * xv.z) + base.z) + gb;
+        t.w = ((gxv.w * a.w + Ga.w * xv.w) + base.w) + gb;
+        *reinterpret_cast<float4*>(d_gy + o) = make_float4(m.x * t.x, m.y * t.y, m.z * t.z, m.w * t.w);
+        *reinterpret_cast<float4*>(d_x + o) = make_float4(r.x * Ga.x, r.y * Ga.y, r.z * Ga.z, r.w * Ga.w);
+        da.x += r.x * gxv.x; da.y += r.y * gxv.y; da.z += r.z * gxv.z; da.w += r.w * gxv.w;
+    }
+    *reinterpret_cast<float4*>(d_amap + b * inner + p) = da;
+}
+
+// out[b * out_bstride + i] = sum over g (ascending) of part[g * plane + b * inner + i]
+__global__ __launch_bounds__(EB) void k_plane_sum_strided(float* __restrict__ out, int64_t out_bstride,
+                                                          const float* __restrict__ part, int64_t plane,
+                                                          int64_t inner, int groups) {
+    const int64_t i = ((int64_t)blockIdx.x * EB + threadIdx.x) * 4;
+    const int64_t b = blockIdx.y;
+    if (i >= inner) return;
+    float4 acc = *reinterpret_cast<const float4*>(part + b * inner + i);
+    for (int g = 1; g < groups; ++g) {
+        const float4 v = *reinterpret_cast<const float4*>(part + g * plane + b * inner + i);
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    *reinterpret_cast<float4*>(out + b * out_bstride + i) = acc;
+}
+
+}  // namespace
+
+extern "C" int64_t sr_noise_bias_act_affine_bwd2_scratch_floats(int64_t n, int64_t c, int64_t inner) {
+    if (n <= 0 || c <= 0 || inner <= 0) return 4;
+    const int64_t groups = sr_ceil_div(c, aff_cgroup(n, c, inner));
+    return groups * n * inner + 4;
+}
+
+extern "C" int sr_noise_bias_act_affine_bwd2(float* d_gy, float* d_x, float* d_amap, int64_t d_amap_bstride,
+                                             const float* Gx, const float* Gmap, int64_t gmap_bstride,
+                                             const float* Gb, const float* Gnw, const float* gy, const float* out,
+                                             const float* x, const float* amap, int64_t map_bstride,
+                                             const float* noise, float alpha, float scale, int64_t n, int64_t c,
+                                             int64_t inner, int64_t noise_bstride, float* scratch,
+                                             sr_stream_t stream) {
+    if (n < 0 || c < 0 || inner < 0) return SR_EINVAL;
+    if (n * c * inner == 0) return SR_OK;
+    if (!d_gy || !d_x || !d_amap || !gy || !out || !x || !amap || !scratch || n > 65535) return SR_EINVAL;
+    if (!vec_ok(inner, d_gy, d_x, gy, out) || !vec_ok(inner, x, amap, noise, Gx) || !vec_ok(inner, d_amap, Gmap, 0, 0) ||
+        map_bstride % 4 != 0 || d_amap_bstride % 4 != 0 || (Gmap && gmap_bstride % 4 != 0) ||
+        (noise && noise_bstride % 4 != 0))
+        return SR_EINVAL;
+    const int chunks = (int)sr_ceil_div(inner, APIX);
+    hipStream_t st = sr_stream(stream);
+    const int cg = aff_cgroup(n, c, inner);
+    const int groups = (int)sr_ceil_div(c, cg);
+    const int64_t plane = n * inner;
+    hipLaunchKernelGGL(k_nba_aff_bwd2, dim3((unsigned)chunks, (unsigned)n, (unsigned)groups), dim3(EB), 0, st, d_gy,
+                       d_x, scratch, Gx, Gmap, gmap_bstride, Gb, Gnw, gy, out, x, amap, map_bstride, noise, alpha, scale,
+                       (int)c, inner, noise_bstride, cg, plane);
+    hipLaunchKernelGGL(k_plane_sum_strided, dim3((unsigned)sr_ceil_div(inner, EB * 4), (unsigned)n), dim3(EB), 0, st,
+                       d_amap, d_amap_bstride, scratch, plane, inner, groups);
+    return sr_launch_status();
+}
+
 extern "C" int64_t sr_rowdot_scratch_floats(int64_t rows, int64_t inner) {
     if (rows <= 0 || inner <= 0) return 1;
     return rows * sr_ceil_div(inner, ECHUNK) + 1;

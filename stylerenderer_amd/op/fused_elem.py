@@ -103,8 +103,8 @@ def noise_bias_act(x, noise, noise_weight, bias, negative_slope=0.2, scale=2 ** 
 
 
 class _NBAAffineBackward(Function):
-    """First-order backward of `_NBAAffine` as its own node, so that a recorded backward (path-length
-    regulariser) differentiates it through the defining tensor algebra."""
+    """First-order backward of `_NBAAffine` as its own node; its own backward is the fused second-order pass the
+    path-length regulariser needs (gradients w.r.t. gy, x and the scale plane)."""
 
     @staticmethod
     def forward(ctx, gy, out, x, smap2, noise, slope, scale):
@@ -125,12 +125,37 @@ class _NBAAffineBackward(Function):
                 _lib.ptr(gy), _lib.ptr(out), _lib.ptr(x), _lib.ptr(smap2), smap2.stride(0), _lib.ptr(noise),
                 float(slope), float(scale), n, c, inner, bstride, _lib.ptr(scratch), stream_of(out))
         _lib.check(rc, "sr_noise_bias_act_affine_bwd")
+        ctx.save_for_backward(gy, out, x, smap2, noise)
+        ctx.cfg = (float(slope), float(scale))
         return gx, gmap.transpose(0, 1), gb, gnw
 
     @staticmethod
-    def backward(ctx, *grads):
-        raise RuntimeError("_NBAAffineBackward is not differentiable: the recorded-backward path re-derives the "
-                           "VJP from tensor algebra (see _NBAAffine.backward)")
+    def backward(ctx, G_gx, G_gmap, G_gb, G_gnw):
+        """The second-order pass (csrc/fused_elem.hip k_nba_aff_bwd2): gradients w.r.t. gy, x and the scale plane."""
+        gy, out, x, smap2, noise = ctx.saved_tensors
+        slope, scale = ctx.cfg
+        n, c, inner = _geometry(out)
+        d_gy = torch.empty_like(out)
+        d_x = torch.empty_like(out)
+        d_smap = torch.zeros_like(smap2, memory_format=torch.contiguous_format)       # channel 1 (shift plane): zero
+        G_gx = G_gx.contiguous() if G_gx is not None else None
+        G_gmap = G_gmap.contiguous() if G_gmap is not None else None                  # [n, 2, H, W]
+        G_gb = G_gb.contiguous() if G_gb is not None else None
+        G_gnw = G_gnw.contiguous() if (G_gnw is not None and noise is not None) else None
+        L = _lib.lib()
+        scratch = torch.empty(L.sr_noise_bias_act_affine_bwd2_scratch_floats(n, c, inner), dtype=out.dtype,
+                              device=out.device)
+        bstride = 0 if noise is None or noise.numel() == inner else inner
+        with on_device_of(out):
+            rc = L.sr_noise_bias_act_affine_bwd2(
+                _lib.ptr(d_gy), _lib.ptr(d_x), _lib.ptr(d_smap), 2 * inner, _lib.ptr(G_gx), _lib.ptr(G_gmap), 2 * inner,
+                _lib.ptr(G_gb), _lib.ptr(G_gnw), _lib.ptr(gy), _lib.ptr(out), _lib.ptr(x), _lib.ptr(smap2),
+                smap2.stride(0), _lib.ptr(noise), float(slope), float(scale), n, c, inner, bstride, _lib.ptr(scratch),
+                stream_of(out))
+        _lib.check(rc, "sr_noise_bias_act_affine_bwd2")
+        needs = ctx.needs_input_grad
+        return (d_gy if needs[0] else None, None, d_x if needs[2] else None, d_smap if needs[3] else None, None,
+                None, None)
 
 
 class _NBAAffine(Function):
@@ -157,21 +182,8 @@ class _NBAAffine(Function):
         x, smap2, noise, noise_w, bias, y = ctx.saved_tensors
         slope, scale = ctx.cfg
         needs = ctx.needs_input_grad
-        if torch.is_grad_enabled():
-            # recorded backward (create_graph): differentiate the defining composition instead
-            with torch.enable_grad():
-                xa, ma = x.view_as(x), smap2.view_as(smap2)
-                nwa = noise_w.view_as(noise_w) if noise_w is not None else None
-                ba = bias.view_as(bias) if bias is not None else None
-                pre = xa * ma[:, :1] + ma[:, 1:2]
-                if noise is not None:
-                    pre = pre + nwa * noise
-                out = fused_leaky_relu(pre, ba, slope, scale)
-                ins = (xa, ma, None, nwa, ba)
-                sel = [t for t, nd in zip(ins, needs[:5]) if nd and t is not None]
-                got = iter(torch.autograd.grad(out, sel, gy, create_graph=True, allow_unused=True)) if sel else iter(())
-                grads = [next(got) if (nd and t is not None) else None for t, nd in zip(ins, needs[:5])]
-            return tuple(grads) + (None, None)
+        # (also when this backward is itself recorded — path-length regulariser: _NBAAffineBackward has a native
+        # second-order pass, k_nba_aff_bwd2; round 2 re-derived the VJP from ~45 tensor-algebra launches per layer)
         gx, gmap, gb, gnw = _NBAAffineBackward.apply(gy, y, x, smap2, noise, slope, scale)
         return (gx if needs[0] else None, gmap if needs[1] else None, None,
                 gnw if (noise is not None and needs[3]) else None, gb if needs[4] else None, None, None)

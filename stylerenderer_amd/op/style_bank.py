@@ -64,8 +64,8 @@ def build(layers, latent):
             s = torch.baddbmm(bias, lat, w, alpha=scale)                           # [L, B, C]
         else:
             s = torch.bmm(lat, w) * scale
-        for k, i in enumerate(idxs):
-            s_of[i] = s[k]
+        for i, row in zip(idxs, s.unbind(0)):      # one unbind (backward: one stack), not a select per layer
+            s_of[i] = row
     packs = [None] * n
     dgroups = {}
     for i, (m, _) in enumerate(layers):
@@ -85,6 +85,6 @@ def build(layers, latent):
         ss = torch.stack([packs[i].s for i in idxs])                               # [L, B, Ci]
         wq = torch.stack([packs[i].wsq for i in idxs])                             # [L, Ci, Co]
         d = torch.rsqrt(torch.bmm(ss * ss, wq) + eps)                              # [L, B, Co]
-        for k, i in enumerate(idxs):
-            packs[i].d = d[k]
+        for i, row in zip(idxs, d.unbind(0)):
+            packs[i].d = row
     return packs
