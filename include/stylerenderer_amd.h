@@ -131,6 +131,11 @@ int sr_adam_flat(float* p, const float* g, float* m, float* v, int64_t n, float 
 int64_t sr_rowdot_scratch_floats(int64_t rows, int64_t inner);
 int sr_rowdot(float* dots, float* out_scaled, const float* a, const float* b, const float* scale,
               int64_t rows, int64_t inner, float* scratch, sr_stream_t stream);
+/* Backward of sr_rowdot in one pass (second-order sweep of the path-length regulariser): ga = gd[r] * b,
+ * gb = gd[r] * a + go * scale[r], gs[r] = sum_p go * b.  ga / gb / gs / gd / go / scale may be NULL (gs needs go and
+ * `scratch` of sr_rowdot_scratch_floats(rows, inner) floats). */
+int sr_rowdot_bwd(float* ga, float* gb, float* gs, const float* a, const float* b, const float* gd, const float* go,
+                  const float* scale, int64_t rows, int64_t inner, float* scratch, sr_stream_t stream);
 
 /* 1x1 modulated convolution with N <= 4 output channels (ToRGB: reference model.py:56-69 via
  * layers.py:293-323 with kernel_size 1, demodulate off), as streaming passes instead of MFMA tiles.

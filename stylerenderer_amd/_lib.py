@@ -37,6 +37,7 @@ SIGNATURES = {
     "sr_adam_flat": (_i, [_p] * 4 + [_l] + [_f] * 4 + [_p, _p]),
     "sr_rowdot_scratch_floats": (_l, [_l, _l]),
     "sr_rowdot": (_i, [_p] * 5 + [_l, _l, _p, _p]),
+    "sr_rowdot_bwd": (_i, [_p] * 8 + [_l, _l, _p, _p]),
     "sr_smallconv_fwd": (_i, [_p] * 4 + [_l] * 4 + [_p]),
     "sr_smallconv_dx": (_i, [_p] * 3 + [_l] * 4 + [_p]),
     "sr_smallconv_dw_scratch_floats": (_l, [_l] * 4),

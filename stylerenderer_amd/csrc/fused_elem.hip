@@ -611,6 +611,73 @@ extern "C" int sr_rowdot(float* dots, float* out_scaled, const float* a, const f
     return sr_launch_status();
 }
 
+// Backward of the row-dot node (dots = sum_p a*b, out = b*s) in one pass — it runs in the second-order sweep of the
+// path-length regulariser, where the node sits in the recorded backward of every modulated convolution:
+//   ga = gd[r] * b,   gb = gd[r] * a + go * s[r],   gs[r] = sum_p go * b        (gd / go / s may be absent)
+// Replaces five element-wise launches and a reduction over full activation tensors.
+namespace {
+
+template <bool VEC>
+__global__ __launch_bounds__(EB) void k_rowdot_bwd(float* __restrict__ partial, float* __restrict__ ga,
+                                                   float* __restrict__ gb, const float* __restrict__ a,
+                                                   const float* __restrict__ b, const float* __restrict__ gd,
+                                                   const float* __restrict__ go, const float* __restrict__ s,
+                                                   int64_t inner, int chunks) {
+    __shared__ float lds8[8];
+    const int64_t row = blockIdx.y;
+    const int64_t off = (int64_t)blockIdx.x * ECHUNK;
+    const int64_t remain = inner - off;
+    const int n = (int)(remain < ECHUNK ? remain : ECHUNK);
+    const float g = gd ? gd[row] : 0.0f;
+    const float sc = s ? s[row] : 1.0f;
+    const int64_t base = row * inner + off;
+    float acc = 0.0f, dummy = 0.0f;
+    if (VEC) {
+        for (int i = threadIdx.x; i < n / 4; i += EB) {
+            const float4 x = reinterpret_cast<const float4*>(a + base)[i], y = reinterpret_cast<const float4*>(b + base)[i];
+            float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (go) o = reinterpret_cast<const float4*>(go + base)[i];
+            if (ga) reinterpret_cast<float4*>(ga + base)[i] = make_float4(g * y.x, g * y.y, g * y.z, g * y.w);
+            if (gb)
+                reinterpret_cast<float4*>(gb + base)[i] =
+                    make_float4(g * x.x + o.x * sc, g * x.y + o.y * sc, g * x.z + o.z * sc, g * x.w + o.w * sc);
+            acc += (o.x * y.x + o.y * y.y) + (o.z * y.z + o.w * y.w);
+        }
+    } else {
+#pragma unroll 4
+        for (int i = threadIdx.x; i < n; i += EB) {
+            const float x = a[base + i], y = b[base + i];
+            const float o = go ? go[base + i] : 0.0f;
+            if (ga) ga[base + i] = g * y;
+            if (gb) gb[base + i] = g * x + o * sc;
+            acc += o * y;
+        }
+    }
+    if (partial) {
+        block_sum2(acc, dummy, lds8);
+        if (threadIdx.x == 0) partial[row * chunks + blockIdx.x] = acc;
+    }
+}
+
+}  // namespace
+
+extern "C" int sr_rowdot_bwd(float* ga, float* gb, float* gs, const float* a, const float* b, const float* gd,
+                             const float* go, const float* scale, int64_t rows, int64_t inner, float* scratch,
+                             sr_stream_t stream) {
+    if (rows < 0 || inner < 0) return SR_EINVAL;
+    if (rows == 0 || inner == 0) return SR_OK;
+    if (!a || !b || rows > 65535 || (gs && (!go || !scratch))) return SR_EINVAL;
+    const bool vec = vec_ok(inner, a, b, ga, gb) && vec_ok(inner, go, nullptr, nullptr, nullptr);
+    hipStream_t st = sr_stream(stream);
+    const int chunks = (int)sr_ceil_div(inner, ECHUNK);
+    const dim3 grid(chunks, (unsigned)rows);
+    float* partial = gs ? scratch : nullptr;
+    if (vec) hipLaunchKernelGGL((k_rowdot_bwd<true>), grid, dim3(EB), 0, st, partial, ga, gb, a, b, gd, go, scale, inner, chunks);
+    else hipLaunchKernelGGL((k_rowdot_bwd<false>), grid, dim3(EB), 0, st, partial, ga, gb, a, b, gd, go, scale, inner, chunks);
+    if (gs) hipLaunchKernelGGL(k_rowdot_finish, dim3((unsigned)rows), dim3(64), 0, st, gs, scratch, chunks);
+    return sr_launch_status();
+}
+
 // ------------------------------------------------------------------------------------------------
 // 1x1 modulated convolution with <= 4 output channels (ToRGB, reference model.py:56-69).  A 128-wide
 // MFMA tile would be 97 % idle here; the layer is one streaming pass over the activation:

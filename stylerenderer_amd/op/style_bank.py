@@ -29,6 +29,38 @@ from . import style as _style
 from .weight_prep import weight_prep as _weight_prep
 
 
+class _Unbind0(torch.autograd.Function):
+    """x.unbind(0) whose backward is `_Stack0` (and vice versa).  torch's own stack / unbind differentiate through
+    narrow + squeeze views, whose SECOND derivative materialises a zero-filled copy of the stacked tensor per layer
+    (select_backward: zeros + copy + accumulate, ~100 launches in the path-length sweep)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.unbind(0)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        return _Stack0.apply(*grads)
+
+
+class _Stack0(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, *ts):
+        return torch.stack(ts)
+
+    @staticmethod
+    def backward(ctx, g):
+        return _Unbind0.apply(g)
+
+
+def stack0(ts):
+    return _Stack0.apply(*ts)
+
+
+def unbind0(x):
+    return _Unbind0.apply(x)
+
+
 class StylePack:
     """Precomputed per-layer style data: s [B, Cin] (modulation), d [B, Cout] | None (demodulation), wt / wsq from
     weight_prep (None for the ToRGB 1x1 layers, which prepare their three rows themselves)."""
@@ -55,16 +87,16 @@ def build(layers, latent):
         groups.setdefault((m.in_channel, float(mod.scale), float(mod.lr_mul), mod.bias is not None), []).append(i)
     for (_, scale, lr_mul, has_bias), idxs in groups.items():
         mods = [layers[i][0].modulation for i in idxs]
-        lat = torch.stack([rows[layers[i][1]] for i in idxs])                      # [L, B, D]
-        w = torch.stack([m.weight for m in mods]).transpose(1, 2)                  # [L, D, C]
+        lat = stack0([rows[layers[i][1]] for i in idxs])                           # [L, B, D]
+        w = stack0([m.weight for m in mods]).transpose(1, 2)                       # [L, D, C]
         if has_bias:
-            bias = torch.stack([m.bias for m in mods]).unsqueeze(1)                # [L, 1, C]
+            bias = stack0([m.bias for m in mods]).unsqueeze(1)                     # [L, 1, C]
             if lr_mul != 1.0:
                 bias = bias * lr_mul
             s = torch.baddbmm(bias, lat, w, alpha=scale)                           # [L, B, C]
         else:
             s = torch.bmm(lat, w) * scale
-        for i, row in zip(idxs, s.unbind(0)):      # one unbind (backward: one stack), not a select per layer
+        for i, row in zip(idxs, unbind0(s)):        # one unbind (backward: one stack), not a select per layer
             s_of[i] = row
     packs = [None] * n
     dgroups = {}
@@ -82,9 +114,9 @@ def build(layers, latent):
             p.d = (_style.demod_scale(p.s, p.wsq, eps) if _style.demod_supported(p.s, p.wsq)
                    else torch.rsqrt(torch.matmul(p.s * p.s, p.wsq) + eps))
             continue
-        ss = torch.stack([packs[i].s for i in idxs])                               # [L, B, Ci]
-        wq = torch.stack([packs[i].wsq for i in idxs])                             # [L, Ci, Co]
+        ss = stack0([packs[i].s for i in idxs])                                    # [L, B, Ci]
+        wq = stack0([packs[i].wsq for i in idxs])                                  # [L, Ci, Co]
         d = torch.rsqrt(torch.bmm(ss * ss, wq) + eps)                              # [L, B, Co]
-        for i, row in zip(idxs, d.unbind(0)):
+        for i, row in zip(idxs, unbind0(d)):
             packs[i].d = row
     return packs
