@@ -138,7 +138,17 @@ class GraphedTrainer(Trainer):
         return flat, flat_views(flat, params, offs), offs
 
     def set_topology(self, tri):
+        """The shared triangle list (made contiguous ONCE: the per-topology incidence lists of the rasterizer gradient
+        and of the vertex normals are cached by its address, and a cache miss inside a capture would run torch.sort /
+        bincount, which synchronise the host and abort the capture).  Both lists are built here."""
         self.tri = tri.contiguous()
+        if self.tri.is_cuda and self.s_mesh is not None:
+            from . import utils_3d
+            from .op.rasterize import incidence
+
+            nv = self.s_mesh["g"][0].shape[1]
+            incidence(self.tri, nv)
+            utils_3d.incidence_lists(self.tri, nv)
 
     def _mesh_tuple(self, key, n=None):
         if not self.use_mesh:

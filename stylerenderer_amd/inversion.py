@@ -29,6 +29,10 @@ class LatentInverter:
         self.perceptual = perceptual.eval()
         for p in list(self.g.parameters()) + list(self.perceptual.parameters()):
             p.requires_grad_(False)
+        # frozen networks: tap-major weights, demodulation matrices and adjoints are prepared once, not per step
+        from .op.weight_prep import freeze_prepared_weights
+
+        freeze_prepared_weights(self.g)
         self.device = target.device
         self.target = target.detach()
         self.v0, self.n0, self.tri = (t.detach() for t in mesh)

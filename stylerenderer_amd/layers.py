@@ -25,6 +25,7 @@ from .op import smallconv as _smallconv
 from .op import style as _style
 from .op.style_bank import StylePack
 from .op.weight_prep import weight_prep as _weight_prep
+from .op.weight_prep import weight_prep_cached as _weight_prep_cached
 
 
 def _fused_tails():
@@ -107,14 +108,14 @@ class EqualConv2d(nn.Module):
         geom = self._geom()
         bias = self.bias if with_bias else None
         if input.device.type == "cuda" and geom is not None:
-            wt, _ = _weight_prep(self.weight, self.scale)
+            wt, _ = _weight_prep_cached(self, self.weight, self.scale)
             return _conv.conv2d(input, wt, None, None, bias, geom)
         return F.conv2d(input, self.weight * self.scale, bias=bias, stride=self.stride,
                         padding=self.padding)
 
     def forward_stride1(self, input):
         """The 1x1 convolution applied to an input that is already decimated (see ConvLayer.forward)."""
-        wt, _ = _weight_prep(self.weight, self.scale)
+        wt, _ = _weight_prep_cached(self, self.weight, self.scale)
         return _conv.conv2d(input, wt, None, None, self.bias, "c1")
 
     def __repr__(self):
@@ -196,6 +197,11 @@ class ModulatedConv2d(nn.Module):
             self.upsample, self.downsample)
 
     # ---- device tensors: shared weights + operand scaling on the MFMA kernels
+    def _wprep(self, want_sq):
+        """Tap-major scaled weights (+ the demodulation matrix): one launch per call, or once per weight version for
+        a module frozen with op.weight_prep.freeze_prepared_weights (inversion, sampling)."""
+        return _weight_prep_cached(self, self.weight, self.scale, want_sq)
+
     def style_of(self, style):
         """Modulation vector [B, Ci]: from the latent row, or precomputed for all layers at once (op.style_bank)."""
         return style.s if isinstance(style, StylePack) else self.modulation(style)
@@ -205,7 +211,7 @@ class ModulatedConv2d(nn.Module):
         if isinstance(style, StylePack) and style.wt is not None:
             return style.wt, style.wsq, style.d
         # one launch: tap-major scaled weights + the demodulation matrix sum_taps (scale*W)^2 [Ci, Co]
-        wt, wsq = _weight_prep(self.weight, self.scale, self.demodulate)
+        wt, wsq = self._wprep(self.demodulate)
         d = None
         if self.demodulate:
             if _style.demod_supported(s, wsq):
@@ -254,7 +260,7 @@ class ModulatedConv2d(nn.Module):
             if not _conv.conv_nba_supported(input, wt, noise):
                 return None
         else:
-            wt, wsq = _weight_prep(self.weight, self.scale, True)
+            wt, wsq = self._wprep(True)
             if not (_conv.conv_nba_supported(input, wt, noise) and _style.demod_supported(s, wsq)):
                 return None
             d = _style.demod_scale(s, wsq, self.eps)
@@ -275,7 +281,7 @@ class ModulatedConv2d(nn.Module):
             if not _conv.upconv_nba_supported(input, wt, noise, oh, ow):
                 return None
         else:
-            wt, wsq = _weight_prep(self.weight, self.scale, True)
+            wt, wsq = self._wprep(True)
             if not (_conv.upconv_nba_supported(input, wt, noise, oh, ow) and _style.demod_supported(s, wsq)):
                 return None
             d = _style.demod_scale(s, wsq, self.eps)
@@ -388,7 +394,7 @@ class ConvLayer(nn.Sequential):
                     # stride-1 3x3 layers of 32^2 .. 256^2 maps: bias + LeakyReLU in the Winograd kernel's store
                     # (the pre-activation tensor is never written or kept for backward)
                     xc = x.contiguous()
-                    wt, _ = _weight_prep(conv.weight, conv.scale)
+                    wt, _ = _weight_prep_cached(conv, conv.weight, conv.scale)
                     if _conv.conv_nba_supported(xc, wt, None):
                         return _conv.conv2d_nba(xc, wt, None, None, None, None, bias, act.negative_slope, act.scale)
                 x = conv(x, with_bias=False)

@@ -87,7 +87,9 @@ class _Conv3x3ReLU(nn.Module):
             tag = (self.weight.device, self.weight._version, self.weight.data_ptr())
             if self._prepared is None or self._prepared[0] != tag:
                 with torch.no_grad():
-                    self._prepared = (tag, _weight_prep(self.weight, 1.0)[0])
+                    wt = _weight_prep(self.weight, 1.0)[0]
+                    wt._sr_frozen = True                # trunk weights never train: ConvFn caches their adjoints
+                    self._prepared = (tag, wt)
             out = _conv.conv2d(x, self._prepared[1], None, None, None, "c3")
             return fused_leaky_relu(out, self.bias, 0.0, 1.0)                     # bias + ReLU in one pass
         return F.relu(F.conv2d(x, self.weight, self.bias, padding=1))

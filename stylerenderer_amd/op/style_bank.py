@@ -26,7 +26,6 @@ import os
 import torch
 
 from . import style as _style
-from .weight_prep import weight_prep as _weight_prep
 
 
 class _Unbind0(torch.autograd.Function):
@@ -104,7 +103,7 @@ def build(layers, latent):
         if m.kernel_size == 1 and not m.demodulate and not m.upsample and not m.downsample:
             packs[i] = StylePack(s_of[i])                                          # ToRGB: modulation only
             continue
-        wt, wsq = _weight_prep(m.weight, m.scale, m.demodulate)
+        wt, wsq = m._wprep(m.demodulate)
         packs[i] = StylePack(s_of[i], None, wt, wsq)
         if m.demodulate:
             dgroups.setdefault((m.in_channel, m.out_channel, float(m.eps)), []).append(i)

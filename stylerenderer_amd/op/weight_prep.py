@@ -100,6 +100,53 @@ def weight_prep(weight, scale, want_sq=False):
     return wt, (wsq if want_sq else None)
 
 
+# ---- frozen weights (latent inversion, sampling): prepare once per weight version --------------------------------
+# OPT-IN per module (`freeze_prepared_weights(net)`), never inferred from `requires_grad`: the training loop toggles
+# that flag on the discriminator while its weights keep changing under the flat Adam kernel, which writes through raw
+# pointers and does not bump tensor versions.
+_FROZEN_ADJ = None
+
+
+def freeze_prepared_weights(net, flag=True):
+    """Marks every convolution of `net` whose weights the caller guarantees not to change behind torch's back (in-place
+    torch ops bump the version and refresh the cache): their tap-major weights, demodulation matrices and
+    data-gradient adjoints are prepared once instead of per call (k_wprep / k_wadjoint: ~90 launches per inversion
+    step at batch 1, where every launch is ~5 us of a 10 ms step)."""
+    for m in net.modules():
+        m._frozen_weights = bool(flag)          # read by weight_prep_cached through layers.*Conv2d
+    return net
+
+
+def weight_prep_cached(module, weight, scale, want_sq=False):
+    """`weight_prep` for a module that may have been frozen with `freeze_prepared_weights`."""
+    if not getattr(module, "_frozen_weights", False) or weight.requires_grad:
+        return weight_prep(weight, scale, want_sq)
+    tag = (weight.data_ptr(), weight._version, str(weight.device), float(scale))
+    hit = getattr(module, "_wprep_hit", None)
+    if hit is None or hit[0] != tag or (want_sq and hit[2] is None):
+        with torch.no_grad():
+            wt, wsq = weight_prep(weight, scale, True if want_sq else False)
+        wt._sr_frozen = True                       # lets ConvFn cache the adjoint of this very tensor
+        hit = (tag, wt, wsq)
+        module._wprep_hit = hit
+    return hit[1], (hit[2] if want_sq else None)
+
+
+def adjoint_cached(wt, flip):
+    """`adjoint` of a frozen prepared weight: keyed by the tensor's address / version, the entry holds the tensor."""
+    global _FROZEN_ADJ
+    if _FROZEN_ADJ is None:
+        from ._dispatch import DerivedCache
+
+        _FROZEN_ADJ = DerivedCache(256)
+    key = (wt.data_ptr(), wt._version, tuple(wt.shape), tuple(wt.stride()), bool(flip), str(wt.device))
+    hit = _FROZEN_ADJ.get(key)
+    if hit is None:
+        with torch.no_grad():
+            hit = _FROZEN_ADJ.put(key, (_adjoint_launch(wt, flip), wt))
+    return hit[0]
+
+
 def _adjoint_launch(wt, flip):
     taps, c, n = wt.shape
     if not (wt.stride(2) == 1 and wt.stride(0) == c * wt.stride(1) and wt.stride(1) >= n):

@@ -193,7 +193,9 @@ def test_full_gradient_tensors_gpu_vs_own_cpu_path(size, batch, slope, tol):
         scale = float(want[n].abs().max())
         # scalar noise strengths are sums of ~4e5 signed terms: 5x the bar (measured 2.1e-5; all others <= 3.6e-6)
         t = tol * (5 if want[n].numel() == 1 else 1)
-        assert float((got[n].cpu() - want[n]).abs().max()) <= t * scale + 1e-9, n
+        err = float((got[n].cpu() - want[n]).abs().max())
+        assert err <= t * scale + 1e-9, "%s: |err| %.3e = %.3e of the tensor's scale %.3e (bar %.1e)" % (
+            n, err, err / max(scale, 1e-30), scale, t)
 
 
 @pytest.mark.parametrize("tag,kw", [("plain", dict(in_channel=8, out_channel=6, kernel_size=3, style_dim=16)),

@@ -41,6 +41,6 @@ def check_grad_samples(named_grads, names, values, offsets, tol):
         assert got.shape == want.shape, n
         scale = max(float(np.abs(want).max()), 1e-12)
         err = float(np.abs(got - want).max()) / scale
-        assert err <= tol, (n, err)
+        assert err <= tol, "%s: sampled-gradient error %.3e of the tensor's scale (bar %.1e)" % (n, err, tol)
         worst = max(worst, err)
     return worst
