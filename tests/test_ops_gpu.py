@@ -599,3 +599,54 @@ def test_torgb_fused_bias_and_skip_add_equal_the_separate_operators():
         assert (u is None) == (v is None)
         if v is not None:
             assert float((u - v).abs().max()) <= 1e-5 * float(v.abs().max()) + 1e-9
+
+
+@pytest.mark.parametrize("persp", [False, True])
+def test_rasterize_tiled_path_list_overflow_wide_boxes_and_tile_borders(persp):
+    """The LDS-tiled forward (k_tile_bin / k_tile_raster) on inputs built to leave its common path: > 2 048 small
+    triangles inside ONE 32x32 tile (list capacity overflow -> the sample's wide list), boxes that straddle two, three
+    and four tiles, boxes larger than 64 pixels (wide list), equal depths (ties -> lowest id) and an image whose edge
+    is not a multiple of the tile (80).  Bit-exact against the C oracle, like every other rasterizer test."""
+    R = importlib.import_module("stylerenderer_amd.op.rasterize")
+    rng = np.random.RandomState(11)
+    res = 80
+    tris = []
+
+    def add(cx, cy, size, z, n=1):
+        for _ in range(n):
+            a = rng.rand() * 2 * np.pi
+            pts = [(cx + size * np.cos(a + k * 2.1), cy + size * np.sin(a + k * 2.1)) for k in range(3)]
+            tris.append([(x, y, z + 0.01 * rng.randn()) for x, y in pts])
+
+    for _ in range(6000):                                   # one tile (pixels 32..63 x 0..31): ~3 000 accepted > capacity 2 048
+        add(32 + 32 * rng.rand(), 32 * rng.rand(), 0.6 + 1.5 * rng.rand(), -2.0 - rng.rand())
+    for _ in range(300):                                    # straddle the tile borders at 32 and 64
+        add(rng.choice([31.5, 63.5]) + rng.randn(), rng.choice([31.5, 63.5]) + rng.randn(), 1.0 + 2 * rng.rand(), -2.5)
+    for _ in range(40):                                     # thin strips: three tiles in a row
+        y = 80 * rng.rand()
+        tris.append([(20.0, y, -3.0), (75.0, y + 0.6, -3.0), (47.0, y + 1.2, -3.0)])
+    for _ in range(12):                                     # large boxes
+        add(80 * rng.rand(), 80 * rng.rand(), 10 + 25 * rng.rand(), -3.5)
+    for _ in range(60):                                     # exact ties: identical triangles, different ids
+        tris.append(tris[int(rng.randint(0, 3000))])
+    pix = np.asarray(tris, np.float64)                      # [nf, 3, (px, py, z)]
+    ndc = np.empty_like(pix)
+    ndc[..., 0] = (pix[..., 0] + 0.5) * 2 / res - 1
+    ndc[..., 1] = 1 - (pix[..., 1] + 0.5) * 2 / res
+    ndc[..., 2] = pix[..., 2]
+    if persp:
+        ndc[..., 0] *= -ndc[..., 2]
+        ndc[..., 1] *= -ndc[..., 2]
+    v1 = ndc.reshape(-1, 3).astype(np.float32)
+    nf = pix.shape[0]
+    tri = np.arange(3 * nf, dtype=np.int64).reshape(nf, 3)
+    flip = rng.rand(nf) < 0.5                               # both windings: half are culled
+    tri[flip] = tri[flip][:, ::-1]
+    v = np.stack([v1, v1 * np.float32(0.97)], 0)
+    want_i, want_c, want_z = raster.forward_buffers(v, tri, res, res, persp, 1e-6)
+    idx, coeff, zbuf = R.forward_with_depth(T(v), T(tri), res, res, persp, 1e-6)
+    assert np.array_equal(idx.cpu().numpy(), want_i)
+    assert bits_equal(coeff.cpu().numpy(), want_c)
+    assert bits_equal(zbuf.cpu().numpy(), want_z)
+    covered = int((want_i != 0).any(-1).sum())
+    assert covered > 2000
