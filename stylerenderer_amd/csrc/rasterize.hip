@@ -1306,18 +1306,23 @@ __global__ __launch_bounds__(256) void k_grad_vert(long long nv, long long nf, c
 
 // The tiled path serves fp32 on square images (x and y ranges are swapped by the reference's call sites, SURVEY D8:
 // on a non-square image pixel columns beyond the width alias into the next row, which only a global key buffer
-// reproduces).  SR_RASTER_TILED=0 keeps the global-key path (ablation).
+// reproduces).  It pays when there are thousands of (sample, tile) workgroups with a few hundred triangles each —
+// BASELINE config[3]: 64 samples x 64 tiles, ~400 accepted triangles per tile: 0.116 vs 0.129 ms.  With few tiles (low
+// resolution under the same mesh: sub-pixel triangles that the global path rejects in a handful of instructions) or
+// few samples (training: 4, inversion: 1) each workgroup walks a long list serially and the global-key path wins by
+// 2-5x (scripts/raster_res_probe.py), so the choice is made per call.  SR_RASTER_TILED=1 forces the tiled path (tests),
+// =0 the global-key path.
 template <typename R>
 inline bool tiled_ok(long long, long long, long long, long long) { return false; }
 template <>
 inline bool tiled_ok<float>(long long b, long long nf, long long h, long long w) {
-    static const bool enabled = [] {
-        const char* e = getenv("SR_RASTER_TILED");
-        return !(e && e[0] == '0');
-    }();
-    const long long ntx = sr_ceil_div(h, TILE);
-    return enabled && h == w && nf > 0 && h < 0x40000000LL && b <= 65535 && b * ntx * ntx < 0x7FFFFFFFLL &&
-           b * nf < 0x7FFFFFFFLL;
+    const char* e = getenv("SR_RASTER_TILED");               // read per call: tests flip it at run time
+    const int mode = !e ? 2 : (e[0] == '0' ? 0 : 1);
+    const long long ntx = sr_ceil_div(h, TILE), ntile = ntx * ntx;
+    const bool possible = mode != 0 && h == w && nf > 0 && h < 0x40000000LL && b <= 65535 && b * ntile < 0x7FFFFFFFLL &&
+                          b * nf < 0x7FFFFFFFLL;
+    if (!possible) return false;
+    return mode == 1 || (b * ntile >= 4096 && nf <= 1024 * ntile);
 }
 
 template <typename R>

@@ -156,8 +156,21 @@ def test_upfirdn2d_full_size_properties():
 RASTER_CASES = ["raster_ellipsoid_32", "raster_ellipsoid_64", "raster_perspective_32", "raster_adversarial_16"]
 
 
+@pytest.fixture(params=["auto", "tiled"])
+def raster_path(request, monkeypatch):
+    """The forward has two device paths chosen per call (csrc/rasterize.hip tiled_ok): the LDS-tiled one only pays for
+    thousands of (sample, tile) workgroups, so small test inputs would never reach it — every bit-exactness test runs
+    once with the automatic choice and once with the tiled path forced."""
+    if request.param == "tiled":
+        monkeypatch.setenv("SR_RASTER_TILED", "1")
+    else:
+        monkeypatch.delenv("SR_RASTER_TILED", raising=False)
+    return request.param
+
+
+
 @pytest.mark.parametrize("name", RASTER_CASES)
-def test_rasterize_bitexact_vs_golden(golden, name):
+def test_rasterize_bitexact_vs_golden(golden, name, raster_path):
     R = importlib.import_module("stylerenderer_amd.op.rasterize")
 
     g = golden(name)
@@ -175,7 +188,7 @@ def test_rasterize_bitexact_vs_golden(golden, name):
     assert torch.equal(i2, idx) and torch.equal(c2, coeff)
 
 
-def test_rasterize_misc_topologies(golden):
+def test_rasterize_misc_topologies(golden, raster_path):
     R = importlib.import_module("stylerenderer_amd.op.rasterize")
 
     g = golden("raster_misc")
@@ -187,7 +200,7 @@ def test_rasterize_misc_topologies(golden):
     assert bits_equal(coeff.cpu().numpy(), g["coeff_bf"])
 
 
-def test_rasterize_known_answer_fp64_and_gradcheck(golden):
+def test_rasterize_known_answer_fp64_and_gradcheck(golden, raster_path):
     """The reference's __main__ test (reference op/rasterize.py:83-107) on the HIP path."""
     import stylerenderer_amd.op as op
     R = importlib.import_module("stylerenderer_amd.op.rasterize")
@@ -211,7 +224,7 @@ def test_rasterize_known_answer_fp64_and_gradcheck(golden):
 
 
 @pytest.mark.parametrize("res", [32, 64])
-def test_rasterize_interp_and_grads_vs_golden(golden, res):
+def test_rasterize_interp_and_grads_vs_golden(golden, res, raster_path):
     import stylerenderer_amd.op as op
 
     g = golden("raster_ellipsoid_%d" % res)
@@ -227,7 +240,7 @@ def test_rasterize_interp_and_grads_vs_golden(golden, res):
     assert np.abs(gt.cpu().numpy() - g["grad_tex"]).max() <= 2e-6 * np.abs(g["grad_tex"]).max()
 
 
-def test_rasterize_face_mesh_256_vs_oracle_and_determinism():
+def test_rasterize_face_mesh_256_vs_oracle_and_determinism(raster_path):
     """BFM-size-class mesh (24 770 vertices, 49 536 triangles) at 256x256: bitwise equal to the C
     oracle on the same inputs, and byte-identical across repeated launches (the reference's CUDA
     kernel is racy)."""
@@ -249,7 +262,7 @@ def test_rasterize_face_mesh_256_vs_oracle_and_determinism():
     assert bits_equal(d.cpu().numpy(), raster.backward_dcoeff(v, wi, False, 1e-6))
 
 
-def test_rasterize_batch64_properties():
+def test_rasterize_batch64_properties(raster_path):
     """BASELINE config 4 size (B=64): per-sample independence — each sample of the batch equals the
     same sample rasterised alone."""
     from stylerenderer_amd import synth
@@ -271,7 +284,7 @@ def _oracle_grads(v, tex, tri, go, res):
     return raster.rasterize_grads(v, tex, tri, go, res)
 
 
-def test_rasterize_gradients_are_deterministic_and_match_oracle_256():
+def test_rasterize_gradients_are_deterministic_and_match_oracle_256(raster_path):
     """BFM-size-class mesh at 256x256: the two-phase gather (no float atomics) gives byte-identical grad_v /
     grad_tex on every launch, and agrees with the float64-accumulated oracle."""
     import stylerenderer_amd.op as op
@@ -295,7 +308,7 @@ def test_rasterize_gradients_are_deterministic_and_match_oracle_256():
 
 
 @pytest.mark.parametrize("c", [1, 2, 3, 6])
-def test_rasterize_large_triangles_forward_and_gradients(c):
+def test_rasterize_large_triangles_forward_and_gradients(c, raster_path):
     """A 218-triangle mesh at 256x256: every bounding box exceeds 64 pixels, so the workgroup-cooperative
     paths of k_depth_keys and k_grad_tri run; forward bitwise vs the C oracle, gradients vs the oracle, any
     attribute width (register accumulators are chunked by 4 channels), run-to-run identical."""
@@ -602,12 +615,13 @@ def test_torgb_fused_bias_and_skip_add_equal_the_separate_operators():
 
 
 @pytest.mark.parametrize("persp", [False, True])
-def test_rasterize_tiled_path_list_overflow_wide_boxes_and_tile_borders(persp):
+def test_rasterize_tiled_path_list_overflow_wide_boxes_and_tile_borders(persp, monkeypatch):
     """The LDS-tiled forward (k_tile_bin / k_tile_raster) on inputs built to leave its common path: > 2 048 small
     triangles inside ONE 32x32 tile (list capacity overflow -> the sample's wide list), boxes that straddle two, three
     and four tiles, boxes larger than 64 pixels (wide list), equal depths (ties -> lowest id) and an image whose edge
     is not a multiple of the tile (80).  Bit-exact against the C oracle, like every other rasterizer test."""
     R = importlib.import_module("stylerenderer_amd.op.rasterize")
+    monkeypatch.setenv("SR_RASTER_TILED", "1")
     rng = np.random.RandomState(11)
     res = 80
     tris = []
