@@ -292,6 +292,155 @@ __global__ __launch_bounds__(256 * NG) void k_wgrad_mfma(const WgradParams p) {
         }
 }
 
+// ---- stride-2 3x3 weight gradient with LDS-DMA staging -----------------------------------------------------------
+// Same tiling, same k order and same arithmetic as k_wgrad_mfma<2, 3, 3, 16, 4, 1, 32, 128, 2> (bit-identical
+// results), but the patch arrives by 16-byte buffer-addressed LDS-DMA instead of dword loads through registers:
+// 12 DMA instructions per wave and stage replace 36 global loads + 36 LDS writes + their masks and the per-lane
+// offset arithmetic of every patch.  Possible because a 16-byte DMA takes any 4-byte aligned global address and LDS
+// destination (profiles/r02_notes.md), and because for pad-0 stride-2 layers (U extent 2G + 1) the window of a full
+// patch never leaves the image: no zero fill, the per-lane offsets are patch-invariant and the patch origin is one
+// wave-uniform soffset.
+//   U: per channel and row group g (window rows 4g .. 4g + 4; row 4 is staged for both groups so that every operand
+//      address is a compile-time immediate) one instruction of 45 lanes: 5 rows x 9 float4 (33 used columns + 3);
+//      channel pitch 181 floats (odd: the 32 lanes of an operand fetch hit 32 banks)
+//   V: one instruction stages the 64 pixels of FOUR channels l, l + 32, l + 64, l + 96 (one per wave column): the
+//      channels one ds_read touches lie in 32 different instructions, pitch 257.
+namespace s2d {
+constexpr int RP = 36;                    // floats per staged window row
+constexpr int UP = 5 * RP + 1;            // 181
+constexpr int OFF_UG = 32 * UP;           // second row group
+constexpr int OFF_V = 2 * OFF_UG;         // 11584
+constexpr int VP = 4 * 64 + 1;            // 257
+constexpr int OFF_S = OFF_V + 32 * VP;    // 19808: scale rows [32 u][128 v]
+constexpr int BUF = OFF_S + 160;          // 19968 floats
+constexpr int LDS_BYTES = 2 * BUF * 4;    // 159744
+static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
+}  // namespace s2d
+
+__global__ __launch_bounds__(512) void k_wgrad_s2_dma(const WgradParams p) {
+#if __HIP_DEVICE_COMPILE__
+    using namespace s2d;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int bid = blockIdx.x;
+    const int tile_uv = bid % (p.tiles_u * p.tiles_v);
+    const int slice = bid / (p.tiles_u * p.tiles_v);
+    const int u0 = (tile_uv / p.tiles_v) * 32, v0 = (tile_uv % p.tiles_v) * 128;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = lane >> 5, l31 = lane & 31;
+    const int grp = wave >> 2, wv = wave & 3;
+    const int a_base = grp * OFF_UG + l31 * UP + half * 2;
+    const int b_base = OFF_V + l31 * VP + wv * 64 + half + grp * 2 * 16;
+
+    const int npatch = p.tiles_x * p.tiles_y * p.tiles_b;
+    const int first = slice * p.patches_per_slice;
+    int last = first + p.patches_per_slice;
+    if (last > npatch) last = npatch;
+    const int plane_u = p.UH * p.UW, plane_v = p.GH * p.GW;
+
+    const __amdgpu_buffer_rsrc_t r_u = uniform_rsrc(p.U, p.B * p.CU * plane_u * 4);
+    const __amdgpu_buffer_rsrc_t r_v = uniform_rsrc(p.V, p.B * p.CV * plane_v * 4);
+    const int u_lane_off = ((lane / 9) * p.UW + 4 * (lane % 9)) * 4;
+    const int v_lane_off = ((lane >> 4) * 32 * plane_v + ((lane >> 2) & 3) * p.GW + 4 * (lane & 3)) * 4;
+    const bool u_lane = lane < 45;
+
+    int d_us = 0, d_vs = 0, pat_b = 0;       // wave-uniform byte offsets of the patch origin at channels u0 / v0
+    auto prepare = [&](int patch) {
+        const int tx_i = patch % p.tiles_x;
+        const int ty_i = (patch / p.tiles_x) % p.tiles_y;
+        pat_b = patch / (p.tiles_x * p.tiles_y);
+        d_us = ((pat_b * p.CU + u0) * plane_u + ty_i * 8 * p.UW + tx_i * 32) * 4;
+        d_vs = ((pat_b * p.CV + v0) * plane_v + ty_i * 4 * p.GW + tx_i * 16) * 4;
+    };
+    // DMA item i of this wave (compile-time i): 0..7 = U channel wave + 8 (i >> 1), row group i & 1; 8..11 = V
+    // quadruple wave + 8 (i - 8)
+    auto dma = [&](int i, float* dst) {
+        if (i < 8) {
+            const int ch = wave + 8 * (i >> 1), g = i & 1;
+            if (u_lane)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(r_u, (lptr_t)(dst + g * OFF_UG + ch * UP), 16, u_lane_off,
+                                                         d_us + (ch * plane_u + g * 4 * p.UW) * 4, 0, 0);
+        } else {
+            const int l = wave + 8 * (i - 8);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(r_v, (lptr_t)(dst + OFF_V + l * VP), 16, v_lane_off,
+                                                     d_vs + l * plane_v * 4, 0, 0);
+        }
+    };
+    auto scale_load = [&]() -> float {
+        float val = 1.0f;
+        if (tid < 32) {
+            if (p.uscale) val = p.uscale[(int64_t)pat_b * p.CU + u0 + tid];
+        } else if (tid < 160) {
+            if (p.vscale) val = p.vscale[(int64_t)pat_b * p.CV + v0 + tid - 32];
+        }
+        return val;
+    };
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+
+    if (first < last) {
+        prepare(first);
+#pragma unroll
+        for (int i = 0; i < 12; ++i) dma(i, smem);
+        const float sv = scale_load();
+        if (tid < 160) smem[OFF_S + tid] = sv;
+    }
+    int buf = 0;
+    for (int patch = first; patch < last; ++patch) {
+        // "my DMAs landed" + "my LDS accesses retired", then the barrier: buffer `buf` complete, the other one idle
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        prepare(patch + 1 < last ? patch + 1 : patch);        // after the last patch: re-stage it into the idle buffer
+        const float* sb = smem + buf * BUF;
+        float* so = smem + (buf ^ 1) * BUF;
+        const float a_sc = sb[OFF_S + l31], b_sc = sb[OFF_S + 32 + wv * 32 + l31];
+        float a_raw[9], b_raw;
+        auto fetch_operands = [&](int step) {
+            const int qx = step & 7, pyl = step >> 3;
+            b_raw = sb[b_base + pyl * 16 + 2 * qx];
+            const int ua = a_base + 2 * pyl * RP + 4 * qx;
+#pragma unroll
+            for (int ty = 0; ty < 3; ++ty)
+#pragma unroll
+                for (int tx = 0; tx < 3; ++tx) a_raw[ty * 3 + tx] = sb[ua + ty * RP + tx];
+        };
+        fetch_operands(0);
+        float sc_next = 1.0f;
+#pragma unroll
+        for (int step = 0; step < 16; ++step) {
+            if (step < 12) dma(step, so);
+            if (step == 12) sc_next = scale_load();
+            if (step == 15 && tid < 160) so[OFF_S + tid] = sc_next;
+            const float bv = b_raw * b_sc;
+            float av[9];
+#pragma unroll
+            for (int t = 0; t < 9; ++t) av[t] = a_raw[t] * a_sc;
+            if (step + 1 < 16) fetch_operands(step + 1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 0; t < 9; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], bv, acc[t], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        buf ^= 1;
+    }
+    // surplus fetches are still landing in this workgroup's LDS: drain them before the wave can retire
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    float* dst = p.partial + ((int64_t)slice * 2 + grp) * 9 * p.UP * p.VP;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int u = u0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            const int v = v0 + wv * 32 + l31;
+            dst[((int64_t)t * p.UP + u) * p.VP + v] = acc[t][r];
+        }
+#endif
+}
+
 // Sums the K slices in a fixed order and writes the requested layout: element (t, u, v) goes to
 // out[tmap[t] * slab + u * su + v * sv].
 struct ReduceParams {
@@ -385,9 +534,29 @@ int launch_wgrad_s1(const WgradParams& p, const Plan& pl, hipStream_t st) {
     if (pl.pw == 8) return launch_wgrad_one<1, TY, TX, 8, 8, 1, 64, 64>(p, grid, st);
     return launch_wgrad_one<1, TY, TX, 4, 4, 4, 64, 64>(p, grid, st);
 }
+// k_wgrad_s2_dma serves full 16 x 4 patches of whole channel tiles whose windows stay inside U (pad-0 stride-2 layers
+// of 2G + 1 pixels: every up- / down-sampling convolution from 16^2 up); SR_WGRAD_DMA=0 keeps the dword staging.
+bool s2_dma_ok(const WgradParams& p, const Plan& pl) {
+    const char* e = std::getenv("SR_WGRAD_DMA");
+    if (e && e[0] == '0') return false;
+    return pl.pw == 16 && pl.ph == 4 && pl.pb == 1 && pl.ut == 32 && pl.vt == 128 && p.CU % 32 == 0 && p.CV % 128 == 0 &&
+           p.GW % 16 == 0 && p.GH % 4 == 0 && p.dy0 == 0 && p.dx0 == 0 && p.UH >= 2 * p.GH + 1 && p.UW >= 2 * p.GW + 1 &&
+           (int64_t)p.B * p.CU * p.UH * p.UW < (1LL << 29) && (int64_t)p.B * p.CV * p.GH * p.GW < (1LL << 29);
+}
+
 template <int TY, int TX>
 int launch_wgrad_s2(const WgradParams& p, const Plan& pl, hipStream_t st) {
     const dim3 grid((unsigned)(pl.tiles_u * pl.tiles_v * pl.ks));
+    if (TY == 3 && TX == 3 && s2_dma_ok(p, pl)) {
+        static bool configured = false;
+        if (!configured) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_wgrad_s2_dma),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, s2d::LDS_BYTES);
+            configured = true;
+        }
+        hipLaunchKernelGGL(k_wgrad_s2_dma, grid, dim3(512), s2d::LDS_BYTES, st, p);
+        return sr_launch_status();
+    }
     if (pl.pw == 16) return launch_wgrad_one<2, TY, TX, 16, 4, 1, 32, 128>(p, grid, st);
     return launch_wgrad_one<2, TY, TX, 8, 8, 1, 32, 128>(p, grid, st);
 }

@@ -56,6 +56,9 @@ CASES = [
     (1, 6, 130, 32, 32, 3, 2, 0, True),
     (2, 8, 130, 32, 32, 3, 2, 0, True),          # fused four-phase kernel (interior) + border strips
     (1, 12, 64, 8, 64, 3, 2, 0, True),
+    (2, 128, 32, 16, 16, 3, 2, 0, True),         # weight gradient: DMA-staged stride-2 kernel (k_wgrad_s2_dma)
+    (3, 256, 64, 32, 32, 3, 2, 0, True),         # same, two channel tiles each way, several patches per slice
+    (2, 32, 128, 33, 33, 3, 2, 0, False),        # same kernel, down-sampling convolution
     (2, 8, 3, 8, 8, 1, 1, 0, False),
     (2, 16, 5, 32, 32, 1, 1, 0, False),
     (2, 6, 4, 9, 9, 1, 2, 0, False),
@@ -144,6 +147,29 @@ def test_wgrad_vs_float64(case, scaled):
     scale = want.abs().max().item() + 1e-30
     # K = B * pixels terms per output, fp32 partial sums: relative to the largest gradient entry
     assert float((got.cpu().double() - want).abs().max()) < 3e-5 * scale * max(1.0, np.sqrt(b * h * w) / 30)
+
+
+def test_stride2_wgrad_dma_staging_equals_dword_staging(monkeypatch):
+    """k_wgrad_s2_dma stages the same operands as the dword kernel and runs the same MFMA chain in the same k
+    order: the weight gradients are bit-identical (SR_WGRAD_DMA=0 selects the dword kernel)."""
+    from stylerenderer_amd.op.conv import conv2d_wgrad_mfma
+
+    g = torch.Generator().manual_seed(11)
+    for b, c, n, res, tr in ((2, 128, 32, 16, True), (3, 256, 64, 32, True), (4, 128, 64, 64, True),
+                             (2, 32, 128, 33, False), (3, 64, 256, 129, False)):
+        out = 2 * res + 1 if tr else (res - 3) // 2 + 1
+        x = torch.randn(b, c, res, res, generator=g).to(DEV)
+        gy = torch.randn(b, n, out, out, generator=g).to(DEV)
+        xs, gs = torch.randn(b, c, generator=g).to(DEV), torch.randn(b, n, generator=g).to(DEV)
+        monkeypatch.setenv("SR_WGRAD_DMA", "1")
+        a = conv2d_wgrad_mfma(x, gy, xs, gs, 3, 2, 0, tr)
+        a2 = conv2d_wgrad_mfma(x, gy, None, None, 3, 2, 0, tr)
+        monkeypatch.setenv("SR_WGRAD_DMA", "0")
+        d = conv2d_wgrad_mfma(x, gy, xs, gs, 3, 2, 0, tr)
+        d2 = conv2d_wgrad_mfma(x, gy, None, None, 3, 2, 0, tr)
+        assert torch.isfinite(a).all()
+        assert torch.equal(a, d), (b, c, n, res, tr, float((a - d).abs().max()))
+        assert torch.equal(a2, d2), (b, c, n, res, tr)
 
 
 def test_wgrad_deterministic_and_large():
