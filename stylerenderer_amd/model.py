@@ -20,6 +20,7 @@ from .layers import (Blur, ConstantInput, ConvLayer, EqualLinear, ModulatedConv2
 from .op import FusedLeakyReLU, rasterize
 from .op import smallconv as _smallconv
 from .op import style_bank as _style_bank
+from .op import weight_bank as _weight_bank
 from .op.fused_elem import blur_noise_bias_act, noise_bias_act, noise_bias_act_affine
 from .op.upfirdn2d import upsample2_add
 
@@ -195,7 +196,14 @@ class Generator(nn.Module):
     def _latents(self, styles, inject_index, truncation, truncation_latent, input_is_latent, noise,
                  randomize_noise):
         if not input_is_latent:
-            styles = [self.style(s) for s in styles]
+            if (len(styles) > 1 and styles[0].device.type == "cuda"
+                    and all(s.shape == styles[0].shape for s in styles[1:])):
+                # style mixing on the device: the mapping network (row-wise: PixelNorm + 8 EqualLinear) runs ONCE
+                # over the stacked latents — half the launches of its forward and backward, and every weight
+                # receives one gradient instead of two that autograd would have to add
+                styles = list(self.style(torch.cat(list(styles), 0)).chunk(len(styles), 0))
+            else:
+                styles = [self.style(s) for s in styles]
         if noise is None:
             if randomize_noise:
                 noise = [None] * self.num_layers
@@ -248,17 +256,18 @@ class Generator(nn.Module):
                 truncation_latent=None, input_is_latent=False, noise=None, randomize_noise=True):
         latent, noise = self._latents(styles, inject_index, truncation, truncation_latent,
                                       input_is_latent, noise, randomize_noise)
-        out = self.input(latent)
-        st = self._layer_styles(latent)
-        out = self.conv1(out, st[0], noise=noise[0])
-        skip = self.to_rgb1(out, st[1])
-        k = 2
-        for conv_up, conv, n_up, n_conv, to_rgb in zip(self.convs[::2], self.convs[1::2],
-                                                       noise[1::2], noise[2::2], self.to_rgbs):
-            out = conv_up(out, st[k], noise=n_up)
-            out = conv(out, st[k + 1], noise=n_conv)
-            skip = to_rgb(out, st[k + 2], skip)
-            k += 3
+        with _weight_bank.Scope(self):          # device tensors: every convolution weight prepared up front
+            out = self.input(latent)
+            st = self._layer_styles(latent)
+            out = self.conv1(out, st[0], noise=noise[0])
+            skip = self.to_rgb1(out, st[1])
+            k = 2
+            for conv_up, conv, n_up, n_conv, to_rgb in zip(self.convs[::2], self.convs[1::2],
+                                                           noise[1::2], noise[2::2], self.to_rgbs):
+                out = conv_up(out, st[k], noise=n_up)
+                out = conv(out, st[k + 1], noise=n_conv)
+                skip = to_rgb(out, st[k + 2], skip)
+                k += 3
         return skip, (latent if return_latents else None)
 
 
@@ -286,6 +295,10 @@ class GeneratorWithMap(Generator):
         latent, noise = self._latents(styles, inject_index, truncation, truncation_latent,
                                       input_is_latent, noise, randomize_noise)
         vert, attr, tri = mesh[0], mesh[1], mesh[2]
+        with _weight_bank.Scope(self):          # device tensors: every convolution weight prepared up front
+            return self._synthesis_with_maps(latent, noise, vert, attr, tri, return_normals, return_latents)
+
+    def _synthesis_with_maps(self, latent, noise, vert, attr, tri, return_normals, return_latents):
         out = self.input(latent)
         norm_maps = [rasterize(vert, attr, tri, int(out.shape[2]), int(out.shape[3])).permute(0, 3, 1, 2)]
         maps = self.norm1(norm_maps[-1])
@@ -330,6 +343,10 @@ class Discriminator(nn.Module):
             EqualLinear(channels[4], 1))
 
     def forward(self, input):
+        with _weight_bank.Scope(self):          # device tensors: every convolution weight prepared up front
+            return self._forward(input)
+
+    def _forward(self, input):
         out = self.convs(input)
         batch, channel, height, width = out.shape
         group = min(batch, self.stddev_group)

@@ -123,10 +123,13 @@ _GEOM = {  # name -> (ksize, stride, pad, transposed)
 }
 
 
-def adjoint_weight(wt, geom, frozen=False):
+def adjoint_weight(wt, geom, frozen=False, banked=None):
     """Weights of the data-gradient convolution: channels swapped; taps reversed for the
     stride-1 3x3 correlation (the strided pair c3s2 <-> t3s2 keeps tap order).  `frozen`: the prepared weight
-    belongs to a module frozen with op.weight_prep.freeze_prepared_weights — its adjoint is computed once."""
+    belongs to a module frozen with op.weight_prep.freeze_prepared_weights — its adjoint is computed once.
+    `banked`: (flip, adjoint) prepared together with `wt` by op.weight_bank for all layers of the pass."""
+    if banked is not None and banked[0] == (geom == "c3"):
+        return banked[1]
     if frozen and not wt.requires_grad and not torch.is_grad_enabled():
         return _wp.adjoint_cached(wt, geom == "c3")
     return _wp.adjoint(wt, geom == "c3")
@@ -142,6 +145,7 @@ class ConvFn(torch.autograd.Function):
         k, stride, pad, tr = _GEOM[geom]
         out = conv2d_mfma(x, wt, iscale, oscale, bias, k, stride, pad, tr)
         ctx.frozen = bool(getattr(wt, "_sr_frozen", False))
+        ctx.adj = getattr(wt, "_sr_adj", None)
         ctx.geom = geom
         ctx.has = (iscale is not None, oscale is not None, bias is not None)
         ctx.save_for_backward(x, wt, iscale, oscale, bias, out if oscale is not None else None)
@@ -156,11 +160,11 @@ class ConvFn(torch.autograd.Function):
         gx = gw = gis = gos = gb = None
         if need_x or need_is:
             if geom == "c1s2":
-                inner = ConvFn.apply(g, adjoint_weight(wt, "c1", ctx.frozen), oscale, None, None, "c1")
+                inner = ConvFn.apply(g, adjoint_weight(wt, "c1", ctx.frozen, ctx.adj), oscale, None, None, "c1")
                 dxu = torch.zeros_like(x)
                 dxu[:, :, ::2, ::2] = inner
             else:
-                dxu = ConvFn.apply(g, adjoint_weight(wt, geom, ctx.frozen), oscale, None, None, _ADJOINT[geom])
+                dxu = ConvFn.apply(g, adjoint_weight(wt, geom, ctx.frozen, ctx.adj), oscale, None, None, _ADJOINT[geom])
             # style gradient sum_p x*dxu and dx = s*dxu in one sweep (csrc/fused_elem.hip)
             if need_is and need_x and iscale is not None:
                 gis, gx = rowdot(x, dxu, iscale)
@@ -278,6 +282,7 @@ class ConvNBAFn(torch.autograd.Function):
         ctx.save_for_backward(x, wt, iscale, oscale, noise, noise_w, abias, out)
         ctx.cfg = (float(slope), float(gain))
         ctx.frozen = bool(getattr(wt, "_sr_frozen", False))
+        ctx.adj = getattr(wt, "_sr_adj", None)
         return out
 
     @staticmethod
@@ -300,7 +305,7 @@ class ConvNBAFn(torch.autograd.Function):
         g, gb, gnw, rdot = _nba_bwd_dot(gy, out, noise, noise_w, abias, slope, gain)
         gx = gw = gis = gos = None
         if needs[0] or needs[2]:
-            dxu = ConvFn.apply(g, adjoint_weight(wt, "c3", ctx.frozen), oscale, None, None, "c3")
+            dxu = ConvFn.apply(g, adjoint_weight(wt, "c3", ctx.frozen, ctx.adj), oscale, None, None, "c3")
             if needs[2] and needs[0] and iscale is not None:
                 gis, gx = rowdot(x, dxu, iscale)
             else:
@@ -362,6 +367,7 @@ class UpConvNBAFn(torch.autograd.Function):
         ctx.save_for_backward(x, wt, iscale, oscale, kernel, noise, noise_w, abias, out)
         ctx.cfg = (tuple(pad), float(slope), float(gain), tuple(y257.shape))
         ctx.frozen = bool(getattr(wt, "_sr_frozen", False))
+        ctx.adj = getattr(wt, "_sr_adj", None)
         return out
 
     @staticmethod
@@ -389,7 +395,7 @@ class UpConvNBAFn(torch.autograd.Function):
                             shape257[3] - ow + p0, 3 - p0, shape257[2] - oh + p0).view(shape257)
         gx = gw = gis = gos = None
         if needs[0] or needs[2]:
-            dxu = ConvFn.apply(g257, adjoint_weight(wt, "t3s2", ctx.frozen), oscale, None, None, "c3s2")
+            dxu = ConvFn.apply(g257, adjoint_weight(wt, "t3s2", ctx.frozen, ctx.adj), oscale, None, None, "c3s2")
             if needs[2] and needs[0] and iscale is not None:
                 gis, gx = rowdot(x, dxu, iscale)
             else:

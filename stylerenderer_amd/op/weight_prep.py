@@ -117,9 +117,28 @@ def freeze_prepared_weights(net, flag=True):
     return net
 
 
+_BANK = None
+
+
+def _bank():
+    global _BANK
+    if _BANK is None:
+        from . import weight_bank
+
+        _BANK = weight_bank
+    return _BANK
+
+
 def weight_prep_cached(module, weight, scale, want_sq=False):
-    """`weight_prep` for a module that may have been frozen with `freeze_prepared_weights`."""
+    """`weight_prep` for a module: from the pass-wide batched preparation when the network's forward opened a
+    `weight_bank.Scope`, from the version-keyed cache when the module was frozen with `freeze_prepared_weights`, else
+    one launch."""
     if not getattr(module, "_frozen_weights", False) or weight.requires_grad:
+        bank = _bank()
+        hit = bank.lookup(module, want_sq) if weight is getattr(module, "weight", None) else None
+        if hit is not None:
+            return hit
+        bank.note(module, want_sq)
         return weight_prep(weight, scale, want_sq)
     tag = (weight.data_ptr(), weight._version, str(weight.device), float(scale))
     hit = getattr(module, "_wprep_hit", None)

@@ -1,0 +1,120 @@
+"""op.weight_bank: the batched weight preparation of a whole network equals the per-layer launches bit for bit."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _weights(seed):
+    g = torch.Generator().manual_seed(seed)
+    shapes = [(64, 32, 3), (6, 20, 3), (130, 12, 1), (3, 64, 1), (128, 128, 3), (7, 5, 3), (512, 64, 1)]
+    return [torch.randn(co, ci, k, k, generator=g).to(DEV).requires_grad_() for co, ci, k in shapes]
+
+
+def test_batched_prep_adjoint_and_pullback_equal_the_per_layer_launches():
+    from stylerenderer_amd.op import weight_bank as wb
+    from stylerenderer_amd.op import weight_prep as wp
+
+    ws = _weights(3)
+    meta = tuple((0.5 + 0.1 * i, i % 2 == 0) for i in range(len(ws)))
+    outs = wb._WPrepBatch.apply(meta, *ws)
+    flips = tuple(w.shape[2] == 3 and i % 3 != 0 for i, w in enumerate(ws))
+    adjs = wb._AdjointBatch.apply(flips, *[outs[2 * i] for i in range(len(ws))])
+    g = torch.Generator().manual_seed(4)
+    loss = 0
+    cots = []
+    for i, w in enumerate(ws):
+        wt, wsq = outs[2 * i], outs[2 * i + 1]
+        ref_wt, ref_wsq = wp.weight_prep(w, meta[i][0], meta[i][1])
+        assert wt.shape == ref_wt.shape and torch.equal(wt, ref_wt), i
+        assert wt.data_ptr() % 16 == 0 and wt.stride(1) % 4 == 0
+        if meta[i][1]:
+            assert torch.equal(wsq, ref_wsq), i
+        else:
+            assert wsq.numel() == 0 and not wsq.requires_grad
+        assert torch.equal(adjs[i], wp.adjoint(ref_wt, flips[i])), i
+        c_wt = torch.randn(wt.shape, generator=g).to(DEV)
+        c_sq = torch.randn(wsq.shape, generator=g).to(DEV)
+        cots.append((c_wt, c_sq))
+        if i != 2:                                             # layer 2 receives no cotangent at all
+            loss = loss + (wt * c_wt).sum()
+            if meta[i][1] and i != 4:                          # layer 4: only the tap-major cotangent
+                loss = loss + (wsq * c_sq).sum()
+    grads = torch.autograd.grad(loss, ws, allow_unused=True)
+    for i, w in enumerate(ws):
+        if i == 2:
+            assert grads[i] is None
+            continue
+        ref_wt, ref_wsq = wp.weight_prep(w, meta[i][0], meta[i][1])
+        ref_loss = (ref_wt * cots[i][0]).sum()
+        if meta[i][1] and i != 4:
+            ref_loss = ref_loss + (ref_wsq * cots[i][1]).sum()
+        (ref,) = torch.autograd.grad(ref_loss, w)
+        assert torch.equal(grads[i], ref), i
+
+
+def _grads(net, loss_of, create_graph=False):
+    for p in net.parameters():
+        p.grad = None
+    loss_of().backward()
+    return [None if p.grad is None else p.grad.clone() for p in net.parameters()]
+
+
+@pytest.mark.parametrize("which", ["generator", "discriminator"])
+def test_network_passes_with_and_without_the_bank_are_bit_identical(which, monkeypatch):
+    from stylerenderer_amd import model
+    from stylerenderer_amd.op import weight_bank as wb
+
+    torch.manual_seed(0)
+    if which == "generator":
+        net = model.Generator(64, 64, 2).to(DEV)
+        z = torch.randn(3, 64, device=DEV)
+        noise = [torch.randn(3, 1, 2 ** (2 + (i + 1) // 2), 2 ** (2 + (i + 1) // 2), device=DEV) for i in range(net.num_layers)]
+
+        def run():
+            img, _ = net([z], noise=noise)
+            return img
+    else:
+        net = model.Discriminator(64).to(DEV)
+        x = torch.randn(4, 3, 64, 64, device=DEV).requires_grad_()
+
+        def run():
+            return net(x)
+
+    def first_order():
+        return run().square().mean()
+
+    def second_order():                      # R1-style: the backward is recorded and differentiated
+        inp = x if which == "discriminator" else net.input.input
+        (g,) = torch.autograd.grad(run().sum(), inp, create_graph=True)
+        return g.square().sum()
+
+    res = {}
+    for mode in ("1", "0", "1"):
+        monkeypatch.setenv("SR_WEIGHT_BANK", mode)
+        out = run().detach().clone()
+        res.setdefault(mode, []).append((out, _grads(net, first_order), _grads(net, second_order)))
+    assert getattr(net, "_bank_plan", None), "the first banked pass records the layers"
+    assert all(getattr(m, "_bank", None) is None for m in net.modules()), "entries are released with the scope"
+    (o1, g1, h1), (o0, g0, h0), (o2, g2, h2) = res["1"][0], res["0"][0], res["1"][1]
+    for a, b in ((o1, o0), (o2, o0)):
+        assert torch.equal(a, b)
+    for ga, gb in ((g1, g0), (g2, g0), (h1, h0), (h2, h0)):
+        for a, b in zip(ga, gb):
+            assert (a is None) == (b is None)
+            if a is not None:
+                assert torch.equal(a, b)
+    # the banked pass issues a handful of preparation launches, not one per layer
+    from torch.profiler import ProfilerActivity, profile
+    counts = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("SR_WEIGHT_BANK", mode)
+        first_order().backward()
+        torch.cuda.synchronize()
+        with profile(activities=[ProfilerActivity.CUDA]) as prof:
+            first_order().backward()
+            torch.cuda.synchronize()
+        names = [e.key for e in prof.key_averages() for _ in range(e.count)]
+        counts[mode] = sum(1 for n in names if "k_wprep" in n or "k_wadjoint" in n)
+    assert counts["1"] <= 3 * wb.n_groups() and counts["0"] >= 2 * counts["1"], counts
