@@ -199,15 +199,12 @@ int sr_weight_prep_bwd(float* gw, const float* gwt, const float* gwsq, const flo
 int sr_weight_adjoint(float* out, const float* in, int64_t taps, int64_t C, int64_t N, int64_t ldn,
                       int64_t ldc, int flip, sr_stream_t stream);
 
-/* Batched forms: n layers per call, per-layer arguments as host arrays (pointers to device tensors, shapes); one launch
- * per 48 layers instead of one per layer — a training iteration at 4 images per GPU prepares ~290 weights, each a
- * 5 us launch (stylerenderer_amd/op/weight_bank.py).  Same arithmetic per element as the single-layer entry points:
- * results are bit-identical.  wsq[i] / gwt[i] / gwsq[i] may be NULL as in the single forms. */
+/* Batched forms of the two preparations a forward pass needs: n layers per call, per-layer arguments as host arrays
+ * (pointers to device tensors, shapes); one launch per 48 layers instead of one per layer — a training iteration at 4
+ * images per GPU prepares ~230 weights in its forward passes, each a 5 us launch (stylerenderer_amd/op/weight_bank.py).
+ * Same arithmetic per element as the single-layer entry points: results are bit-identical.  wsq[i] may be NULL. */
 int sr_weight_prep_batch(int n, float* const* wt, float* const* wsq, const float* const* w, const float* scale,
                          const int64_t* Co, const int64_t* Ci, const int* ksize, const int64_t* ld, sr_stream_t stream);
-int sr_weight_prep_bwd_batch(int n, float* const* gw, const float* const* gwt, const float* const* gwsq,
-                             const float* const* w, const float* scale, const int64_t* Co, const int64_t* Ci,
-                             const int* ksize, const int64_t* ldg, sr_stream_t stream);
 int sr_weight_adjoint_batch(int n, float* const* out, const float* const* in, const int64_t* taps, const int64_t* C,
                             const int64_t* N, const int64_t* ldn, const int64_t* ldc, const int* flip,
                             sr_stream_t stream);

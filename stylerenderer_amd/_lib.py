@@ -52,7 +52,6 @@ SIGNATURES = {
     "sr_weight_prep_bwd": (_i, [_p, _p, _p, _p, _f, _l, _l, _i, _l, _p]),
     "sr_weight_adjoint": (_i, [_p, _p, _l, _l, _l, _l, _l, _i, _p]),
     "sr_weight_prep_batch": (_i, [_i] + [_p] * 9),
-    "sr_weight_prep_bwd_batch": (_i, [_i] + [_p] * 10),
     "sr_weight_adjoint_batch": (_i, [_i] + [_p] * 9),
     "sr_upfirdn2d": (_i, [_p, _p, _p, _l] + [_i] * 14 + [_p]),
     "sr_upsample2_add": (_i, [_p] * 4 + [_l] + [_i] * 6 + [_p]),

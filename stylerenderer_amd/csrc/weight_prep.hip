@@ -103,9 +103,9 @@ __global__ __launch_bounds__(256) void k_wadjoint(float* __restrict__ out, const
 
 
 // ---- batched forms: every layer of a network in ONE launch ---------------------------------------------------------
-// A training iteration at the reference's per-GPU batch prepares ~290 weights (k_wprep + k_wadjoint + k_wprep_bwd per
-// convolution and phase), each a 5 us launch on a tensor of a few hundred KB: launch count, not bytes.  The batched
-// kernels take the per-layer pointers and shapes BY VALUE in the kernel argument (<= SR_WB_MAX items, 2.3 KB; no
+// A training iteration at the reference's per-GPU batch prepares ~230 weights in its forward passes (k_wprep +
+// k_wadjoint per convolution and phase), each a 5 us launch on a tensor of a few hundred KB: launch count, not bytes.
+// The batched kernels take the per-layer pointers and shapes BY VALUE in the kernel argument (<= SR_WB_MAX items, 2.3 KB; no
 // device-side table to keep alive, graph capture bakes them in) and map a flat workgroup index to (item, tile).
 constexpr int SR_WB_MAX = 48;
 
@@ -155,63 +155,6 @@ __global__ __launch_bounds__(256) void k_wprep_batch(const WPrepBatch b) {
     const int gx = (b.ld[it] + 63) / 64;
     if (b.kk[it] == 9) wprep_tile<9>(b.wt[it], b.wsq[it], b.w[it], b.scale[it], b.co[it], b.ci[it], b.ld[it], local % gx, local / gx);
     else wprep_tile<1>(b.wt[it], b.wsq[it], b.w[it], b.scale[it], b.co[it], b.ci[it], b.ld[it], local % gx, local / gx);
-}
-
-struct WPrepBwdBatch {
-    float* gw[SR_WB_MAX];
-    const float* gwt[SR_WB_MAX];
-    const float* gwsq[SR_WB_MAX];
-    const float* w[SR_WB_MAX];
-    float scale[SR_WB_MAX];
-    int co[SR_WB_MAX], ci[SR_WB_MAX], ldg[SR_WB_MAX], kk[SR_WB_MAX];
-    int first[SR_WB_MAX + 1];
-    int n;
-};
-
-template <int KK>
-__device__ __forceinline__ void wprep_bwd_tile(float (*tile)[16 * 9 + 1], float* __restrict__ gw,
-                                               const float* __restrict__ gwt, const float* __restrict__ gwsq,
-                                               const float* __restrict__ w, float scale, int Co, int Ci, int ldg,
-                                               int bx, int by) {
-    const int co0 = bx * 16, ci0 = by * 16;
-    const int row_floats = 16 * KK;
-    if (gwsq) {
-        for (int e = threadIdx.x; e < 16 * row_floats; e += 256) {
-            const int r = e / row_floats, q = e % row_floats;
-            const int co = co0 + r, ci = ci0 + q / KK;
-            tile[r][q] = (co < Co && ci < Ci) ? w[((int64_t)co * Ci + ci0) * KK + q] : 0.0f;
-        }
-        __syncthreads();
-    }
-    const int lco = threadIdx.x & 15, lci = threadIdx.x >> 4;
-    const int co = co0 + lco, ci = ci0 + lci;
-    const bool ok = co < Co && ci < Ci;
-    const float q2 = (gwsq && ok) ? 2.0f * scale * scale * gwsq[(int64_t)ci * Co + co] : 0.0f;
-#pragma unroll
-    for (int t = 0; t < KK; ++t) {
-        float g = (gwt && ok) ? scale * gwt[((int64_t)t * Ci + ci) * ldg + co] : 0.0f;
-        if (gwsq) g += q2 * tile[lco][lci * KK + t];
-        tile[lco][lci * KK + t] = g;
-    }
-    __syncthreads();
-    for (int e = threadIdx.x; e < 16 * row_floats; e += 256) {
-        const int r = e / row_floats, q = e % row_floats;
-        const int oco = co0 + r, oci = ci0 + q / KK;
-        if (oco < Co && oci < Ci) gw[((int64_t)oco * Ci + ci0) * KK + q] = tile[r][q];
-    }
-}
-
-__global__ __launch_bounds__(256) void k_wprep_bwd_batch(const WPrepBwdBatch b) {
-    __shared__ float tile[16][16 * 9 + 1];
-    const int it = wb_item(b.first, b.n, blockIdx.x);
-    const int local = blockIdx.x - b.first[it];
-    const int gx = (b.co[it] + 15) / 16;
-    if (b.kk[it] == 9)
-        wprep_bwd_tile<9>(tile, b.gw[it], b.gwt[it], b.gwsq[it], b.w[it], b.scale[it], b.co[it], b.ci[it], b.ldg[it],
-                          local % gx, local / gx);
-    else
-        wprep_bwd_tile<1>(tile, b.gw[it], b.gwt[it], b.gwsq[it], b.w[it], b.scale[it], b.co[it], b.ci[it], b.ldg[it],
-                          local % gx, local / gx);
 }
 
 struct WAdjBatch {
@@ -317,33 +260,6 @@ extern "C" int sr_weight_prep_batch(int n, float* const* wt, float* const* wsq, 
         }
         b.first[b.n] = (int)total;
         if (total > 0) hipLaunchKernelGGL(k_wprep_batch, dim3((unsigned)total), dim3(256), 0, st, b);
-    }
-    return sr_launch_status();
-}
-
-extern "C" int sr_weight_prep_bwd_batch(int n, float* const* gw, const float* const* gwt, const float* const* gwsq,
-                                        const float* const* w, const float* scale, const int64_t* Co,
-                                        const int64_t* Ci, const int* ksize, const int64_t* ldg, sr_stream_t stream) {
-    if (n < 0 || (n > 0 && (!gw || !gwt || !gwsq || !w || !scale || !Co || !Ci || !ksize || !ldg))) return SR_EINVAL;
-    hipStream_t st = sr_stream(stream);
-    for (int base = 0; base < n; base += SR_WB_MAX) {
-        WPrepBwdBatch b;
-        b.n = n - base < SR_WB_MAX ? n - base : SR_WB_MAX;
-        int64_t total = 0;
-        for (int i = 0; i < b.n; ++i) {
-            const int g = base + i;
-            if (Co[g] <= 0 || Ci[g] <= 0 || !gw[g] || (!gwt[g] && !gwsq[g]) || (gwsq[g] && !w[g]) ||
-                (gwt[g] && ldg[g] < Co[g]) || (ksize[g] != 1 && ksize[g] != 3))
-                return SR_EINVAL;
-            if (Co[g] > (1 << 20) || Ci[g] > (1 << 20)) return SR_ERANGE;
-            b.gw[i] = gw[g]; b.gwt[i] = gwt[g]; b.gwsq[i] = gwsq[g]; b.w[i] = w[g]; b.scale[i] = scale[g];
-            b.co[i] = (int)Co[g]; b.ci[i] = (int)Ci[g]; b.ldg[i] = (int)ldg[g]; b.kk[i] = ksize[g] * ksize[g];
-            b.first[i] = (int)total;
-            total += sr_ceil_div(Co[g], 16) * sr_ceil_div(Ci[g], 16);
-            if (total > 0x7FFFFFFFLL) return SR_ERANGE;
-        }
-        b.first[b.n] = (int)total;
-        if (total > 0) hipLaunchKernelGGL(k_wprep_bwd_batch, dim3((unsigned)total), dim3(256), 0, st, b);
     }
     return sr_launch_status();
 }

@@ -127,8 +127,9 @@ def adjoint_weight(wt, geom, frozen=False, banked=None):
     """Weights of the data-gradient convolution: channels swapped; taps reversed for the
     stride-1 3x3 correlation (the strided pair c3s2 <-> t3s2 keeps tap order).  `frozen`: the prepared weight
     belongs to a module frozen with op.weight_prep.freeze_prepared_weights — its adjoint is computed once.
-    `banked`: (flip, adjoint) prepared together with `wt` by op.weight_bank for all layers of the pass."""
-    if banked is not None and banked[0] == (geom == "c3"):
+    `banked`: (flip, adjoint) prepared together with `wt` by op.weight_bank for all layers of the pass — plain data,
+    used when this backward is not itself being recorded (a recorded one needs the adjoint as a function of `wt`)."""
+    if banked is not None and banked[0] == (geom == "c3") and not torch.is_grad_enabled():
         return banked[1]
     if frozen and not wt.requires_grad and not torch.is_grad_enabled():
         return _wp.adjoint_cached(wt, geom == "c3")

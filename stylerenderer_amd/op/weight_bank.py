@@ -1,26 +1,29 @@
-"""Every convolution weight of a network prepared by a handful of launches per pass.
+"""Every convolution weight of a network prepared by one or two launches per forward pass.
 
-Per convolution and pass the MFMA path needs the tap-major scaled weights (+ the demodulation matrix) — `k_wprep` —, for
-the data gradient their channel-transposed (tap-reversed) adjoint — `k_wadjoint` — and, in the backward, the pull-back
-of both cotangents onto the parameter — `k_wprep_bwd` (op/weight_prep.py).  Each is a ~5 us launch on a few hundred KB,
-and a training iteration at the reference's per-GPU batch (4 images: BASELINE config[2]) issues ~290 of them: launch
-count, not bytes.  None depends on activations, only on the parameters, so a network's forward opens a SCOPE that
-prepares all of its convolutions up front:
+Per convolution and pass the MFMA path needs the tap-major scaled weights (+ the demodulation matrix) — `k_wprep` — and,
+for the data gradient, their channel-transposed (tap-reversed) adjoint — `k_wadjoint` (op/weight_prep.py).  Each is a
+~5 us launch on a few hundred KB, and a training iteration at the reference's per-GPU batch (4 images: BASELINE
+config[2]) issues ~230 of them in its forward passes: launch count, not bytes.  Neither depends on activations, only on
+the parameters, so a network's forward opens a SCOPE that prepares all of its convolutions up front:
 
-    first pass of a network   runs layer by layer and records which modules asked for prepared weights, in call order
-    every later pass          SR_WEIGHT_BANK_GROUPS (4) groups of consecutive layers; per group ONE batched `k_wprep`
-                              launch, ONE batched `k_wadjoint` launch when gradients are recorded, and in the backward
-                              ONE batched `k_wprep_bwd` launch (C ABI sr_weight_prep_batch / _adjoint_batch / _bwd_batch:
+    first pass of a network   runs layer by layer and records which modules asked for prepared weights
+    every later pass          ONE batched `k_wprep` launch for all recorded layers and, when gradients are recorded, ONE
+                              batched `k_wadjoint` launch (C ABI sr_weight_prep_batch / sr_weight_adjoint_batch:
                               per-layer pointers by value in the kernel argument; same arithmetic per element, so the
                               results are bit-identical to the per-layer launches)
 
-Groups, not one launch for the whole network: a group's backward node runs when the LAST of its layers has produced
-its weight gradient.  With a single node every convolution weight of the network — most of the gradient bytes — would
-reach the parameters only at the very end of the backward, and the bucketed all-reduce that overlaps the backward
-(distributed.BucketedGradReducer) would have nothing to send until then.  Groups of consecutive layers keep the
-arrival order of the buckets.
+The batched launches are plain data producers (no autograd node).  A layer that picks its entry up gets it through
+`_WPrepUse`, a per-layer node created AT THE POINT OF USE whose forward returns the prepared tensors and whose backward is
+the layer's own `k_wprep_bwd` pull-back — exactly the node `weight_prep` would have recorded.  (A batched backward node
+was measured and dropped: autograd runs ready nodes in reverse creation order, a node created at the start of the
+forward therefore runs at the very END of the backward, and every convolution weight gradient — most of the gradient
+bytes — reached the parameters only then: the bucketed all-reduce that overlaps the backward,
+distributed.BucketedGradReducer, had nothing to send until the replay was over.)
 
-Layers pick their entry up through `weight_prep.weight_prep_cached`; `ConvFn` finds the adjoint on the prepared tensor.
+The banked adjoint is data too: `ConvFn.backward` uses it when the backward is NOT being recorded, and re-derives the
+adjoint differentiably from `wt` when it is (R1, path-length regulariser: the gradient with respect to the weights
+flows through the data-gradient convolution's weights).
+
 Modules frozen with `freeze_prepared_weights` keep their version-keyed cache.  SR_WEIGHT_BANK=0 disables the scope.
 CPU tensors never take this path.
 """
@@ -41,10 +44,6 @@ def enabled():
     return os.environ.get("SR_WEIGHT_BANK", "1") != "0"
 
 
-def n_groups():
-    return max(1, int(os.environ.get("SR_WEIGHT_BANK_GROUPS", "4")))
-
-
 def _arr(ctype, vals):
     return (ctype * len(vals))(*vals)
 
@@ -57,112 +56,79 @@ def _pitch(n):
     return (n + 3) // 4 * 4
 
 
-class _WPrepBatch(Function):
-    """weights [Co, Ci, k, k] x n -> (wt_0, wsq_0, wt_1, wsq_1, ...) carved from one buffer."""
+def prep_batch(weights, scales, want_sqs):
+    """[(wt [k*k, Ci, Co] view of the padded buffer, wsq [Ci, Co] | None)] for n weights [Co, Ci, k, k]: one launch."""
+    dims = [_wp._as3(w) for w in weights]
+    ws = [w.detach().contiguous() for w in weights]
+    lds = [_pitch(co) for co, _, _ in dims]
+    sizes = [(k * k * ci * ld, _pitch(ci * co) if sq else 0) for (co, ci, k), ld, sq in zip(dims, lds, want_sqs)]
+    store = torch.empty(sum(a + b for a, b in sizes), dtype=ws[0].dtype, device=ws[0].device)
+    wts, wsqs, outs, off = [], [], [], 0
+    for (co, ci, k), ld, (a, b), sq in zip(dims, lds, sizes, want_sqs):
+        wt = store[off:off + a].view(k * k, ci, ld)
+        wsq = store[off + a:off + a + ci * co].view(ci, co) if sq else None
+        off += a + b
+        wts.append(wt)
+        wsqs.append(wsq)
+        outs.append((wt if ld == co else wt[:, :, :co], wsq))
+    with on_device_of(store):
+        rc = _lib.lib().sr_weight_prep_batch(
+            len(ws), _ptrs(wts), _ptrs(wsqs), _ptrs(ws), _arr(ctypes.c_float, [float(s) for s in scales]),
+            _arr(ctypes.c_int64, [d[0] for d in dims]), _arr(ctypes.c_int64, [d[1] for d in dims]),
+            _arr(ctypes.c_int, [d[2] for d in dims]), _arr(ctypes.c_int64, lds), stream_of(store))
+    _lib.check(rc, "sr_weight_prep_batch")
+    return outs
+
+
+def adjoint_batch(wts, flips):
+    """[adjoint_i [taps, N, C]] of wt_i [taps, C, N] (taps reversed where flips[i]): one launch."""
+    srcs = []
+    for wt in wts:
+        taps, c, n = wt.shape
+        ok = wt.stride(2) == 1 and wt.stride(0) == c * wt.stride(1) and wt.stride(1) >= n
+        srcs.append(wt.detach() if ok else wt.detach().contiguous())
+    shapes = [tuple(wt.shape) for wt in wts]
+    ldcs = [_pitch(c) for _, c, _ in shapes]
+    sizes = [t * n * ldc for (t, _, n), ldc in zip(shapes, ldcs)]
+    store = torch.empty(sum(sizes), dtype=srcs[0].dtype, device=srcs[0].device)
+    full, outs, off = [], [], 0
+    for (t, c, n), ldc, m in zip(shapes, ldcs, sizes):
+        a = store[off:off + m].view(t, n, ldc)
+        off += m
+        full.append(a)
+        outs.append(a if ldc == c else a[:, :, :c])
+    with on_device_of(store):
+        rc = _lib.lib().sr_weight_adjoint_batch(
+            len(srcs), _ptrs(full), _ptrs(srcs), _arr(ctypes.c_int64, [s[0] for s in shapes]),
+            _arr(ctypes.c_int64, [s[1] for s in shapes]), _arr(ctypes.c_int64, [s[2] for s in shapes]),
+            _arr(ctypes.c_int64, [s.stride(1) for s in srcs]), _arr(ctypes.c_int64, ldcs),
+            _arr(ctypes.c_int, [int(bool(f)) for f in flips]), stream_of(store))
+    _lib.check(rc, "sr_weight_adjoint_batch")
+    return outs
+
+
+class _WPrepUse(Function):
+    """(weight, prepared wt, prepared wsq) -> (wt, wsq): the autograd node of weight_prep._WPrep around tensors that
+    the scope's batched launch has already filled."""
 
     @staticmethod
-    def forward(ctx, meta, *weights):
-        dims = [_wp._as3(w) for w in weights]
-        ws = [w.contiguous() for w in weights]
-        lds = [_pitch(co) for co, _, _ in dims]
-        sizes = []
-        for (co, ci, k), ld, (_, want_sq) in zip(dims, lds, meta):
-            sizes.append((k * k * ci * ld, _pitch(ci * co) if want_sq else 0))
-        store = torch.empty(sum(a + b for a, b in sizes), dtype=ws[0].dtype, device=ws[0].device)
-        wts, wsqs, outs, off = [], [], [], 0
-        for (co, ci, k), ld, (a, b), (_, want_sq) in zip(dims, lds, sizes, meta):
-            wt = store[off:off + a].view(k * k, ci, ld)
-            wsq = store[off + a:off + a + ci * co].view(ci, co) if want_sq else store.new_empty(0)
-            off += a + b
-            wts.append(wt)
-            wsqs.append(wsq)
-            outs += [wt if ld == co else wt[:, :, :co], wsq]
-        with on_device_of(store):
-            rc = _lib.lib().sr_weight_prep_batch(
-                len(ws), _ptrs(wts), _ptrs(wsqs), _ptrs(ws), _arr(ctypes.c_float, [float(s) for s, _ in meta]),
-                _arr(ctypes.c_int64, [d[0] for d in dims]), _arr(ctypes.c_int64, [d[1] for d in dims]),
-                _arr(ctypes.c_int, [d[2] for d in dims]), _arr(ctypes.c_int64, lds), stream_of(store))
-        _lib.check(rc, "sr_weight_prep_batch")
-        ctx.save_for_backward(*weights)
-        ctx.meta = meta
+    def forward(ctx, weight, wt, wsq, scale, want_sq):
+        ctx.save_for_backward(weight)
         ctx.set_materialize_grads(False)
-        ctx.mark_non_differentiable(*[q for q, (_, want_sq) in zip(wsqs, meta) if not want_sq])
-        return tuple(outs)
+        ctx.scale, ctx.want_sq = float(scale), bool(want_sq)
+        out_sq = wsq.detach() if want_sq else weight.new_empty(0)
+        if not want_sq:
+            ctx.mark_non_differentiable(out_sq)
+        return wt.detach(), out_sq
 
     @staticmethod
-    def backward(ctx, *grads):
-        weights = ctx.saved_tensors
-        n = len(weights)
-        gwts = [grads[2 * i] for i in range(n)]
-        gwsqs = [grads[2 * i + 1] if ctx.meta[i][1] else None for i in range(n)]
-        live = [i for i in range(n) if ctx.needs_input_grad[1 + i] and (gwts[i] is not None or gwsqs[i] is not None)]
-        out = [None] * n
-        if not live:
-            return (None,) + tuple(out)
-        if torch.is_grad_enabled():
-            # the backward itself is being recorded (path-length regulariser): per-layer differentiable nodes
-            for i in live:
-                out[i] = _wp._WPrepBwd.apply(gwts[i], gwsqs[i], weights[i], ctx.meta[i][0])
-            return (None,) + tuple(out)
-        dims = [_wp._as3(weights[i]) for i in live]
-        ws = [weights[i].contiguous() for i in live]
-        gts = [gwts[i].contiguous() if gwts[i] is not None else None for i in live]
-        gqs = [gwsqs[i].contiguous() if gwsqs[i] is not None else None for i in live]
-        numels = [_pitch(w.numel()) for w in ws]
-        store = torch.empty(sum(numels), dtype=ws[0].dtype, device=ws[0].device)
-        gws, off = [], 0
-        for w, m in zip(ws, numels):
-            gws.append(store[off:off + w.numel()].view(w.shape))
-            off += m
-        with on_device_of(store):
-            rc = _lib.lib().sr_weight_prep_bwd_batch(
-                len(ws), _ptrs(gws), _ptrs(gts), _ptrs(gqs), _ptrs(ws),
-                _arr(ctypes.c_float, [float(ctx.meta[i][0]) for i in live]),
-                _arr(ctypes.c_int64, [d[0] for d in dims]), _arr(ctypes.c_int64, [d[1] for d in dims]),
-                _arr(ctypes.c_int, [d[2] for d in dims]), _arr(ctypes.c_int64, [d[0] for d in dims]),
-                stream_of(store))
-        _lib.check(rc, "sr_weight_prep_bwd_batch")
-        for i, g in zip(live, gws):
-            out[i] = g.view(weights[i].shape)
-        return (None,) + tuple(out)
-
-
-class _AdjointBatch(Function):
-    """wt_i [taps, C, N] -> adjoint_i [taps, N, C] (taps reversed where flips[i]) for n layers in one launch."""
-
-    @staticmethod
-    def forward(ctx, flips, *wts):
-        srcs = []
-        for wt in wts:
-            taps, c, n = wt.shape
-            ok = wt.stride(2) == 1 and wt.stride(0) == c * wt.stride(1) and wt.stride(1) >= n
-            srcs.append(wt if ok else wt.contiguous())
-        shapes = [tuple(wt.shape) for wt in wts]
-        ldcs = [_pitch(c) for _, c, _ in shapes]
-        sizes = [t * n * ldc for (t, _, n), ldc in zip(shapes, ldcs)]
-        store = torch.empty(sum(sizes), dtype=wts[0].dtype, device=wts[0].device)
-        full, outs, off = [], [], 0
-        for (t, c, n), ldc, m in zip(shapes, ldcs, sizes):
-            a = store[off:off + m].view(t, n, ldc)
-            off += m
-            full.append(a)
-            outs.append(a if ldc == c else a[:, :, :c])
-        with on_device_of(store):
-            rc = _lib.lib().sr_weight_adjoint_batch(
-                len(wts), _ptrs(full), _ptrs(srcs), _arr(ctypes.c_int64, [s[0] for s in shapes]),
-                _arr(ctypes.c_int64, [s[1] for s in shapes]), _arr(ctypes.c_int64, [s[2] for s in shapes]),
-                _arr(ctypes.c_int64, [s.stride(1) for s in srcs]), _arr(ctypes.c_int64, ldcs),
-                _arr(ctypes.c_int, [int(bool(f)) for f in flips]), stream_of(store))
-        _lib.check(rc, "sr_weight_adjoint_batch")
-        ctx.flips = flips
-        ctx.set_materialize_grads(False)
-        return tuple(outs)
-
-    @staticmethod
-    def backward(ctx, *grads):
-        # reached only when a data-gradient convolution is itself differentiated with respect to its weights
-        # (second-order passes): the permutation is its own inverse
-        return (None,) + tuple(None if g is None else _wp.adjoint(g, f) for g, f in zip(grads, ctx.flips))
+    def backward(ctx, gwt, gwsq):
+        (weight,) = ctx.saved_tensors
+        if not ctx.want_sq:
+            gwsq = None
+        if gwt is None and gwsq is None:
+            return None, None, None, None, None
+        return _wp._WPrepBwd.apply(gwt, gwsq, weight, ctx.scale), None, None, None, None
 
 
 def _flip_of(module):
@@ -202,28 +168,14 @@ class Scope:
                 and m.weight.dtype == torch.float32]
         if not live:
             return self
-        want_adj = torch.is_grad_enabled()
-        g = min(n_groups(), len(live))
-        total = sum(m.weight.numel() for m, _ in live)
-        groups, cur, acc = [], [], 0
-        for m, sq in live:                                   # consecutive layers, ~equal bytes per group
-            cur.append((m, sq))
-            acc += m.weight.numel()
-            if acc * g >= total * (len(groups) + 1) and len(groups) < g - 1:
-                groups.append(cur)
-                cur = []
-        if cur:
-            groups.append(cur)
-        for grp in groups:
-            meta = tuple((float(m.scale), sq) for m, sq in grp)
-            outs = _WPrepBatch.apply(meta, *[m.weight for m, _ in grp])
-            wts = [outs[2 * i] for i in range(len(grp))]
-            adjs = [None] * len(grp)
-            if want_adj:
-                adjs = _AdjointBatch.apply(tuple(_flip_of(m) for m, _ in grp), *wts)
-            for i, (m, sq) in enumerate(grp):
-                m._bank = (wts[i], outs[2 * i + 1] if sq else None, None if adjs[i] is None else (_flip_of(m), adjs[i]))
-                self.filled.append(m)
+        outs = prep_batch([m.weight for m, _ in live], [m.scale for m, _ in live], [sq for _, sq in live])
+        adjs = [None] * len(live)
+        if torch.is_grad_enabled():
+            flips = [_flip_of(m) for m, _ in live]
+            adjs = list(zip(flips, adjoint_batch([wt for wt, _ in outs], flips)))
+        for (m, _), (wt, wsq), adj in zip(live, outs, adjs):
+            m._bank = (wt, wsq, adj)
+            self.filled.append(m)
         return self
 
     def __exit__(self, *exc):
@@ -246,11 +198,15 @@ class Scope:
 
 
 def lookup(module, want_sq):
-    """The scope's entry for `module`: (wt, wsq) with the adjoint attached to wt, or None."""
+    """The scope's entry for `module` as (wt, wsq) behind the layer's own autograd node, the banked adjoint attached
+    to wt; None when the scope holds nothing usable for this request."""
     hit = getattr(module, "_bank", None)
     if hit is None or (want_sq and hit[1] is None):
         return None
     wt, wsq, adj = hit
+    weight = module.weight
+    if weight.requires_grad and torch.is_grad_enabled():
+        wt, wsq = _WPrepUse.apply(weight, wt, wsq, module.scale, want_sq)
     if adj is not None:
         wt._sr_adj = adj
     return wt, (wsq if want_sq else None)
