@@ -26,6 +26,7 @@
 //     the fetch (each slot of four MFMAs refills the registers it has just read), so no MFMA ever waits for an
 //     LDS round trip behind the (one per sub-chunk) barrier.  Body j: MFMAs of sub-chunk j-1 | fetch sub-chunk j | transform sub-chunk j+1
 //     | (odd j) DMA of strip (j+1)/2 + 1.
+#include <cstdlib>
 #include <type_traits>
 #include "common.h"
 #include "conv_wino.h"
@@ -42,14 +43,21 @@ constexpr int G_INSTR = 64 * GS / 64;       // 9
 constexpr int X_FLOATS = X_INSTR * 256 + 4; // 6404: the image starts one float in (see above)
 constexpr int G_FLOATS = G_INSTR * 256;     // 2304
 constexpr int RAW = X_FLOATS + G_FLOATS;    // 8708 floats = 34 KB per strip
-constexpr int OB = 4096;                    // floats of one operand (V or Z) of a sub-chunk: [8][2][2][64][2]
+constexpr int OB = 4096;                    // floats of one operand (V or Z) of a sub-chunk: [4][2][2][64][4]
 constexpr int OBUF = 2 * OB;                // V then Z
-constexpr int PAD = 4 * 256;                // landing zone of the surplus DMA instructions (never read)
-constexpr int X_PER_WAVE = (X_INSTR + 3) / 4;   // 7
-constexpr int G_PER_WAVE = (G_INSTR + 3) / 4;   // 3
-constexpr int N_DMA = X_PER_WAVE + G_PER_WAVE;  // 10 per wave and strip
 constexpr int MAX_B = 32;                   // scale tables [B][64] x 2 in LDS
 constexpr int OOB = 0x7FFFFFF0;             // buffer offset beyond every tensor: the load returns zeros
+// NW waves per workgroup (4: one per SIMD, 8: two per SIMD, see k_wgrad_wino): DMA instructions per wave and strip,
+// landing zone of the surplus ones (never read)
+template <int NW>
+struct WgW {
+    static constexpr int PAD = NW * 256;
+    static constexpr int X_PER_WAVE = (X_INSTR + NW - 1) / NW;   // 7 | 4
+    static constexpr int G_PER_WAVE = (G_INSTR + NW - 1) / NW;   // 3 | 2
+    static constexpr int N_DMA = X_PER_WAVE + G_PER_WAVE;        // 10 | 6
+    static constexpr int NPOS = 64 / NW;                         // positions per wave: 16 | 8
+    static constexpr int LDS_FLOATS = 2 * RAW + 2 * OBUF + PAD + 2 * MAX_B * 64;
+};
 
 #ifdef WGW_TIMING
 // debug build only (scripts/build_variant.sh): per-workgroup time stamps of wave 0
@@ -70,13 +78,22 @@ struct WgWinoParams {
     int cty, ctx;            // strip grid per sample: H/2 x W/16
 };
 
-__global__ __launch_bounds__(256) void k_wgrad_wino(const WgWinoParams p) {
+// NW = 8 (two waves per SIMD): wave w < 4 owns positions 0..7 of its 32 x 32 (channel, output) block and transforms the
+// INPUT tile (w, lane) of every sub-chunk, wave w + 4 positions 8..15 and the OUTPUT-GRADIENT tile — the same slot
+// schedule with half the MFMAs, operand fetches, transform work and DMA instructions per wave, so that on every SIMD the
+// vector / LDS / DMA instructions of one wave are issued while an MFMA of the other is executing
+// (scripts/mfma_valu_probe.cpp: a second wave's vector instructions cost the MFMA wave nothing, the same instructions in
+// the MFMA wave's own stream ~10 cycles each).  Same transforms, same MFMA chain per accumulator: bit-identical slabs.
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void k_wgrad_wino(const WgWinoParams p) {
 #if __HIP_DEVICE_COMPILE__   // buffer-resource builtins: device pass only (the host pass needs just the stub)
+    using K = WgW<NW>;
+    constexpr int X_PER_WAVE = K::X_PER_WAVE, G_PER_WAVE = K::G_PER_WAVE, N_DMA = K::N_DMA, NPOS = K::NPOS;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* const raw = smem;                          // [2][RAW]
     float* const obuf = smem + 2 * RAW;               // [2][OBUF]
     float* const pad = obuf + 2 * OBUF;
-    float* const tabx = pad + PAD;                    // [B][64] style of this channel block
+    float* const tabx = pad + K::PAD;                 // [B][64] style of this channel block
     float* const tabg = tabx + MAX_B * 64;            // [B][64] demodulation of this output block
 
     const int nwg = gridDim.x;
@@ -97,7 +114,8 @@ __global__ __launch_bounds__(256) void k_wgrad_wino(const WgWinoParams p) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = lane >> 5, l31 = lane & 31;
-    const int wc = wave >> 1, wn = wave & 1;
+    const int ph = wave >> 2, wq = wave & 3;          // position half (NW = 8); tile of this wave's transform item
+    const int wc = wq >> 1, wn = wq & 1;
     WGW_STAMP(0);
 #ifdef WGW_TIMING
     const long long wgw_c0 = clock64();
@@ -115,19 +133,19 @@ __global__ __launch_bounds__(256) void k_wgrad_wino(const WgWinoParams p) {
     int xd[X_PER_WAVE];                      // byte offset (a multiple of 16) | flags
 #pragma unroll
     for (int i = 0; i < X_PER_WAVE; ++i) {
-        const int s = 64 * (wave + 4 * i) + lane;
+        const int s = 64 * (wave + NW * i) + lane;
         const int c = s / XS, rem = s % XS;
         const int r = rem / 6, q = rem % 6;
-        const bool payload = wave + 4 * i < X_INSTR && rem < XS - 1;
+        const bool payload = wave + NW * i < X_INSTR && rem < XS - 1;
         xd[i] = payload ? (((c * p.H + r) * p.W + 4 * q) * 4) | (r == 0 ? 1 : 0) | (r == 3 ? 2 : 0) | (q == 0 ? 4 : 0) | (q == 5 ? 8 : 0)
                         : OOB;
     }
     int gd_off[G_PER_WAVE];
 #pragma unroll
     for (int i = 0; i < G_PER_WAVE; ++i) {
-        const int s = 64 * (wave + 4 * i) + lane;
+        const int s = 64 * (wave + NW * i) + lane;
         const int n = s / GS, rem = s % GS;
-        gd_off[i] = (wave + 4 * i < G_INSTR && rem < GS - 1) ? ((n * p.H + rem / 4) * p.W + 4 * (rem % 4)) * 4 : OOB;
+        gd_off[i] = (wave + NW * i < G_INSTR && rem < GS - 1) ? ((n * p.H + rem / 4) * p.W + 4 * (rem % 4)) * 4 : OOB;
     }
     const int plane = p.H * p.W;
     // x descriptor starts W + 4 floats in front of the tensor: strip offsets stay non-negative
@@ -155,18 +173,18 @@ __global__ __launch_bounds__(256) void k_wgrad_wino(const WgWinoParams p) {
         if (i < X_PER_WAVE) {
             const int off = (xd[i] & d_edge) ? OOB : (xd[i] & ~15);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(
-                r_x, (lptr_t)(wave + 4 * i < X_INSTR ? d_dst + 1 + (wave + 4 * i) * 256 : pad + wave * 256), 16, off, d_xs, 0, 0);
+                r_x, (lptr_t)(wave + NW * i < X_INSTR ? d_dst + 1 + (wave + NW * i) * 256 : pad + wave * 256), 16, off, d_xs, 0, 0);
         } else {
             const int g = i - X_PER_WAVE;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(
-                r_g, (lptr_t)(wave + 4 * g < G_INSTR ? d_dst + X_FLOATS + (wave + 4 * g) * 256 : pad + wave * 256), 16,
+                r_g, (lptr_t)(wave + NW * g < G_INSTR ? d_dst + X_FLOATS + (wave + NW * g) * 256 : pad + wave * 256), 16,
                 gd_off[g], d_gs, 0, 0);
         }
     };
 
-    f32x16 acc[16];
+    f32x16 acc[NPOS];
 #pragma unroll
-    for (int pos = 0; pos < 16; ++pos)
+    for (int pos = 0; pos < NPOS; ++pos)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[pos][r] = 0.0f;
 
@@ -174,6 +192,14 @@ __global__ __launch_bounds__(256) void k_wgrad_wino(const WgWinoParams p) {
     typedef float f2 __attribute__((ext_vector_type(2)));
     auto ld2 = [](const float* q) { return *reinterpret_cast<const f2*>(q); };
     auto st2 = [](float* q, f2 v) { *reinterpret_cast<f2*>(q) = v; };
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    auto ld4 = [](const float* q) { return *reinterpret_cast<const f4*>(q); };
+    auto st4 = [](float* q, f2 lo, f2 hi) {        // one ds_write_b128: positions (4q .. 4q + 3) of a (k, channel)
+        f4 v;
+        v.x = lo.x; v.y = lo.y; v.z = hi.x; v.w = hi.y;
+        *reinterpret_cast<f4*>(q) = v;
+    };
+    (void)st2;
     auto pk_mul = [](f2 a, f2 b) { f2 r; asm("v_pk_mul_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; };
     auto pk_add = [](f2 a, f2 b) { f2 r; asm("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; };
     auto pk_sub = [](f2 a, f2 b) {
@@ -232,8 +258,10 @@ __global__ __launch_bounds__(256) void k_wgrad_wino(const WgWinoParams p) {
     c01.x = 0.0f; c01.y = 1.0f;
     c10.x = 1.0f; c10.y = 0.0f;
 
-    // ---- transform item of this thread in a sub-chunk: tile = wave (k pair wave >> 1, k parity wave & 1),
-    // channel = lane.  Seven steps, pinned one per MFMA slot inside the loop.
+    // ---- transform item of this thread in a sub-chunk: tile = wq (k pair wq >> 1, k parity wq & 1), channel = lane.
+    // Eight steps, pinned one per MFMA slot inside the loop.  NW = 4: every thread transforms the input tile AND the
+    // output-gradient tile; NW = 8: waves 0..3 the input tile, waves 4..7 the output-gradient tile (uniform branches).
+    const bool do_v = NW == 4 || ph == 0, do_z = NW == 4 || ph == 1;
     struct XF {
         f2 P[4], Q[4], g0, g1;            // raw: tile rows (columns 0,1 | 2,3), gradient rows
         f2 sp1, sp2, sq1, sq2;            // s * rows 1, 2
@@ -243,72 +271,92 @@ __global__ __launch_bounds__(256) void k_wgrad_wino(const WgWinoParams p) {
         f2 z01[4], z23[4];
         f2 sv, gv;                        // style / demodulation of this (sample, channel), both halves
     };
-    const int t_wr = (wave >> 1) * 256 + (wave & 1) * 128 + lane * 2;
+    const int t_wr = (wq >> 1) * 512 + (wq & 1) * 256 + lane * 4;
     auto xf_step = [&](XF& x, int step, const float* rw, int hsel, int b_smp, float* ob) {
         // rw: strip image; hsel: which half of the strip (tiles 4 hsel + wave); ob: operand buffer written
-        const float* xr = rw + 1 + lane * (XS * 4) + 3 + 2 * (4 * hsel + wave);
-        const float* gr = rw + X_FLOATS + lane * (GS * 4) + 2 * (4 * hsel + wave);
+        const float* xr = rw + 1 + lane * (XS * 4) + 3 + 2 * (4 * hsel + wq);
+        const float* gr = rw + X_FLOATS + lane * (GS * 4) + 2 * (4 * hsel + wq);
         if (step == 0) {
-            x.P[0] = ld2(xr); x.Q[0] = ld2(xr + 2);
-            x.P[1] = ld2(xr + 24); x.Q[1] = ld2(xr + 26);
-            const float sx = tabx[b_smp * 64 + lane], sg = tabg[b_smp * 64 + lane];
-            x.sv.x = x.sv.y = sx;
-            x.gv.x = x.gv.y = sg;
+            if (do_v) {
+                x.P[0] = ld2(xr); x.Q[0] = ld2(xr + 2);
+                x.P[1] = ld2(xr + 24); x.Q[1] = ld2(xr + 26);
+                const float sx = tabx[b_smp * 64 + lane];
+                x.sv.x = x.sv.y = sx;
+            }
+            if (do_z) {
+                const float sg = tabg[b_smp * 64 + lane];
+                x.gv.x = x.gv.y = sg;
+            }
         } else if (step == 1) {
-            x.P[2] = ld2(xr + 48); x.Q[2] = ld2(xr + 50);
-            x.P[3] = ld2(xr + 72); x.Q[3] = ld2(xr + 74);
-            x.g0 = ld2(gr);
-            x.g1 = ld2(gr + 16);
+            if (do_v) {
+                x.P[2] = ld2(xr + 48); x.Q[2] = ld2(xr + 50);
+                x.P[3] = ld2(xr + 72); x.Q[3] = ld2(xr + 74);
+            }
+            if (do_z) {
+                x.g0 = ld2(gr);
+                x.g1 = ld2(gr + 16);
+            }
         } else if (step == 2) {
-            x.sp1 = pk_mul(x.P[1], x.sv); x.sp2 = pk_mul(x.P[2], x.sv);
-            x.sq1 = pk_mul(x.Q[1], x.sv); x.sq2 = pk_mul(x.Q[2], x.sv);
-            x.tp[0] = pk_fms(x.P[0], x.sv, x.sp2); x.tq[0] = pk_fms(x.Q[0], x.sv, x.sq2);
+            if (do_v) {
+                x.sp1 = pk_mul(x.P[1], x.sv); x.sp2 = pk_mul(x.P[2], x.sv);
+                x.sq1 = pk_mul(x.Q[1], x.sv); x.sq2 = pk_mul(x.Q[2], x.sv);
+                x.tp[0] = pk_fms(x.P[0], x.sv, x.sp2); x.tq[0] = pk_fms(x.Q[0], x.sv, x.sq2);
+            }
         } else if (step == 3) {
-            x.tp[1] = pk_add(x.sp1, x.sp2); x.tq[1] = pk_add(x.sq1, x.sq2);
-            x.tp[2] = pk_sub(x.sp2, x.sp1); x.tq[2] = pk_sub(x.sq2, x.sq1);
-            x.tp[3] = pk_fnma(x.P[3], x.sv, x.sp1); x.tq[3] = pk_fnma(x.Q[3], x.sv, x.sq1);
+            if (do_v) {
+                x.tp[1] = pk_add(x.sp1, x.sp2); x.tq[1] = pk_add(x.sq1, x.sq2);
+                x.tp[2] = pk_sub(x.sp2, x.sp1); x.tq[2] = pk_sub(x.sq2, x.sq1);
+                x.tp[3] = pk_fnma(x.P[3], x.sv, x.sp1); x.tq[3] = pk_fnma(x.Q[3], x.sv, x.sq1);
+            }
         } else if (step == 4) {
-            x.o01[0] = col01(x.tp[0], x.tq[0]); x.o23[0] = col23(x.tp[0], x.tq[0]);
-            x.o01[1] = col01(x.tp[1], x.tq[1]); x.o23[1] = col23(x.tp[1], x.tq[1]);
-            x.w0 = pk_mul(x.g0, x.gv); x.w3 = pk_mul(x.g1, x.gv);
-            x.w1 = pk_add(x.w0, x.w3); x.w2 = pk_sub(x.w0, x.w3);
+            if (do_v) {
+                x.o01[0] = col01(x.tp[0], x.tq[0]); x.o23[0] = col23(x.tp[0], x.tq[0]);
+                x.o01[1] = col01(x.tp[1], x.tq[1]); x.o23[1] = col23(x.tp[1], x.tq[1]);
+            }
+            if (do_z) {
+                x.w0 = pk_mul(x.g0, x.gv); x.w3 = pk_mul(x.g1, x.gv);
+                x.w1 = pk_add(x.w0, x.w3); x.w2 = pk_sub(x.w0, x.w3);
+            }
         } else if (step == 5) {
-            x.o01[2] = col01(x.tp[2], x.tq[2]); x.o23[2] = col23(x.tp[2], x.tq[2]);
-            x.o01[3] = col01(x.tp[3], x.tq[3]); x.o23[3] = col23(x.tp[3], x.tq[3]);
+            if (do_v) {
+                x.o01[2] = col01(x.tp[2], x.tq[2]); x.o23[2] = col23(x.tp[2], x.tq[2]);
+                x.o01[3] = col01(x.tp[3], x.tq[3]); x.o23[3] = col23(x.tp[3], x.tq[3]);
 #pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                st2(ob + t_wr + (2 * q) * 512, x.o01[q]);
-                st2(ob + t_wr + (2 * q + 1) * 512, x.o23[q]);
+                for (int q = 0; q < 2; ++q) st4(ob + t_wr + q * 1024, x.o01[q], x.o23[q]);
             }
         } else if (step == 6) {
-            x.z01[0] = z_lo(x.w0, c01); x.z23[0] = z_hi(x.w0, c10);
-            x.z01[1] = z_lo(x.w1, c01); x.z23[1] = z_hi(x.w1, c10);
+            if (do_z) {
+                x.z01[0] = z_lo(x.w0, c01); x.z23[0] = z_hi(x.w0, c10);
+                x.z01[1] = z_lo(x.w1, c01); x.z23[1] = z_hi(x.w1, c10);
+            }
+            if (do_v) {
 #pragma unroll
-            for (int q = 2; q < 4; ++q) {
-                st2(ob + t_wr + (2 * q) * 512, x.o01[q]);
-                st2(ob + t_wr + (2 * q + 1) * 512, x.o23[q]);
+                for (int q = 2; q < 4; ++q) st4(ob + t_wr + q * 1024, x.o01[q], x.o23[q]);
             }
         } else {
-            x.z01[2] = z_lo(x.w2, c01); x.z23[2] = z_hi(x.w2, c10);
-            x.z01[3] = z3_lo(x.w3, c01); x.z23[3] = z3_hi(x.w3, c10);
+            if (do_z) {
+                x.z01[2] = z_lo(x.w2, c01); x.z23[2] = z_hi(x.w2, c10);
+                x.z01[3] = z3_lo(x.w3, c01); x.z23[3] = z3_hi(x.w3, c10);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                st2(ob + OB + t_wr + (2 * q) * 512, x.z01[q]);
-                st2(ob + OB + t_wr + (2 * q + 1) * 512, x.z23[q]);
+                for (int q = 0; q < 4; ++q) st4(ob + OB + t_wr + q * 1024, x.z01[q], x.z23[q]);
             }
         }
     };
 
-    // ---- operand registers [k pair][position pair]: ONE set.  Slot s of a body issues the four MFMAs that read
-    // av / bz [s >> 2][2 (s & 3) .. + 1] and then refills exactly those registers with the next sub-chunk's values
-    // (consumed in the same slot of the next body, a whole body later).
-    f2 av[2][8], bz[2][8];
-    const int a_rd = half * 128 + (wc * 32 + l31) * 2;
-    const int b_rd = OB + half * 128 + (wn * 32 + l31) * 2;
+    // ---- operand registers [k pair][position quad]: ONE set, four positions per 16-byte LDS read.  A slot issues the
+    // MFMAs that read av / bz [kp][quad] and, once a quad is consumed, refills exactly those registers with the next
+    // sub-chunk's values (consumed in the same slot of the next body, a whole body later).
+    f4 av[2][NPOS / 4], bz[2][NPOS / 4];
+    const int a_rd = half * 256 + (wc * 32 + l31) * 4 + ph * 2 * 1024;     // (NW = 8: position quads 2 ph, 2 ph + 1)
+    const int b_rd = OB + half * 256 + (wn * 32 + l31) * 4 + ph * 2 * 1024;
     auto mfma_step = [&](int m) {
-        const int kp = m >> 4, pos = m & 15, pp = pos >> 1;
-        if (pos & 1) acc[pos] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kp][pp].y, bz[kp][pp].y, acc[pos], 0, 0, 0);
-        else acc[pos] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kp][pp].x, bz[kp][pp].x, acc[pos], 0, 0, 0);
+        const int kp = m / NPOS, pos = m % NPOS, pq = pos >> 2;
+        switch (pos & 3) {
+        case 0: acc[pos] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kp][pq].x, bz[kp][pq].x, acc[pos], 0, 0, 0); break;
+        case 1: acc[pos] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kp][pq].y, bz[kp][pq].y, acc[pos], 0, 0, 0); break;
+        case 2: acc[pos] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kp][pq].z, bz[kp][pq].z, acc[pos], 0, 0, 0); break;
+        default: acc[pos] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kp][pq].w, bz[kp][pq].w, acc[pos], 0, 0, 0); break;
+        }
     };
 
     // sample of the strip whose tiles are being transformed (advanced once per strip)
@@ -325,7 +373,7 @@ __global__ __launch_bounds__(256) void k_wgrad_wino(const WgWinoParams p) {
     dma_begin(1);
 #pragma unroll
     for (int i = 0; i < N_DMA; ++i) dma1(i);
-    for (int i = tid; i < p.B * 64; i += 256) {
+    for (int i = tid; i < p.B * 64; i += 64 * NW) {
         const int b = i >> 6, ch = i & 63;
         tabx[i] = p.xscale ? p.xscale[(int64_t)b * p.C + c0 + ch] : 1.0f;
         tabg[i] = p.gscale ? p.gscale[(int64_t)b * p.N + n0 + ch] : 1.0f;
@@ -347,7 +395,9 @@ __global__ __launch_bounds__(256) void k_wgrad_wino(const WgWinoParams p) {
         // body j (parity j_par, compile time) of strip s = j >> 1 (parity strip_par, run time)
         constexpr int j_par = decltype(j_tag)::value;
         constexpr bool FIRST = decltype(first_tag)::value;
-        if (j_par == 0) asm volatile("s_waitcnt vmcnt(10) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        // even body: the strip fetched last (N_DMA instructions of this wave) may still be in flight
+        if (j_par == 0 && NW == 4) asm volatile("s_waitcnt vmcnt(10) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        else if (j_par == 0) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)\n\ts_barrier" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
         // even body: transforms the second half of the current strip; odd body: the first half of the next one
         // (sample advanced) and starts the fetch of the strip after that into the buffer of the current one
@@ -357,20 +407,23 @@ __global__ __launch_bounds__(256) void k_wgrad_wino(const WgWinoParams p) {
         const float* ob_rd = obuf + j_par * OBUF;
         float* ob_wr = obuf + (j_par ^ 1) * OBUF;
         XF x;
-        auto load_ops = [&](int kp, int pp) {
-            av[kp][pp] = ld2(ob_rd + a_rd + pp * 512 + kp * 256);
-            bz[kp][pp] = ld2(ob_rd + b_rd + pp * 512 + kp * 256);
+        auto load_ops = [&](int kp, int pq) {
+            av[kp][pq] = ld4(ob_rd + a_rd + pq * 1024 + kp * 512);
+            bz[kp][pq] = ld4(ob_rd + b_rd + pq * 1024 + kp * 512);
         };
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
             if (!FIRST) {
 #pragma unroll
-                for (int u = 0; u < 4; ++u) mfma_step(4 * s + u);
+                for (int u = 0; u < NPOS / 4; ++u) mfma_step((NPOS / 4) * s + u);
             }
-            load_ops(s >> 2, 2 * (s & 3));
-            load_ops(s >> 2, 2 * (s & 3) + 1);
+            if (NW == 4) load_ops(s >> 2, s & 3);                       // the quad this slot has just consumed
+            else if (s & 1) load_ops(s >> 2, (s & 3) >> 1);             // (two slots per quad)
 #ifndef WGW_NO_DMA
-            if (j_par == 1 && s < 5) { dma1(2 * s); dma1(2 * s + 1); }
+            if (j_par == 1) {
+                if (2 * s < N_DMA) dma1(2 * s);
+                if (2 * s + 1 < N_DMA) dma1(2 * s + 1);
+            }
 #endif
 #ifndef WGW_NO_XFORM
             xf_step(x, s, rw, j_par == 0 ? 1 : 0, b_smp, ob_wr);
@@ -387,7 +440,7 @@ __global__ __launch_bounds__(256) void k_wgrad_wino(const WgWinoParams p) {
     }
     // MFMAs of the last sub-chunk
 #pragma unroll
-    for (int m = 0; m < 32; ++m) mfma_step(m);
+    for (int m = 0; m < 2 * NPOS; ++m) mfma_step(m);
     // surplus fetches are still landing in this workgroup's LDS: drain them before the wave can retire
     __builtin_amdgcn_s_waitcnt(0x0F70);
     WGW_STAMP(2);
@@ -395,11 +448,11 @@ __global__ __launch_bounds__(256) void k_wgrad_wino(const WgWinoParams p) {
     // ---- partial dU slab of this slice: rows = channels (r & 3) + 8 (r >> 2) + 4 half, cols = l31
     float* out = p.partial + (int64_t)slice * 16 * p.C * p.N;
 #pragma unroll
-    for (int pos = 0; pos < 16; ++pos)
+    for (int pos = 0; pos < NPOS; ++pos)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int c = c0 + wc * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-            out[((int64_t)pos * p.C + c) * p.N + n0 + wn * 32 + l31] = acc[pos][r];
+            out[((int64_t)(ph * 8 + pos) * p.C + c) * p.N + n0 + wn * 32 + l31] = acc[pos][r];
         }
     WGW_STAMP(3);
 #ifdef WGW_TIMING
@@ -487,10 +540,14 @@ int sr_wgrad_wino_3x3(float* dwt, const float* x, const float* gy, const float* 
     p.tiles_c = (int)(C / 64); p.tiles_n = (int)(N / 64);
     p.cty = (int)(H / 2); p.ctx = (int)(W / 16);
     plan(B, C, N, H, W, p.slices, p.chunks_per_slice, p.chunks_total);
-    const int lds = (2 * RAW + 2 * OBUF + PAD + 2 * MAX_B * 64) * 4;
+    // SR_WGW_WAVES=4: one wave per SIMD (round 2's form); default 8: two per SIMD (same bits)
+    const char* e = getenv("SR_WGW_WAVES");
+    const bool two = !(e && e[0] == '4');
     static bool configured = false;
     if (!configured) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_wgrad_wino), hipFuncAttributeMaxDynamicSharedMemorySize,
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_wgrad_wino<4>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                160 * 1024) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(k_wgrad_wino<8>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 160 * 1024) != hipSuccess) {
             (void)hipGetLastError();
             return SR_EINVAL;
@@ -498,7 +555,8 @@ int sr_wgrad_wino_3x3(float* dwt, const float* x, const float* gy, const float* 
         configured = true;
     }
     const int64_t blocks = (int64_t)p.tiles_c * p.tiles_n * p.slices;
-    hipLaunchKernelGGL(k_wgrad_wino, dim3((unsigned)blocks), dim3(256), lds, st, p);
+    if (two) hipLaunchKernelGGL(k_wgrad_wino<8>, dim3((unsigned)blocks), dim3(512), WgW<8>::LDS_FLOATS * 4, st, p);
+    else hipLaunchKernelGGL(k_wgrad_wino<4>, dim3((unsigned)blocks), dim3(256), WgW<4>::LDS_FLOATS * 4, st, p);
     const int64_t cn = C * N;
     hipLaunchKernelGGL(k_wgrad_wino_finish, dim3((unsigned)sr_ceil_div(cn, 64)), dim3(256), 0, st, dwt, scratch,
                        p.slices, (int)C, (int)N);

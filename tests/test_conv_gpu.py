@@ -172,6 +172,28 @@ def test_stride2_wgrad_dma_staging_equals_dword_staging(monkeypatch):
         assert torch.equal(a2, d2), (b, c, n, res, tr)
 
 
+def test_winograd_wgrad_two_waves_per_simd_equals_one_wave_kernel(monkeypatch):
+    """k_wgrad_wino<8> (512 threads, positions split over a wave pair) runs the same transforms and the same MFMA chain
+    per accumulator as k_wgrad_wino<4>: bit-identical weight gradients (SR_WGW_WAVES=4 selects the one-wave kernel)."""
+    from stylerenderer_amd.op.conv import conv2d_wgrad_mfma
+
+    g = torch.Generator().manual_seed(17)
+    for b, c, n, h, w in ((1, 64, 64, 2, 16), (3, 64, 128, 8, 32), (2, 128, 64, 64, 64), (5, 64, 64, 6, 48),
+                          (4, 128, 128, 128, 128)):
+        x = torch.randn(b, c, h, w, generator=g).to(DEV)
+        gy = torch.randn(b, n, h, w, generator=g).to(DEV)
+        xs, gs = torch.randn(b, c, generator=g).to(DEV), torch.randn(b, n, generator=g).to(DEV)
+        monkeypatch.setenv("SR_WGW_WAVES", "8")
+        a = conv2d_wgrad_mfma(x, gy, xs, gs, 3, 1, 1)
+        a2 = conv2d_wgrad_mfma(x, gy, None, None, 3, 1, 1)
+        monkeypatch.setenv("SR_WGW_WAVES", "4")
+        d = conv2d_wgrad_mfma(x, gy, xs, gs, 3, 1, 1)
+        d2 = conv2d_wgrad_mfma(x, gy, None, None, 3, 1, 1)
+        assert torch.isfinite(a).all()
+        assert torch.equal(a, d), (b, c, n, h, w, float((a - d).abs().max()))
+        assert torch.equal(a2, d2), (b, c, n, h, w)
+
+
 def test_wgrad_deterministic_and_large():
     from stylerenderer_amd.op.conv import conv2d_wgrad_mfma
 
