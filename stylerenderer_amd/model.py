@@ -101,7 +101,8 @@ class StyledMapConv(nn.Module):
             if noise is None:
                 noise = out.new_empty(out.shape[0], 1, out.shape[2], out.shape[3]).normal_()
             # per-pixel affine + noise + bias + LeakyReLU in one pass over the activation (and one in backward)
-            return noise_bias_act_affine(out, stylemap[:, :2], noise, self.noise.weight, self.activate.bias,
+            sm = stylemap if stylemap.shape[1] == 2 else stylemap[:, :2]
+            return noise_bias_act_affine(out, sm, noise, self.noise.weight, self.activate.bias,
                                          self.activate.negative_slope, self.activate.scale)
         out = out * stylemap[:, :1] + stylemap[:, 1:2]
         out = self.noise(out, noise=noise)
@@ -315,8 +316,11 @@ class GeneratorWithMap(Generator):
                 maps = self.norm_to_style[i](self.norm_to_style[i - 1](norm_maps[-1]))
             else:
                 maps = self.norm_to_style[i // 2](norm_maps[-1])
-            out = conv_up(out, st[k], maps[:, :2], noise=n_up)
-            out = conv(out, st[k + 1], maps[:, 2:], noise=n_conv)
+            # one split (its backward is one cat) instead of two slices, whose backward zero-fills and adds two
+            # full-size copies of `maps` — per resolution and per order of differentiation
+            maps_up, maps_conv = maps.split([2, maps.shape[1] - 2], 1)
+            out = conv_up(out, st[k], maps_up, noise=n_up)
+            out = conv(out, st[k + 1], maps_conv, noise=n_conv)
             skip = to_rgb(out, st[k + 2], skip)
             i += 2
             k += 3
