@@ -29,8 +29,10 @@
 //
 // Backward: k_dcoeff (API parity with rasterize_gpu_backward, coalesced through LDS), and the fused gradient
 // of the autograd Function as a deterministic two-phase GATHER — no float atomics, run-to-run identical:
-//   k_grad_pix   one lane per PIXEL (coalesced winner-map / grad_out reads): the first pixel a triangle won, in
-//                box order, is its leader and sums, in box order, d/d(3 vertices) and d/d(3 attribute rows) over
+//   k_first_pix  one lane per pixel: integer atomicMin of the row-major pixel index into a per-(sample, triangle)
+//                table — the first pixel a triangle won in box order, its LEADER (order-independent, deterministic);
+//   k_grad_pix   one lane per PIXEL (coalesced winner-map reads); the leaders of a workgroup's 256 pixels are
+//                compacted through LDS, then each sums, in box order, d/d(3 vertices) and d/d(3 attribute rows) over
 //                the triangle's pixels (winner map written by k_resolve) into the triangle's three corner records;
 //   k_grad_big   the large triangles k_depth_keys listed: one workgroup each, fixed-order tree over the lanes;
 //   k_grad_vert  one lane per (sample, vertex): sums the corner blocks of its incident triangles in the fixed
@@ -1094,6 +1096,45 @@ __device__ __forceinline__ void grad_pixel(TriAcc<R, CT, PERSP>& acc, const Tri<
     }
 }
 
+// The same pixel with the triangle's three attribute rows already in registers (tex_c <= 4: the normal maps of
+// the generator): k_grad_pix fetches them together with the vertex positions, one round trip earlier, and once per
+// triangle instead of once per pixel.  Same operations in the same order as grad_pixel.
+template <typename R, int CT, bool PERSP>
+__device__ __forceinline__ void grad_pixel_regs(TriAcc<R, CT, PERSP>& acc, const Tri<R>& t, const JacTri<R, PERSP>& jt,
+                                                bool want_v, int x, int y, long long w, long long hw, long long h_arg,
+                                                R eps, const int* __restrict__ wins, int ti,
+                                                const R* __restrict__ gos, const R (&tx)[3][4], int tex_c, int ch0) {
+    const long long pix = x + (long long)y * w;
+    if (pix >= hw || wins[pix] != ti) return;
+    R c0, c1, c2, z;
+    shade<R>(t, x, y, PERSP, eps, c0, c1, c2, z);
+    const R* go = gos + pix * tex_c;
+    R gch[4];
+#pragma unroll
+    for (int ch = 0; ch < 4; ++ch) gch[ch] = ch < tex_c ? go[ch] : (R)0;
+    acc.n += 1;
+#pragma unroll
+    for (int j = 0; j < CT; ++j) {
+        if (j < tex_c) {                                 // (tex_c <= 4: one channel chunk, ch0 == 0)
+            acc.gt[j] += gch[j] * c0;
+            acc.gt[CT + j] += gch[j] * c1;
+            acc.gt[2 * CT + j] += gch[j] * c2;
+        }
+    }
+    if (want_v) {
+        R d0 = 0, d1 = 0, d2 = 0;
+#pragma unroll
+        for (int ch = 0; ch < 4; ++ch) {
+            if (ch < tex_c) {
+                d0 += gch[ch] * tx[0][ch];
+                d1 += gch[ch] * tx[1][ch];
+                d2 += gch[ch] * tx[2][ch];
+            }
+        }
+        jt.add(acc.gv, d0, d1, d2, (R)x, (R)y, (R)h_arg, (R)w, eps);
+    }
+}
+
 __device__ __forceinline__ float sr_shfl_down(float x, int off) { return __shfl_down(x, off, SR_WAVE); }
 __device__ __forceinline__ double sr_shfl_down(double x, int off) { return __shfl_down(x, off, SR_WAVE); }
 
@@ -1193,21 +1234,68 @@ __global__ __launch_bounds__(256) void k_grad_big(long long nv, long long nf, lo
     }
 }
 
-// Small triangles, PIXEL-parallel (coalesced winner-map / grad_out reads, no lanes spent on culled or pixel-less
-// triangles): the FIRST pixel a triangle won, in box order, is its leader; the leader sums the triangle's pixels
-// in box order and writes the records.  Every other lane leaves after the leader test.
+// first[s * nf + t] = the smallest row-major pixel index triangle t of sample s won (INT_MAX: none).  Row-major order
+// over the image restricted to a triangle's box IS box order, so that pixel is the triangle's leader.
+// A pixel whose left or upper neighbour was won by the same triangle cannot be the minimum and skips the atomic
+// (most of a triangle's pixels: the table sees little more than one update per visible triangle).
+__global__ __launch_bounds__(256) void k_first_pix(long long total, long long hw, long long w, long long nf,
+                                                   const int* __restrict__ win, int* __restrict__ first) {
+    const long long g = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (g >= total) return;
+    const int ti = win[g];
+    if (ti < 0) return;
+    const long long s = g / hw, pix = g - s * hw;
+    const long long x = pix % w;
+    if (x > 0 && win[g - 1] == ti) return;
+    if (pix >= w && win[g - w] == ti) return;
+    atomicMin(&first[s * nf + ti], (int)pix);                    // integer minimum: order independent
+}
+
+// Small triangles, PIXEL-parallel (coalesced winner-map reads, no lanes spent on culled or pixel-less triangles): the
+// FIRST pixel a triangle won, in box order, is its leader (k_first_pix); the leader sums the triangle's pixels in box
+// order and writes the records.  The leaders of a workgroup's 256 pixels (typically a few dozen: background and the
+// other pixels of a triangle drop out after one or two loads) are COMPACTED through LDS before the long part — the
+// vertex gathers, the setup and the 16 winner-map probes then run in one dense wave instead of four sparse ones.
 template <typename R, int CT, bool PERSP>
 __global__ __launch_bounds__(256) void k_grad_pix(long long b, long long nv, long long nf, long long h,
                                                   long long w, bool repeat_f, const R* __restrict__ v,
                                                   const R* __restrict__ tex, int tex_c, int ch0,
                                                   const long long* __restrict__ f, const int* __restrict__ win,
+                                                  const int* __restrict__ first,
                                                   const R* __restrict__ grad_out, bool want_v,
                                                   R* __restrict__ tg, unsigned char* __restrict__ flag, R eps) {
+    __shared__ int s_list[256], s_tri[256];
+    __shared__ int s_cnt[4];
     const long long hw = h * w;
-    const long long g = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (g >= b * hw) return;
-    const int ti = win[g];
-    if (ti < 0) return;
+    const long long g0 = (long long)blockIdx.x * 256;
+    bool leader = false;
+    int tq = -1;
+    {
+        const long long gq = g0 + threadIdx.x;
+        if (gq < b * hw) {
+            tq = win[gq];
+            if (tq >= 0) {
+                const long long sq = gq / hw;
+                leader = first[sq * nf + tq] == (int)(gq - sq * hw);
+            }
+        }
+    }
+    const unsigned long long lead_mask = __ballot(leader);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (lane == 0) s_cnt[wv] = __popcll(lead_mask);
+    __syncthreads();
+    int base = 0;
+    for (int i = 0; i < wv; ++i) base += s_cnt[i];
+    const int n_lead = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+    if (leader) {
+        const int slot = base + __popcll(lead_mask & ((1ull << lane) - 1ull));
+        s_list[slot] = threadIdx.x;
+        s_tri[slot] = tq;
+    }
+    __syncthreads();
+    if ((int)threadIdx.x >= n_lead) return;
+    const long long g = g0 + s_list[threadIdx.x];
+    const int ti = s_tri[threadIdx.x];
     const long long s = g / hw, pix = g - s * hw;
     const int py = (int)(pix / w), px = (int)(pix - (long long)py * w);
     const R* vs = v + s * nv * 3;
@@ -1215,6 +1303,17 @@ __global__ __launch_bounds__(256) void k_grad_pix(long long b, long long nv, lon
     Tri<R> t;
     long long i0, i1, i2;
     load_tri<R>(t, vs, fs, ti, nv, i0, i1, i2);
+    // attribute rows of the three corners: in flight together with the vertex positions (up to four channels)
+    const R* tb = tex + s * nv * tex_c;
+    const bool tex_regs = tex_c <= 4;
+    R tx[3][4];
+#pragma unroll
+    for (int ch = 0; ch < 4; ++ch) {
+        const bool have = tex_regs && ch < tex_c;
+        tx[0][ch] = have ? tb[i0 * tex_c + ch] : (R)0;
+        tx[1][ch] = have ? tb[i1 * tex_c + ch] : (R)0;
+        tx[2][ch] = have ? tb[i2 * tex_c + ch] : (R)0;
+    }
     const R praw[9] = {t.p0, t.p1, t.p2, t.p3, t.p4, t.p5, t.p6, t.p7, t.p8};
     tri_setup<R>(t, h, w, PERSP, eps);
     if ((long long)(t.x1 - t.x0 + 1) * (t.y1 - t.y0 + 1) > BIG_BOX) return;      // k_grad_big owns it
@@ -1249,14 +1348,17 @@ __global__ __launch_bounds__(256) void k_grad_pix(long long b, long long nv, lon
     TriAcc<R, CT, PERSP> acc;
     acc.clear();
     const bool distinct = want_v && jt.ok && i0 != i1 && i0 != i2 && i1 != i2;
-    const R* tb = tex + s * nv * tex_c;
     while (mask) {                                        // ascending bit = box order
         const int p = __ffsll((long long)mask) - 1;
         mask &= mask - 1ull;
         const int yy = p / bw;
-        grad_pixel<R, CT, PERSP>(acc, t, jt, distinct, t.x0 + (p - yy * bw), t.y0 + yy, w, hw, h, eps, wins, ti,
-                                 grad_out + s * hw * tex_c, tb + i0 * tex_c, tb + i1 * tex_c, tb + i2 * tex_c, tex_c,
-                                 ch0);
+        if (tex_regs)
+            grad_pixel_regs<R, CT, PERSP>(acc, t, jt, distinct, t.x0 + (p - yy * bw), t.y0 + yy, w, hw, h, eps, wins, ti,
+                                          grad_out + s * hw * tex_c, tx, tex_c, ch0);
+        else
+            grad_pixel<R, CT, PERSP>(acc, t, jt, distinct, t.x0 + (p - yy * bw), t.y0 + yy, w, hw, h, eps, wins, ti,
+                                     grad_out + s * hw * tex_c, tb + i0 * tex_c, tb + i1 * tex_c, tb + i2 * tex_c, tex_c,
+                                     ch0);
     }
     store_row<R, CT, PERSP>(acc, tg, flag, s * nf + ti);
 }
@@ -1419,7 +1521,7 @@ template <typename R, int CT, bool PERSP>
 void grad_launch(long long b, long long nv, long long nf, long long h, long long w, bool repeat_f, const R* v,
                  const R* tex, int tex_c, int ch0, const long long* tri, const int* win, const int* big,
                  const R* grad_out, const int* adj_off, const int* adj, long long off_bs, long long adj_bs,
-                 R* grad_v, R* grad_tex, R eps, R* tg, unsigned char* flag, hipStream_t st) {
+                 R* grad_v, R* grad_tex, R eps, R* tg, unsigned char* flag, const int* first, hipStream_t st) {
     const bool want_v = grad_v != nullptr && ch0 == 0;
     // (a fill kernel, not hipMemsetAsync: captured memset nodes replay a corrupted value on the HIP 7.0 runtime
     // torch bundles — csrc/capi.hip sr_graph_replace_memset_nodes; `flag` is 4-byte aligned and padded to 4 bytes)
@@ -1428,7 +1530,7 @@ void grad_launch(long long b, long long nv, long long nf, long long h, long long
     hipLaunchKernelGGL((k_grad_big<R, CT, PERSP>), dim3(SR_NUM_CU * 2), dim3(256), 0, st, nv, nf, h, w, repeat_f, v,
                        tex, tex_c, ch0, tri, win, big, grad_out, want_v, tg, flag, eps);
     hipLaunchKernelGGL((k_grad_pix<R, CT, PERSP>), dim3((unsigned)sr_ceil_div(b * h * w, 256)), dim3(256), 0, st, b,
-                       nv, nf, h, w, repeat_f, v, tex, tex_c, ch0, tri, win, grad_out, want_v, tg, flag, eps);
+                       nv, nf, h, w, repeat_f, v, tex, tex_c, ch0, tri, win, first, grad_out, want_v, tg, flag, eps);
     hipLaunchKernelGGL((k_grad_vert<R, CT, PERSP>), dim3((unsigned)sr_ceil_div(nv, 256), (unsigned)b), dim3(256), 0,
                        st, nv, nf, adj_off, adj, off_bs, adj_bs, tg, flag, tex_c, ch0, grad_v, grad_tex);
 }
@@ -1443,14 +1545,23 @@ int grad_impl(long long b, long long nv, long long nf, long long h, long long w,
     if (b > 65535 || nf >= 0x7FFFFFFFLL / 3 || tex_c > 0x7FFFFFFF) return SR_ERANGE;
     if (!v || !tex || !grad_out || !adj_off || !work || (nf > 0 && (!tri || !adj || !win || !big))) return SR_EINVAL;
     if (eps < 0) eps = -eps;
+    if (h * w >= 0x7FFFFFFFLL) return SR_ERANGE;
     R* tg = reinterpret_cast<R*>(work);
-    unsigned char* flag = reinterpret_cast<unsigned char*>(tg + b * nf * grad_row_floats());
+    int* first = reinterpret_cast<int*>(tg + b * nf * grad_row_floats());
+    unsigned char* flag = reinterpret_cast<unsigned char*>(first + b * nf);
+    // leaders of all triangles, once per call (the attribute-channel chunks below share them)
+    if (b * nf > 0) {
+        hipLaunchKernelGGL(k_fill_u32, dim3(sr_stream_grid(b * nf, 256)), dim3(256), 0, st,
+                           reinterpret_cast<unsigned*>(first), 0x7FFFFFFFu, b * nf);
+        hipLaunchKernelGGL(k_first_pix, dim3((unsigned)sr_ceil_div(b * h * w, 256)), dim3(256), 0, st, b * h * w, h * w, w,
+                           nf, win, first);
+    }
     // attribute channels in chunks of <= 4 register accumulators; the vertex gradient rides with chunk 0
     for (long long ch0 = 0; ch0 < (grad_tex ? tex_c : 1); ch0 += 4) {
         const long long ct = tex_c - ch0 < 4 ? tex_c - ch0 : 4;
 #define SR_GRAD_ARGS                                                                                              \
     b, nv, nf, h, w, repeat_f != 0, v, tex, (int)tex_c, (int)ch0, tri, win, big, grad_out, adj_off, adj, off_bs, \
-        adj_bs, grad_v, grad_tex, eps, tg, flag, st
+        adj_bs, grad_v, grad_tex, eps, tg, flag, first, st
 #define SR_GRAD_CASE(CT)                                          \
     do {                                                          \
         if (perspective) grad_launch<R, CT, true>(SR_GRAD_ARGS);  \
@@ -1550,7 +1661,7 @@ extern "C" int64_t sr_rasterize_scratch_bytes(int64_t b, int64_t nf, int64_t h, 
 extern "C" int64_t sr_rasterize_grad_scratch_bytes(int64_t b, int64_t nf, int64_t tex_c, int is_double) {
     (void)tex_c;
     const int64_t rows = (b > 0 ? b : 0) * (nf > 0 ? nf : 0);
-    return rows * grad_row_floats() * (is_double ? 8 : 4) + rows + 16;
+    return rows * grad_row_floats() * (is_double ? 8 : 4) + rows * 4 + rows + 16;      // rows | leaders | flags
 }
 
 extern "C" int sr_rasterize_forward_f32(int64_t b, int64_t nv, int64_t nf, int64_t h, int64_t w,
