@@ -1162,7 +1162,7 @@ struct RowShape {
 
 template <typename R, int CT, bool PERSP>
 __device__ __forceinline__ void store_row(const TriAcc<R, CT, PERSP>& acc, R* __restrict__ tg,
-                                          unsigned char* __restrict__ flag, long long rowid) {
+                                          long long rowid) {
     using S = RowShape<CT, PERSP>;
     R vals[S::RS];
 #pragma unroll
@@ -1185,7 +1185,6 @@ __device__ __forceinline__ void store_row(const TriAcc<R, CT, PERSP>& acc, R* __
 #pragma unroll
         for (int i = 0; i < S::RS / 2; ++i) dst[i] = make_double2((double)vals[2 * i], (double)vals[2 * i + 1]);
     }
-    flag[rowid] = 1;
 }
 
 // Large triangles (the list k_depth_keys recorded): one workgroup per triangle walks the box together; each lane
@@ -1197,7 +1196,7 @@ __global__ __launch_bounds__(256) void k_grad_big(long long nv, long long nf, lo
                                                   const long long* __restrict__ f, const int* __restrict__ win,
                                                   const int* __restrict__ big, const R* __restrict__ grad_out,
                                                   bool want_v, R* __restrict__ tg,
-                                                  unsigned char* __restrict__ flag, R eps) {
+                                                  R eps) {
     __shared__ R s_part[4];
     const long long hw = h * w;
     const int count = big[0];
@@ -1230,7 +1229,7 @@ __global__ __launch_bounds__(256) void k_grad_big(long long nv, long long nf, lo
         for (int j = 0; j < JacTri<R, PERSP>::NV; ++j) acc.gv[j] = block_sum_256<R>(acc.gv[j], s_part);
 #pragma unroll
         for (int j = 0; j < 3 * CT; ++j) acc.gt[j] = block_sum_256<R>(acc.gt[j], s_part);
-        if (threadIdx.x == 0 && cnt > 0) store_row<R, CT, PERSP>(acc, tg, flag, g);
+        if (threadIdx.x == 0 && cnt > 0) store_row<R, CT, PERSP>(acc, tg, g);
     }
 }
 
@@ -1251,52 +1250,33 @@ __global__ __launch_bounds__(256) void k_first_pix(long long total, long long hw
     atomicMin(&first[s * nf + ti], (int)pix);                    // integer minimum: order independent
 }
 
-// Small triangles, PIXEL-parallel (coalesced winner-map reads, no lanes spent on culled or pixel-less triangles): the
-// FIRST pixel a triangle won, in box order, is its leader (k_first_pix); the leader sums the triangle's pixels in box
-// order and writes the records.  The leaders of a workgroup's 256 pixels (typically a few dozen: background and the
-// other pixels of a triangle drop out after one or two loads) are COMPACTED through LDS before the long part — the
-// vertex gathers, the setup and the 16 winner-map probes then run in one dense wave instead of four sparse ones.
+// Small triangles: one lane per (sample, TRIANGLE).  The leader table says in ONE coalesced load whether the triangle
+// won a pixel at all (culled, hidden and sub-pixel triangles leave at once) and where its first pixel is; the lane
+// then sums the triangle's pixels in box order and writes the records.  Consecutive lanes own consecutive triangles:
+// the index loads and the row stores are coalesced, and because visibility is spatially coherent on a mesh the waves are
+// mostly dense or empty.  (History at config[3]: one lane per pixel with a 16-probe leader test, 202 us; leaders
+// compacted per workgroup through LDS, 122-129 us; a dense leader list, 86 us + 600 us for its single append
+// counter; this form needs neither list nor counter.)
 template <typename R, int CT, bool PERSP>
 __global__ __launch_bounds__(256) void k_grad_pix(long long b, long long nv, long long nf, long long h,
                                                   long long w, bool repeat_f, const R* __restrict__ v,
                                                   const R* __restrict__ tex, int tex_c, int ch0,
                                                   const long long* __restrict__ f, const int* __restrict__ win,
                                                   const int* __restrict__ first,
+                                                  unsigned long long* __restrict__ valid,
                                                   const R* __restrict__ grad_out, bool want_v,
-                                                  R* __restrict__ tg, unsigned char* __restrict__ flag, R eps) {
-    __shared__ int s_list[256], s_tri[256];
-    __shared__ int s_cnt[4];
+                                                  R* __restrict__ tg, R eps) {
     const long long hw = h * w;
-    const long long g0 = (long long)blockIdx.x * 256;
-    bool leader = false;
-    int tq = -1;
-    {
-        const long long gq = g0 + threadIdx.x;
-        if (gq < b * hw) {
-            tq = win[gq];
-            if (tq >= 0) {
-                const long long sq = gq / hw;
-                leader = first[sq * nf + tq] == (int)(gq - sq * hw);
-            }
-        }
-    }
-    const unsigned long long lead_mask = __ballot(leader);
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    if (lane == 0) s_cnt[wv] = __popcll(lead_mask);
-    __syncthreads();
-    int base = 0;
-    for (int i = 0; i < wv; ++i) base += s_cnt[i];
-    const int n_lead = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
-    if (leader) {
-        const int slot = base + __popcll(lead_mask & ((1ull << lane) - 1ull));
-        s_list[slot] = threadIdx.x;
-        s_tri[slot] = tq;
-    }
-    __syncthreads();
-    if ((int)threadIdx.x >= n_lead) return;
-    const long long g = g0 + s_list[threadIdx.x];
-    const int ti = s_tri[threadIdx.x];
-    const long long s = g / hw, pix = g - s * hw;
+    const long long row = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int lead_pix = row < b * nf ? first[row] : 0x7FFFFFFF;
+    // one bit per record, "this triangle won a pixel: its record is written" (by this kernel or by k_grad_big) — what
+    // k_grad_vert tests before it reads a record: a wave's 64 consecutive rows are one word
+    const unsigned long long won = __ballot(lead_pix != 0x7FFFFFFF);
+    if ((threadIdx.x & 63) == 0 && row < b * nf) valid[row >> 6] = won;       // (waves beyond the last row own no word)
+    if (lead_pix == 0x7FFFFFFF) return;
+    const long long s = row / nf;
+    const int ti = (int)(row - s * nf);
+    const long long pix = lead_pix;
     const int py = (int)(pix / w), px = (int)(pix - (long long)py * w);
     const R* vs = v + s * nv * 3;
     const long long* fs = repeat_f ? f : f + s * nf * 3;
@@ -1360,7 +1340,7 @@ __global__ __launch_bounds__(256) void k_grad_pix(long long b, long long nv, lon
                                      grad_out + s * hw * tex_c, tb + i0 * tex_c, tb + i1 * tex_c, tb + i2 * tex_c, tex_c,
                                      ch0);
     }
-    store_row<R, CT, PERSP>(acc, tg, flag, s * nf + ti);
+    store_row<R, CT, PERSP>(acc, tg, row);
 }
 
 // ---- fused gradient, phase 2: per-vertex sum over its incident corners, in incidence-list order ---------------
@@ -1368,7 +1348,7 @@ template <typename R, int CT, bool PERSP>
 __global__ __launch_bounds__(256) void k_grad_vert(long long nv, long long nf, const int* __restrict__ adj_off,
                                                    const int* __restrict__ adj, long long off_bstride,
                                                    long long adj_bstride, const R* __restrict__ tg,
-                                                   const unsigned char* __restrict__ flag, int tex_c, int ch0,
+                                                   const unsigned long long* __restrict__ valid, int tex_c, int ch0,
                                                    R* __restrict__ grad_v, R* __restrict__ grad_tex) {
     using S = RowShape<CT, PERSP>;
     const long long vert = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -1385,7 +1365,7 @@ __global__ __launch_bounds__(256) void k_grad_vert(long long nv, long long nf, c
         const int idx = ad[e];                       // corner-major: k * nf + f
         const int k = idx / (int)nf;
         const long long row = s * nf + (idx - k * (int)nf);
-        if (!flag[row]) continue;
+        if (!((valid[row >> 6] >> (row & 63)) & 1ull)) continue;      // the triangle won no pixel: no record
         const R* r = tg + row * S::RS + k * S::CORNER;
 #pragma unroll
         for (int j = 0; j < S::NVC; ++j) av[j] += r[j];
@@ -1521,18 +1501,15 @@ template <typename R, int CT, bool PERSP>
 void grad_launch(long long b, long long nv, long long nf, long long h, long long w, bool repeat_f, const R* v,
                  const R* tex, int tex_c, int ch0, const long long* tri, const int* win, const int* big,
                  const R* grad_out, const int* adj_off, const int* adj, long long off_bs, long long adj_bs,
-                 R* grad_v, R* grad_tex, R eps, R* tg, unsigned char* flag, const int* first, hipStream_t st) {
+                 R* grad_v, R* grad_tex, R eps, R* tg, const int* first, unsigned long long* valid, hipStream_t st) {
     const bool want_v = grad_v != nullptr && ch0 == 0;
-    // (a fill kernel, not hipMemsetAsync: captured memset nodes replay a corrupted value on the HIP 7.0 runtime
-    // torch bundles — csrc/capi.hip sr_graph_replace_memset_nodes; `flag` is 4-byte aligned and padded to 4 bytes)
-    hipLaunchKernelGGL(k_fill_u32, dim3(sr_stream_grid(sr_ceil_div(b * nf, 4), 256)), dim3(256), 0, st,
-                       reinterpret_cast<unsigned*>(flag), 0u, (long long)sr_ceil_div(b * nf, 4));
     hipLaunchKernelGGL((k_grad_big<R, CT, PERSP>), dim3(SR_NUM_CU * 2), dim3(256), 0, st, nv, nf, h, w, repeat_f, v,
-                       tex, tex_c, ch0, tri, win, big, grad_out, want_v, tg, flag, eps);
-    hipLaunchKernelGGL((k_grad_pix<R, CT, PERSP>), dim3((unsigned)sr_ceil_div(b * h * w, 256)), dim3(256), 0, st, b,
-                       nv, nf, h, w, repeat_f, v, tex, tex_c, ch0, tri, win, first, grad_out, want_v, tg, flag, eps);
+                       tex, tex_c, ch0, tri, win, big, grad_out, want_v, tg, eps);
+    if (b * nf > 0)
+        hipLaunchKernelGGL((k_grad_pix<R, CT, PERSP>), dim3((unsigned)sr_ceil_div(b * nf, 256)), dim3(256), 0, st, b,
+                           nv, nf, h, w, repeat_f, v, tex, tex_c, ch0, tri, win, first, valid, grad_out, want_v, tg, eps);
     hipLaunchKernelGGL((k_grad_vert<R, CT, PERSP>), dim3((unsigned)sr_ceil_div(nv, 256), (unsigned)b), dim3(256), 0,
-                       st, nv, nf, adj_off, adj, off_bs, adj_bs, tg, flag, tex_c, ch0, grad_v, grad_tex);
+                       st, nv, nf, adj_off, adj, off_bs, adj_bs, tg, valid, tex_c, ch0, grad_v, grad_tex);
 }
 
 template <typename R>
@@ -1547,8 +1524,11 @@ int grad_impl(long long b, long long nv, long long nf, long long h, long long w,
     if (eps < 0) eps = -eps;
     if (h * w >= 0x7FFFFFFFLL) return SR_ERANGE;
     R* tg = reinterpret_cast<R*>(work);
-    int* first = reinterpret_cast<int*>(tg + b * nf * grad_row_floats());
-    unsigned char* flag = reinterpret_cast<unsigned char*>(first + b * nf);
+    if (b * h * w >= 0x7FFFFFFFLL) return SR_ERANGE;
+    // (records: 24 floats each, so the two tables behind them stay 8-byte aligned)
+    unsigned long long* valid = reinterpret_cast<unsigned long long*>(tg + b * nf * grad_row_floats());
+    int* first = reinterpret_cast<int*>(valid + (b * nf + 63) / 64 + 1);
+
     // leaders of all triangles, once per call (the attribute-channel chunks below share them)
     if (b * nf > 0) {
         hipLaunchKernelGGL(k_fill_u32, dim3(sr_stream_grid(b * nf, 256)), dim3(256), 0, st,
@@ -1561,7 +1541,7 @@ int grad_impl(long long b, long long nv, long long nf, long long h, long long w,
         const long long ct = tex_c - ch0 < 4 ? tex_c - ch0 : 4;
 #define SR_GRAD_ARGS                                                                                              \
     b, nv, nf, h, w, repeat_f != 0, v, tex, (int)tex_c, (int)ch0, tri, win, big, grad_out, adj_off, adj, off_bs, \
-        adj_bs, grad_v, grad_tex, eps, tg, flag, first, st
+        adj_bs, grad_v, grad_tex, eps, tg, first, valid, st
 #define SR_GRAD_CASE(CT)                                          \
     do {                                                          \
         if (perspective) grad_launch<R, CT, true>(SR_GRAD_ARGS);  \
@@ -1661,7 +1641,8 @@ extern "C" int64_t sr_rasterize_scratch_bytes(int64_t b, int64_t nf, int64_t h, 
 extern "C" int64_t sr_rasterize_grad_scratch_bytes(int64_t b, int64_t nf, int64_t tex_c, int is_double) {
     (void)tex_c;
     const int64_t rows = (b > 0 ? b : 0) * (nf > 0 ? nf : 0);
-    return rows * grad_row_floats() * (is_double ? 8 : 4) + rows * 4 + rows + 16;      // rows | leaders | flags
+    // records | valid bits | leader table
+    return rows * grad_row_floats() * (is_double ? 8 : 4) + ((rows + 63) / 64 + 1) * 8 + rows * 4 + 16;
 }
 
 extern "C" int sr_rasterize_forward_f32(int64_t b, int64_t nv, int64_t nf, int64_t h, int64_t w,
