@@ -1153,11 +1153,17 @@ __device__ __forceinline__ R block_sum_256(R x, R* s_part) {
     return tot;
 }
 
+// One record per triangle: for each corner k the first four of its CORNER values (d/d(vertex) then d/d(attribute row))
+// as an aligned quad at 4 k, the remaining CORNER - 4 behind the three quads.  k_grad_vert, which is bound by the number
+// of scattered load instructions it issues (every lane of a wave hits a different line), fetches a corner with one
+// 16-byte load + one scalar instead of five scalars.
 template <int CT, bool PERSP>
 struct RowShape {
     static constexpr int NVC = PERSP ? 3 : 2;
     static constexpr int CORNER = NVC + CT;
-    static constexpr int RS = (3 * CORNER + 3) / 4 * 4;          // floats per row, multiple of 4
+    static constexpr int TAIL = CORNER > 4 ? CORNER - 4 : 0;     // values of a corner behind its quad
+    static constexpr int RS = (12 + 3 * TAIL + 3) / 4 * 4;       // values per record, multiple of 4
+    static __host__ __device__ constexpr int at(int k, int j) { return j < 4 ? 4 * k + j : 12 + k * TAIL + (j - 4); }
 };
 
 template <typename R, int CT, bool PERSP>
@@ -1170,9 +1176,9 @@ __device__ __forceinline__ void store_row(const TriAcc<R, CT, PERSP>& acc, R* __
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
 #pragma unroll
-        for (int j = 0; j < S::NVC; ++j) vals[k * S::CORNER + j] = JacTri<R, PERSP>::get(acc.gv, k, j);
+        for (int j = 0; j < S::NVC; ++j) vals[S::at(k, j)] = JacTri<R, PERSP>::get(acc.gv, k, j);
 #pragma unroll
-        for (int j = 0; j < CT; ++j) vals[k * S::CORNER + S::NVC + j] = acc.gt[k * CT + j];
+        for (int j = 0; j < CT; ++j) vals[S::at(k, S::NVC + j)] = acc.gt[k * CT + j];
     }
     R* row = tg + rowid * S::RS;
     if (sizeof(R) == 4) {
@@ -1360,17 +1366,52 @@ __global__ __launch_bounds__(256) void k_grad_vert(long long nv, long long nf, c
     R at[CT];
 #pragma unroll
     for (int j = 0; j < CT; ++j) at[j] = 0;
-    const int e1 = off[vert + 1];
-    for (int e = off[vert]; e < e1; ++e) {
-        const int idx = ad[e];                       // corner-major: k * nf + f
-        const int k = idx / (int)nf;
-        const long long row = s * nf + (idx - k * (int)nf);
-        if (!((valid[row >> 6] >> (row & 63)) & 1ull)) continue;      // the triangle won no pixel: no record
-        const R* r = tg + row * S::RS + k * S::CORNER;
+    // The incident corners of a vertex (~6) are independent; a loop that walks them one by one is a chain of three
+    // dependent loads per corner (list entry -> validity word -> record) and the kernel, three waves per SIMD slot
+    // deep, is pure latency: 85 us at config[3].  Six corners per step instead: all list entries, then all validity
+    // words, then all records are in flight together (unconditional loads from clamped addresses, masked afterwards);
+    // the sums keep the order of the list.
+    const int e0 = off[vert], e1 = off[vert + 1];
+    constexpr int U = 6;                        // (the valence of an interior vertex of a triangulated grid)
+    constexpr int NC = S::CORNER < 4 ? 4 : S::CORNER;
+    for (int base = e0; base < e1; base += U) {
+        int idx[U];
 #pragma unroll
-        for (int j = 0; j < S::NVC; ++j) av[j] += r[j];
+        for (int u = 0; u < U; ++u) idx[u] = ad[min(base + u, e1 - 1)];
+        int kk[U];
+        long long row[U];
+        unsigned long long word[U];
 #pragma unroll
-        for (int j = 0; j < CT; ++j) at[j] += r[S::NVC + j];
+        for (int u = 0; u < U; ++u) {
+            kk[u] = idx[u] >= 2 * (int)nf ? 2 : (idx[u] >= (int)nf ? 1 : 0);
+            row[u] = s * nf + (idx[u] - kk[u] * (int)nf);
+            word[u] = valid[row[u] >> 6];
+        }
+        R c[U][NC];
+        bool ok[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            ok[u] = base + u < e1 && ((word[u] >> (row[u] & 63)) & 1ull);      // won a pixel: the record exists
+            const R* rec = tg + (ok[u] ? row[u] : s * nf) * S::RS;
+            if (sizeof(R) == 4) {
+                const float4 q = *reinterpret_cast<const float4*>(rec + 4 * kk[u]);
+                c[u][0] = (R)q.x; c[u][1] = (R)q.y; c[u][2] = (R)q.z; c[u][3] = (R)q.w;
+            } else {
+                const double2 q0 = *reinterpret_cast<const double2*>(rec + 4 * kk[u]);
+                const double2 q1 = *reinterpret_cast<const double2*>(rec + 4 * kk[u] + 2);
+                c[u][0] = (R)q0.x; c[u][1] = (R)q0.y; c[u][2] = (R)q1.x; c[u][3] = (R)q1.y;
+            }
+#pragma unroll
+            for (int j = 4; j < S::CORNER; ++j) c[u][j] = rec[12 + kk[u] * S::TAIL + (j - 4)];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (!ok[u]) continue;
+#pragma unroll
+            for (int j = 0; j < S::NVC; ++j) av[j] += c[u][j];
+#pragma unroll
+            for (int j = 0; j < CT; ++j) at[j] += c[u][S::NVC + j];
+        }
     }
     if (grad_v && ch0 == 0) {
         R* o = grad_v + (s * nv + vert) * 3;
