@@ -1272,14 +1272,36 @@ __global__ __launch_bounds__(256) void k_grad_pix(long long b, long long nv, lon
                                                   unsigned long long* __restrict__ valid,
                                                   const R* __restrict__ grad_out, bool want_v,
                                                   R* __restrict__ tg, R eps) {
+    __shared__ int s_row[256], s_pix[256];
+    __shared__ int s_cnt[4];
     const long long hw = h * w;
-    const long long row = (long long)blockIdx.x * 256 + threadIdx.x;
-    const int lead_pix = row < b * nf ? first[row] : 0x7FFFFFFF;
-    // one bit per record, "this triangle won a pixel: its record is written" (by this kernel or by k_grad_big) — what
-    // k_grad_vert tests before it reads a record: a wave's 64 consecutive rows are one word
-    const unsigned long long won = __ballot(lead_pix != 0x7FFFFFFF);
-    if ((threadIdx.x & 63) == 0 && row < b * nf) valid[row >> 6] = won;       // (waves beyond the last row own no word)
-    if (lead_pix == 0x7FFFFFFF) return;
+    const long long row0 = (long long)blockIdx.x * 256;
+    int lead_pix;
+    long long row;
+    {
+        const long long rq = row0 + threadIdx.x;
+        const int pq = rq < b * nf ? first[rq] : 0x7FFFFFFF;
+        // one bit per record, "this triangle won a pixel: its record is written" (by this kernel or by k_grad_big) —
+        // what k_grad_vert tests before it reads a record: a wave's 64 consecutive rows are one word
+        const unsigned long long won = __ballot(pq != 0x7FFFFFFF);
+        const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+        if (lane == 0 && rq < b * nf) valid[rq >> 6] = won;                    // (waves beyond the last row own no word)
+        // the winning triangles of the workgroup's 256 rows, compacted: the long part below runs in dense waves
+        if (lane == 0) s_cnt[wv] = __popcll(won);
+        __syncthreads();
+        int base = 0;
+        for (int i = 0; i < wv; ++i) base += s_cnt[i];
+        const int n_won = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+        if (pq != 0x7FFFFFFF) {
+            const int slot = base + __popcll(won & ((1ull << lane) - 1ull));
+            s_row[slot] = threadIdx.x;
+            s_pix[slot] = pq;
+        }
+        __syncthreads();
+        if ((int)threadIdx.x >= n_won) return;
+        row = row0 + s_row[threadIdx.x];
+        lead_pix = s_pix[threadIdx.x];
+    }
     const long long s = row / nf;
     const int ti = (int)(row - s * nf);
     const long long pix = lead_pix;
