@@ -257,10 +257,14 @@ extern "C" int sr_noise_bias_act_bwd(float* gx, float* gbias, float* gnoise_w, c
                        noise, alpha, scale, (int)c, inner, noise_bstride, chunks, (const float*)nullptr,
                        (const float*)nullptr, 0.0f, 0.0f, (float*)nullptr);
     float* chan_nw = scratch + 2 * n * c * (int64_t)chunks;
-    hipLaunchKernelGGL(k_nba_finish, dim3((unsigned)c), dim3(64), 0, st, gbias, chan_nw, scratch, n, (int)c,
-                       chunks);
-    if (noise && gnoise_w)
-        hipLaunchKernelGGL(k_nba_finish2, dim3(1), dim3(64), 0, st, gnoise_w, chan_nw, (int)c);
+    // gbias == NULL: the caller's bias and noise strength are frozen (sampling, inversion, the discriminator inside the
+    // generator's phase) — no finish launches
+    if (gbias) {
+        hipLaunchKernelGGL(k_nba_finish, dim3((unsigned)c), dim3(64), 0, st, gbias, chan_nw, scratch, n, (int)c,
+                           chunks);
+        if (noise && gnoise_w)
+            hipLaunchKernelGGL(k_nba_finish2, dim3(1), dim3(64), 0, st, gnoise_w, chan_nw, (int)c);
+    }
     return sr_launch_status();
 }
 
@@ -287,9 +291,11 @@ extern "C" int sr_noise_bias_act_bwd_dot(float* gx, float* gbias, float* gnoise_
     hipLaunchKernelGGL(k_nba_bwd<true>, dim3(chunks, (unsigned)(n * c)), dim3(EB), 0, st, gx, scratch, gy, out, noise,
                        alpha, scale, (int)c, inner, noise_bstride, chunks, noise_w, bias, 1.0f / scale,
                        1.0f / (alpha * scale), dot_partial);
-    hipLaunchKernelGGL(k_nba_finish, dim3((unsigned)c), dim3(64), 0, st, gbias, chan_nw, scratch, n, (int)c, chunks);
-    if (noise && gnoise_w)
-        hipLaunchKernelGGL(k_nba_finish2, dim3(1), dim3(64), 0, st, gnoise_w, chan_nw, (int)c);
+    if (gbias) {                                            // (NULL: frozen bias / noise strength)
+        hipLaunchKernelGGL(k_nba_finish, dim3((unsigned)c), dim3(64), 0, st, gbias, chan_nw, scratch, n, (int)c, chunks);
+        if (noise && gnoise_w)
+            hipLaunchKernelGGL(k_nba_finish2, dim3(1), dim3(64), 0, st, gnoise_w, chan_nw, (int)c);
+    }
     hipLaunchKernelGGL(k_rowdot_finish, dim3((unsigned)(n * c)), dim3(64), 0, st, rowdot, dot_partial, chunks);
     return sr_launch_status();
 }
@@ -468,10 +474,12 @@ extern "C" int sr_noise_bias_act_affine_bwd(float* gx, float* gamap, float* gsma
         hipLaunchKernelGGL(k_plane_sum, dim3(g1), dim3(EB), 0, st, gamap, ga_part, plane, groups);
         hipLaunchKernelGGL(k_plane_sum, dim3(g1), dim3(EB), 0, st, gsmap, gs_part, plane, groups);
     }
-    hipLaunchKernelGGL(k_nba_finish, dim3((unsigned)c), dim3(64), 0, st, gbias, chan_nw, scratch, n, (int)c,
-                       chunks * 4);
-    if (noise && gnoise_w)
-        hipLaunchKernelGGL(k_nba_finish2, dim3(1), dim3(64), 0, st, gnoise_w, chan_nw, (int)c);
+    if (gbias) {                                            // (NULL: frozen bias / noise strength)
+        hipLaunchKernelGGL(k_nba_finish, dim3((unsigned)c), dim3(64), 0, st, gbias, chan_nw, scratch, n, (int)c,
+                           chunks * 4);
+        if (noise && gnoise_w)
+            hipLaunchKernelGGL(k_nba_finish2, dim3(1), dim3(64), 0, st, gnoise_w, chan_nw, (int)c);
+    }
     return sr_launch_status();
 }
 

@@ -303,7 +303,8 @@ class ConvNBAFn(torch.autograd.Function):
                 got = iter(torch.autograd.grad(y, sel, gy, create_graph=True, allow_unused=True)) if sel else iter(())
                 grads = [next(got) if (nd and t is not None) else None for t, nd in zip(ins, needs[:7])]
             return tuple(grads) + (None, None)
-        g, gb, gnw, rdot = _nba_bwd_dot(gy, out, noise, noise_w, abias, slope, gain)
+        want_p = bool(needs[6] or (noise is not None and needs[5]))
+        g, gb, gnw, rdot = _nba_bwd_dot(gy, out, noise, noise_w, abias, slope, gain, want_p)
         gx = gw = gis = gos = None
         if needs[0] or needs[2]:
             dxu = ConvFn.apply(g, adjoint_weight(wt, "c3", ctx.frozen, ctx.adj), oscale, None, None, "c3")
@@ -318,25 +319,28 @@ class ConvNBAFn(torch.autograd.Function):
             gw = WgradFn.apply(x, g, iscale, oscale, "c3")
         if needs[3] and oscale is not None:
             gos = rdot / oscale
-        return (gx, gw, gis, gos, None, (gnw if noise is not None and needs[5] else None),
-                (gb if needs[6] else None), None, None)
+        return (gx, gw, gis, gos, None, (gnw if noise is not None and want_p and needs[5] else None),
+                (gb if want_p and needs[6] else None), None, None)
 
 
-def _nba_bwd_dot(gy, out, noise, noise_w, abias, slope, gain):
-    """Activation backward + bias / noise-strength gradients + demodulation row-dots in one pass."""
+def _nba_bwd_dot(gy, out, noise, noise_w, abias, slope, gain, want_params=True):
+    """Activation backward + bias / noise-strength gradients + demodulation row-dots in one pass (want_params False:
+    frozen bias / noise strength — their reduction launches are skipped, gb / gnw come back empty)."""
     gy = gy.contiguous()
     b, n, h, w = out.shape
     inner = h * w
     L = _lib.lib()
     g = torch.empty_like(out)
-    gb = (torch.zeros if out.numel() == 0 else torch.empty)(n, dtype=out.dtype, device=out.device)
+    gb = (torch.zeros if out.numel() == 0 else torch.empty)(n if want_params else 0, dtype=out.dtype, device=out.device)
     # written by the finish kernel whenever there is noise; a fill launch only for the cases that need the zero
-    gnw = (torch.empty if (noise is not None and out.numel() > 0) else torch.zeros)(1, dtype=out.dtype, device=out.device)
+    gnw = (torch.empty if (noise is not None and out.numel() > 0) else torch.zeros)(1 if want_params else 0,
+                                                                                        dtype=out.dtype, device=out.device)
     rdot = torch.empty((b, n), dtype=out.dtype, device=out.device)
     scratch = torch.empty(L.sr_noise_bias_act_bwd_dot_scratch_floats(b, n, inner), dtype=out.dtype, device=out.device)
     bstride = 0 if noise is None or noise.numel() == inner else inner
     with on_device_of(out):
-        rc = L.sr_noise_bias_act_bwd_dot(_lib.ptr(g), _lib.ptr(gb), _lib.ptr(gnw), _lib.ptr(rdot), _lib.ptr(gy),
+        rc = L.sr_noise_bias_act_bwd_dot(_lib.ptr(g), _lib.ptr(gb) if want_params else None,
+                                         _lib.ptr(gnw) if want_params else None, _lib.ptr(rdot), _lib.ptr(gy),
                                          _lib.ptr(out), _lib.ptr(noise), _lib.ptr(noise_w), _lib.ptr(abias), slope, gain,
                                          b, n, inner, bstride, _lib.ptr(scratch), stream_of(out))
     _lib.check(rc, "sr_noise_bias_act_bwd_dot")
@@ -389,7 +393,8 @@ class UpConvNBAFn(torch.autograd.Function):
                 got = iter(torch.autograd.grad(o, sel, gy, create_graph=True, allow_unused=True)) if sel else iter(())
                 grads = [next(got) if (nd and t is not None) else None for t, nd in zip(ins, needs[:9])]
             return tuple(grads) + (None, None)
-        g, gb, gnw, rdot = _nba_bwd_dot(gy, out, noise, noise_w, abias, slope, gain)
+        want_p = bool(needs[8] or (noise is not None and needs[7]))
+        g, gb, gnw, rdot = _nba_bwd_dot(gy, out, noise, noise_w, abias, slope, gain, want_p)
         p0 = pad[0]
         oh, ow = out.shape[2], out.shape[3]
         g257 = upfirdn2d_op(g.reshape(-1, oh, ow, 1), flipped(kernel), 1, 1, 1, 1, 3 - p0,
@@ -408,8 +413,8 @@ class UpConvNBAFn(torch.autograd.Function):
             gw = WgradFn.apply(x, g257, iscale, oscale, "t3s2")
         if needs[3] and oscale is not None:
             gos = rdot / oscale
-        return (gx, gw, gis, gos, None, None, None, (gnw if noise is not None and needs[7] else None),
-                (gb if needs[8] else None), None, None)
+        return (gx, gw, gis, gos, None, None, None, (gnw if noise is not None and want_p and needs[7] else None),
+                (gb if want_p and needs[8] else None), None, None)
 
 
 class _NoCtx:

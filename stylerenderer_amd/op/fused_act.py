@@ -50,8 +50,9 @@ def fused_bias_act(input, bias, refer, act, grad, alpha, scale):
     return y
 
 
-def _act_backward(grad_output, out, negative_slope, scale):
-    """(grad_input, grad_bias) in one sweep (C ABI sr_fused_act_bwd)."""
+def _act_backward(grad_output, out, negative_slope, scale, want_bias=True):
+    """(grad_input, grad_bias) in one sweep (C ABI sr_fused_act_bwd); without the bias gradient (frozen bias: the
+    discriminator inside the generator's phase, the LPIPS trunk) one elementwise launch and no reduction."""
     g = grad_output.contiguous()
     o = out.contiguous()
     require_f32(g, "fused_leaky_relu backward")
@@ -62,11 +63,12 @@ def _act_backward(grad_output, out, negative_slope, scale):
         inner *= o.size(i)
     gx = torch.empty_like(o)
     # an empty input launches nothing: its bias gradient is the empty sum, not uninitialised memory
-    gb = (torch.zeros if o.numel() == 0 else torch.empty)(c, dtype=o.dtype, device=o.device)
+    gb = (torch.zeros if o.numel() == 0 else torch.empty)(c if want_bias else 0, dtype=o.dtype, device=o.device)
     L = _lib.lib()
-    scratch = torch.empty(L.sr_fused_act_bwd_scratch_floats(n, c, inner), dtype=o.dtype, device=o.device)
+    scratch = (torch.empty(L.sr_fused_act_bwd_scratch_floats(n, c, inner), dtype=o.dtype, device=o.device)
+               if want_bias else None)
     with on_device_of(o):
-        rc = L.sr_fused_act_bwd(_lib.ptr(gx), _lib.ptr(gb), _lib.ptr(g), _lib.ptr(o),
+        rc = L.sr_fused_act_bwd(_lib.ptr(gx), _lib.ptr(gb) if want_bias else None, _lib.ptr(g), _lib.ptr(o),
                                 float(negative_slope), float(scale), n, c, inner,
                                 _lib.ptr(scratch), stream_of(o))
     _lib.check(rc, "sr_fused_act_bwd")
@@ -75,18 +77,21 @@ def _act_backward(grad_output, out, negative_slope, scale):
 
 class FusedLeakyReLUFunctionBackward(Function):
     @staticmethod
-    def forward(ctx, grad_output, out, negative_slope, scale):
+    def forward(ctx, grad_output, out, negative_slope, scale, want_bias=True):
         ctx.save_for_backward(out)
         ctx.negative_slope = negative_slope
         ctx.scale = scale
-        return _act_backward(grad_output, out, negative_slope, scale)
+        gx, gb = _act_backward(grad_output, out, negative_slope, scale, want_bias)
+        if not want_bias:
+            ctx.mark_non_differentiable(gb)
+        return gx, gb
 
     @staticmethod
     def backward(ctx, gradgrad_input, gradgrad_bias):
         (out,) = ctx.saved_tensors
         gradgrad_out = fused_bias_act(gradgrad_input, gradgrad_bias, out, 3, 1,
                                       ctx.negative_slope, ctx.scale)
-        return gradgrad_out, None, None, None
+        return gradgrad_out, None, None, None, None
 
 
 class FusedLeakyReLUFunction(Function):
@@ -101,9 +106,10 @@ class FusedLeakyReLUFunction(Function):
     @staticmethod
     def backward(ctx, grad_output):
         (out,) = ctx.saved_tensors
+        need_bias = ctx.needs_input_grad[1]
         grad_input, grad_bias = FusedLeakyReLUFunctionBackward.apply(
-            grad_output, out, ctx.negative_slope, ctx.scale)
-        return grad_input, grad_bias, None, None
+            grad_output, out, ctx.negative_slope, ctx.scale, need_bias)
+        return grad_input, (grad_bias if need_bias else None), None, None
 
 
 def fused_leaky_relu(input, bias, negative_slope=0.2, scale=2 ** 0.5):

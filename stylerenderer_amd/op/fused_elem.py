@@ -48,19 +48,24 @@ def _launch_fwd(x, noise, noise_w, bias, ref, slope, scale):
 
 class _NBABackward(Function):
     @staticmethod
-    def forward(ctx, gy, out, noise, slope, scale):
+    def forward(ctx, gy, out, noise, slope, scale, want_params=True):
+        """want_params False: bias and noise strength are frozen (sampling, inversion) — no reduction launches, empty
+        gb / gnw."""
         n, c, inner = _geometry(out)
         gy = gy.contiguous()
         gx = torch.empty_like(out)
-        gb = (torch.zeros if out.numel() == 0 else torch.empty)(c, dtype=out.dtype, device=out.device)
-        gnw = (torch.empty if (noise is not None and out.numel() > 0) else torch.zeros)(1, dtype=out.dtype,
+        gb = (torch.zeros if out.numel() == 0 else torch.empty)(c if want_params else 0, dtype=out.dtype,
+                                                                device=out.device)
+        gnw = (torch.empty if (noise is not None and out.numel() > 0) else torch.zeros)(1 if want_params else 0,
+                                                                                            dtype=out.dtype,
                                                                                             device=out.device)
         L = _lib.lib()
         scratch = torch.empty(L.sr_noise_bias_act_bwd_scratch_floats(n, c, inner), dtype=out.dtype,
                               device=out.device)
         bstride = 0 if noise is None or noise.numel() == inner else inner
         with on_device_of(out):
-            rc = L.sr_noise_bias_act_bwd(_lib.ptr(gx), _lib.ptr(gb), _lib.ptr(gnw), _lib.ptr(gy),
+            rc = L.sr_noise_bias_act_bwd(_lib.ptr(gx), _lib.ptr(gb) if want_params else None,
+                                         _lib.ptr(gnw) if want_params else None, _lib.ptr(gy),
                                          _lib.ptr(out), _lib.ptr(noise), float(slope), float(scale), n, c,
                                          inner, bstride, _lib.ptr(scratch), stream_of(out))
         _lib.check(rc, "sr_noise_bias_act_bwd")
@@ -71,9 +76,15 @@ class _NBABackward(Function):
     @staticmethod
     def backward(ctx, ggx, ggb, ggnw):
         out, noise = ctx.saved_tensors
-        gg = _launch_fwd(ggx.contiguous(), noise, ggnw.contiguous() if noise is not None else None,
-                         ggb.contiguous(), out, ctx.slope, ctx.scale)
-        return gg, None, None, None, None
+        c = out.shape[1]
+        # (frozen parameters: gb / gnw were not produced, their cotangents are absent = zero)
+        ggb = ggb.contiguous() if ggb is not None and ggb.numel() == c else out.new_zeros(c)
+        if noise is not None:
+            ggnw = ggnw.contiguous() if ggnw is not None and ggnw.numel() == 1 else out.new_zeros(1)
+        else:
+            ggnw = None
+        gg = _launch_fwd(ggx.contiguous(), noise, ggnw, ggb, out, ctx.slope, ctx.scale)
+        return gg, None, None, None, None, None
 
 
 class _NBA(Function):
@@ -87,8 +98,11 @@ class _NBA(Function):
     @staticmethod
     def backward(ctx, gy):
         y, noise = ctx.saved_tensors
-        gx, gb, gnw = _NBABackward.apply(gy, y, noise, ctx.slope, ctx.scale)
-        return gx, None, (gnw if noise is not None else None), gb, None, None
+        needs = ctx.needs_input_grad
+        want = bool(needs[3] or (noise is not None and needs[2]))
+        gx, gb, gnw = _NBABackward.apply(gy, y, noise, ctx.slope, ctx.scale, want)
+        return (gx, None, (gnw if noise is not None and want and needs[2] else None), (gb if want and needs[3] else None),
+                None, None)
 
 
 def noise_bias_act(x, noise, noise_weight, bias, negative_slope=0.2, scale=2 ** 0.5):
@@ -107,13 +121,16 @@ class _NBAAffineBackward(Function):
     path-length regulariser needs (gradients w.r.t. gy, x and the scale plane)."""
 
     @staticmethod
-    def forward(ctx, gy, out, x, smap2, noise, slope, scale):
+    def forward(ctx, gy, out, x, smap2, noise, slope, scale, want_params=True):
         n, c, inner = _geometry(out)
         gy = gy.contiguous()
         gx = torch.empty_like(out)
         gmap = torch.empty((2, n) + tuple(out.shape[2:]), dtype=out.dtype, device=out.device)   # [a | s] planes
-        gb = (torch.zeros if out.numel() == 0 else torch.empty)(c, dtype=out.dtype, device=out.device)
-        gnw = (torch.empty if (noise is not None and out.numel() > 0) else torch.zeros)(1, dtype=out.dtype,
+        # want_params False: bias and noise strength are frozen (inversion, sampling) — no reduction launches
+        gb = (torch.zeros if out.numel() == 0 else torch.empty)(c if want_params else 0, dtype=out.dtype,
+                                                                device=out.device)
+        gnw = (torch.empty if (noise is not None and out.numel() > 0) else torch.zeros)(1 if want_params else 0,
+                                                                                            dtype=out.dtype,
                                                                                             device=out.device)
         L = _lib.lib()
         scratch = torch.empty(L.sr_noise_bias_act_affine_bwd_scratch_floats(n, c, inner), dtype=out.dtype,
@@ -121,7 +138,8 @@ class _NBAAffineBackward(Function):
         bstride = 0 if noise is None or noise.numel() == inner else inner
         with on_device_of(out):
             rc = L.sr_noise_bias_act_affine_bwd(
-                _lib.ptr(gx), gmap.data_ptr(), gmap.data_ptr() + 4 * n * inner, _lib.ptr(gb), _lib.ptr(gnw),
+                _lib.ptr(gx), gmap.data_ptr(), gmap.data_ptr() + 4 * n * inner, _lib.ptr(gb) if want_params else None,
+                _lib.ptr(gnw) if want_params else None,
                 _lib.ptr(gy), _lib.ptr(out), _lib.ptr(x), _lib.ptr(smap2), smap2.stride(0), _lib.ptr(noise),
                 float(slope), float(scale), n, c, inner, bstride, _lib.ptr(scratch), stream_of(out))
         _lib.check(rc, "sr_noise_bias_act_affine_bwd")
@@ -140,8 +158,8 @@ class _NBAAffineBackward(Function):
         d_smap = torch.zeros_like(smap2, memory_format=torch.contiguous_format)       # channel 1 (shift plane): zero
         G_gx = G_gx.contiguous() if G_gx is not None else None
         G_gmap = G_gmap.contiguous() if G_gmap is not None else None                  # [n, 2, H, W]
-        G_gb = G_gb.contiguous() if G_gb is not None else None
-        G_gnw = G_gnw.contiguous() if (G_gnw is not None and noise is not None) else None
+        G_gb = G_gb.contiguous() if (G_gb is not None and G_gb.numel() == c) else None
+        G_gnw = G_gnw.contiguous() if (G_gnw is not None and G_gnw.numel() == 1 and noise is not None) else None
         L = _lib.lib()
         scratch = torch.empty(L.sr_noise_bias_act_affine_bwd2_scratch_floats(n, c, inner), dtype=out.dtype,
                               device=out.device)
@@ -155,7 +173,7 @@ class _NBAAffineBackward(Function):
         _lib.check(rc, "sr_noise_bias_act_affine_bwd2")
         needs = ctx.needs_input_grad
         return (d_gy if needs[0] else None, None, d_x if needs[2] else None, d_smap if needs[3] else None, None,
-                None, None)
+                None, None, None)
 
 
 class _NBAAffine(Function):
@@ -184,9 +202,11 @@ class _NBAAffine(Function):
         needs = ctx.needs_input_grad
         # (also when this backward is itself recorded — path-length regulariser: _NBAAffineBackward has a native
         # second-order pass, k_nba_aff_bwd2; round 2 re-derived the VJP from ~45 tensor-algebra launches per layer)
-        gx, gmap, gb, gnw = _NBAAffineBackward.apply(gy, y, x, smap2, noise, slope, scale)
+        want = bool(needs[4] or (noise is not None and needs[3]))
+        gx, gmap, gb, gnw = _NBAAffineBackward.apply(gy, y, x, smap2, noise, slope, scale, want)
         return (gx if needs[0] else None, gmap if needs[1] else None, None,
-                gnw if (noise is not None and needs[3]) else None, gb if needs[4] else None, None, None)
+                gnw if (noise is not None and want and needs[3]) else None, gb if (want and needs[4]) else None, None,
+                None)
 
 
 def noise_bias_act_affine(x, smap2, noise, noise_weight, bias, negative_slope=0.2, scale=2 ** 0.5):

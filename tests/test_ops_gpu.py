@@ -664,3 +664,45 @@ def test_rasterize_tiled_path_list_overflow_wide_boxes_and_tile_borders(persp, m
     assert bits_equal(zbuf.cpu().numpy(), want_z)
     covered = int((want_i != 0).any(-1).sum())
     assert covered > 2000
+
+
+def test_frozen_bias_and_noise_strength_skip_their_reductions_same_input_gradients():
+    """With frozen parameters (inversion, sampling, the discriminator inside the generator's phase) the fused
+    activation nodes skip the bias / noise-strength reductions: the gradients with respect to the activations — first
+    and second order — are the same bits, the parameter gradients are simply absent."""
+    from stylerenderer_amd.op import fused_leaky_relu
+    from stylerenderer_amd.op.fused_elem import noise_bias_act, noise_bias_act_affine
+
+    g = torch.Generator().manual_seed(21)
+    x0 = torch.randn(3, 8, 16, 16, generator=g).to(DEV)
+    noise = torch.randn(3, 1, 16, 16, generator=g).to(DEV)
+    smap = torch.randn(3, 2, 16, 16, generator=g).to(DEV)
+    gy = torch.randn(3, 8, 16, 16, generator=g).to(DEV)
+    b0, nw0 = torch.randn(8, generator=g).to(DEV), torch.randn(1, generator=g).to(DEV)
+
+    def run(kind, frozen):
+        x = x0.clone().requires_grad_()
+        bias = b0.clone().requires_grad_(not frozen)
+        nw = nw0.clone().requires_grad_(not frozen)
+        if kind == "act":
+            y = fused_leaky_relu(x, bias)
+        elif kind == "nba":
+            y = noise_bias_act(x, noise, nw, bias)
+        else:
+            y = noise_bias_act_affine(x, smap, noise, nw, bias)
+        (gx,) = torch.autograd.grad(y, x, gy, create_graph=True)
+        (ggy,) = torch.autograd.grad(gx.square().sum(), x, allow_unused=True) if kind == "aff" else (None,)
+        y2 = fused_leaky_relu(x, bias) if kind == "act" else (noise_bias_act(x, noise, nw, bias) if kind == "nba"
+                                                               else noise_bias_act_affine(x, smap, noise, nw, bias))
+        y2.backward(gy)
+        return (y.detach(), gx.detach(), x.grad.clone(), ggy, bias.grad, nw.grad)
+
+    for kind in ("act", "nba", "aff"):
+        a, f = run(kind, False), run(kind, True)
+        for u, v in zip(a[:3], f[:3]):
+            assert torch.equal(u, v), kind
+        if a[3] is not None:
+            assert torch.equal(a[3], f[3]), kind
+        assert a[4] is not None and f[4] is None, kind
+        if kind != "act":
+            assert a[5] is not None and f[5] is None, kind
