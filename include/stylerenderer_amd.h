@@ -385,6 +385,17 @@ int sr_signal_wait(const uint32_t* counter, uint32_t at_least, sr_stream_t strea
  * reference has no counterpart: it never captures its step (train.py enqueues ~4 000 launches per iteration). */
 int sr_graph_replace_memset_nodes(void* hip_graph, int* replaced);
 
+/* One layer of the LPIPS distance (reference lpips/networks_basic.py:62-85 + lpips/__init__.py:42-44: normalize_tensor,
+ * squared difference, 1x1 `lin` convolution, spatial average) fused — used by the latent-inversion loop:
+ *   d[b] = mean_hw sum_c lin[c] * (f0[b,c,p] / (sqrt(sum_c f0^2) + eps) - t[b,c,p])^2
+ * f0 [b, c, hw] raw features, t [b | 1, c, hw] NORMALISED target features (t_bstride = c*hw or 0), lin [c].
+ * sr_lpips_layer_bwd: gf = d(sum_b gd[b] d[b]) / d f0.  scratch: sr_lpips_layer_scratch_floats(b, hw) floats. */
+int64_t sr_lpips_layer_scratch_floats(int64_t b, int64_t hw);
+int sr_lpips_layer_fwd(float* d, const float* f0, const float* t, const float* lin, int64_t b, int64_t c, int64_t hw,
+                       int64_t t_bstride, float eps, float* scratch, sr_stream_t stream);
+int sr_lpips_layer_bwd(float* gf, const float* gd, const float* f0, const float* t, const float* lin, int64_t b,
+                       int64_t c, int64_t hw, int64_t t_bstride, float eps, sr_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -53,6 +53,9 @@ SIGNATURES = {
     "sr_weight_adjoint": (_i, [_p, _p, _l, _l, _l, _l, _l, _i, _p]),
     "sr_weight_prep_batch": (_i, [_i] + [_p] * 9),
     "sr_weight_adjoint_batch": (_i, [_i] + [_p] * 9),
+    "sr_lpips_layer_scratch_floats": (_l, [_l, _l]),
+    "sr_lpips_layer_fwd": (_i, [_p] * 4 + [_l] * 4 + [_f, _p, _p]),
+    "sr_lpips_layer_bwd": (_i, [_p] * 5 + [_l] * 4 + [_f, _p]),
     "sr_upfirdn2d": (_i, [_p, _p, _p, _l] + [_i] * 14 + [_p]),
     "sr_upsample2_add": (_i, [_p] * 4 + [_l] + [_i] * 6 + [_p]),
     "sr_blur_noise_bias_act": (_i, [_p] * 6 + [_f, _f, _l, _l] + [_i] * 6 + [_l, _p]),

@@ -34,6 +34,7 @@ SOURCES = [
     ("weight_prep.hip", EXACT),
     ("style_linear.hip", EXACT),
     ("mesh.hip", EXACT),
+    ("lpips.hip", EXACT),
     ("conv_mfma.hip", []),
     ("conv_wino.hip", []),
     ("conv_wgrad_wino.hip", []),

@@ -13,8 +13,11 @@ reference's own files load unchanged:
                              `lin0.model.1.weight` ... as in lpips/weights/v0.1/vgg.pth   networks_basic.py:103-112
     distance                 sum_k spatial_mean( lin_k( (f0_k - f1_k)^2 ) )          networks_basic.py:62-85
 
-On device tensors every 3x3 convolution runs on the MFMA kernels (op.conv.conv2d, Winograd where eligible) and
-bias + ReLU is the fused activation kernel (negative_slope = 0, scale = 1); CPU tensors use torch's own ops.
+On device tensors every 3x3 convolution runs on the MFMA kernels (op.conv.conv2d, Winograd where eligible),
+bias + ReLU is the fused activation kernel (negative_slope = 0, scale = 1), and — against a fixed target, the case of
+the inversion loop — normalisation, squared difference, `lin` and the spatial mean of a layer are one fused launch
+forward and one backward (op.lpips_layer, csrc/lpips.hip: ~25 ATen launches per layer otherwise, at batch 1 where
+every launch is 5 us of a 9 ms step); CPU tensors use torch's own ops.
 
 WEIGHTS.  The five learned heads ARE the reference's (`lpips/weights/v0.1/vgg.pth`, 1 472 floats, BSD-2 LICENSE-LPIPS;
 shipped as data in `lpips_heads_v0_1.npz`, written by oracle/make_golden.py) and are loaded by default.  The trunk
@@ -34,6 +37,7 @@ from torch.nn import functional as F
 from . import synth
 from .op import conv as _conv
 from .op import fused_leaky_relu
+from .op import lpips_layer as _lpips_layer
 from .op.weight_prep import weight_prep as _weight_prep
 
 VGG_CFG = ((64, 64), (128, 128), (256, 256, 256), (512, 512, 512), (512, 512, 512))
@@ -197,7 +201,14 @@ class PNetLin(nn.Module):
 
     def distance_to(self, feats1, in0):
         """Distance of `in0` to precomputed `features(in1)` (the target of an optimisation is fixed)."""
-        res = self.per_layer(self.features(in0), feats1)
+        raw = self.net(self.scaling_layer(in0))
+        lins = self.lins
+        if all(_lpips_layer.supported(raw[k], feats1[k], lins[k]) for k in range(self.L)):
+            # device tensors, fixed target and heads: normalisation, squared difference, `lin` and the spatial mean
+            # of a layer are one launch forward and one backward (op/lpips_layer.py) instead of ~25
+            res = [_lpips_layer.lpips_layer(raw[k], feats1[k], lins[k]) for k in range(self.L)]
+        else:
+            res = self.per_layer([normalize_tensor(f) for f in raw], feats1)
         val = res[0]
         for r in res[1:]:
             val = val + r

@@ -1,0 +1,60 @@
+"""One LPIPS layer — normalize_tensor, squared difference, `lin` 1x1 convolution, spatial average — as one fused forward
+and one fused backward launch (C ABI sr_lpips_layer_fwd / _bwd, csrc/lpips.hip) instead of ~25 ATen launches.
+
+    lpips_layer(f0 [B, C, H, W], t_normalised [B | 1, C, H, W], lin [1, C, 1, 1] | [C]) -> [B, 1, 1, 1]
+
+Differentiable once, with respect to f0 (the latent-inversion loop optimises the image behind f0; the target and the
+learned heads are fixed).  reference lpips/networks_basic.py:62-85, lpips/__init__.py:42-44.
+"""
+import torch
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+
+from .. import _lib
+from ._dispatch import on_device_of, require_f32, stream_of
+
+EPS = 1e-10
+
+
+def supported(f0, t, lin):
+    return (f0.device.type == "cuda" and f0.dtype == torch.float32 and f0.dim() == 4 and t.dtype == torch.float32
+            and t.shape[1:] == f0.shape[1:] and t.shape[0] in (1, f0.shape[0]) and lin.numel() == f0.shape[1]
+            and not t.requires_grad and not lin.requires_grad)
+
+
+class _LpipsLayer(Function):
+    @staticmethod
+    def forward(ctx, f0, t, lin):
+        require_f32(f0, "lpips_layer")
+        f0 = f0.contiguous()
+        t = t.contiguous()
+        lin = lin.reshape(-1).contiguous()
+        b, c, h, w = f0.shape
+        hw = h * w
+        d = torch.empty(b, dtype=f0.dtype, device=f0.device)
+        L = _lib.lib()
+        scratch = torch.empty(L.sr_lpips_layer_scratch_floats(b, hw), dtype=f0.dtype, device=f0.device)
+        ctx.bstride = c * hw if t.shape[0] == b else 0            # (one target for the whole batch: stride 0)
+        with on_device_of(f0):
+            rc = L.sr_lpips_layer_fwd(_lib.ptr(d), _lib.ptr(f0), _lib.ptr(t), _lib.ptr(lin), b, c, hw, ctx.bstride,
+                                      EPS, _lib.ptr(scratch), stream_of(f0))
+        _lib.check(rc, "sr_lpips_layer_fwd")
+        ctx.save_for_backward(f0, t, lin)
+        return d.view(b, 1, 1, 1)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gd):
+        f0, t, lin = ctx.saved_tensors
+        b, c, h, w = f0.shape
+        gd = gd.reshape(b).contiguous()
+        gf = torch.empty_like(f0)
+        with on_device_of(f0):
+            rc = _lib.lib().sr_lpips_layer_bwd(_lib.ptr(gf), _lib.ptr(gd), _lib.ptr(f0), _lib.ptr(t), _lib.ptr(lin), b, c,
+                                               h * w, ctx.bstride, EPS, stream_of(f0))
+        _lib.check(rc, "sr_lpips_layer_bwd")
+        return gf, None, None
+
+
+def lpips_layer(f0, t_normalised, lin):
+    return _LpipsLayer.apply(f0, t_normalised, lin)

@@ -126,3 +126,27 @@ def test_config4_full_size_graph_equals_eager_is_reproducible_and_converges():
     assert np.array_equal(runs["graph"][0], runs["graph2"][0])
     assert torch.equal(runs["graph"][1], runs["graph2"][1]) and torch.equal(runs["graph"][2], runs["graph2"][2])
     assert float(runs["graph"][2].abs().max()) > 1e-4        # the pose moved
+
+
+def test_fused_lpips_layer_matches_the_operator_chain():
+    """op.lpips_layer (normalisation, squared difference, lin, spatial mean in one launch each way) against the chain of
+    tensor operators the reference spells out (networks_basic.py:62-85): value and gradient, per-sample and shared target."""
+    from stylerenderer_amd import lpips
+    from stylerenderer_amd.op.lpips_layer import lpips_layer
+
+    DEV = "cuda"
+    g = torch.Generator().manual_seed(8)
+    for b, c, h, w, tb in ((1, 64, 32, 32, 1), (3, 128, 9, 7, 3), (2, 512, 16, 16, 1)):
+        f0 = torch.relu(torch.randn(b, c, h, w, generator=g)).to(DEV).requires_grad_()
+        t = lpips.normalize_tensor(torch.relu(torch.randn(tb, c, h, w, generator=g)).to(DEV))
+        lin = torch.rand(1, c, 1, 1, generator=g).to(DEV)
+        gd = torch.randn(b, 1, 1, 1, generator=g).to(DEV)
+        want = lpips.spatial_average((((lpips.normalize_tensor(f0) - t) ** 2) * lin).sum(1, keepdim=True))
+        (gw,) = torch.autograd.grad(want, f0, gd)
+        got = lpips_layer(f0, t, lin)
+        (gg,) = torch.autograd.grad(got, f0, gd)
+        assert got.shape == want.shape
+        assert torch.allclose(got, want, rtol=2e-5, atol=1e-9), (b, c, float((got - want).abs().max()))
+        assert float((gg - gw).abs().max()) <= 2e-5 * float(gw.abs().max()) + 1e-12, (b, c)
+        again = lpips_layer(f0, t, lin)
+        assert torch.equal(got, again)                       # fixed-order reduction: run-to-run identical
