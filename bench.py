@@ -276,26 +276,18 @@ def train_leg(dev, rank, world, iters, batch, size=256):
     # flops 2*B*H*W*Cin*Cout*k^2 of every convolution / weight-gradient launch; executed = what the matrix cores
     # issue: 16/36 of that on the Winograd-eligible stride-1 3x3 launches)
     phases, roof = None, None
-    if graphs and rank == 0:
+    if graphs:
+        # EVERY rank runs this block: the phases issue their gradient collectives (replayed: after the replay; eager:
+        # from the backward hooks), a rank that sat it out would leave the others' all-reduces unmatched.  Rank 0 reports.
         from stylerenderer_amd.op import conv as conv_op
 
         cadence = {"d": 1.0, "r1": 1.0 / 16, "g": 1.0, "path": 1.0 / 4, "d_opt": 1.0 + 1.0 / 16, "g_opt": 1.0 + 1.0 / 4}
         phases = {}
         for name in ("d", "r1", "g", "path", "d_opt", "g_opt"):
-            gr = tr.graphs[name]
-            gr.replay()
-            torch.cuda.synchronize()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(3):
-                gr.replay()
-            e1.record()
-            torch.cuda.synchronize()
-            phases[name] = {"ms_per_replay": round(e0.elapsed_time(e1) / 3, 3), "per_iteration": round(cadence[name], 4)}
-        bodies = tr._bodies()
+            phases[name] = {"ms_per_replay": round(tr.time_phase(name, 3), 3), "per_iteration": round(cadence[name], 4)}
         for name in ("d", "r1", "g", "path"):
             conv_op.PROFILE = []
-            bodies[name]()
+            tr._eager_phase(name)
             torch.cuda.synchronize()
             prof, conv_op.PROFILE = conv_op.PROFILE, None
             alg = sum(fl for (_k, _g, fl, _a, _b) in prof)
@@ -321,6 +313,8 @@ def train_leg(dev, rank, world, iters, batch, size=256):
                 "algorithmic_tflops": round(alg_it / ms_it, 2),
                 "note": "whole-iteration rate: executed matrix-core flops of every phase at its cadence / measured "
                         "ms per iteration (includes all non-MFMA kernels and the optimiser steps in the time)"}
+        if rank != 0:
+            phases, roof = None, None
     collective = None
     if graphs and world > 1:
         # chosen collective, bucket sizes, and when each bucket's reduction finished relative to the END of the

@@ -296,6 +296,19 @@ class GraphedTrainer(Trainer):
             red.issue_all()
             red.wait()
 
+    def time_phase(self, name, reps=3):
+        """Milliseconds per `_run(name)` (replay + the phase's gradient collectives, like an iteration issues them),
+        averaged over `reps` after one untimed run.  Every rank must call it (the collectives are part of the phase)."""
+        self._run(name)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            self._run(name)
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps
+
     def measure_overlap(self, name="path"):
         """Replays phase `name` once with timing events: returns the replay's duration and, per bucket, when its
         reduction FINISHED relative to the end of the replay (ms; negative = while the backward was still running).

@@ -108,3 +108,12 @@ def test_overlapped_reduction_inside_the_replayed_backward(one_rank_group):
     # the first half of the replay, not merely before its end (a weight-gradient node that autograd schedules at the end
     # of the backward passes the weaker check above while destroying the overlap)
     assert any(t["bucket_done_ms_after_replay_end"][0] < -0.25 * t["replay_ms"] for t in tries), tries
+    # bench.py's per-phase timing goes through the same replay + issue + wait path on every rank: the host's count of
+    # launched runs and the device counters of the signal nodes stay in step (a bare graph.replay() would bump the
+    # counters alone and release the NEXT run's collectives before their buckets are complete)
+    ms = a.time_phase("d", 2)
+    assert ms > 0
+    torch.cuda.synchronize()
+    assert a.reduce_d.counters.cpu().tolist() == [r & 0xFFFFFFFF for r in a.reduce_d.runs]
+    again = a.measure_overlap("d")["bucket_done_ms_after_replay_end"]
+    assert again == sorted(again)
