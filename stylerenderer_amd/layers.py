@@ -14,6 +14,7 @@ layers.py (so reference checkpoints load unchanged), different execution:
     reference executes for them; device tensors never take that route.
 """
 import math
+import os
 
 import torch
 from torch import nn
@@ -24,6 +25,7 @@ from .op import conv as _conv
 from .op import smallconv as _smallconv
 from .op import style as _style
 from .op.style_bank import StylePack
+from .op.upfirdn2d import skip_down as _skip_down
 from .op.weight_prep import weight_prep as _weight_prep
 from .op.weight_prep import weight_prep_cached as _weight_prep_cached
 
@@ -415,5 +417,15 @@ class ResBlock(nn.Module):
                               bias=False)
 
     def forward(self, input):
+        mods = list(self.skip)
+        if (input.device.type == "cuda" and input.dtype == torch.float32 and len(mods) == 2 and isinstance(mods[0], Blur)
+                and isinstance(mods[1], EqualConv2d) and mods[1].weight.shape[2] == 1 and mods[1].stride == 2
+                and mods[1].padding == 0 and input.shape[2] == input.shape[3] and tuple(mods[0].kernel.shape) == (4, 4)
+                and os.environ.get("SR_SKIP_FUSED", "1") != "0"):
+            # the input feeds conv1 and the (blurred, decimated) skip branch: one node whose backward adds the two
+            # input gradients inside the up-sampling FIR kernel of the skip branch (op.upfirdn2d.SkipDown)
+            same, down = _skip_down(input, mods[0].kernel, mods[0].pad)
+            out = self.conv2(self.conv1(same))
+            return (out + mods[1].forward_stride1(down)) / math.sqrt(2)
         out = self.conv2(self.conv1(input))
         return (out + self.skip(input)) / math.sqrt(2)

@@ -180,6 +180,38 @@ def upsample2_add(skip, kernel, pad, addend):
     return UpsampleAdd.apply(skip, k, addend, tuple(pad))
 
 
+class SkipDown(Function):
+    """x -> (x, upfirdn2d(x, kernel, down = 2, pad)): the fork at the top of a down-sampling ResBlock (reference
+    layers.py:381-400: the input feeds conv1 AND the blur in front of the 1x1 stride-2 skip convolution).  As two
+    consumers of one tensor, autograd adds the two input gradients with a full-size elementwise pass after the
+    up-sampling FIR of the skip branch has written its own full-size tensor; as one node the backward is
+    `upsample2_add`: FIR of the small gradient + the conv1 gradient in one kernel (two HBM passes instead of four).
+    Built from differentiable operators, so gradients of any order (R1) stay on the same kernels."""
+
+    @staticmethod
+    def forward(ctx, x, kernel, pad):
+        ctx.save_for_backward(kernel)
+        ctx.pad, ctx.in_h = tuple(pad), x.shape[2]
+        ctx.set_materialize_grads(False)
+        return x.view_as(x), upfirdn2d(x, kernel, down=2, pad=pad)
+
+    @staticmethod
+    def backward(ctx, g_same, g_down):
+        (kernel,) = ctx.saved_tensors
+        if g_down is None:
+            return g_same, None, None
+        p0 = ctx.pad[0]
+        g_pad = (kernel.shape[1] - p0 - 1, ctx.in_h - g_down.shape[2] * 2 + p0 - 1 + 1)
+        fk = flipped(kernel)
+        if g_same is None:
+            return upfirdn2d(g_down, fk, up=2, down=1, pad=g_pad), None, None
+        return upsample2_add(g_down, fk, g_pad, g_same), None, None
+
+
+def skip_down(x, kernel, pad):
+    return SkipDown.apply(x, kernel if kernel.device == x.device else kernel.to(x.device), tuple(pad))
+
+
 def upfirdn2d(input, kernel, up=1, down=1, pad=(0, 0)):
     if not is_device_tensor(input):
         return _upfirdn2d_cpu(input, kernel, up, down, pad)

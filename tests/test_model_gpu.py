@@ -235,3 +235,29 @@ def test_generator_256_full_size_properties():
     with torch.no_grad():
         one, _ = g([z[5:6]], noise=noise)
     assert rel_err(one.cpu().numpy(), img[5:6].detach().cpu().numpy()) < TOL
+
+
+def test_resblock_fork_node_equals_two_consumers(monkeypatch):
+    """ResBlock with the fused fork (op.upfirdn2d.SkipDown: the two input gradients are added inside the up-sampling FIR
+    kernel of the skip branch) against the plain two-consumer form: same output, same first- and second-order gradients
+    (R1) bit for bit — the fused kernel adds the same two values."""
+    from stylerenderer_amd.layers import ResBlock
+
+    torch.manual_seed(3)
+    blk = ResBlock(8, 16).to("cuda")
+    x0 = torch.randn(2, 8, 32, 32, device="cuda")
+    res = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("SR_SKIP_FUSED", mode)
+        x = x0.clone().requires_grad_()
+        y = blk(x)
+        (gx,) = torch.autograd.grad(y.square().sum(), x, create_graph=True)
+        for p in blk.parameters():
+            p.grad = None
+        gx.square().sum().backward()
+        res[mode] = (y.detach(), gx.detach(), x.grad.clone(), [p.grad.clone() for p in blk.parameters()])
+    assert torch.equal(res["1"][0], res["0"][0])
+    assert torch.equal(res["1"][1], res["0"][1])
+    assert torch.equal(res["1"][2], res["0"][2])
+    for a, b in zip(res["1"][3], res["0"][3]):
+        assert torch.equal(a, b)
