@@ -144,8 +144,8 @@ int sr_rowdot_bwd(float* ga, float* gb, float* gs, const float* a, const float* 
  *   dw:  dws[b,j,c] = sum_p g[b,j,p]*x[b,c,p]  (deterministic two-stage reduction) */
 int sr_smallconv_fwd(float* out, const float* x, const float* ws, const float* bias, int64_t B, int64_t C,
                      int64_t N, int64_t hw, sr_stream_t stream);
-int sr_smallconv_dx(float* dx, const float* g, const float* ws, const float* addend, int64_t B, int64_t C, int64_t N,
-                    int64_t hw, sr_stream_t stream);   /* addend [B, C, hw] or NULL: dx = addend + (sum above) */
+int sr_smallconv_dx(float* dx, const float* g, const float* ws, int64_t B, int64_t C, int64_t N, int64_t hw,
+                    sr_stream_t stream);
 int64_t sr_smallconv_dw_scratch_floats(int64_t B, int64_t C, int64_t N, int64_t hw);
 int sr_smallconv_dw(float* dws, const float* g, const float* x, int64_t B, int64_t C, int64_t N, int64_t hw,
                     float* scratch, sr_stream_t stream);

@@ -749,8 +749,7 @@ __global__ __launch_bounds__(256) void k_smallconv_fwd(float* __restrict__ out, 
 
 template <int N>
 __global__ __launch_bounds__(256) void k_smallconv_dx(float* __restrict__ dx, const float* __restrict__ g,
-                                                      const float* __restrict__ ws, const float* __restrict__ addend,
-                                                      int C, int64_t hw4) {
+                                                      const float* __restrict__ ws, int C, int64_t hw4) {
     extern __shared__ float s_ws[];
     const int b = blockIdx.y;
     for (int i = threadIdx.x; i < N * C; i += 256) s_ws[i] = ws[(int64_t)b * N * C + i];
@@ -761,9 +760,6 @@ __global__ __launch_bounds__(256) void k_smallconv_dx(float* __restrict__ dx, co
 #pragma unroll
     for (int j = 0; j < N; ++j) gv[j] = reinterpret_cast<const float4*>(g)[((int64_t)b * N + j) * hw4 + p4];
     float4* dst = reinterpret_cast<float4*>(dx) + (int64_t)b * C * hw4 + p4;
-    // addend: the gradient the other consumer of x produced (the activation feeds ToRGB and the next layer): summed
-    // here instead of by a separate full-size pass.  Added AFTER the dot product, like the separate pass would.
-    const float4* add4 = addend ? reinterpret_cast<const float4*>(addend) + (int64_t)b * C * hw4 + p4 : nullptr;
 #pragma unroll 4
     for (int c = 0; c < C; ++c) {
         float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -771,10 +767,6 @@ __global__ __launch_bounds__(256) void k_smallconv_dx(float* __restrict__ dx, co
         for (int j = 0; j < N; ++j) {
             const float w = s_ws[j * C + c];
             r.x += w * gv[j].x; r.y += w * gv[j].y; r.z += w * gv[j].z; r.w += w * gv[j].w;
-        }
-        if (add4) {
-            const float4 a = add4[(int64_t)c * hw4];
-            r.x = a.x + r.x; r.y = a.y + r.y; r.z = a.z + r.z; r.w = a.w + r.w;
         }
         dst[(int64_t)c * hw4] = r;
     }
@@ -867,15 +859,14 @@ extern "C" int sr_smallconv_fwd(float* out, const float* x, const float* ws, con
     return sr_launch_status();
 }
 
-extern "C" int sr_smallconv_dx(float* dx, const float* g, const float* ws, const float* addend, int64_t B, int64_t C,
-                               int64_t N, int64_t hw, sr_stream_t stream) {
+extern "C" int sr_smallconv_dx(float* dx, const float* g, const float* ws, int64_t B, int64_t C, int64_t N,
+                               int64_t hw, sr_stream_t stream) {
     if (!dx || !g || !ws || !smallconv_ok(B, C, N, hw, dx, g)) return SR_EINVAL;
-    if (addend && (reinterpret_cast<uintptr_t>(addend) & 15)) return SR_EINVAL;
     const int64_t hw4 = hw / 4;
     const dim3 grid((unsigned)sr_ceil_div(hw4, 256), (unsigned)B);
     const size_t lds = (size_t)N * C * sizeof(float);
     hipStream_t st = sr_stream(stream);
-    SR_SMALLCONV_DISPATCH(k_smallconv_dx, grid, dim3(256), lds, st, dx, g, ws, addend, (int)C, hw4);
+    SR_SMALLCONV_DISPATCH(k_smallconv_dx, grid, dim3(256), lds, st, dx, g, ws, (int)C, hw4);
     return sr_launch_status();
 }
 

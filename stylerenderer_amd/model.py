@@ -10,7 +10,6 @@ reference checkpoints with 165 keys at 256x256 load with strict=True).
   Discriminator     reference model.py:296-336
 """
 import math
-import os
 
 import numpy as np
 import torch
@@ -132,19 +131,6 @@ class ToRGB(nn.Module):
         if skip is not None:
             out = out + self.upsample(skip)
         return out
-
-    def forward_fork(self, input, style, skip=None):
-        """(input, forward(input, style, skip)) with the fork of `input` — it also feeds the next layer — as one
-        autograd node on device tensors (op.smallconv.SmallConvFork); the caller continues with the returned input."""
-        conv = self.conv
-        if _smallconv.supported(input, conv.out_channel) and os.environ.get("SR_RGB_FORK", "1") != "0":
-            same, out = _smallconv.modulated_conv1x1_small_fork(
-                input, conv.weight.view(conv.out_channel, conv.in_channel) * conv.scale, conv.style_of(style),
-                self.bias.view(-1))
-            if skip is not None:
-                out = upsample2_add(skip, self.upsample.kernel, self.upsample.pad, out)
-            return same, out
-        return input, self.forward(input, style, skip)
 
 
 class Generator(nn.Module):
@@ -275,13 +261,13 @@ class Generator(nn.Module):
             out = self.input(latent)
             st = self._layer_styles(latent)
             out = self.conv1(out, st[0], noise=noise[0])
-            out, skip = self.to_rgb1.forward_fork(out, st[1])
+            skip = self.to_rgb1(out, st[1])
             k = 2
             for conv_up, conv, n_up, n_conv, to_rgb in zip(self.convs[::2], self.convs[1::2],
                                                            noise[1::2], noise[2::2], self.to_rgbs):
                 out = conv_up(out, st[k], noise=n_up)
                 out = conv(out, st[k + 1], noise=n_conv)
-                out, skip = to_rgb.forward_fork(out, st[k + 2], skip)
+                skip = to_rgb(out, st[k + 2], skip)
                 k += 3
         return skip, (latent if return_latents else None)
 
@@ -319,7 +305,7 @@ class GeneratorWithMap(Generator):
         maps = self.norm1(norm_maps[-1])
         st = self._layer_styles(latent)
         out = self.conv1(out, st[0], maps, noise=noise[0])
-        out, skip = self.to_rgb1.forward_fork(out, st[1])
+        skip = self.to_rgb1(out, st[1])
         two_stage = len(self.convs) == len(self.norm_to_style)
         i, k = 1, 2
         for conv_up, conv, n_up, n_conv, to_rgb in zip(self.convs[::2], self.convs[1::2],
@@ -335,7 +321,7 @@ class GeneratorWithMap(Generator):
             maps_up, maps_conv = maps.split([2, maps.shape[1] - 2], 1)
             out = conv_up(out, st[k], maps_up, noise=n_up)
             out = conv(out, st[k + 1], maps_conv, noise=n_conv)
-            out, skip = to_rgb.forward_fork(out, st[k + 2], skip)
+            skip = to_rgb(out, st[k + 2], skip)
             i += 2
             k += 3
         return skip, (latent if return_latents else None), (norm_maps if return_normals else None)

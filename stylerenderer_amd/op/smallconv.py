@@ -31,16 +31,13 @@ def _fwd(x, ws, bias=None):
     return out
 
 
-def _dx(g, ws, addend=None):
+def _dx(g, ws):
     g, ws = g.contiguous(), ws.contiguous()
     b, n, h, w = g.shape
     c = ws.size(2)
     dx = torch.empty((b, c, h, w), dtype=g.dtype, device=g.device)
-    if addend is not None:
-        addend = addend.contiguous()
     with on_device_of(g):
-        rc = _lib.lib().sr_smallconv_dx(_lib.ptr(dx), _lib.ptr(g), _lib.ptr(ws), _lib.ptr(addend), b, c, n, h * w,
-                                        stream_of(g))
+        rc = _lib.lib().sr_smallconv_dx(_lib.ptr(dx), _lib.ptr(g), _lib.ptr(ws), b, c, n, h * w, stream_of(g))
     _lib.check(rc, "sr_smallconv_dx")
     return dx
 
@@ -75,43 +72,17 @@ class SmallConvFwd(Function):
 
 
 class SmallConvDx(Function):
-    """dx(g, ws) [+ addend]: linear in `addend` as well (its gradient is the incoming one)."""
-
     @staticmethod
-    def forward(ctx, g, ws, addend=None):
+    def forward(ctx, g, ws):
         ctx.save_for_backward(g, ws)
-        return _dx(g, ws, addend)
+        return _dx(g, ws)
 
     @staticmethod
     def backward(ctx, gg):
         g, ws = ctx.saved_tensors
         d_g = SmallConvFwd.apply(gg, ws) if ctx.needs_input_grad[0] else None
         d_ws = SmallConvDw.apply(g, gg) if ctx.needs_input_grad[1] else None
-        d_add = gg if len(ctx.needs_input_grad) > 2 and ctx.needs_input_grad[2] else None
-        return d_g, d_ws, d_add
-
-
-class SmallConvFork(Function):
-    """x -> (x, fwd(x, ws, bias)): the activation that feeds ToRGB AND the next layer as ONE node.  As two consumers
-    autograd adds the two gradients of x with a full-size elementwise pass; here the ToRGB data gradient is computed
-    with the other consumer's gradient as its addend (k_smallconv_dx), bit-identical to the separate add."""
-
-    @staticmethod
-    def forward(ctx, x, ws, bias=None):
-        ctx.save_for_backward(x, ws)
-        ctx.set_materialize_grads(False)
-        return x.view_as(x), _fwd(x, ws, bias)
-
-    @staticmethod
-    def backward(ctx, g_same, g_y):
-        x, ws = ctx.saved_tensors
-        if g_y is None:
-            return g_same, None, None
-        needs = ctx.needs_input_grad
-        gx = SmallConvDx.apply(g_y, ws, g_same) if needs[0] else None
-        gw = SmallConvDw.apply(g_y, x) if needs[1] else None
-        gb = g_y.sum((0, 2, 3)) if len(needs) > 2 and needs[2] else None
-        return gx, gw, gb
+        return d_g, d_ws
 
 
 class SmallConvDw(Function):
@@ -132,9 +103,3 @@ def modulated_conv1x1_small(x, weight_jc, style, bias=None):
     """weight_jc [N, C] (already scaled), style [B, C], optional bias [N] -> [B, N, H, W]."""
     ws = weight_jc[None, :, :] * style[:, None, :]
     return SmallConvFwd.apply(x, ws, bias)
-
-
-def modulated_conv1x1_small_fork(x, weight_jc, style, bias=None):
-    """(x, modulated_conv1x1_small(x, ...)) as one autograd node: use the returned x for the other consumer."""
-    ws = weight_jc[None, :, :] * style[:, None, :]
-    return SmallConvFork.apply(x, ws, bias)
