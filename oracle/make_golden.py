@@ -216,23 +216,62 @@ def gold_generator(ns):
         save("generator_" + tag, **arrays)
 
 
-def gold_generator_with_map(ns):
-    size, sdim, nmlp, batch = 16, 64, 2, 2
+def _gwm_case(ns, tag, size, sdim, nmlp, batch, mesh_res, salt=51, zkey=52, nkey=5300):
+    """GeneratorWithMap (reference model.py:224-295) on a posed ellipsoid: image, latent, normal maps, and — the
+    gradients the training step and the inversion loop depend on — d/d(params, vertices, normals) of a fixed linear
+    functional, plus ONE evaluation of the reference's g_path_regularize(img, [latents] + norm_maps)
+    (train.py:118-134 as called at train.py:340-347): lengths, penalty, running mean and the double-backward
+    gradients of every parameter and of the mesh."""
+    fn = _reference_train_functions(reshape_grads=True)
     g = ns.model.GeneratorWithMap(size, sdim, nmlp)
-    synth.fill_state_dict(g.state_dict(), salt=51)
-    v0, tri = synth.uv_ellipsoid(12, 10)
+    synth.fill_state_dict(g.state_dict(), salt=salt)
+    v0, tri = synth.uv_ellipsoid(*mesh_res)
     v = synth.random_poses(v0, batch, seed=7)
     nrm = synth.vertex_normals(v, tri)
-    z = T(dn((batch, sdim), 52))
-    noise = _noise_list(g, 5300)
-    img, lat, maps = g([z], (T(v), T(nrm), T(tri)), return_normals=True, return_latents=True,
-                       noise=noise)
+    z = T(dn((batch, sdim), zkey))
+    noise = _noise_list(g, nkey)
+    tv, tn = T(v).requires_grad_(), T(nrm).requires_grad_()
+    img, lat, maps = g([z], (tv, tn, T(tri)), return_normals=True, return_latents=True, noise=noise)
     arrays = {"image": img.detach().numpy(), "latent": lat.detach().numpy(), "v": v, "nrm": nrm,
               "tri": tri.astype(np.int32),
               "n_params": np.array(sum(p.numel() for p in g.parameters()))}
     for i, m in enumerate(maps):
         arrays["normmap_%d" % i] = m.detach().numpy()
-    save("generator_map_s16", **arrays)
+    # first-order gradients of <img, proj>: every parameter (sampled) and the mesh (full tensors)
+    proj = T(dn(tuple(img.shape), zkey + 4))
+    named = dict(g.named_parameters())
+    grads = torch.autograd.grad((img * proj).sum(), list(named.values()) + [tv, tn], allow_unused=True,
+                                retain_graph=True)
+    gd = {n: gr for n, gr in zip(named, grads[:-2]) if gr is not None}
+    arrays["unused"] = np.array(sorted(n for n, gr in zip(named, grads[:-2]) if gr is None))
+    arrays["grad_names"] = np.array(sorted(gd))
+    arrays["grad_samples"], arrays["grad_sample_offsets"] = grad_samples(gd)
+    arrays["grad_v"], arrays["grad_nrm"] = grads[-2].numpy(), grads[-1].numpy()
+    # path-length regulariser over [latents] + normal maps, the way the step calls it
+    torch.manual_seed(321)
+    probe = torch.randn_like(img)                     # what g_path_regularize draws next under this seed
+    torch.manual_seed(321)
+    pen, mean, lengths = fn["g_path_regularize"](img, [lat] + maps, torch.tensor(0.25))
+    g.zero_grad()
+    tv.grad = tn.grad = None
+    (2.0 * 4 * pen + 0 * img[0, 0, 0, 0]).backward()
+    arrays["pl_probe"], arrays["pl_penalty"], arrays["pl_mean"] = probe.numpy(), pen.detach().numpy(), mean.numpy()
+    arrays["pl_lengths"] = lengths.detach().numpy()
+    gg = {n: p.grad.clone() for n, p in g.named_parameters() if p.grad is not None}
+    arrays["pl_grad_names"] = np.array(sorted(gg))
+    arrays["pl_grad_samples"], arrays["pl_grad_sample_offsets"] = grad_samples(gg)
+    arrays["pl_grad_v"], arrays["pl_grad_nrm"] = tv.grad.numpy(), tn.grad.numpy()
+    save("generator_map_" + tag, **arrays)
+
+
+def gold_generator_with_map(ns):
+    _gwm_case(ns, "s16", 16, 64, 2, 2, (12, 10))
+    # 64^2: the 32^2 / 64^2 layers of the HIP path are Winograd kernels and LDS-tiled FIRs (a 16^2 network never
+    # reaches them); 512 channels, a mesh whose triangles are a few pixels wide at 64^2
+    # zkey 61: a latent on which the reference and the HIP path take the same side of every LeakyReLU kink
+    # (scripts/gwm_flip_probe.py: keys 56, 58-60 put ONE of 5.5e6 pre-activations (|value| ~ 1e-7) on opposite sides,
+    # which moves upstream gradients by 2e-4 — a property of the activation, see tests/test_model_gpu.py)
+    _gwm_case(ns, "s64", 64, 64, 2, 1, (28, 24), salt=53, zkey=61, nkey=5700)
 
 
 def gold_discriminator(ns):
@@ -254,19 +293,30 @@ def gold_discriminator(ns):
 
 
 def gold_generator_256(ns):
-    """The exact network bench.py times (Generator(256, 512, 8), BASELINE config[1]) on one latent: image only
-    (0.8 MB).  Pins the 128^2 / 256^2 kernel variants no smaller fixture reaches."""
+    """The exact network bench.py times (Generator(256, 512, 8), BASELINE config[1]) on one latent: image (0.8 MB)
+    and the first-order gradients of a fixed linear functional w.r.t. every parameter (256 samples per tensor) and
+    the W+ latent (full).  Pins the 128^2 / 256^2 forward, data-gradient and weight-gradient kernel variants no
+    smaller fixture reaches."""
     g = ns.model.Generator(256, 512, 8)
     synth.fill_state_dict(g.state_dict(), salt=41)
-    with torch.no_grad():
-        img, lat = g([T(dn((1, 512), 42))], return_latents=True, noise=_noise_list(g, 4300))
-    save("generator_s256", image=img.numpy(), latent_row=lat[0, 0].numpy(),
-         n_keys=np.array(len(g.state_dict())))
+    img, lat = g([T(dn((1, 512), 42))], return_latents=True, noise=_noise_list(g, 4300))
+    lat.retain_grad()
+    proj = T(dn(tuple(img.shape), 46))
+    named = dict(g.named_parameters())
+    grads = torch.autograd.grad((img * proj).sum(), list(named.values()) + [lat], allow_unused=True)
+    gd = {n: gr for n, gr in zip(named, grads[:-1]) if gr is not None}
+    vals, offs = grad_samples(gd)
+    save("generator_s256", image=img.detach().numpy(), latent_row=lat[0, 0].detach().numpy(),
+         n_keys=np.array(len(g.state_dict())), grad_names=np.array(sorted(gd)), grad_samples=vals,
+         grad_sample_offsets=offs, grad_latent=grads[-1].numpy())
 
 
-def _reference_train_functions():
+def _reference_train_functions(reshape_grads=False):
     """The loss / regulariser / EMA definitions of the reference's train.py (lines 96-145), exec'ed from where the
-    file lies: the module as a whole does not parse, these top-level defs do."""
+    file lies: the module as a whole does not parse, these top-level defs do.
+    reshape_grads: train.py:129 flattens each Jacobian with ``.view``; the gradient of a normal map (a permuted
+    rasterizer output, model.py:262) is not contiguous under torch 2.10 and ``.view`` raises — the call the reference
+    itself makes at train.py:346 cannot run here unless that one token reads ``.reshape`` (same values)."""
     import re
 
     text = open(os.path.join(ref_shim.REF, "train.py")).read().replace("\t", "    ")
@@ -275,7 +325,11 @@ def _reference_train_functions():
     env = {"torch": torch, "np": np, "F": torch.nn.functional, "autograd": torch.autograd, "nn": torch.nn}
     for n in names:
         m = re.search(r"^def %s\(.*?(?=^def |^if __name__)" % n, text, flags=re.S | re.M)
-        exec(m.group(0), env)
+        src = m.group(0)
+        if reshape_grads and n == "g_path_regularize":
+            assert "grad.view(int(grad.shape[0]),-1)" in src
+            src = src.replace("grad.view(int(grad.shape[0]),-1)", "grad.reshape(int(grad.shape[0]),-1)")
+        exec(src, env)
     return env
 
 

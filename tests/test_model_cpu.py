@@ -154,3 +154,12 @@ def test_discriminator_s16(golden):
     got = {n: p.grad for n, p in d.named_parameters() if p.grad is not None}
     check_grad_digest(got, gold["r1_grad_names"], gold["r1_grad_norms"], gold["r1_grad_heads"], 1e-3)
     check_grad_samples(got, gold["r1_grad_names"], gold["r1_grad_samples"], gold["r1_grad_sample_offsets"], 4e-6)
+
+
+def test_generator_with_map_s16_gradients_vs_reference(golden):
+    """M7 on CPU tensors: image, normal maps, parameter / mesh gradients and the path-length regulariser over
+    [latents] + normal maps (reference model.py:224-295, train.py:118-134, 340-347)."""
+    from util import run_generator_with_map_case
+
+    meas = run_generator_with_map_case(golden("generator_map_s16"), 16, "cpu", 5e-5, 1e-5, 1e-4, 2e-5, 2e-4)
+    print(meas)

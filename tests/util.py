@@ -27,9 +27,12 @@ def rel_err(a, b):
     return float(np.abs(a - b).max()) / den
 
 
-def check_grad_samples(named_grads, names, values, offsets, tol):
+def check_grad_samples(named_grads, names, values, offsets, tol, scalar_factor=1.0):
     """Sampled entries of every gradient tensor (fixtures written by oracle/make_golden.grad_samples): the error of
-    each tensor's samples relative to that tensor's largest sampled magnitude.  Returns the worst ratio."""
+    each tensor's samples relative to that tensor's largest sampled magnitude.  Returns the worst ratio.
+    scalar_factor widens the bar for one-element tensors only (a noise strength is ONE sum of up to 2e6 signed terms
+    that cancel to a few percent of their magnitude: its relative error is the summation order's, also between two
+    CPUs running the same code)."""
     from stylerenderer_amd import synth
 
     assert sorted(named_grads) == list(names)
@@ -41,6 +44,61 @@ def check_grad_samples(named_grads, names, values, offsets, tol):
         assert got.shape == want.shape, n
         scale = max(float(np.abs(want).max()), 1e-12)
         err = float(np.abs(got - want).max()) / scale
-        assert err <= tol, "%s: sampled-gradient error %.3e of the tensor's scale (bar %.1e)" % (n, err, tol)
-        worst = max(worst, err)
+        bar = tol * (scalar_factor if g.size == 1 else 1.0)
+        assert err <= bar, "%s: sampled-gradient error %.3e of the tensor's scale (bar %.1e)" % (n, err, bar)
+        worst = max(worst, err / (scalar_factor if g.size == 1 else 1.0))
     return worst
+
+
+def run_generator_with_map_case(gold, tag_size, dev, tol_img, tol_g1, tol_g2, tol_mesh1, tol_mesh2):
+    """GeneratorWithMap against tests/golden/generator_map_s<size>.npz (written by oracle/make_golden._gwm_case from
+    the reference's model.GeneratorWithMap + train.g_path_regularize): image, normal maps, first-order gradients of
+    <img, proj> w.r.t. every parameter (sampled) and the mesh (full tensors), and one path-length regulariser
+    evaluation over [latents] + normal maps with its double-backward gradients.  Returns the measured errors."""
+    import torch
+
+    from stylerenderer_amd import model, synth, train
+    from test_model_cpu import noise_list
+
+    size, sdim, batch, zkey, nkey, salt = {16: (16, 64, 2, 52, 5300, 51), 64: (64, 64, 1, 61, 5700, 53)}[tag_size]
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
+    g = model.GeneratorWithMap(size, sdim, 2)
+    assert sum(p.numel() for p in g.parameters()) == int(gold["n_params"])
+    synth.fill_state_dict(g.state_dict(), salt=salt)
+    g = g.to(dev)
+    v, n = T(gold["v"]).requires_grad_(), T(gold["nrm"]).requires_grad_()
+    tri = T(gold["tri"].astype(np.int64))
+    z = T(synth.det_normal((batch, sdim), zkey))
+    noise = [x.to(dev) for x in noise_list(g, nkey)]
+    img, lat, maps = g([z], (v, n, tri), return_normals=True, return_latents=True, noise=noise)
+    meas = {"img": rel_err(img.detach().cpu().numpy(), gold["image"])}
+    assert meas["img"] < tol_img
+    for i, m in enumerate(maps):
+        assert np.abs(m.detach().cpu().numpy() - gold["normmap_%d" % i]).max() <= 2e-7
+    proj = T(synth.det_normal(tuple(img.shape), zkey + 4))
+    params = dict(g.named_parameters())
+    grads = torch.autograd.grad((img * proj).sum(), list(params.values()) + [v, n], allow_unused=True,
+                                retain_graph=True)
+    got = {k: x for k, x in zip(params, grads[:-2]) if x is not None}
+    assert sorted(k for k, x in zip(params, grads[:-2]) if x is None) == list(gold["unused"])
+    meas["g1"] = check_grad_samples(got, gold["grad_names"], gold["grad_samples"], gold["grad_sample_offsets"], tol_g1,
+                                    scalar_factor=10.0)
+    meas["gv"] = rel_err(grads[-2].cpu().numpy(), gold["grad_v"])
+    meas["gn"] = rel_err(grads[-1].cpu().numpy(), gold["grad_nrm"])
+    assert meas["gv"] < tol_mesh1 and meas["gn"] < tol_mesh1, meas
+    # the regulariser the training step evaluates (reference train.py:340-347)
+    pen, mean, lengths = train.g_path_regularize(img, [lat] + list(maps), torch.tensor(0.25, device=dev),
+                                                 noise=T(gold["pl_probe"]))
+    assert rel_err(lengths.detach().cpu().numpy(), gold["pl_lengths"]) < 1e-4
+    assert abs(float(pen) - float(gold["pl_penalty"])) < 2e-4 * abs(float(gold["pl_penalty"]))
+    assert abs(float(mean) - float(gold["pl_mean"])) < 1e-5 * abs(float(gold["pl_mean"]))
+    g.zero_grad()
+    v.grad = n.grad = None
+    (2.0 * 4 * pen + 0 * img[0, 0, 0, 0]).backward()
+    got = {k: p.grad for k, p in g.named_parameters() if p.grad is not None}
+    meas["g2"] = check_grad_samples(got, gold["pl_grad_names"], gold["pl_grad_samples"],
+                                    gold["pl_grad_sample_offsets"], tol_g2, scalar_factor=10.0)
+    meas["gv2"] = rel_err(v.grad.cpu().numpy(), gold["pl_grad_v"])
+    meas["gn2"] = rel_err(n.grad.cpu().numpy(), gold["pl_grad_nrm"])
+    assert meas["gv2"] < tol_mesh2 and meas["gn2"] < tol_mesh2, meas
+    return meas
