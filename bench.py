@@ -47,6 +47,40 @@ FLOP_PER_IMAGE_FWD_BWD = 270.7e9       # 3 x 90.24 GFLOP of co
 G_PARAM_BYTES = 31.29e6 * 4            # Generator(256) gradients per step
 
 
+def executed_flops(kind, geom, flops):
+    """Matrix-core flops a convolution / weight-gradient launch EXECUTES for `flops` direct-convolution flops: the
+    Winograd-eligible stride-1 3x3 shapes (op/conv.py's dispatch rule) issue 16/36 of the direct multiplies."""
+    k, stride, transposed, _b, c, n, gh, gw = geom
+    wino = (k == 3 and stride == 1 and transposed == 0 and c % 64 == 0 and n % 64 == 0 and
+            (gw % 32 == 0 and gh % 8 == 0 if kind == "conv" else gw % 16 == 0 and gh % 2 == 0))
+    return flops * (16.0 / 36.0 if wino and os.environ.get("SR_WINOGRAD", "1") != "0" else 1.0)
+
+
+_STASH = {"line": None}
+
+
+def _fail_fast(rank, world, what, exc_text):
+    """A leg that raised on THIS rank of a multi-rank run: the other ranks are (or will be) blocked in collectives
+    this rank will never enter.  Print what is already measured (rank 0) and leave at once — the launcher tears the
+    job down — instead of hanging every rank until an outer time limit."""
+    sys.stderr.write("bench.py: rank %d failed in %s; aborting the %d-rank job\n%s\n" % (rank, what, world, exc_text))
+    sys.stderr.flush()
+    if rank == 0 and _STASH["line"] is not None:
+        line = dict(_STASH["line"])
+        line[what] = {"error": exc_text.strip().splitlines()[-1][:400]}
+        print(json.dumps(line), flush=True)
+    os._exit(13)
+
+
+def _on_sigterm(signum, frame):
+    # a PEER rank failed and the launcher is tearing the job down: rank 0 still reports the headline it holds
+    if _STASH["line"] is not None:
+        line = dict(_STASH["line"])
+        line["aborted"] = "peer rank failed (see stderr)"
+        print(json.dumps(line), flush=True)
+    os._exit(14)
+
+
 def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -219,32 +253,60 @@ def pmc_traffic(kernel_rows):
 
 
 # ---------------------------------------------------------------------------------------------------
-def train_leg(dev, rank, world, iters, batch, size=256):
+def _time_ms(fn, reps, on_gpu):
+    """Milliseconds per call of `fn` (a collective), after 3 untimed calls; device events on a GPU, wall clock on CPU."""
+    import torch
+
+    for _ in range(3):
+        fn()
+    if on_gpu:
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    return (time.perf_counter() - t0) / reps * 1e3
+
+
+def train_leg(dev, rank, world, iters, batch, size=256, plumbing=False):
     """BASELINE config[2]: the reference's full training iteration (train.py:239-358) — D step, lazy R1
     every 16, G step, lazy path-length regulariser every 4 on batch // 2 (double backward through every
     operator), EMA — on GeneratorWithMap + Discriminator, `batch` images per GPU (4 x 8 GPUs = global 32),
     synthetic in-memory images and a 3DMM-size-class mesh sampled per step.  The timed
     window starts at iteration 0 of the lazy-regulariser cadence, so `iters` = 64 holds 4 R1 and 16
-    path-length iterations like any aligned window of a long run."""
+    path-length iterations like any aligned window of a long run.
+    plumbing=True (bench.py --plumbing, tests/test_bench_launch.py): the SAME function on CPU tensors over gloo —
+    GraphedTrainer(capture=False) on an 8x8 network and a small mesh: the phases, bucket hooks, collectives and every
+    N > 1 branch of this leg (gradient_collective, allreduce timing against the xGMI bounds) run without a GPU."""
     import torch
     import torch.distributed as dist
 
     from stylerenderer_amd import graph_train, train
 
-    faces = train.SyntheticFaceSource(dev, seed=0)
+    on_gpu = dev.type == "cuda"
+    latent, n_mlp = (32, 2) if plumbing else (512, 8)
+    faces = train.SyntheticFaceSource(dev, seed=0, face_sized=not plumbing)
     graphs = os.environ.get("SR_TRAIN_GRAPHS", "1") != "0"
     if graphs:
         # forward + backward of each phase and the Adam steps replayed from hipGraphs (graph_train.py)
-        tr = graph_train.GraphedTrainer(size=size, latent=512, n_mlp=8, channel_multiplier=2, use_mesh=True,
-                                        device=dev, seed=0, batch=batch, mesh_vertices=faces.model.dim[2] // 3)
+        tr = graph_train.GraphedTrainer(size=size, latent=latent, n_mlp=n_mlp, channel_multiplier=2, use_mesh=True,
+                                        device=dev, seed=0, batch=batch, mesh_vertices=faces.model.dim[2] // 3,
+                                        capture=on_gpu)
     else:
-        tr = train.Trainer(size=size, latent=512, n_mlp=8, channel_multiplier=2, use_mesh=True, device=dev, seed=0)
+        tr = train.Trainer(size=size, latent=latent, n_mlp=n_mlp, channel_multiplier=2, use_mesh=True, device=dev, seed=0)
     data = train.SyntheticImages(64, size, dev)
 
     def fence():
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        if on_gpu:
+            torch.cuda.synchronize()
 
     for _ in range(2):                                   # iterations 0 (both regularisers) and 1 (plain)
         tr.step(data.batch(batch), faces=faces, log=False)
@@ -276,7 +338,7 @@ def train_leg(dev, rank, world, iters, batch, size=256):
     # flops 2*B*H*W*Cin*Cout*k^2 of every convolution / weight-gradient launch; executed = what the matrix cores
     # issue: 16/36 of that on the Winograd-eligible stride-1 3x3 launches)
     phases, roof = None, None
-    if graphs:
+    if graphs and on_gpu:
         # EVERY rank runs this block: the phases issue their gradient collectives (replayed: after the replay; eager:
         # from the backward hooks), a rank that sat it out would leave the others' all-reduces unmatched.  Rank 0 reports.
         from stylerenderer_amd.op import conv as conv_op
@@ -284,19 +346,15 @@ def train_leg(dev, rank, world, iters, batch, size=256):
         cadence = {"d": 1.0, "r1": 1.0 / 16, "g": 1.0, "path": 1.0 / 4, "d_opt": 1.0 + 1.0 / 16, "g_opt": 1.0 + 1.0 / 4}
         phases = {}
         for name in ("d", "r1", "g", "path", "d_opt", "g_opt"):
-            phases[name] = {"ms_per_replay": round(tr.time_phase(name, 3), 3), "per_iteration": round(cadence[name], 4)}
+            phases[name] = {"ms_per_replay": round(tr.time_phase(name, 3), 3), "per_iteration": round(cadence[name], 4),
+                            "kernel_nodes": getattr(tr.graphs[name], "kernel_nodes", None)}
         for name in ("d", "r1", "g", "path"):
             conv_op.PROFILE = []
             tr._eager_phase(name)
             torch.cuda.synchronize()
             prof, conv_op.PROFILE = conv_op.PROFILE, None
             alg = sum(fl for (_k, _g, fl, _a, _b) in prof)
-            exe = 0.0
-            for kind, geom, fl, _a, _b in prof:
-                k, stride, tr_, _b2, c, n, gh, gw = geom
-                wino = (k == 3 and stride == 1 and tr_ == 0 and c % 64 == 0 and n % 64 == 0 and
-                        (gw % 32 == 0 and gh % 8 == 0 if kind == "conv" else gw % 16 == 0 and gh % 2 == 0))
-                exe += fl * (16.0 / 36.0 if wino and os.environ.get("SR_WINOGRAD", "1") != "0" else 1.0)
+            exe = sum(executed_flops(kind, geom, fl) for kind, geom, fl, _a, _b in prof)
             ms = phases[name]["ms_per_replay"]
             phases[name].update({"mfma_launches": len(prof), "algorithmic_gflop": round(alg / 1e9, 1),
                                  "executed_gflop": round(exe / 1e9, 1),
@@ -310,6 +368,8 @@ def train_leg(dev, rank, world, iters, batch, size=256):
                 "achieved": round(exe_it / ms_it, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(exe_it / ms_it / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
                 "executed_gflop_per_iteration": round(exe_it, 1), "algorithmic_gflop_per_iteration": round(alg_it, 1),
+                "kernel_launches_per_iteration": round(sum((phases[n].get("kernel_nodes") or 0) * cadence[n]
+                                                           for n in phases), 1),
                 "algorithmic_tflops": round(alg_it / ms_it, 2),
                 "note": "whole-iteration rate: executed matrix-core flops of every phase at its cadence / measured "
                         "ms per iteration (includes all non-MFMA kernels and the optimiser steps in the time)"}
@@ -321,6 +381,12 @@ def train_leg(dev, rank, world, iters, batch, size=256):
         # path-length backward (negative = overlapped with it)
         collective = {"generator_grads": tr.reduce_g.describe(), "discriminator_grads": tr.reduce_d.describe(),
                       "overlap_path_phase": tr.measure_overlap("path"), "overlap_d_phase": tr.measure_overlap("d")}
+        if not on_gpu:
+            # eager (CPU / gloo) form of the same measurement: the order in which the hooks issued the buckets of the
+            # last path-length phase and how many were on the wire before the backward produced its last gradient
+            tr._eager_phase("path")
+            issues = [b for kind, b, _t in tr.reduce_g.log if kind == "issue"]
+            collective["eager_issue_order_path_phase"] = issues
     out = {"workload": "BASELINE config[2]: GeneratorWithMap(%d) + Discriminator(%d) full G+D step, %d img/GPU "
                        "(global %d), d_reg_every 16, g_reg_every 4, path batch %d, synthetic images + mesh "
                        "nv=%d nf=%d" % (size, size, batch, batch * world, max(1, batch // 2),
@@ -330,47 +396,43 @@ def train_leg(dev, rank, world, iters, batch, size=256):
            "host_enqueue_ms_per_iter": round(t_enq / iters * 1e3, 3),
            "launch_bound": bool(t_enq > 0.95 * elapsed),
            "execution": ("hipGraph replay per phase (graph_train.GraphedTrainer); bucketed all-reduce of the flat "
-                         "gradient buffer on a communication stream, released by event-record nodes inside the "
-                         "replayed backward" if graphs else "eager launches (train.Trainer, DDP buckets)"),
+                         "gradient buffer on a communication stream: each bucket is released by a signal kernel node "
+                         "inside the replayed backward (sr_signal_set publishes the replay's epoch) that a one-lane "
+                         "polling kernel in front of the collective waits for (sr_signal_wait_timeout)"
+                         if graphs and on_gpu else
+                         "graph_train.GraphedTrainer(capture=False): the same phases, bucket hooks and collectives "
+                         "launched eagerly" if graphs else "eager launches (train.Trainer, DDP buckets)"),
            "losses_finite": finite, "parallelism": "dp%d" % world, "gradient_collective": collective,
            "roofline": roof, "phases": phases}
     if world > 1:
-        n = int(G_PARAM_BYTES // 4)
+        nbytes = G_PARAM_BYTES if not plumbing else 1.0e6        # (the CPU stand-in keeps the keys, not the size)
+        n = int(nbytes // 4)
         buf = torch.zeros(n, device=dev)
-        for _ in range(3):
-            dist.all_reduce(buf)
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(10):
-            dist.all_reduce(buf)
-        e1.record()
-        torch.cuda.synchronize()
-        ms = e0.elapsed_time(e1) / 10
+        ms = _time_ms(lambda: dist.all_reduce(buf), 10, on_gpu)
         # the same reduction as reduce-scatter + all-gather (each GPU owns 1/N of the buffer in between): on the
         # fully connected xGMI mesh every peer link carries 1/N of the data at once instead of a ring's hops
         n_pad = (n + world - 1) // world * world
         full = torch.zeros(n_pad, device=dev)
         shard = torch.zeros(n_pad // world, device=dev)
-        for _ in range(3):
+
+        def rsag():
             dist.reduce_scatter_tensor(shard, full)
             dist.all_gather_into_tensor(full, shard)
-        torch.cuda.synchronize()
-        e0.record()
-        for _ in range(10):
-            dist.reduce_scatter_tensor(shard, full)
-            dist.all_gather_into_tensor(full, shard)
-        e1.record()
-        torch.cuda.synchronize()
-        ms_rsag = e0.elapsed_time(e1) / 10
-        ring = 2.0 * (world - 1) / world * G_PARAM_BYTES / (XGMI_LINK_GBPS * 1e9) * 1e3
-        direct = 2.0 * (G_PARAM_BYTES / world) / (XGMI_LINK_GBPS * 1e9) * 1e3
-        out["allreduce_125MB"] = {"ms": round(ms, 3), "reduce_scatter_all_gather_ms": round(ms_rsag, 3),
+
+        try:
+            ms_rsag = round(_time_ms(rsag, 10, on_gpu), 3)
+        except RuntimeError:             # a backend without reduce_scatter_tensor (gloo): every rank lands here
+            ms_rsag = None
+        ring = 2.0 * (world - 1) / world * nbytes / (XGMI_LINK_GBPS * 1e9) * 1e3
+        direct = 2.0 * (nbytes / world) / (XGMI_LINK_GBPS * 1e9) * 1e3
+        out["allreduce_125MB"] = {"bytes": int(nbytes), "ms": round(ms, 3), "reduce_scatter_all_gather_ms": ms_rsag,
                                   "ring_bound_ms": round(ring, 3),
                                   "direct_mesh_bound_ms": round(direct, 3),
-                                  "busbw_GBps": round(2.0 * (world - 1) / world * G_PARAM_BYTES / ms / 1e6, 1)}
+                                  "frac_of_ring_bound": round(ring / ms, 3) if ms > 0 else None,
+                                  "busbw_GBps": round(2.0 * (world - 1) / world * nbytes / ms / 1e6, 1)}
     del tr, data, faces
-    torch.cuda.empty_cache()
+    if on_gpu:
+        torch.cuda.empty_cache()
     return out
 
 
@@ -398,6 +460,10 @@ def inversion_leg(dev, steps=400, size=256):
         noise = [n.detach() for n in g.make_noise()]
         target, _, _ = g([w_true], posed, input_is_latent=True, noise=noise)
 
+    from stylerenderer_amd.op import conv as conv_op
+
+    census = {}
+
     def timed(use_graph, n):
         inv = inversion.LatentInverter(g, net, target, mesh, noise=noise, use_graph=use_graph)
         torch.cuda.synchronize()
@@ -408,19 +474,46 @@ def inversion_leg(dev, steps=400, size=256):
         h = hist.cpu()
         steady = None
         if use_graph:
+            census["kernel_nodes"] = getattr(inv.graph, "kernel_nodes", None)
             # replay rate alone (the 400-step figure above includes mean-latent draws, 3 eager warm-up iterations
             # and the capture)
             t1 = time.perf_counter()
             inv.run(100)
             torch.cuda.synchronize()
             steady = 100 / (time.perf_counter() - t1)
+            # matrix-core work of ONE step (every convolution / weight-gradient launch of generator + VGG trunk,
+            # forward and backward), counted by running the same iteration once eagerly under op.conv's launch hook
+            conv_op.PROFILE = []
+            inv._iteration()
+            torch.cuda.synchronize()
+            prof, conv_op.PROFILE = conv_op.PROFILE, None
+            census["mfma_launches"] = len(prof)
+            census["alg"] = sum(fl for (_k, _g, fl, _a, _b) in prof)
+            census["exe"] = sum(executed_flops(kind, geom, fl) for (kind, geom, fl, _a, _b) in prof)
         return n / dt, float(h[0]), float(h[-1]), bool(torch.isfinite(h).all()), steady
 
     sps, l0, l1, finite, steady = timed(True, steps)
     sps_eager = timed(False, max(8, steps // 10))[0]
     del g, net
     torch.cuda.empty_cache()
-    return {"workload": "BASELINE config[4]: latent inversion, %d Adam steps, GeneratorWithMap(%d) + rasterizer "
+    roof = None
+    if steady and census.get("exe"):
+        ms = 1e3 / steady
+        nodes = census.get("kernel_nodes") or 0
+        roof = {"bound": "mfma", "kernel": "all MFMA convolution / weight-gradient launches of one replayed step "
+                                          "(GeneratorWithMap(256) + VGG16 trunk, forward + backward, batch 1)",
+                "achieved": round(census["exe"] / ms / 1e9, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(census["exe"] / ms / 1e9 / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                "executed_gflop_per_step": round(census["exe"] / 1e9, 1),
+                "algorithmic_gflop_per_step": round(census["alg"] / 1e9, 1),
+                "ms_per_replay": round(ms, 3), "kernel_launches_per_step": nodes,
+                "mfma_launches_per_step": census.get("mfma_launches"),
+                "avg_us_per_launch": round(ms * 1e3 / nodes, 2) if nodes else None,
+                "mfma_time_at_peak_ms": round(census["exe"] / (FP32_MFMA_PEAK_TFLOPS * 1e12) * 1e3, 3),
+                "note": "batch 1: the step is bounded by launch count x per-launch latency inside the graph and by "
+                        "tiles that cannot fill 256 CUs (a 4x4..32x32 map at batch 1 is 1-16 workgroups), not by a "
+                        "roof: mfma_time_at_peak_ms is what the matrix-core work alone would take"}
+    return {"roofline": roof, "workload": "BASELINE config[4]: latent inversion, %d Adam steps, GeneratorWithMap(%d) + rasterizer "
                         "(nv=%d nf=%d) + LPIPS-shaped VGG16 metric, batch 1" % (steps, size, v0.shape[0], tri.shape[0]),
             "value": round(sps, 2), "unit": "steps/s", "steps": steps,
             "seconds_for_%d_steps" % steps: round(steps / sps, 2),
@@ -463,12 +556,19 @@ def plumbing_main(args, rank, world):
         t = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    del net
+    # the G+D iteration leg of the GPU run, same function: GraphedTrainer(capture=False), bucketed reducer, the
+    # gradient_collective and all-reduce timing branches of N > 1
+    train_res = None
+    if not args.no_train:
+        train_res = train_leg(torch.device("cpu"), rank, world, 2, 4, size=8, plumbing=True)
+    if world > 1:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps({"metric": "generator fwd+bwd images/sec at 256^2", "plumbing": True, "n_gpus": world,
                           "value": round(2 * world * args.steps / elapsed, 2), "unit": "images/s",
-                          "steps": args.steps, "warmup": 0, "data": "synthetic"}))
+                          "steps": args.steps, "warmup": 0, "data": "synthetic", "train_step": train_res}))
 
 
 def main():
@@ -541,8 +641,15 @@ def main():
     for p_ in g.parameters():
         p_.grad = None
 
-    roof, breakdown = None, None
+    roof, breakdown, step_exec = None, None, None
     if rank == 0:
+        # matrix-core flops the WHOLE step executes (every convolution / weight-gradient launch, Winograd launches
+        # at 16/36 of their direct flops) over the step's wall time — the time-weighted companion of roofline.frac
+        # (which is the dominant kernel alone) and of model_flop_frac_of_mfma_peak (direct-convolution flops)
+        exe_step = sum(executed_flops(kind, geom, fl) for (kind, geom, fl, _e0, _e1) in prof) / max(args.steps, 1)
+        step_exec = {"executed_gflop_per_step": round(exe_step / 1e9, 1),
+                     "executed_tflops": round(exe_step / (elapsed / args.steps) / 1e12, 2),
+                     "frac": round(exe_step / (elapsed / args.steps) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4)}
         # ---- roofline of the dominant kernel: the stride-1 3x3 convolution (forward and data-gradient
         # launches of the 64^2..256^2 layers; k_conv_wino, or k_conv_mfma with SR_WINOGRAD=0), timed
         # inside the steps above
@@ -582,14 +689,34 @@ def main():
 
     def leg(fn, *a, **k):
         """A secondary leg that raises is REPORTED in the line ({"error": ...}), it does not take the headline
-        measurement above down with it.  (Collective legs: every rank runs the same code, so they fail together.)"""
+        measurement above down with it.  At N > 1 a leg that fails on ONE rank (an out-of-memory, a timed-out signal)
+        would leave the others blocked in collectives: that rank aborts the whole job at once (_fail_fast; rank 0
+        still prints the headline it holds, also when a peer's exit makes the launcher terminate it)."""
         try:
             return fn(*a, **k)
         except Exception as e:           # noqa: BLE001
             import traceback
 
-            sys.stderr.write(traceback.format_exc())
+            text = traceback.format_exc()
+            if world > 1:
+                _fail_fast(rank, world, {"train_leg": "train_step", "raster_leg": "rasterizer",
+                                         "inversion_leg": "inversion"}.get(fn.__name__, fn.__name__), text)
+            sys.stderr.write(text)
             return {"error": "%s: %s" % (type(e).__name__, str(e)[:400])}
+
+    if world > 1 and rank == 0:
+        import signal
+
+        _STASH["line"] = {"metric": "generator fwd+bwd images/sec at 256^2",
+                          "value": round(args.batch * world * args.steps / elapsed, 2), "unit": "images/s",
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
+                          "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                          "config": {"workload": "BASELINE config[1]: 256x256 Generator fwd+bwd, batch %d per GPU, "
+                                                 "random latents" % args.batch, "global_batch": args.batch * world,
+                                     "size": args.size, "parallelism": "dp%d" % world},
+                          "roofline": roof, "kernel_breakdown": breakdown}
+        signal.signal(signal.SIGTERM, _on_sigterm)
 
     train_res = None
     if not args.no_train:
@@ -629,6 +756,7 @@ def main():
                        "parallelism": "dp%d" % world,
                        "step": "zero_grad + forward + backward" + (" + DDP all-reduce (RCCL)" if world > 1 else "")},
             "model_flop_frac_of_mfma_peak": round(value / world * FLOP_PER_IMAGE_FWD_BWD / (FP32_MFMA_PEAK_TFLOPS * 1e12), 4),
+            "step_executed_mfma_frac": step_exec["frac"] if step_exec else None, "step_executed_mfma": step_exec,
             "roofline": roof, "cpu_baseline": cpu, "kernel_breakdown": breakdown,
             "train_step": train_res, "rasterizer": raster, "inversion": inversion_res,
         }

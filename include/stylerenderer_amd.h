@@ -371,19 +371,28 @@ int sr_conv2d_wgrad_mfma(float* dwt, const float* x, const float* gy, const floa
  * The reference overlaps the gradient all-reduce with the backward through torch DDP's bucket hooks
  * (reference distributed.py:98-105, used for the path-length step at train.py:335-352).  This build replays each
  * training phase as ONE hipGraph; a bucket of the flat gradient buffer that is complete in the middle of that graph
- * is announced by a one-lane kernel node: sr_signal_bump increments `*counter` (device memory, initially 0) once all
- * work enqueued before it on `stream` has finished.  sr_signal_wait enqueues a one-lane kernel on another stream that
- * returns when `*counter - at_least >= 0` (signed 32-bit distance): with at_least = the number of runs launched so
- * far, everything enqueued behind it starts at that point of the replay.  The producer must already be enqueued when
- * the wait is (the wait spins on the device). */
+ * is announced by a one-lane kernel node.  sr_signal_set stores `*epoch` (a device word the host writes, in stream
+ * order, in front of every replay it launches) into `*word` once all work enqueued before it on `stream` has finished;
+ * sr_signal_bump is the incrementing form (`*counter += 1`).  sr_signal_wait enqueues a one-lane kernel on another
+ * stream that returns when `*counter - at_least >= 0` (signed 32-bit distance): with at_least = the epoch of the replay
+ * just launched, everything enqueued behind it starts at that point of the replay.  The producer must already be
+ * enqueued when the wait is (the wait spins on the device).  sr_signal_wait_timeout gives up after `timeout_us`
+ * (0 = never): it stores `code` into `*status_host` (pinned host memory the caller polls; may be NULL) and returns, so
+ * a lost signal becomes a host-side error instead of a silent device-side spin. */
 int sr_signal_bump(uint32_t* counter, sr_stream_t stream);
+int sr_signal_set(uint32_t* word, const uint32_t* epoch, sr_stream_t stream);
 int sr_signal_wait(const uint32_t* counter, uint32_t at_least, sr_stream_t stream);
+int sr_signal_wait_timeout(const uint32_t* counter, uint32_t at_least, uint64_t timeout_us, int32_t* status_host,
+                           int32_t code, sr_stream_t stream);
 
 /* Repairs a captured, not yet instantiated hipGraph_t for the HIP 7.0 runtime PyTorch-ROCm 2.10 bundles: memset nodes
  * replay a corrupted value from the second launch on (torch's multi-block reductions zero their semaphores that way),
  * so each memset node is replaced by a fill-kernel node with the same edges.  `replaced` receives the count.  The
  * reference has no counterpart: it never captures its step (train.py enqueues ~4 000 launches per iteration). */
 int sr_graph_replace_memset_nodes(void* hip_graph, int* replaced);
+/* Number of kernel nodes / of all nodes of a captured hipGraph_t (launch census of a replayed phase: bench.py reports
+ * launches per step beside the device time). */
+int sr_graph_node_count(void* graph, int* kernel_nodes, int* all_nodes);
 
 /* One layer of the LPIPS distance (reference lpips/networks_basic.py:62-85 + lpips/__init__.py:42-44: normalize_tensor,
  * squared difference, 1x1 `lin` convolution, spatial average) fused — used by the latent-inversion loop:

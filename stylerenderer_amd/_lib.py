@@ -77,7 +77,10 @@ SIGNATURES = {
     "sr_rasterize_grad_f64": (_i, [_l] * 5 + [_i] * 2 + [_p, _p, _l] + [_p] * 6 + [_l, _l, _p, _p, _d, _p, _p]),
     "sr_signal_bump": (_i, [_p, _p]),
     "sr_signal_wait": (_i, [_p, ctypes.c_uint32, _p]),
+    "sr_signal_set": (_i, [_p, _p, _p]),
+    "sr_signal_wait_timeout": (_i, [_p, ctypes.c_uint32, ctypes.c_uint64, _p, _i, _p]),
     "sr_graph_replace_memset_nodes": (_i, [_p, ctypes.POINTER(_i)]),
+    "sr_graph_node_count": (_i, [_p, ctypes.POINTER(_i), ctypes.POINTER(_i)]),
 }
 
 _lib = None

@@ -90,8 +90,15 @@ def save_checkpoint(path, trainer):
 
 def load_checkpoint(path, trainer, map_location="cpu", strict=True):
     """Resume semantics of reference train.py:537-556: every key is optional; `g_ema` falls back to `g`;
-    the start iteration comes from the file name unless the checkpoint carries one."""
+    the start iteration comes from the file name unless the checkpoint carries one.
+
+    COLLECTIVE at world size > 1: EVERY rank must call it with the same file (the reference does: train.py:537 runs on
+    all ranks).  A GraphedTrainer drops its captured graphs here and re-captures on the next step(); the warm-up
+    iterations of that re-capture issue gradient collectives, so a "rank 0 loads and broadcasts" flow would leave the
+    other ranks without matching calls.  The check below turns that mistake into an error (or a hang AT THIS LINE
+    that the RCCL watchdog names) instead of a hang somewhere inside the next step."""
     ckpt = torch.load(path, map_location=map_location, weights_only=False)
+    _assert_collective_load(trainer, int(ckpt.get("iteration", start_iter_from_name(path))))
     g = trainer.generator
     if "g" in ckpt:
         g.load_state_dict(ckpt["g"], strict=strict)
@@ -122,6 +129,20 @@ def load_checkpoint(path, trainer, map_location="cpu", strict=True):
         # step() (build_graphs restores the loaded state after its warm-up iterations)
         trainer.graphs = {}
     return ckpt
+
+
+def _assert_collective_load(trainer, iteration):
+    from . import distributed as sr_dist
+
+    if sr_dist.get_world_size() <= 1:
+        return
+    dev = getattr(trainer, "device", torch.device("cpu"))
+    mine = torch.tensor([float(iteration), -float(iteration)], dtype=torch.float64, device=dev)
+    torch.distributed.all_reduce(mine, op=torch.distributed.ReduceOp.MAX)
+    lo, hi = -float(mine[1]), float(mine[0])
+    if lo != hi:
+        raise RuntimeError("load_checkpoint must load the SAME checkpoint on every rank: start iterations %d..%d "
+                           "differ (rank %d has %d)" % (lo, hi, sr_dist.get_rank(), iteration))
 
 
 def load_generator(path, size, latent=512, n_mlp=8, channel_multiplier=2, device="cpu", with_map=False):

@@ -18,10 +18,13 @@ extern "C" const char* sr_error_string(int code) {
 // all-reduce on another stream while the rest of the graph keeps running.  The API for that is an event-record node
 // (hipEventRecordWithFlags(..., hipEventRecordExternal)); it works on the ROCm 7.2 runtime but returns
 // hipErrorInvalidValue on the HIP 7.0.51831 runtime PyTorch-ROCm 2.10 bundles, and hipStreamWaitValue32 does not
-// release early on either (scripts/event_graph_probe.cpp, event_graph_probe_torch.py).  Plain kernels do: k_bump is a
-// node of the graph that increments a device counter once everything captured before it has finished, k_poll is the
-// first thing in the communication stream and spins (one lane, s_sleep) until the counter reaches the number of
-// runs the host has launched.  Measured inside a replay: the consumer starts 0.5 us after the producer node.
+// release early on either (scripts/event_graph_probe.cpp, event_graph_probe_torch.py).  Plain kernels do: k_signal_set
+// is a node of the graph that publishes the replay's EPOCH (a device word the host writes, in stream order, in front
+// of the replay) into the bucket's word once everything captured before it has finished; k_signal_wait is the first
+// thing in the communication stream and spins (one lane, s_sleep) until the bucket's word reaches the epoch of the
+// replay the host has just launched.  A replay the host did not announce (a bare graph.replay() in a test or probe)
+// republishes the epoch already reached: it cannot run ahead of the host's count the way an incrementing counter
+// does.  Measured inside a replay: the consumer starts 0.5 us after the producer node.
 namespace {
 
 __global__ void k_signal_bump(unsigned* counter) {
@@ -29,10 +32,26 @@ __global__ void k_signal_bump(unsigned* counter) {
     atomicAdd(counter, 1u);
 }
 
-__global__ void k_signal_wait(const unsigned* counter, unsigned at_least) {
-    // signed distance: correct across the 2^32 wrap of a counter that only ever grows
-    while ((int)(__hip_atomic_load(counter, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - at_least) < 0)
+__global__ void k_signal_set(unsigned* word, const unsigned* epoch) {
+    __threadfence();
+    __hip_atomic_store(word, __hip_atomic_load(epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __ATOMIC_RELEASE,
+                       __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// timeout_ticks in 100 MHz wall-clock ticks (0: wait for ever).  On expiry the kernel stores `code` into *status (pinned
+// host memory, system scope) and RETURNS: what is queued behind it runs on unfinished data, but the host finds the code
+// at its next check and raises instead of the job sitting in a silent device-side spin until an outer limit kills it.
+__global__ void k_signal_wait(const unsigned* counter, unsigned at_least, unsigned long long timeout_ticks, int* status,
+                              int code) {
+    const unsigned long long t0 = wall_clock64();
+    // signed distance: correct across the 2^32 wrap of a word that only ever grows
+    while ((int)(__hip_atomic_load(counter, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - at_least) < 0) {
         __builtin_amdgcn_s_sleep(16);
+        if (timeout_ticks && wall_clock64() - t0 > timeout_ticks) {
+            if (status) __hip_atomic_store(status, code, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            return;
+        }
+    }
 }
 
 }  // namespace
@@ -43,9 +62,23 @@ extern "C" int sr_signal_bump(uint32_t* counter, sr_stream_t stream) {
     return sr_launch_status();
 }
 
+extern "C" int sr_signal_set(uint32_t* word, const uint32_t* epoch, sr_stream_t stream) {
+    if (!word || !epoch) return SR_EINVAL;
+    hipLaunchKernelGGL(k_signal_set, dim3(1), dim3(1), 0, sr_stream(stream), word, epoch);
+    return sr_launch_status();
+}
+
 extern "C" int sr_signal_wait(const uint32_t* counter, uint32_t at_least, sr_stream_t stream) {
     if (!counter) return SR_EINVAL;
-    hipLaunchKernelGGL(k_signal_wait, dim3(1), dim3(1), 0, sr_stream(stream), counter, at_least);
+    hipLaunchKernelGGL(k_signal_wait, dim3(1), dim3(1), 0, sr_stream(stream), counter, at_least, 0ull, (int*)nullptr, 0);
+    return sr_launch_status();
+}
+
+extern "C" int sr_signal_wait_timeout(const uint32_t* counter, uint32_t at_least, uint64_t timeout_us,
+                                      int32_t* status_host, int32_t code, sr_stream_t stream) {
+    if (!counter) return SR_EINVAL;
+    hipLaunchKernelGGL(k_signal_wait, dim3(1), dim3(1), 0, sr_stream(stream), counter, at_least,
+                       (unsigned long long)timeout_us * 100ull, status_host, code);
     return sr_launch_status();
 }
 
@@ -76,6 +109,25 @@ __global__ __launch_bounds__(256) void k_graph_fill(unsigned char* __restrict__ 
 }
 
 }  // namespace
+
+extern "C" int sr_graph_node_count(void* graph_handle, int* kernel_nodes, int* all_nodes) {
+    if (!graph_handle) return SR_EINVAL;
+    hipGraph_t graph = static_cast<hipGraph_t>(graph_handle);
+    size_t n = 0;
+    hipError_t e = hipGraphGetNodes(graph, nullptr, &n);
+    if (e != hipSuccess) return static_cast<int>(e);
+    std::vector<hipGraphNode_t> nodes(n);
+    if (n && (e = hipGraphGetNodes(graph, nodes.data(), &n)) != hipSuccess) return static_cast<int>(e);
+    int kernels = 0;
+    for (size_t k = 0; k < n; ++k) {
+        hipGraphNodeType type;
+        if ((e = hipGraphNodeGetType(nodes[k], &type)) != hipSuccess) return static_cast<int>(e);
+        kernels += type == hipGraphNodeTypeKernel;
+    }
+    if (kernel_nodes) *kernel_nodes = kernels;
+    if (all_nodes) *all_nodes = (int)n;
+    return SR_OK;
+}
 
 extern "C" int sr_graph_replace_memset_nodes(void* graph_handle, int* replaced) {
     if (!graph_handle) return SR_EINVAL;

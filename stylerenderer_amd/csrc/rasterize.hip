@@ -759,7 +759,9 @@ __global__ __launch_bounds__(256) void k_tile_raster(unsigned b, unsigned nv, un
             s_rec[8][l] = t.e5; s_rec[9][l] = t.e6; s_rec[10][l] = t.e7; s_rec[11][l] = t.e8; s_rec[12][l] = t.area;
             s_box[0][l] = x0; s_box[1][l] = y0; s_box[3][l] = (int)ti;
             // box width and ceil(2^16 / width): item -> row is a multiply + shift (exact: item < 1024, width <= 32)
-            s_box[2][l] = (x1 - x0 + 1) | ((65536 + (x1 - x0)) / (x1 - x0 + 1)) << 8;
+            // (a wide-list triangle whose clipped box misses this tile has npx = 0 and possibly x1 = x0 - 1: nothing reads
+            // its entry, and the division is not evaluated)
+            s_box[2][l] = npx > 0 ? (x1 - x0 + 1) | ((65536 + (x1 - x0)) / (x1 - x0 + 1)) << 8 : 0;
         }
         int total;
         const int before = block_scan_256(npx, s_wave, total);

@@ -222,11 +222,19 @@ class BucketedGradReducer:
     slices of linearly decreasing size.  A post-accumulate hook per parameter counts arrivals; when the last gradient of a
     bucket is there, the bucket's gradients are copied into their flat views (one multi-tensor copy) and the bucket
     is SIGNALLED.  Under stream capture the signal is a one-lane kernel node in the middle of the phase graph that
-    increments the bucket's device counter (`sr_signal_bump`, include/stylerenderer_amd.h); after each
-    `graph.replay()` the host calls `issue_all()`: for every bucket, `sr_signal_wait(counter_k, runs so far)` +
+    publishes the replay's EPOCH into the bucket's device word (`sr_signal_set`, include/stylerenderer_amd.h).  The
+    host calls `arm()` in front of every replay (epoch += 1, written to a device scalar in stream order) and
+    `issue_all()` right after it: for every bucket, `sr_signal_wait_timeout(word_k, epoch)` +
     `all_reduce(flat[lo_k:hi_k])` on the communication stream — bucket k is on the xGMI links while the graph is
-    still computing the gradients of bucket k+1.  Eagerly (warm-up, `capture=False`, CPU / gloo) the same hooks
-    record an ordinary event and issue the collective directly.
+    still computing the gradients of bucket k+1.  The release test is "the word has reached THIS replay's epoch": a
+    replay nobody armed (a bare `graph.replay()` in a probe, an exception between replay and `issue_all()`) republishes
+    an epoch already reached and cannot put the device ahead of the host's count, which is what an incrementing
+    counter does (then every later wait passes at once and RCCL reduces a half-written bucket).
+    A wait that is not released within SR_SIGNAL_TIMEOUT_S (default 120) stores the bucket's id into pinned host
+    memory and returns; `check()` — called by arm() / issue_all() / wait() and by `wait(deadline_s=...)`'s host-side
+    poll — raises with that id instead of the job hanging until an outer limit kills it.
+    Eagerly (warm-up, `capture=False`, CPU / gloo) the same hooks record an ordinary event and issue the collective
+    directly.
     Buckets are issued in index order on every rank, whatever order they completed in.  `wait()` makes the
     current stream (CPU: the caller) wait for all reductions — it sits in front of the optimiser step.
 
@@ -267,7 +275,10 @@ class BucketedGradReducer:
             # of the process had shifted the round-robin).  High-priority streams get queues of their own.
             self.comm = torch.cuda.Stream(device=flat.device, priority=-1)
             self.counters = torch.zeros(len(self.buckets), dtype=torch.int32, device=flat.device)
-            self.runs = [0] * len(self.buckets)          # bumps launched so far, per bucket (replays only)
+            self.epoch = 0                               # replays announced so far (arm())
+            self.epoch_dev = torch.zeros(1, dtype=torch.int32, device=flat.device)
+            self.status = torch.zeros(len(self.buckets), dtype=torch.int32).pin_memory()   # written by a timed-out wait
+            self.timeout_us = int(float(os.environ.get("SR_SIGNAL_TIMEOUT_S", "120")) * 1e6)
             self.eager_events = [None] * len(self.buckets)
         self.active = False
         self.pending, self.done, self.next_issue = [], [], 0
@@ -322,8 +333,9 @@ class BucketedGradReducer:
         if self.is_cuda:
             stream = torch.cuda.current_stream(self.flat.device)      # the producing stream (autograd thread: the op's)
             if self._capturing():
-                self._lib.check(self._lib.lib().sr_signal_bump(self.counters.data_ptr() + 4 * b, stream.cuda_stream),
-                                "sr_signal_bump")
+                self._lib.check(self._lib.lib().sr_signal_set(self.counters.data_ptr() + 4 * b,
+                                                              self.epoch_dev.data_ptr(), stream.cuda_stream),
+                                "sr_signal_set")
                 return                               # issued by issue_all() after every replay
             ev = torch.cuda.Event()
             ev.record(stream)
@@ -341,10 +353,9 @@ class BucketedGradReducer:
         self.log.append(("issue", b, self._now()))
         if self.is_cuda:
             if replay:
-                self.runs[b] += 1
-                self._lib.check(self._lib.lib().sr_signal_wait(self.counters.data_ptr() + 4 * b,
-                                                               self.runs[b] & 0xFFFFFFFF, self.comm.cuda_stream),
-                                "sr_signal_wait")
+                self._lib.check(self._lib.lib().sr_signal_wait_timeout(
+                    self.counters.data_ptr() + 4 * b, self.epoch & 0xFFFFFFFF, self.timeout_us,
+                    self.status.data_ptr() + 4 * b, b + 1, self.comm.cuda_stream), "sr_signal_wait_timeout")
             else:
                 self.comm.wait_event(self.eager_events[b])
             with torch.cuda.stream(self.comm):
@@ -365,12 +376,32 @@ class BucketedGradReducer:
                 self._flush(b)
         self.active = False
 
-    # ---- after a replay / before the optimiser ------------------------------------------------------------------
+    # ---- around a replay / before the optimiser ----------------------------------------------------------------
+    def check(self):
+        """Raises when a device-side wait gave up (its bucket's signal node never ran within SR_SIGNAL_TIMEOUT_S)."""
+        if self.enabled and self.is_cuda and bool(self.status.any()):
+            stuck = [int(x) - 1 for x in self.status.tolist() if x]
+            self.status.zero_()
+            raise RuntimeError("BucketedGradReducer: the signal of bucket(s) %s (of %d) was not published within %.0f s "
+                               "at epoch %d on rank %d — the replay that should produce it did not run or did not "
+                               "finish; the gradient buffer is NOT reduced" % (
+                                   stuck, len(self.buckets), self.timeout_us / 1e6, self.epoch, get_rank()))
+
+    def arm(self):
+        """In front of `graph.replay()` of a captured phase: announce the replay (epoch += 1) to its signal nodes."""
+        if self.enabled and self.is_cuda:
+            self.check()
+            self.epoch += 1
+            u = self.epoch & 0xFFFFFFFF                 # the device word is the epoch mod 2^32 (int32 bit pattern)
+            self.epoch_dev.fill_(u - (1 << 32) if u >> 31 else u)
+
     def issue_all(self, stamps=None):
-        """After `graph.replay()` of a captured phase (ONLY then: the waits spin on the device until the replay's
-        signal nodes have run): queue every bucket's wait + collective on the comm stream.
+        """After an arm()ed `graph.replay()` of a captured phase (ONLY then: the waits spin on the device until the
+        replay's signal nodes have published the epoch): queue every bucket's wait + collective on the comm stream.
         `stamps` (a list): a timing event is recorded on the comm stream after every bucket's collective."""
         if self.enabled:
+            if self.is_cuda:
+                self.check()
             for b in range(len(self.buckets)):
                 self._issue(b, replay=True)
                 if stamps is not None and self.is_cuda:
@@ -378,11 +409,30 @@ class BucketedGradReducer:
                     ev.record(self.comm)
                     stamps.append(ev)
 
-    def wait(self):
+    def wait(self, deadline_s=None):
+        """The current stream (CPU: the caller) waits for all reductions.  deadline_s (or SR_COMM_WATCHDOG_S): a
+        host-side watchdog — the caller polls the communication stream until it drains, raising with the stuck
+        bucket (check()) or, at the deadline, with the device words it can still read from pinned memory."""
         if not self.enabled:
             return
         if self.is_cuda:
+            self.check()
             torch.cuda.current_stream(self.flat.device).wait_stream(self.comm)
+            if deadline_s is None and os.environ.get("SR_COMM_WATCHDOG_S"):
+                deadline_s = float(os.environ["SR_COMM_WATCHDOG_S"])
+            if deadline_s:
+                import time
+
+                t0 = time.perf_counter()
+                while not self.comm.query():
+                    self.check()
+                    if time.perf_counter() - t0 > deadline_s:
+                        raise RuntimeError("BucketedGradReducer: communication stream still busy %.1f s after the "
+                                           "replay of epoch %d on rank %d (%d buckets; a peer rank may not have "
+                                           "entered the collective)" % (deadline_s, self.epoch, get_rank(),
+                                                                        len(self.buckets)))
+                    time.sleep(0.0005)
+                self.check()
         else:
             for work, piece in self.works:
                 work.wait()

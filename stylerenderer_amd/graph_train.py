@@ -18,10 +18,10 @@ Gradient reduction overlapped with the backward (reference distributed.py:98-105
 all-reduce over xGMI overlapped with the StyleGAN2 path-length-regulariser backward").  No RCCL call is captured:
 the flat gradient buffer of each network is laid out in gradient ARRIVAL order and cut into SR_GRAD_BUCKETS (4)
 contiguous buckets; the captured backward holds, after the last gradient of each bucket, one multi-tensor copy into the
-bucket's flat views and a SIGNAL NODE (`sr_signal_bump`: a one-lane kernel that increments the bucket's device counter;
-include/stylerenderer_amd.h — event-record nodes are refused by the HIP runtime torch bundles).  Right after
-`graph.replay()` the host queues, for every bucket, `sr_signal_wait(counter_k, runs)` + `all_reduce(flat[lo_k:hi_k])`
-on a communication stream: bucket k is on the xGMI links while the replay
+bucket's flat views and a SIGNAL NODE (`sr_signal_set`: a one-lane kernel that publishes the replay's epoch — a device
+scalar the host bumps in front of every replay — into the bucket's device word; include/stylerenderer_amd.h —
+event-record nodes are refused by the HIP runtime torch bundles).  Right after `graph.replay()` the host queues, for
+every bucket, `sr_signal_wait_timeout(word_k, epoch)` + `all_reduce(flat[lo_k:hi_k])` on a communication stream: bucket k is on the xGMI links while the replay
 is still producing bucket k+1; the optimiser graph waits for the communication stream
 (distributed.BucketedGradReducer).  SR_GRAD_OVERLAP=0: one bucket, reduced after the backward by the autotuned
 all-reduce / reduce-scatter + all-gather of distributed.FlatGradReducer (round 2's mode).  With `capture=False` the
@@ -238,7 +238,8 @@ class GraphedTrainer(Trainer):
     def _snapshot(self):
         """Everything the warm-up iterations change: parameters, Adam moments / step, the path-length EMA and the
         random streams.  Restored before capture, so training starts (or resumes) from exactly the loaded state and
-        the lazy-regularisation cadence is not advanced by untracked steps."""
+        the lazy-regularisation cadence is not advanced by untracked steps.  (Module buffers — noise maps, FIR taps —
+        are constants no phase writes, and the EMA copy is only touched by step(): neither needs a snapshot.)"""
         snap = {"tensors": [(t, t.detach().clone()) for t in (
             self.g_optim.flat_p, self.g_optim.m, self.g_optim.v, self.g_optim.step_t, self.d_optim.flat_p,
             self.d_optim.m, self.d_optim.v, self.d_optim.step_t, self.mean_path_length)],
@@ -285,14 +286,17 @@ class GraphedTrainer(Trainer):
         torch.cuda.synchronize()
 
     def _run(self, name):
-        """One phase (or optimiser step).  Captured: replay, then queue every bucket's wait-for-event + collective on
-        the communication stream (they start as soon as the replay passes the bucket's event-record node); the
-        current stream — hence the optimiser graph replayed next — waits for the communication stream."""
+        """One phase (or optimiser step).  Captured: announce the replay's epoch, replay, then queue every bucket's
+        wait-for-signal kernel (sr_signal_wait_timeout) + collective on the communication stream (each starts as soon
+        as the replay passes the bucket's signal node, sr_signal_set); the current stream — hence the optimiser graph
+        replayed next — waits for the communication stream."""
         if not self.capture:
             return self._eager_phase(name)
+        red = getattr(self, self.PHASE_REDUCER[name]) if name in self.PHASE_REDUCER else None
+        if red is not None:
+            red.arm()
         self.graphs[name].replay()
-        if name in self.PHASE_REDUCER:
-            red = getattr(self, self.PHASE_REDUCER[name])
+        if red is not None:
             red.issue_all()
             red.wait()
 
@@ -319,6 +323,7 @@ class GraphedTrainer(Trainer):
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
+        red.arm()
         self.graphs[name].replay()
         e1.record()
         stamps = []

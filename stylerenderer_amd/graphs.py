@@ -12,10 +12,12 @@ by a fill-kernel node with the same edges (`sr_graph_replace_memset_nodes`, csrc
 Replay stays torch's (`graph.replay()`), so the Philox offset bookkeeping of captured random ops is untouched.
 """
 import ctypes
+import weakref
 
 import torch
 
 from . import _lib
+from .op import _dispatch
 
 
 def capture(body, pool=None):
@@ -26,12 +28,21 @@ def capture(body, pool=None):
     # thread_local: only THIS thread's calls are policed during capture.  Under the default (global) mode the RCCL
     # watchdog thread's routine hipEventQuery on an earlier collective aborts the process with "operation not
     # permitted when stream is capturing".
-    with torch.cuda.graph(graph, capture_error_mode="thread_local", **kw):
+    # derived-tensor cache entries (flipped FIR taps, incidence lists, frozen weight adjoints) touched by the capture
+    # stay pinned exactly as long as this graph object lives
+    scope = _dispatch.PinScope()
+    with _dispatch.pin_scope(scope), torch.cuda.graph(graph, capture_error_mode="thread_local", **kw):
         body()
+    weakref.finalize(graph, scope.release)
+    graph.pin_scope = scope
     n = ctypes.c_int(0)
     raw = graph.raw_cuda_graph()
     _lib.check(_lib.lib().sr_graph_replace_memset_nodes(ctypes.c_void_p(int(raw)), ctypes.byref(n)),
                "sr_graph_replace_memset_nodes")
+    kernels, total = ctypes.c_int(0), ctypes.c_int(0)
+    _lib.check(_lib.lib().sr_graph_node_count(ctypes.c_void_p(int(raw)), ctypes.byref(kernels), ctypes.byref(total)),
+               "sr_graph_node_count")
     graph.instantiate()
     graph.memset_nodes_replaced = int(n.value)
+    graph.kernel_nodes, graph.nodes = int(kernels.value), int(total.value)       # launches per replay
     return graph

@@ -13,7 +13,7 @@ import torch
 from torch.autograd import Function
 
 from .. import _lib
-from ._dispatch import on_device_of, require_f32, stream_of
+from ._dispatch import hold_for_capture, on_device_of, require_f32, stream_of
 
 
 def _pitch(n):
@@ -148,6 +148,10 @@ def weight_prep_cached(module, weight, scale, want_sq=False):
         wt._sr_frozen = True                       # lets ConvFn cache the adjoint of this very tensor
         hit = (tag, wt, wsq)
         module._wprep_hit = hit
+    # a graph under capture bakes these addresses in: it keeps them alive even if a later weight version replaces
+    # the module's entry.  (A frozen module's weights must not change while a captured graph that read them is
+    # replayed: the graph would keep using the OLD prepared tensors.)
+    hold_for_capture(hit)
     return hit[1], (hit[2] if want_sq else None)
 
 

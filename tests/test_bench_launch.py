@@ -19,14 +19,36 @@ def run_bench(*extra, env_extra=None):
     return json.loads(lines[0])
 
 
-def test_gpus_2_self_launches_two_ranks():
+def test_gpus_2_self_launches_two_ranks_and_runs_the_train_leg():
+    """Two gloo ranks run bench.py's OWN train_leg (GraphedTrainer capture=False, bucketed reducer) — the N > 1 branches
+    of the line the driver's SCALE run parses: gradient_collective (bucket layout, issue order) and the all-reduce
+    timing against the xGMI ring / direct-mesh bounds."""
     out = run_bench("--gpus", "2")
     assert out["n_gpus"] == 2 and out["plumbing"] is True and out["value"] > 0
+    tl = out["train_step"]
+    assert "error" not in tl and tl["value"] > 0 and tl["losses_finite"] is True and tl["parallelism"] == "dp2"
+    assert tl["iters"] == 2 and tl["ms_per_iter"] > 0 and tl["host_enqueue_ms_per_iter"] > 0
+    gc = tl["gradient_collective"]
+    for k in ("generator_grads", "discriminator_grads"):
+        assert gc[k]["mode"] == "overlapped, 4 buckets" and len(gc[k]["bucket_MB"]) == 4
+        assert gc[k]["bucket_MB"] == sorted(gc[k]["bucket_MB"], reverse=True)          # the last bucket is the smallest
+    assert set(gc) >= {"overlap_path_phase", "overlap_d_phase"}
+    assert gc["eager_issue_order_path_phase"] == [0, 1, 2, 3]                           # in index order on every rank
+    ar = tl["allreduce_125MB"]
+    assert set(ar) >= {"bytes", "ms", "reduce_scatter_all_gather_ms", "ring_bound_ms", "direct_mesh_bound_ms",
+                       "frac_of_ring_bound", "busbw_GBps"}
+    assert ar["ms"] > 0 and ar["ring_bound_ms"] == ar["direct_mesh_bound_ms"] > 0      # equal at N = 2: 2(N-1)/N = 2/N
+
+
+def test_train_leg_single_rank_has_no_collective_block():
+    out = run_bench()
+    tl = out["train_step"]
+    assert tl["gradient_collective"] is None and "allreduce_125MB" not in tl and tl["parallelism"] == "dp1"
 
 
 def test_single_rank_default():
-    out = run_bench()
-    assert out["n_gpus"] == 1
+    out = run_bench("--no-train")
+    assert out["n_gpus"] == 1 and out["train_step"] is None
 
 
 def test_world_size_mismatch_is_refused():

@@ -38,3 +38,34 @@ def test_flipped_taps_cache_hits_by_address_and_version():
     for t in many:
         ufd.flipped(t)
     assert len(ufd._FLIP_CACHE) <= 64 + len(ufd._FLIP_CACHE.pinned) + 1
+
+
+def test_pins_are_released_with_the_graph_that_took_them(monkeypatch):
+    """pins used to live for the life of the process.  A capture made through graphs.capture opens a
+    PinScope; when that graph dies its entries become evictable again, while entries shared with a graph that is still
+    alive stay — and a scope keeps the VALUE it read alive even if the cache replaced the entry meanwhile."""
+    c = _dispatch.DerivedCache(2)
+    c.put("shared", ("s",))
+    a, b = _dispatch.PinScope(), _dispatch.PinScope()
+    monkeypatch.setattr(_dispatch, "_capturing", lambda: True)
+    with _dispatch.pin_scope(a):
+        c.get("shared")
+        c.get("shared")                                  # pinned once per scope
+        c.put("only_a", ("a",))
+        held = _dispatch.hold_for_capture(("frozen weights",))
+    with _dispatch.pin_scope(b):
+        c.get("shared")
+    monkeypatch.setattr(_dispatch, "_capturing", lambda: False)
+    assert c.pinned == {"shared": 2, "only_a": 1} and a.keep == [held]
+    for k in range(10):
+        c.put(k, (k,))
+    assert c.get("shared") and c.get("only_a") and len(c) == 2 + 2
+    c.put("only_a", ("replaced",))                       # the live graph a still owns the old value
+    assert ("a",) in [v for _c, _k, v in a.items]
+    a.release()
+    a.release()                                          # idempotent (weakref.finalize + explicit)
+    assert c.pinned == {"shared": 1} and a.keep == [] and len(c) == 2 + 1
+    b.release()
+    assert c.pinned == {}
+    c.put("x", (0,))
+    assert len(c) == 2

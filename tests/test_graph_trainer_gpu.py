@@ -1,6 +1,7 @@
 """GPU: graph_train.GraphedTrainer at BASELINE config[2]'s size, and its overlapped gradient reduction on a ONE-rank
-RCCL group (the only group a 1-GPU box can form): the event-record nodes inside the replayed backward, the
-communication stream and the RCCL calls between replays are exactly what runs at N > 1."""
+RCCL group (the only group a 1-GPU box can form): the signal nodes (sr_signal_set) inside the replayed backward, the
+wait kernels (sr_signal_wait_timeout) on the communication stream and the RCCL calls between replays are exactly what
+runs at N > 1."""
 import os
 import socket
 
@@ -11,6 +12,7 @@ import torch
 from stylerenderer_amd import graph_train, train
 
 pytestmark = pytest.mark.gpu
+DEV = "cuda"
 
 
 def full_size_trainer(**kw):
@@ -108,12 +110,51 @@ def test_overlapped_reduction_inside_the_replayed_backward(one_rank_group):
     # the first half of the replay, not merely before its end (a weight-gradient node that autograd schedules at the end
     # of the backward passes the weaker check above while destroying the overlap)
     assert any(t["bucket_done_ms_after_replay_end"][0] < -0.25 * t["replay_ms"] for t in tries), tries
-    # bench.py's per-phase timing goes through the same replay + issue + wait path on every rank: the host's count of
-    # launched runs and the device counters of the signal nodes stay in step (a bare graph.replay() would bump the
-    # counters alone and release the NEXT run's collectives before their buckets are complete)
+    # bench.py's per-phase timing goes through the same arm + replay + issue + wait path on every rank: the signal
+    # words hold the epoch of the last announced replay
     ms = a.time_phase("d", 2)
     assert ms > 0
     torch.cuda.synchronize()
-    assert a.reduce_d.counters.cpu().tolist() == [r & 0xFFFFFFFF for r in a.reduce_d.runs]
-    again = a.measure_overlap("d")["bucket_done_ms_after_replay_end"]
+    assert a.reduce_d.counters.cpu().tolist() == [a.reduce_d.epoch] * 4
+    # a replay NOBODY announced (probes, an exception between replay and issue_all) republishes the epoch already
+    # reached: the words do not run ahead of the host, so the next announced replay's collectives still wait for
+    # their buckets — the LAST bucket cannot be reduced long before the replay that fills it ends (an incrementing
+    # counter would release all four at the start of the replay: about -replay_ms)
+    a.graphs["d"].replay()
+    a.graphs["d"].replay()
+    torch.cuda.synchronize()
+    assert a.reduce_d.counters.cpu().tolist() == [a.reduce_d.epoch] * 4
+    ov = a.measure_overlap("d")
+    again = ov["bucket_done_ms_after_replay_end"]
     assert again == sorted(again)
+    assert again[-1] > -0.1 * ov["replay_ms"], ov
+    assert not a.reduce_d.status.any()
+    a.reduce_d.check()
+
+
+def test_lost_signal_times_out_and_raises(monkeypatch):
+    """A wait whose signal never comes (here: an epoch nobody replays) gives up after SR_SIGNAL_TIMEOUT_S, stores the
+    bucket id in pinned host memory, and the next host-side check raises with it instead of hanging."""
+    from stylerenderer_amd import _lib
+    from stylerenderer_amd import distributed as sr_dist
+
+    monkeypatch.setenv("SR_SIGNAL_TIMEOUT_S", "0.2")
+    ps = [torch.nn.Parameter(torch.zeros(64, device=DEV)) for _ in range(4)]
+    flat = torch.zeros(4 * 64, device=DEV)
+    views = [flat[i * 64:(i + 1) * 64] for i in range(4)]
+    red = sr_dist.BucketedGradReducer(ps, views, [0, 64, 128, 192], flat, world=1, n_buckets=2, force=True)
+    assert red.timeout_us == 200000
+    red.arm()                              # epoch 1 announced, but no graph publishes it
+    L = _lib.lib()
+    _lib.check(L.sr_signal_wait_timeout(red.counters.data_ptr() + 4, 1, red.timeout_us, red.status.data_ptr() + 4, 2,
+                                        red.comm.cuda_stream), "wait")
+    torch.cuda.synchronize()
+    with pytest.raises(RuntimeError, match=r"bucket\(s\) \[1\]"):
+        red.check()
+    assert not red.status.any()            # reported once
+    # a published epoch releases at once and leaves the status clean
+    _lib.check(L.sr_signal_set(red.counters.data_ptr() + 4, red.epoch_dev.data_ptr(), _lib.current_stream()), "set")
+    _lib.check(L.sr_signal_wait_timeout(red.counters.data_ptr() + 4, 1, red.timeout_us, red.status.data_ptr() + 4, 2,
+                                        red.comm.cuda_stream), "wait")
+    torch.cuda.synchronize()
+    red.check()
