@@ -295,20 +295,36 @@ def gold_discriminator(ns):
 def gold_generator_256(ns):
     """The exact network bench.py times (Generator(256, 512, 8), BASELINE config[1]) on one latent: image (0.8 MB)
     and the first-order gradients of a fixed linear functional w.r.t. every parameter (256 samples per tensor) and
-    the W+ latent (full).  Pins the 128^2 / 256^2 forward, data-gradient and weight-gradient kernel variants no
-    smaller fixture reaches."""
+    the W+ latent (full) — twice:
+      lin_*   with every FusedLeakyReLU of the synthesis network at negative_slope = 1 (the reference module's own
+              attribute, op/fused_act.py:78-83): the network is then linear in its activations and the gradients pin
+              the 128^2 / 256^2 forward, data-gradient and weight-gradient kernel variants as exact adjoints, at fp32
+              round-off;
+      grad_*  at the real slope 0.2.  Of the 3.3e7 pre-activations of this network a few dozen have |value| ~ 1e-7 and
+              land on different sides of the kink under ANY two fp32 implementations (the same CPU code on two hosts
+              differs from this fixture by 2e-3 of a tensor's scale, scripts/g256_parity_probe.py): these entries
+              bound the agreement of the full non-linear backward, they cannot pin kernels."""
     g = ns.model.Generator(256, 512, 8)
     synth.fill_state_dict(g.state_dict(), salt=41)
-    img, lat = g([T(dn((1, 512), 42))], return_latents=True, noise=_noise_list(g, 4300))
-    lat.retain_grad()
-    proj = T(dn(tuple(img.shape), 46))
-    named = dict(g.named_parameters())
-    grads = torch.autograd.grad((img * proj).sum(), list(named.values()) + [lat], allow_unused=True)
-    gd = {n: gr for n, gr in zip(named, grads[:-1]) if gr is not None}
-    vals, offs = grad_samples(gd)
-    save("generator_s256", image=img.detach().numpy(), latent_row=lat[0, 0].detach().numpy(),
-         n_keys=np.array(len(g.state_dict())), grad_names=np.array(sorted(gd)), grad_samples=vals,
-         grad_sample_offsets=offs, grad_latent=grads[-1].numpy())
+    proj = None
+    arrays = {"n_keys": np.array(len(g.state_dict()))}
+    for prefix, slope in (("grad", 0.2), ("lin_grad", 1.0)):
+        for m in g.modules():
+            if isinstance(m, ns.op.FusedLeakyReLU):
+                m.negative_slope = slope
+        img, lat = g([T(dn((1, 512), 42))], return_latents=True, noise=_noise_list(g, 4300))
+        if proj is None:
+            proj = T(dn(tuple(img.shape), 46))
+            arrays.update(image=img.detach().numpy(), latent_row=lat[0, 0].detach().numpy())
+        else:
+            arrays["lin_image"] = img.detach().numpy()[:, :, ::4, ::4].copy()
+        named = dict(g.named_parameters())
+        grads = torch.autograd.grad((img * proj).sum(), list(named.values()) + [lat], allow_unused=True)
+        gd = {n: gr for n, gr in zip(named, grads[:-1]) if gr is not None}
+        vals, offs = grad_samples(gd)
+        arrays.update({prefix + "_names": np.array(sorted(gd)), prefix + "_samples": vals,
+                       prefix + "_sample_offsets": offs, prefix + "_latent": grads[-1].numpy()})
+    save("generator_s256", **arrays)
 
 
 def _reference_train_functions(reshape_grads=False):

@@ -141,7 +141,16 @@ class VGG16Trunk(nn.Module):
         return feats
 
     def load_trunk_state_dict(self, features_state):
-        """torchvision vgg16().features.state_dict() ('0.weight', '0.bias', '2.weight', ...)."""
+        """The ImageNet trunk the reference takes from torchvision (pretrained_networks.py:97-135:
+        `tv.vgg16(pretrained=True).features`, sliced at Sequential indices 0-3 / 4-8 / 9-15 / 16-22 / 23-29).  Accepts
+        either `vgg16().features.state_dict()` ('0.weight', '0.bias', '2.weight', ...) or the whole model's
+        `vgg16().state_dict()` ('features.0.weight', ...; `classifier.*` entries are ignored)."""
+        if any(k.startswith("features.") for k in features_state):
+            features_state = {k[len("features."):]: v for k, v in features_state.items() if k.startswith("features.")}
+        want = ["%d.%s" % (i, kind) for idxs in VGG_FEATURE_INDEX for i in idxs for kind in ("weight", "bias")]
+        missing = [k for k in want if k not in features_state]
+        if missing:
+            raise KeyError("VGG16 trunk state is missing %s" % missing[:4])
         with torch.no_grad():
             for layers, idxs in zip(self.slices, VGG_FEATURE_INDEX):
                 for layer, i in zip(layers, idxs):

@@ -187,3 +187,63 @@ def test_single_image_grid_is_unpadded_like_make_grid():
     one = generate.to_uint8_grid(torch.zeros(1, 3, 8, 8))
     assert one.shape == (8, 8, 3) and int(one[0, 0, 0]) == 128
     assert generate.to_uint8_grid(torch.zeros(2, 3, 8, 8)).shape == (2 * (8 + 2) + 2, 8 + 2 + 2, 3)
+
+
+def test_lmdb_branch_runs_against_an_lmdb_shaped_module(tmp_path, monkeypatch):
+    """dataset.py's LMDB branch executed (never run — `lmdb` is not installable here): a stand-in module
+    with the reader API the reference uses (dataset.py:59-67 `lmdb.open(path, max_readers=32, readonly=True, lock=False,
+    readahead=False, meminit=False)`, `env.begin(write=False)` as a context manager, `txn.get(key)`,
+    `txn.cursor().iternext(values=False)`) serves a store written with the reference's key format
+    `"%d-%0Nd"` / `length` (prepare_data.py:99-116), N = max(5, digits)."""
+    import sys
+    import types
+
+    from stylerenderer_amd import dataset
+
+    rng = np.random.RandomState(0)
+    n = 12
+    imgs = [{r: rng.randint(0, 256, (r, r, 3), dtype=np.uint8) for r in (8, 16)} for _ in range(n)]
+    table = {}
+    dataset.write_store(table, imgs, (8, 16), fmt="NPY")
+    assert b"8-00000" in table and b"16-00011" in table and table[b"length"] == b"12"
+    opened = {}
+
+    class Txn:
+        def __enter__(self):
+            return self
+
+        def __exit__(self, *exc):
+            return False
+
+        def get(self, key):
+            assert isinstance(key, bytes)
+            return table.get(key)
+
+        def cursor(self):
+            return types.SimpleNamespace(iternext=lambda values=True: iter(sorted(table)))
+
+    class Env:
+        def begin(self, write=False):
+            assert write is False
+            return Txn()
+
+    def lmdb_open(path, **kw):
+        opened.update(path=path, **kw)
+        return Env()
+
+    monkeypatch.setitem(sys.modules, "lmdb", types.SimpleNamespace(open=lmdb_open))
+    root = tmp_path / "faces_lmdb"
+    root.mkdir()
+    (root / "data.mdb").write_bytes(b"")                       # what makes open_store take the LMDB branch
+    ds = dataset.MultiResolutionDataset(str(root), resolution=16)
+    assert isinstance(ds.store, dataset._LmdbStore)
+    assert opened == dict(path=str(root), max_readers=32, readonly=True, lock=False, readahead=False, meminit=False)
+    assert len(ds) == n
+    x = ds[11]
+    assert x.shape == (3, 16, 16) and x.dtype == torch.float32
+    want = torch.from_numpy(imgs[11][16].copy()).permute(2, 0, 1).float().div(255).sub(0.5).div(0.5)
+    assert torch.equal(x, want)
+    with pytest.raises(KeyError):
+        dataset.MultiResolutionDataset(str(root), resolution=32)
+    # six-digit stores: the index width grows with the length, like prepare_data.py:100
+    assert dataset.make_key(256, 7, 123456) == b"256-000007" and dataset.make_key(256, 7, 99999) == b"256-00007"

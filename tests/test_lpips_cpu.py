@@ -62,3 +62,31 @@ def test_distance_per_layer_and_gradient_match_the_reference(golden):
     with torch.no_grad():
         d2 = net.distance_to(feats, T(gold["in0"]))
     assert torch.allclose(d2, val.detach(), rtol=1e-6)
+
+
+def test_trunk_loads_from_torchvision_keyed_state_and_reproduces_the_reference(golden):
+    """`load_trunk_state_dict` executed (never run): a trunk that was overwritten is restored from a
+    state dict with torchvision's OWN key names (`features.N.weight`, plus the `classifier.*` entries a whole-model
+    checkpoint carries, reference lpips/pretrained_networks.py:97-135) and then reproduces the reference's distance."""
+    gold = golden("lpips_vgg")
+    net = lpips.PNetLin()
+    with torch.no_grad():
+        for p in net.net.parameters():
+            p.normal_(0, 0.02)                                  # not the trunk the fixture was made with
+        scrambled = net(T(gold["in0"]), T(gold["in1"]))
+    assert rel_err(scrambled.numpy(), gold["value"]) > 1e-2
+    feat = lpips.synthetic_trunk_state()                        # '0.weight', '0.bias', '2.weight', ...
+    whole = {"features." + k: v for k, v in feat.items()}
+    whole.update({"classifier.0.weight": torch.zeros(8, 8), "classifier.0.bias": torch.zeros(8)})
+    net.net.load_trunk_state_dict(whole)
+    with torch.no_grad():
+        val = net(T(gold["in0"]), T(gold["in1"]))
+    assert rel_err(val.numpy(), gold["value"]) < 2e-5
+    net2 = lpips.PNetLin()
+    net2.net.load_trunk_state_dict(feat)                            # the `.features.state_dict()` form
+    for a, b in zip(net.net.parameters(), net2.net.parameters()):
+        assert torch.equal(a, b)
+    import pytest
+
+    with pytest.raises(KeyError):
+        net.net.load_trunk_state_dict({"features.0.weight": feat["0.weight"]})

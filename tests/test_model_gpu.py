@@ -139,26 +139,54 @@ def test_discriminator_s16(golden):
 
 
 def test_generator_256_vs_reference_image_and_gradients(golden):
-    """The network bench.py times (Generator(256, 512, 8)): image of one latent against the reference's, and the
-    gradients of <img, proj> w.r.t. every parameter (256 samples per tensor) and the W+ latent (full tensor)
-    (tests/golden/generator_s256.npz).  Reaches the 128^2 / 256^2 Winograd forward / data-gradient / weight-gradient,
-    k_wgrad_s2_dma, k_convt_fused backward, fused up-sampling and ToRGB variants."""
+    """The network bench.py times (Generator(256, 512, 8)) against the reference (tests/golden/generator_s256.npz):
+    image of one latent (1e-5), and the gradients of <img, proj> w.r.t. every parameter (256 samples per tensor) and
+    the W+ latent (full tensor) —
+      * with linear activations (every FusedLeakyReLU at negative_slope = 1, in the reference too): 2e-5 of each
+        tensor's scale.  This is the pin of the 128^2 / 256^2 Winograd forward / data-gradient / weight-gradient,
+        k_wgrad_s2_dma, k_convt_fused backward, fused up-sampling and ToRGB variants: exact adjoints at round-off;
+      * at the real slope 0.2: bounded by the kink, not by the kernels — a few dozen of the 3.3e7 pre-activations sit
+        within 1e-7 of zero and take different sides under any two fp32 implementations (the CPU path on another
+        host differs from the fixture by 2e-3 as well, scripts/g256_parity_probe.py); 2e-2 of the tensor's scale,
+        scalar noise strengths against the largest of them."""
+    from stylerenderer_amd.op import FusedLeakyReLU
+
     gold = golden("generator_s256")
     g = model.Generator(256, 512, 8)
     assert len(g.state_dict()) == int(gold["n_keys"])
     synth.fill_state_dict(g.state_dict(), salt=41)
     g = g.to(DEV)
-    img, lat = g([T(synth.det_normal((1, 512), 42))], return_latents=True, noise=dev_noise(g, 4300))
-    assert rel_err(lat[0, 0].detach().cpu().numpy(), gold["latent_row"]) < 1e-5
-    assert rel_err(img.detach().cpu().numpy(), gold["image"]) < 1e-5            # measured 2.4e-6
-    proj = T(synth.det_normal(tuple(img.shape), 46))
-    params = dict(g.named_parameters())
-    grads = torch.autograd.grad((img * proj).sum(), list(params.values()) + [lat], allow_unused=True)
-    got = {n: x for n, x in zip(params, grads[:-1]) if x is not None}
-    worst = check_grad_samples(got, gold["grad_names"], gold["grad_samples"], gold["grad_sample_offsets"], 2e-5)
-    e_lat = rel_err(grads[-1].cpu().numpy(), gold["grad_latent"])
-    print("256^2 gradients: worst sampled %.2e, latent %.2e" % (worst, e_lat))
-    assert e_lat < 2e-5
+    proj = None
+    for prefix, slope in (("grad", 0.2), ("lin_grad", 1.0)):
+        for m in g.modules():
+            if isinstance(m, FusedLeakyReLU):
+                m.negative_slope = slope
+        img, lat = g([T(synth.det_normal((1, 512), 42))], return_latents=True, noise=dev_noise(g, 4300))
+        if proj is None:
+            proj = T(synth.det_normal(tuple(img.shape), 46))
+            assert rel_err(lat[0, 0].detach().cpu().numpy(), gold["latent_row"]) < 1e-5
+            assert rel_err(img.detach().cpu().numpy(), gold["image"]) < 1e-5            # measured 2.4e-6
+        else:
+            assert rel_err(img.detach().cpu().numpy()[:, :, ::4, ::4], gold["lin_image"]) < 1e-5
+        params = dict(g.named_parameters())
+        grads = torch.autograd.grad((img * proj).sum(), list(params.values()) + [lat], allow_unused=True)
+        got = {n: x for n, x in zip(params, grads[:-1]) if x is not None}
+        names, vals, offs = gold[prefix + "_names"], gold[prefix + "_samples"], gold[prefix + "_sample_offsets"]
+        e_lat = rel_err(grads[-1].cpu().numpy(), gold[prefix + "_latent"])
+        if slope == 1.0:
+            worst = check_grad_samples(got, names, vals, offs, 2e-5, scalar_factor=10.0)
+            assert e_lat < 2e-5, e_lat
+        else:
+            scalars = [float(np.abs(vals[offs[i]:offs[i + 1]]).max()) for i, n in enumerate(names)
+                       if got[n].numel() == 1]
+            vals = np.array(vals, np.float64)
+            for i, n in enumerate(names):                 # one-element tensors: error relative to the largest of them
+                if got[n].numel() == 1:
+                    assert abs(float(got[n]) - vals[offs[i]]) <= 2e-2 * max(scalars), n
+                    got[n] = torch.as_tensor(vals[offs[i]]).reshape(got[n].shape)
+            worst = check_grad_samples(got, names, vals, offs, 2e-2)
+            assert e_lat < 2e-2, e_lat
+        print("256^2 gradients, slope %.1f: worst sampled %.2e, latent %.2e" % (slope, worst, e_lat))
 
 
 def _activation_signs(net, store):
