@@ -308,11 +308,23 @@ def gold_generator_256(ns):
     synth.fill_state_dict(g.state_dict(), salt=41)
     proj = None
     arrays = {"n_keys": np.array(len(g.state_dict()))}
+    import types
+
+    ref_fused = sys.modules[ns.op.FusedLeakyReLU.__module__]
+    real_F = ref_fused.F
     for prefix, slope in (("grad", 0.2), ("lin_grad", 1.0)):
         for m in g.modules():
             if isinstance(m, ns.op.FusedLeakyReLU):
                 m.negative_slope = slope
-        img, lat = g([T(dn((1, 512), 42))], return_latents=True, noise=_noise_list(g, 4300))
+        # the reference's CUDA branch passes the module's slope to its kernel (op/fused_act.py:96); its CPU branch —
+        # the only one that runs here — hard-codes 0.2 (op/fused_act.py:91).  For the linear pass that one call is
+        # given the identity (= leaky_relu with slope 1), everything around it (bias add, sqrt(2) scale) stays the
+        # reference's.
+        # reference's.  The mapping network (EqualLinear -> fused_leaky_relu, layers.py) keeps the real slope: it is
+        # evaluated before the patch, and the synthesis network is entered with input_is_latent=True.
+        w = g.style(T(dn((1, 512), 42)))
+        ref_fused.F = types.SimpleNamespace(leaky_relu=lambda x, negative_slope=0.2: x) if slope == 1.0 else real_F
+        img, lat = g([w], return_latents=True, input_is_latent=True, noise=_noise_list(g, 4300))
         if proj is None:
             proj = T(dn(tuple(img.shape), 46))
             arrays.update(image=img.detach().numpy(), latent_row=lat[0, 0].detach().numpy())
@@ -324,6 +336,7 @@ def gold_generator_256(ns):
         vals, offs = grad_samples(gd)
         arrays.update({prefix + "_names": np.array(sorted(gd)), prefix + "_samples": vals,
                        prefix + "_sample_offsets": offs, prefix + "_latent": grads[-1].numpy()})
+    ref_fused.F = real_F
     save("generator_s256", **arrays)
 
 
