@@ -182,21 +182,28 @@ def raster_leg(dev, world, batch=64, res=256, iters=10, cpu_baseline=True):
            "fwd_api_ms": round(ms_api, 4),
            "fwd_bwd_mtri_s": round(world * batch * nf / ms_fb / 1e3, 1), "fwd_bwd_ms": round(ms_fb, 4),
            "bwd_ms": round(ms_b, 4),
-           "roofline": {"bound": "hbm", "kernel": "sr_rasterize_forward_f32 (k_tile_zero + k_tile_bin + k_tile_raster: "
+           "roofline": {"bound": "hbm", "kernel": "sr_rasterize_forward_f32 (k_tile_zero + k_tile_bin_lds + k_tile_raster: "
                                                   "LDS-staged 32x32 triangle tiles)",
                         "achieved": round(fwd_bytes / ms_api / 1e6, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                         "frac": round(fwd_bytes / ms_api / 1e6 / HBM_PEAK_GBPS, 4), "traffic": None,
                         "bytes_per_launch": fwd_bytes,
                         "note": "per-triangle setup / per-pixel shading (vector ALU) bound, priced against the HBM roof as "
-                                "SURVEY 8(d) asks"},
-           "roofline_bwd": {"bound": "hbm", "kernel": "sr_rasterize_grad_f32 (k_first_pix + k_grad_big + k_grad_pix + "
-                                                      "k_grad_vert), timed as the backward of a recorded forward",
+                                "SURVEY 8(d) asks; roofline_valu prices it against the vector-ALU issue rate"},
+           "roofline_bwd": {"bound": "hbm", "kernel": "sr_rasterize_grad_f32 (k_grad_big + k_grad_pix + k_grad_vert; the "
+                                                      "leader table comes from the tiled forward), timed as the backward "
+                                                      "of a recorded forward",
                             "achieved": round(bwd_bytes / ms_b / 1e6, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                             "frac": round(bwd_bytes / ms_b / 1e6 / HBM_PEAK_GBPS, 4), "bytes_per_launch": bwd_bytes},
            "bit_exact_vs_cpu_oracle": "tests/test_ops_gpu.py"}
-    out["roofline"].update(pmc_traffic(["k_tile_zero", "k_tile_bin<false>", "k_tile_raster<false>"]))
-    out["roofline_bwd"].update(pmc_traffic(["k_first_pix", "k_grad_big<float; 3; false>", "k_grad_pix<float; 3; false>",
-                                            "k_grad_vert<float; 3; false>"]))
+    fwd_kernels = ["k_tile_zero", "k_tile_bin_lds<false>", "k_tile_raster<false>"]
+    bwd_kernels = ["k_grad_big<float; 3; false>", "k_grad_pix<float; 3; false>", "k_grad_vert<float; 3; false>"]
+    out["roofline"].update(pmc_traffic(fwd_kernels))
+    out["roofline_bwd"].update(pmc_traffic(bwd_kernels))
+    # the bound these kernels actually run against: vector-ALU issue.  A wave64 VALU instruction occupies its SIMD for 4
+    # cycles, so a launch that issues I wave-instructions needs at least 4 I / (1024 SIMDs x 2.4 GHz); I = SQ_INSTS_VALU
+    # of the committed PMC pass (profiles/r*_raster_pmc.csv, scripts/raster_pmc.sh)
+    out["roofline_valu"] = valu_roofline(fwd_kernels, ms_api)
+    out["roofline_valu_bwd"] = valu_roofline(bwd_kernels, ms_b)
     if cpu_baseline:
         import raster as oracle_raster
 
@@ -213,6 +220,34 @@ def raster_leg(dev, world, batch=64, res=256, iters=10, cpu_baseline=True):
                                          "op/rasterize.cpp:21-67), forward, batch %d of the same mesh, %d repeats, "
                                          "single thread like the reference" % (nb, reps)}
     return out
+
+
+VALU_PEAK_GINST = 1024 * 2.4 / 4.0      # wave64 VALU instructions / ns over 1024 SIMDs at 2.4 GHz, 4 cycles each
+
+
+def valu_roofline(kernel_rows, measured_ms):
+    """Vector-ALU issue bound of an operator made of `kernel_rows`: SQ_INSTS_VALU (wave-instructions per launch, from
+    the newest committed profiles/r*_raster_pmc.csv) against 1024 SIMDs x 2.4 GHz / 4 cycles per wave64 instruction."""
+    import csv
+    import glob
+
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_raster_pmc.csv")))
+    if not files:
+        return None
+    insts, seen = 0.0, 0
+    with open(files[-1]) as f:
+        for r in csv.DictReader(l for l in f if not l.startswith("#")):
+            if r["kernel"] in kernel_rows and r.get("SQ_INSTS_VALU"):
+                insts += float(r["SQ_INSTS_VALU"])
+                seen += 1
+    if seen != len(kernel_rows) or not measured_ms:
+        return None
+    floor_ms = insts / (VALU_PEAK_GINST * 1e9) * 1e3
+    return {"bound": "valu", "wave_instructions_per_launch": round(insts), "peak": round(VALU_PEAK_GINST, 1),
+            "unit": "G wave-inst/s", "achieved": round(insts / (measured_ms * 1e-3) / 1e9, 1),
+            "frac": round(floor_ms / measured_ms, 4), "issue_floor_ms": round(floor_ms, 4),
+            "counters_measured_in_this_run": False,
+            "source": "profiles/%s (SQ_INSTS_VALU, separate rocprofv3 --pmc pass)" % os.path.basename(files[-1])}
 
 
 def pmc_traffic(kernel_rows):

@@ -255,8 +255,10 @@ int sr_blur_noise_bias_act(float* y, const float* x, const float* k, const float
  * Optional winner map `win` int32 [b,h,w]: id of the triangle that owns the pixel, -1 where uncovered
  * (what sr_rasterize_grad_* walks; index / coeff may then be NULL: the fused autograd path writes
  * 16 B per pixel instead of 48).  Triangles whose bounding box exceeds 64 pixels are walked by the whole
- * workgroup (LDS queue) instead of one lane; optional `big` int32 [1 + b*nf] receives their count and the
- * flat ids sample * nf + triangle (any order) for sr_rasterize_grad_*. */
+ * workgroup (LDS queue) instead of one lane; optional `big` int32 [1 + 2*b*nf] is the gradient state of the call for
+ * sr_rasterize_grad_*: their count, b*nf slots for the flat ids sample * nf + triangle (any order), and b*nf slots
+ * for the leader table (smallest row-major pixel each triangle won) that the LDS-tiled forward path fills while it
+ * resolves its tiles (the other path leaves them untouched: the gradient pass then builds the table itself). */
 int64_t sr_rasterize_scratch_bytes(int64_t b, int64_t nf, int64_t h, int64_t w, int is_double);
 int sr_rasterize_forward_f32(int64_t b, int64_t nv, int64_t nf, int64_t h, int64_t w, int repeat_v,
                              int repeat_f, int perspective, const float* v, const int64_t* tri,

@@ -297,6 +297,16 @@ __host__ __device__ inline unsigned long long key_init_f32() {
 }
 __host__ __device__ inline unsigned long long key_init_f64() { return 0x0010000000000000ULL; }
 
+// Three consecutive values with ONE memory instruction (global_load_dwordx3 for fp32: element alignment is all a
+// global load needs).  The gather kernels are bound by the number of divergent memory instructions a wave issues — the
+// texture-address unit walks a fully divergent load one lane per cycle, whatever its width — not by bytes.
+template <typename R>
+SR_HD void load3(const R* __restrict__ p, R& a, R& b, R& c) {
+    R q[3];
+    __builtin_memcpy(q, p, 3 * sizeof(R));
+    a = q[0]; b = q[1]; c = q[2];
+}
+
 template <typename R>
 SR_HD bool load_tri(Tri<R>& t, const R* __restrict__ vs,
                                          const long long* __restrict__ fs, long long ti,
@@ -305,9 +315,9 @@ SR_HD bool load_tri(Tri<R>& t, const R* __restrict__ vs,
     i1 = fs[3 * ti + 1];
     i2 = fs[3 * ti + 2];
     if (i0 < 0 || i1 < 0 || i2 < 0 || i0 >= nv || i1 >= nv || i2 >= nv) return false;
-    t.p0 = vs[3 * i0]; t.p1 = vs[3 * i0 + 1]; t.p2 = vs[3 * i0 + 2];
-    t.p3 = vs[3 * i1]; t.p4 = vs[3 * i1 + 1]; t.p5 = vs[3 * i1 + 2];
-    t.p6 = vs[3 * i2]; t.p7 = vs[3 * i2 + 1]; t.p8 = vs[3 * i2 + 2];
+    load3<R>(vs + 3 * i0, t.p0, t.p1, t.p2);
+    load3<R>(vs + 3 * i1, t.p3, t.p4, t.p5);
+    load3<R>(vs + 3 * i2, t.p6, t.p7, t.p8);
     return true;
 }
 
@@ -580,16 +590,21 @@ __device__ __forceinline__ bool load_tri32(Tri<float>& t, const float* __restric
     const long long a = fs[3 * (size_t)ti], bq = fs[3 * (size_t)ti + 1], c = fs[3 * (size_t)ti + 2];
     if ((unsigned long long)a >= nv || (unsigned long long)bq >= nv || (unsigned long long)c >= nv) return false;
     i0 = (unsigned)a; i1 = (unsigned)bq; i2 = (unsigned)c;
-    t.p0 = vs[3 * i0]; t.p1 = vs[3 * i0 + 1]; t.p2 = vs[3 * i0 + 2];
-    t.p3 = vs[3 * i1]; t.p4 = vs[3 * i1 + 1]; t.p5 = vs[3 * i1 + 2];
-    t.p6 = vs[3 * i2]; t.p7 = vs[3 * i2 + 1]; t.p8 = vs[3 * i2 + 2];
+    load3<float>(vs + 3 * (size_t)i0, t.p0, t.p1, t.p2);
+    load3<float>(vs + 3 * (size_t)i1, t.p3, t.p4, t.p5);
+    load3<float>(vs + 3 * (size_t)i2, t.p6, t.p7, t.p8);
     return true;
 }
 
-__global__ __launch_bounds__(256) void k_tile_zero(unsigned* __restrict__ p, long long n, int* __restrict__ big) {
+// (also resets the gradient state of the call when there is one: the big-triangle counter and the leader table
+// `first`, which k_tile_raster fills while it resolves its tiles)
+__global__ __launch_bounds__(256) void k_tile_zero(unsigned* __restrict__ p, long long n, int* __restrict__ big,
+                                                   int* __restrict__ first, long long n_first) {
     if (big && blockIdx.x == 0 && threadIdx.x == 0) *big = 0;
     const long long stride = (long long)gridDim.x * 256;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) p[i] = 0u;
+    if (first)
+        for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n_first; i += stride) first[i] = 0x7FFFFFFF;
 }
 
 // Wave-level aggregation of counter increments, split so that the atomics of several groups are in flight together:
@@ -685,6 +700,70 @@ __global__ __launch_bounds__(256) void k_tile_bin(unsigned nv, unsigned nf, int 
     }
 }
 
+// The same binning with the counters of a workgroup aggregated in LDS (images of up to BIN_LDS_TILES tiles): every hit is
+// one returning LDS atomic (its slot inside the workgroup's share of the tile), then ONE global atomic per tile the
+// workgroup touched reserves the share, then the entries are stored.  No wave votes; 256 consecutive triangles of a mesh
+// touch a handful of tiles, so the global atomics drop by the number of waves and the list stores of a tile are contiguous.
+constexpr int BIN_LDS_TILES = 1024;
+template <bool PERSP>
+__global__ __launch_bounds__(256) void k_tile_bin_lds(unsigned nv, unsigned nf, int res, bool repeat_v, bool repeat_f,
+                                                      const float* __restrict__ v, const long long* __restrict__ f,
+                                                      unsigned* __restrict__ tile_cnt, unsigned* __restrict__ tile_list,
+                                                      unsigned* __restrict__ wide_cnt, unsigned* __restrict__ wide_list,
+                                                      int* __restrict__ big, int ntx, float eps) {
+    __shared__ unsigned s_cnt[BIN_LDS_TILES + 1], s_base[BIN_LDS_TILES + 1];       // [ntile] = the sample's wide list
+    const int ntile = ntx * ntx;
+    for (int i = threadIdx.x; i <= ntile; i += 256) s_cnt[i] = 0u;
+    const unsigned ti = blockIdx.x * 256 + threadIdx.x;
+    const unsigned s = blockIdx.y;
+    Tri<float> t;
+    bool ok = false;
+    if (ti < nf) {
+        const float* vs = repeat_v ? v : v + (size_t)s * nv * 3;
+        const long long* fs = repeat_f ? f : f + (size_t)s * nf * 3;
+        unsigned i0, i1, i2;
+        ok = load_tri32(t, vs, fs, ti, nv, i0, i1, i2) && tri_bounds_fast<PERSP>(t, res, eps);
+    }
+    const bool wide0 = ok && ((long long)(t.x1 - t.x0 + 1) * (t.y1 - t.y0 + 1) > BIG_BOX);
+    if (wide0 && big) big[1 + atomicAdd(big, 1)] = (int)(s * nf + ti);   // (gradient pass: one row each, any order)
+    const bool small_ok = ok && !wide0;
+    // a small box (<= 64 pixels) touches <= 4 tiles as 2 x 2, or up to 3 in a row / column
+    const int tx0 = small_ok ? t.x0 / TILE : 0, tx1 = small_ok ? t.x1 / TILE : -1;
+    const int ty0 = small_ok ? t.y0 / TILE : 0, ty1 = small_ok ? t.y1 / TILE : -1;
+    __syncthreads();
+    int tl[6];
+    unsigned slot[6];
+    int n_hit = 0;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        // (0,0) (1,0) (0,1) (1,1) (2,0) (0,2): the last two only for one-pixel-high / -wide strips
+        const int dx = k == 1 || k == 3 ? 1 : (k == 4 ? 2 : 0), dy = k == 2 || k == 3 ? 1 : (k == 5 ? 2 : 0);
+        const bool hit = tx0 + dx <= tx1 && ty0 + dy <= ty1;      // (3 x 2 tiles would need a box of >= 68 pixels)
+        tl[k] = hit ? (ty0 + dy) * ntx + tx0 + dx : -1;
+        slot[k] = hit ? atomicAdd(&s_cnt[tl[k]], 1u) : 0u;
+        n_hit += hit;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < ntile; i += 256) {
+        const unsigned c = s_cnt[i];
+        if (c) s_base[i] = atomicAdd(&tile_cnt[s * ntile + i], c);
+    }
+    __syncthreads();
+    bool wide = wide0;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        if (tl[k] < 0) continue;
+        const unsigned pos = s_base[tl[k]] + slot[k];
+        if (pos < (unsigned)TILE_CAP) tile_list[(size_t)(s * ntile + tl[k]) * TILE_CAP + pos] = ti;
+        else wide = true;                   // this tile is full: every tile of the sample scans the triangle
+    }
+    const unsigned wslot = wide ? atomicAdd(&s_cnt[ntile], 1u) : 0u;
+    __syncthreads();
+    if (threadIdx.x == 0 && s_cnt[ntile]) s_base[ntile] = atomicAdd(&wide_cnt[s], s_cnt[ntile]);
+    __syncthreads();
+    if (wide) wide_list[(size_t)s * nf + s_base[ntile] + wslot] = ti;
+}
+
 // Exclusive prefix sum of one int per lane over the 256 lanes; returns the lane's offset, total in `total`.
 __device__ __forceinline__ int block_scan_256(int x, int* s_wave, int& total) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -714,7 +793,7 @@ __global__ __launch_bounds__(256) void k_tile_raster(unsigned b, unsigned nv, un
                                                      long long* __restrict__ index, float* __restrict__ coeff,
                                                      float* __restrict__ zbuf, const float* __restrict__ tex,
                                                      int tex_c, float* __restrict__ attr, int* __restrict__ win,
-                                                     float eps) {
+                                                     int* __restrict__ first, float eps) {
     __shared__ unsigned long long s_key[TILE * TILE];
     __shared__ float s_rec[REC_F][256];
     __shared__ int s_box[4][256];          // clipped box x0, y0, width; triangle id
@@ -837,6 +916,18 @@ __global__ __launch_bounds__(256) void k_tile_raster(unsigned b, unsigned nv, un
         }
         if (zbuf) zbuf[g] = z;
         if (win) win[g] = ti;
+        if (first && ti >= 0) {
+            // leader table of the gradient pass (k_first_pix's job, done here where the tile's winners sit in LDS):
+            // first[sample, triangle] = smallest row-major pixel the triangle won.  A pixel whose left or upper
+            // neighbour INSIDE the tile has the same winner cannot be the minimum and skips the atomic; tile-border
+            // pixels always try (integer minimum: idempotent and order independent).
+            const unsigned mine = (unsigned)(key & 0xFFFFFFFFull);
+            const bool left = lx > 0 && (unsigned)(s_key[p - 1] & 0xFFFFFFFFull) == mine &&
+                              s_key[p - 1] != key_init_f32();
+            const bool up = ly > 0 && (unsigned)(s_key[p - TILE] & 0xFFFFFFFFull) == mine &&
+                            s_key[p - TILE] != key_init_f32();
+            if (!left && !up) atomicMin(&first[(size_t)s * nf + ti], y * res + x);
+        }
         if (attr) {
             const size_t r0 = (size_t)((long long)i0 + shf) * tex_c, r1 = (size_t)((long long)i1 + shf) * tex_c,
                          r2 = (size_t)((long long)i2 + shf) * tex_c;
@@ -1106,14 +1197,19 @@ __device__ __forceinline__ void grad_pixel_regs(TriAcc<R, CT, PERSP>& acc, const
                                                 bool want_v, int x, int y, long long w, long long hw, long long h_arg,
                                                 R eps, const int* __restrict__ wins, int ti,
                                                 const R* __restrict__ gos, const R (&tx)[3][4], int tex_c, int ch0) {
+    // (the caller walks the pixels of its winner mask: this pixel IS inside the image and won by `ti`)
     const long long pix = x + (long long)y * w;
-    if (pix >= hw || wins[pix] != ti) return;
     R c0, c1, c2, z;
     shade<R>(t, x, y, PERSP, eps, c0, c1, c2, z);
     const R* go = gos + pix * tex_c;
     R gch[4];
+    if (tex_c == 3) {
+        load3<R>(go, gch[0], gch[1], gch[2]);
+        gch[3] = (R)0;
+    } else {
 #pragma unroll
-    for (int ch = 0; ch < 4; ++ch) gch[ch] = ch < tex_c ? go[ch] : (R)0;
+        for (int ch = 0; ch < 4; ++ch) gch[ch] = ch < tex_c ? go[ch] : (R)0;
+    }
     acc.n += 1;
 #pragma unroll
     for (int j = 0; j < CT; ++j) {
@@ -1317,15 +1413,29 @@ __global__ __launch_bounds__(256) void k_grad_pix(long long b, long long nv, lon
     const R* tb = tex + s * nv * tex_c;
     const bool tex_regs = tex_c <= 4;
     R tx[3][4];
+    if (tex_c == 3) {                               // the normal maps of the generator: one instruction per corner
+        load3<R>(tb + i0 * 3, tx[0][0], tx[0][1], tx[0][2]);
+        load3<R>(tb + i1 * 3, tx[1][0], tx[1][1], tx[1][2]);
+        load3<R>(tb + i2 * 3, tx[2][0], tx[2][1], tx[2][2]);
+        tx[0][3] = tx[1][3] = tx[2][3] = (R)0;
+    } else {
 #pragma unroll
-    for (int ch = 0; ch < 4; ++ch) {
-        const bool have = tex_regs && ch < tex_c;
-        tx[0][ch] = have ? tb[i0 * tex_c + ch] : (R)0;
-        tx[1][ch] = have ? tb[i1 * tex_c + ch] : (R)0;
-        tx[2][ch] = have ? tb[i2 * tex_c + ch] : (R)0;
+        for (int ch = 0; ch < 4; ++ch) {
+            const bool have = tex_regs && ch < tex_c;
+            tx[0][ch] = have ? tb[i0 * tex_c + ch] : (R)0;
+            tx[1][ch] = have ? tb[i1 * tex_c + ch] : (R)0;
+            tx[2][ch] = have ? tb[i2 * tex_c + ch] : (R)0;
+        }
     }
     const R praw[9] = {t.p0, t.p1, t.p2, t.p3, t.p4, t.p5, t.p6, t.p7, t.p8};
-    tri_setup<R>(t, h, w, PERSP, eps);
+    if constexpr (sizeof(R) == 4) {
+        // a triangle that won a pixel was accepted by the forward pass: on a square image the short setup (no
+        // rejection tests, no 64-bit conversion emulation) gives the same box and the same edge constants
+        if (h == w && h < 0x40000000LL) tri_setup_accepted<PERSP>(t, (int)h, eps, true);
+        else tri_setup<R>(t, h, w, PERSP, eps);
+    } else {
+        tri_setup<R>(t, h, w, PERSP, eps);
+    }
     if ((long long)(t.x1 - t.x0 + 1) * (t.y1 - t.y0 + 1) > BIG_BOX) return;      // k_grad_big owns it
     const int* wins = win + s * hw;
     // which pixels of the box did this triangle win?  All winner-map loads are issued together (a loop that
@@ -1334,11 +1444,24 @@ __global__ __launch_bounds__(256) void k_grad_pix(long long b, long long nv, lon
     unsigned long long mask = 0;
     if (bw <= 4 && bh <= 4) {
         int got[16];
+        if (t.x0 + 3 < w && t.x0 + 3 + (long long)(t.y0 + 3) * w < hw) {
+            // a row of the box = four consecutive ints inside the image row: one 16-byte load per row (4-byte aligned)
+            typedef int i4u __attribute__((ext_vector_type(4), aligned(4)));
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int xx = i & 3, yy = i >> 2;
-            const long long q = (t.x0 + xx) + (long long)(t.y0 + yy) * w;
-            got[i] = (xx < bw && yy < bh && q < hw) ? wins[q] : -1;
+            for (int yy = 0; yy < 4; ++yy) {
+                const i4u r = *reinterpret_cast<const i4u*>(wins + t.x0 + (long long)(t.y0 + yy) * w);
+                got[4 * yy + 0] = (0 < bw && yy < bh) ? r.x : -1;
+                got[4 * yy + 1] = (1 < bw && yy < bh) ? r.y : -1;
+                got[4 * yy + 2] = (2 < bw && yy < bh) ? r.z : -1;
+                got[4 * yy + 3] = (3 < bw && yy < bh) ? r.w : -1;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int xx = i & 3, yy = i >> 2;
+                const long long q = (t.x0 + xx) + (long long)(t.y0 + yy) * w;
+                got[i] = (xx < bw && yy < bh && q < hw) ? wins[q] : -1;
+            }
         }
 #pragma unroll
         for (int i = 0; i < 16; ++i)
@@ -1374,68 +1497,75 @@ __global__ __launch_bounds__(256) void k_grad_pix(long long b, long long nv, lon
 }
 
 // ---- fused gradient, phase 2: per-vertex sum over its incident corners, in incidence-list order ---------------
+// One step of the gather: U list entries (already in registers; -1 = none) -> validity words -> records, every level's
+// loads in flight together (unconditional loads from clamped addresses, masked afterwards); the sums keep list order.
+template <typename R, int CT, bool PERSP, int U>
+__device__ __forceinline__ void vert_gather(const int (&idx)[U], long long s, long long nf, const R* __restrict__ tg,
+                                            const unsigned long long* __restrict__ valid, R (&av)[3], R (&at)[CT]) {
+    using S = RowShape<CT, PERSP>;
+    constexpr int NC = S::CORNER < 4 ? 4 : S::CORNER;
+    int kk[U];
+    long long row[U];
+    unsigned long long word[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int i = idx[u] < 0 ? 0 : idx[u];
+        kk[u] = i >= 2 * (int)nf ? 2 : (i >= (int)nf ? 1 : 0);
+        row[u] = s * nf + (i - kk[u] * (int)nf);
+        word[u] = valid[row[u] >> 6];
+    }
+    R c[U][NC];
+    bool ok[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        ok[u] = idx[u] >= 0 && ((word[u] >> (row[u] & 63)) & 1ull);      // won a pixel: the record exists
+        const R* rec = tg + (ok[u] ? row[u] : s * nf) * S::RS;
+        if (sizeof(R) == 4) {
+            const float4 q = *reinterpret_cast<const float4*>(rec + 4 * kk[u]);
+            c[u][0] = (R)q.x; c[u][1] = (R)q.y; c[u][2] = (R)q.z; c[u][3] = (R)q.w;
+        } else {
+            const double2 q0 = *reinterpret_cast<const double2*>(rec + 4 * kk[u]);
+            const double2 q1 = *reinterpret_cast<const double2*>(rec + 4 * kk[u] + 2);
+            c[u][0] = (R)q0.x; c[u][1] = (R)q0.y; c[u][2] = (R)q1.x; c[u][3] = (R)q1.y;
+        }
+#pragma unroll
+        for (int j = 4; j < S::CORNER; ++j) c[u][j] = rec[12 + kk[u] * S::TAIL + (j - 4)];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        if (!ok[u]) continue;
+#pragma unroll
+        for (int j = 0; j < S::NVC; ++j) av[j] += c[u][j];
+#pragma unroll
+        for (int j = 0; j < CT; ++j) at[j] += c[u][S::NVC + j];
+    }
+}
+
+// 85 us at config[3] with one corner per step, 70 with six in flight.  (Round 4 tried the incidence list as fixed-width
+// rows — one aligned 32-byte load per vertex instead of offsets -> entries, a dependent level less: no change, 69-74 us;
+// the kernel is bound by the number of divergent L1 accesses, ~14 per lane at 48 % TCP utilisation, not by the chain.)
 template <typename R, int CT, bool PERSP>
 __global__ __launch_bounds__(256) void k_grad_vert(long long nv, long long nf, const int* __restrict__ adj_off,
                                                    const int* __restrict__ adj, long long off_bstride,
                                                    long long adj_bstride, const R* __restrict__ tg,
                                                    const unsigned long long* __restrict__ valid, int tex_c, int ch0,
                                                    R* __restrict__ grad_v, R* __restrict__ grad_tex) {
-    using S = RowShape<CT, PERSP>;
     const long long vert = (long long)blockIdx.x * 256 + threadIdx.x;
     const long long s = blockIdx.y;
     if (vert >= nv) return;
-    const int* off = adj_off + s * off_bstride;
-    const int* ad = adj + s * adj_bstride;
     R av[3] = {0, 0, 0};
     R at[CT];
 #pragma unroll
     for (int j = 0; j < CT; ++j) at[j] = 0;
-    // The incident corners of a vertex (~6) are independent; a loop that walks them one by one is a chain of three
-    // dependent loads per corner (list entry -> validity word -> record) and the kernel, three waves per SIMD slot
-    // deep, is pure latency: 85 us at config[3].  Six corners per step instead: all list entries, then all validity
-    // words, then all records are in flight together (unconditional loads from clamped addresses, masked afterwards);
-    // the sums keep the order of the list.
+    const int* off = adj_off + s * off_bstride;
+    const int* ad = adj + s * adj_bstride;
     const int e0 = off[vert], e1 = off[vert + 1];
     constexpr int U = 6;                        // (the valence of an interior vertex of a triangulated grid)
-    constexpr int NC = S::CORNER < 4 ? 4 : S::CORNER;
     for (int base = e0; base < e1; base += U) {
         int idx[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) idx[u] = ad[min(base + u, e1 - 1)];
-        int kk[U];
-        long long row[U];
-        unsigned long long word[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            kk[u] = idx[u] >= 2 * (int)nf ? 2 : (idx[u] >= (int)nf ? 1 : 0);
-            row[u] = s * nf + (idx[u] - kk[u] * (int)nf);
-            word[u] = valid[row[u] >> 6];
-        }
-        R c[U][NC];
-        bool ok[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            ok[u] = base + u < e1 && ((word[u] >> (row[u] & 63)) & 1ull);      // won a pixel: the record exists
-            const R* rec = tg + (ok[u] ? row[u] : s * nf) * S::RS;
-            if (sizeof(R) == 4) {
-                const float4 q = *reinterpret_cast<const float4*>(rec + 4 * kk[u]);
-                c[u][0] = (R)q.x; c[u][1] = (R)q.y; c[u][2] = (R)q.z; c[u][3] = (R)q.w;
-            } else {
-                const double2 q0 = *reinterpret_cast<const double2*>(rec + 4 * kk[u]);
-                const double2 q1 = *reinterpret_cast<const double2*>(rec + 4 * kk[u] + 2);
-                c[u][0] = (R)q0.x; c[u][1] = (R)q0.y; c[u][2] = (R)q1.x; c[u][3] = (R)q1.y;
-            }
-#pragma unroll
-            for (int j = 4; j < S::CORNER; ++j) c[u][j] = rec[12 + kk[u] * S::TAIL + (j - 4)];
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            if (!ok[u]) continue;
-#pragma unroll
-            for (int j = 0; j < S::NVC; ++j) av[j] += c[u][j];
-#pragma unroll
-            for (int j = 0; j < CT; ++j) at[j] += c[u][S::NVC + j];
-        }
+        for (int u = 0; u < U; ++u) idx[u] = base + u < e1 ? ad[base + u] : -1;
+        vert_gather<R, CT, PERSP, U>(idx, s, nf, tg, valid, av, at);
     }
     if (grad_v && ch0 == 0) {
         R* o = grad_v + (s * nv + vert) * 3;
@@ -1488,16 +1618,26 @@ int forward_tiled<float>(long long b, long long nv, long long nf, long long hres
     unsigned* wide_cnt = tile_cnt + b * ntile;
     unsigned* tile_list = wide_cnt + b;
     unsigned* wide_list = tile_list + b * ntile * TILE_CAP;
-    hipLaunchKernelGGL(k_tile_zero, dim3(sr_stream_grid(b * ntile + b, 256)), dim3(256), 0, st, tile_cnt,
-                       b * ntile + b, big);
+    // gradient state: big = [count | b * nf big-triangle ids | b * nf leader table]
+    int* first = (big && win) ? big + 1 + b * nf : nullptr;
+    hipLaunchKernelGGL(k_tile_zero, dim3(sr_stream_grid(first ? b * nf : b * ntile + b, 256)), dim3(256), 0, st, tile_cnt,
+                       b * ntile + b, big, first, b * nf);
     const dim3 bin_grid((unsigned)sr_ceil_div(nf, 256), (unsigned)b);
+    const char* e_bin = getenv("SR_RASTER_BIN_LDS");                         // =0: the wave-vote binning (A/B, tests)
+    const bool bin_lds = !(e_bin && e_bin[0] == '0');
 #define SR_TILE_LAUNCH(P)                                                                                              \
     do {                                                                                                               \
-        hipLaunchKernelGGL((k_tile_bin<P>), bin_grid, dim3(256), 0, st, (unsigned)nv, (unsigned)nf, (int)hres,          \
-                           repeat_v != 0, repeat_f != 0, v, tri, tile_cnt, tile_list, wide_cnt, wide_list, big, ntx, eps); \
+        if (ntile <= BIN_LDS_TILES && bin_lds)                                                                         \
+            hipLaunchKernelGGL((k_tile_bin_lds<P>), bin_grid, dim3(256), 0, st, (unsigned)nv, (unsigned)nf, (int)hres,  \
+                               repeat_v != 0, repeat_f != 0, v, tri, tile_cnt, tile_list, wide_cnt, wide_list, big, ntx, \
+                               eps);                                                                                   \
+        else                                                                                                           \
+            hipLaunchKernelGGL((k_tile_bin<P>), bin_grid, dim3(256), 0, st, (unsigned)nv, (unsigned)nf, (int)hres,      \
+                               repeat_v != 0, repeat_f != 0, v, tri, tile_cnt, tile_list, wide_cnt, wide_list, big, ntx, \
+                               eps);                                                                                   \
         hipLaunchKernelGGL((k_tile_raster<P>), dim3((unsigned)(b * ntile)), dim3(256), 0, st, (unsigned)b, (unsigned)nv, \
                            (unsigned)nf, (int)hres, repeat_v != 0, repeat_f != 0, v, tri, tile_cnt, tile_list, wide_cnt,  \
-                           wide_list, ntx, index, coeff, zbuf, tex, (int)tex_c, attr, win, eps);                        \
+                           wide_list, ntx, index, coeff, zbuf, tex, (int)tex_c, attr, win, first, eps);                 \
     } while (0)
     if (perspective) SR_TILE_LAUNCH(true);
     else SR_TILE_LAUNCH(false);
@@ -1592,14 +1732,18 @@ int grad_impl(long long b, long long nv, long long nf, long long h, long long w,
     if (b * h * w >= 0x7FFFFFFFLL) return SR_ERANGE;
     // (records: 24 floats each, so the two tables behind them stay 8-byte aligned)
     unsigned long long* valid = reinterpret_cast<unsigned long long*>(tg + b * nf * grad_row_floats());
-    int* first = reinterpret_cast<int*>(valid + (b * nf + 63) / 64 + 1);
+    const int* first = reinterpret_cast<int*>(valid + (b * nf + 63) / 64 + 1);
 
-    // leaders of all triangles, once per call (the attribute-channel chunks below share them)
-    if (b * nf > 0) {
+    // leaders of all triangles, once per call (the attribute-channel chunks below share them).  The tiled forward
+    // (same predicate, same call geometry) has already left them behind the big-triangle list of its gradient state.
+    if (b * nf > 0 && tiled_ok<R>(b, nf, h, w)) {
+        first = big + 1 + b * nf;
+    } else if (b * nf > 0) {
+        int* mine = reinterpret_cast<int*>(valid + (b * nf + 63) / 64 + 1);
         hipLaunchKernelGGL(k_fill_u32, dim3(sr_stream_grid(b * nf, 256)), dim3(256), 0, st,
-                           reinterpret_cast<unsigned*>(first), 0x7FFFFFFFu, b * nf);
+                           reinterpret_cast<unsigned*>(mine), 0x7FFFFFFFu, b * nf);
         hipLaunchKernelGGL(k_first_pix, dim3((unsigned)sr_ceil_div(b * h * w, 256)), dim3(256), 0, st, b * h * w, h * w, w,
-                           nf, win, first);
+                           nf, win, mine);
     }
     // attribute channels in chunks of <= 4 register accumulators; the vertex gradient rides with chunk 0
     for (long long ch0 = 0; ch0 < (grad_tex ? tex_c : 1); ch0 += 4) {
