@@ -261,7 +261,7 @@ def pmc_traffic(kernel_rows):
 
     if isinstance(kernel_rows, str):
         kernel_rows = [kernel_rows]
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.csv")))
+    files = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.csv")) if "raster_pmc" not in f)
     if not files:
         return {}
     total, seen, busy = 0.0, 0, None

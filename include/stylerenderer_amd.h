@@ -159,6 +159,15 @@ int sr_smallconv_dw(float* dws, const float* g, const float* x, int64_t B, int64
 int sr_vertex_normals_f32(float* vn, float* norm_out, const float* v, const int64_t* tri, const int32_t* adj_off,
                           const int32_t* adj, int64_t B, int64_t nv, int64_t nf, float eps, sr_stream_t stream);
 
+/* Posed mesh of the inversion / training loops (reference utils_3d.py random_apply_pose3D: vertices @ R * s + t):
+ *   out[b, i, :] = v[b, i, :] @ M[b] + t[b]     v [B or 1, nv, 3] (v_bstride = nv*3, or 0 to share one mesh), M [B,3,3]
+ * row-major, t [B,3] or NULL.  sr_affine3_bwd: gm[b] = v[b]^T @ g[b] ([3,3]), gt[b] = sum_i g[b, i, :] — fixed-order
+ * sums (run-to-run identical); either may be NULL.  The gradient w.r.t. v is g @ M^T = sr_affine3_fwd(g, M^T). */
+int sr_affine3_fwd(float* out, const float* v, const float* m, const float* t, int64_t B, int64_t nv,
+                   int64_t v_bstride, sr_stream_t stream);
+int sr_affine3_bwd(float* gm, float* gt, const float* v, const float* g, int64_t B, int64_t nv, int64_t v_bstride,
+                   sr_stream_t stream);
+
 /* Skinny linear algebra of the style path, B = per-GPU batch rows (csrc/style_linear.hip).
  * EqualLinear (reference layers.py:222-248), optionally with the fused leaky-ReLU of the mapping
  * network (act != 0: op/fused_act.py:86-97 semantics, bias inside the activation):

@@ -809,7 +809,7 @@ extern "C" int64_t sr_conv2d_scratch_floats(int64_t B, int64_t C, int64_t N, int
         consider(OH, OW);
         if (ksize == 3 && stride == 1 && pad == 1 && wino_enabled() &&
             sr_wino_eligible(B, C, N, IH, IW, nullptr, nullptr)) {
-            const int64_t w = sr_wino_scratch_floats(C, N);
+            const int64_t w = sr_wino_scratch_floats(C, N) + sr_wino_partial_floats(B, C, N, IH, IW);
             need = need > w ? need : w;
         }
     } else {
@@ -874,7 +874,11 @@ extern "C" int sr_conv2d_mfma(float* out, const float* in, const float* wt, cons
     bool fused_ok = false;
     {
         const char* e = std::getenv("SR_CONVT_FUSED");
-        if (!(e && e[0] == '0') && p.IW >= 16 && convt_fused_eligible(p)) {
+        // the fused kernel has no split-K: with fewer workgroups than ~a third of the CUs (batch 1 of the inversion
+        // loop at 32^2 / 64^2) each one walks the whole channel loop alone and the per-phase launches, which split K,
+        // are faster (inversion step 7.26 -> 6.98 ms)
+        const int64_t fused_blocks = (int64_t)(p.IW / TFused::PW) * (p.IH / TFused::PH) * ((p.N + BN - 1) / BN) * p.B;
+        if (!(e && e[0] == '0') && p.IW >= 16 && convt_fused_eligible(p) && (fused_blocks >= 96 || (e && e[0] == '1'))) {
             for (int i = 0; i < 9; ++i) p.wmap[i] = i;
             const int rc = launch_convt_fused(p, st);
             if (rc != SR_OK) return rc;

@@ -19,6 +19,11 @@ struct WinoParams {
     const float* abias;    // [N] or NULL
     int64_t nz_bstride;
     float alpha, gain;
+    // split-K (few tiles, long channel loop: batch 1 of the inversion loop, the 32^2 / 64^2 layers at batch 4): slice s
+    // of `ks` handles chunks [s * kchunks, (s + 1) * kchunks) and writes its raw output-transformed tile to
+    // partial[s] (layout of `out`); k_wino_reduce adds the slices in order and applies oscale / bias / the fused tail
+    int ks, kchunks;
+    float* partial;
 };
 
 struct WinoNba {
@@ -32,6 +37,9 @@ struct WinoNba {
 // stride-1 3x3 pad-1 convolution with H % 8 == 0, W % 32 == 0, C % 8 == 0, N % 64 == 0
 bool sr_wino_eligible(int64_t B, int64_t C, int64_t N, int64_t H, int64_t W, const void* in, const void* out);
 int64_t sr_wino_scratch_floats(int64_t C, int64_t N);
+// number of K slices for a call geometry (1 = no split) and the floats of partial outputs behind the U block
+int sr_wino_split(int64_t B, int64_t C, int64_t N, int64_t H, int64_t W);
+int64_t sr_wino_partial_floats(int64_t B, int64_t C, int64_t N, int64_t H, int64_t W);
 int sr_wino_conv3x3(float* out, const float* in, const float* wt, int64_t ldw, const float* iscale,
                     const float* oscale, const float* obias, int64_t B, int64_t C, int64_t N, int64_t H, int64_t W,
                     float* u_scratch, hipStream_t st, const WinoNba* nba = nullptr);

@@ -28,6 +28,7 @@
 #include <type_traits>
 #include "common.h"
 #include "conv_wino.h"
+#include <cstdlib>
 
 namespace {
 
@@ -83,6 +84,8 @@ __global__ __launch_bounds__(256) void k_conv_wino(const WinoParams p) {
         const int q = nwg / SR_NUM_XCD, r = nwg % SR_NUM_XCD, xcd = bid % SR_NUM_XCD;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + bid / SR_NUM_XCD;
     }
+    const int slice = bid % p.ks;           // K slices of one tile are neighbours: same halo patch on one L2
+    bid /= p.ks;
     const int n_t = bid % p.tiles_n;
     bid /= p.tiles_n;
     const int tx_i = bid % p.tiles_x;
@@ -95,7 +98,11 @@ __global__ __launch_bounds__(256) void k_conv_wino(const WinoParams p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = lane >> 5, l31 = lane & 31;
     const int wn = wave & 1, wt = wave >> 1;
-    const int nchunks = p.C / KC;
+    // this workgroup's channel range: chunks [k_lo, k_lo + nchunks) — realised by moving the bases of the two buffer
+    // resources and of the style row, so the loop below runs k = 0 .. nchunks - 1 whatever the slice
+    const int nchunks = p.kchunks;
+    const int k_lo = slice * p.kchunks;
+    const int all_chunks = p.C / KC;
     WINO_STAMP(0);
 #ifdef WINO_TIMING
     const long long wino_c0 = clock64();
@@ -124,9 +131,10 @@ __global__ __launch_bounds__(256) void k_conv_wino(const WinoParams p) {
     }
     const int chunk_in_bytes = KC * p.H * p.W * 4;
     const __amdgpu_buffer_rsrc_t r_in = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(p.in + (int64_t)b * p.C * p.H * p.W), 0, p.C * p.H * p.W * 4, 0x00020000);
+        const_cast<float*>(p.in + ((int64_t)b * p.C + (int64_t)k_lo * KC) * p.H * p.W), 0, nchunks * chunk_in_bytes,
+        0x00020000);
     const __amdgpu_buffer_rsrc_t r_u = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(p.u + (int64_t)n_t * nchunks * G::UV), 0, nchunks * G::UV * 4, 0x00020000);
+        const_cast<float*>(p.u + ((int64_t)n_t * all_chunks + k_lo) * G::UV), 0, nchunks * G::UV * 4, 0x00020000);
     const int u_voff = lane * 16;
 
     // one DMA instruction each (all waves issue the same number; surplus ones land in the pad zone)
@@ -287,7 +295,8 @@ __global__ __launch_bounds__(256) void k_conv_wino(const WinoParams p) {
     if (nchunks > 1) dma_d(1, 1);
     // style row of this sample (ones when absent), consumed by the input transform: fetched behind the DMAs, so
     // its round trip overlaps theirs
-    for (int c = tid; c < p.C; c += 256) sty[c] = p.iscale ? p.iscale[(int64_t)b * p.C + c] : 1.0f;
+    for (int c = tid; c < nchunks * KC; c += 256)
+        sty[c] = p.iscale ? p.iscale[(int64_t)b * p.C + k_lo * KC + c] : 1.0f;
     __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): this wave's DMAs have landed
     __syncthreads();
     WINO_STAMP(1);
@@ -395,6 +404,13 @@ __global__ __launch_bounds__(256) void k_conv_wino(const WinoParams p) {
             s[0][j] = (m0 + m1) + m2;
             s[1][j] = (m1 - m2) - m3;
         }
+        if (p.ks > 1) {
+            // raw slice sums; scales, bias and the fused tail are k_wino_reduce's
+            float* o = p.partial + (((int64_t)slice * p.B + b) * p.N + n) * plane + (int64_t)oy * p.W + ox;
+            *reinterpret_cast<float2*>(o) = make_float2((s[0][0] + s[0][1]) + s[0][2], (s[0][1] - s[0][2]) - s[0][3]);
+            *reinterpret_cast<float2*>(o + p.W) = make_float2((s[1][0] + s[1][1]) + s[1][2], (s[1][1] - s[1][2]) - s[1][3]);
+            continue;
+        }
         const float os = p.oscale ? p.oscale[(int64_t)b * p.N + n] : 1.0f;
         const float ob = p.obias ? p.obias[n] : 0.0f;
         float* o = p.out + ((int64_t)b * p.N + n) * plane + (int64_t)oy * p.W + ox;
@@ -429,6 +445,44 @@ __global__ __launch_bounds__(256) void k_conv_wino(const WinoParams p) {
 #endif
 }
 
+// Sums the K slices in a fixed order (deterministic) and applies what the unsplit epilogue applies, in the same order:
+// y * oscale + bias, then the optional fused tail lrelu((y + w * noise) + abias) * gain.  Four pixels per lane.
+__global__ __launch_bounds__(256) void k_wino_reduce(const WinoParams p) {
+    const int64_t plane = (int64_t)p.H * p.W, total4 = (int64_t)p.B * p.N * plane / 4;
+    const int64_t slab4 = total4;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (int64_t)gridDim.x * 256) {
+        const float4* src = reinterpret_cast<const float4*>(p.partial) + i;
+        float4 a = src[0];
+        for (int s = 1; s < p.ks; ++s) {
+            const float4 q = src[s * slab4];
+            a.x += q.x; a.y += q.y; a.z += q.z; a.w += q.w;
+        }
+        const int64_t row = (i * 4) / plane;                  // b * N + n  (plane % 4 == 0)
+        const int n = (int)(row % p.N), b = (int)(row / p.N);
+        const int64_t pix = i * 4 - row * plane;
+        const float os = p.oscale ? p.oscale[row] : 1.0f;
+        const float ob = p.obias ? p.obias[n] : 0.0f;
+        float v[4] = {a.x * os + ob, a.y * os + ob, a.z * os + ob, a.w * os + ob};
+        if (p.nba) {
+#pragma clang fp contract(off)
+            const float ab = p.abias ? p.abias[n] : 0.0f;
+            float nz[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+            if (p.nz) {
+                const float nw = p.nz_w[0];
+                const float4 q = *reinterpret_cast<const float4*>(p.nz + b * p.nz_bstride + pix);
+                nz[0] = nw * q.x; nz[1] = nw * q.y; nz[2] = nw * q.z; nz[3] = nw * q.w;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float t = v[j] + nz[j];
+                t = t + ab;
+                v[j] = ((t > 0.0f) ? t : t * p.alpha) * p.gain;
+            }
+        }
+        reinterpret_cast<float4*>(p.out)[i] = make_float4(v[0], v[1], v[2], v[3]);
+    }
+}
+
 // U[pos][c][n] = (G g G^T)[pos], written in the chunk order the kernel DMAs:
 //   [n / 64][c / KC][pos / 2][cq][e][h][n % 64][pos % 2],  chunk-local channel = 4 cq + 2 e + h
 template <int KC>
@@ -459,7 +513,7 @@ __global__ __launch_bounds__(64) void k_wino_weights(float* __restrict__ u, cons
 template <int KC>
 int launch(const WinoParams& p, float* u, const float* wt, int ldw, hipStream_t st) {
     using G = WG<KC>;
-    const int lds = (G::STY + p.C) * 4;
+    const int lds = (G::STY + p.kchunks * KC) * 4;
     auto kern = k_conv_wino<KC>;
     static bool configured = false;
     if (!configured) {
@@ -471,8 +525,14 @@ int launch(const WinoParams& p, float* u, const float* wt, int ldw, hipStream_t 
         configured = true;
     }
     hipLaunchKernelGGL(k_wino_weights<KC>, dim3(p.N / 64, p.C), dim3(64), 0, st, u, wt, p.C, p.N, ldw);
-    const int64_t blocks = (int64_t)p.tiles_n * p.tiles_x * p.tiles_y * p.B;
+    const int64_t blocks = (int64_t)p.tiles_n * p.tiles_x * p.tiles_y * p.B * p.ks;
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, st, p);
+    if (p.ks > 1) {
+        const int64_t total4 = (int64_t)p.B * p.N * p.H * p.W / 4;
+        int64_t grid = (total4 + 255) / 256;
+        if (grid > 8192) grid = 8192;
+        hipLaunchKernelGGL(k_wino_reduce, dim3((unsigned)grid), dim3(256), 0, st, p);
+    }
     return sr_launch_status();
 }
 
@@ -495,6 +555,21 @@ bool sr_wino_eligible(int64_t B, int64_t C, int64_t N, int64_t H, int64_t W, con
 
 int64_t sr_wino_scratch_floats(int64_t C, int64_t N) { return 16 * C * N; }
 
+// K slices: only when the tiles alone leave most of the chip idle; equal slices of >= 8 chunks (64 channels).
+// SR_WINO_SPLIT=0 disables (A/B measurements).
+int sr_wino_split(int64_t B, int64_t C, int64_t N, int64_t H, int64_t W) {
+    const char* e = std::getenv("SR_WINO_SPLIT");
+    if (e && e[0] == '0') return 1;
+    const int64_t blocks = B * (W / (2 * TW)) * (H / (2 * TH)) * (N / NB), nchunks = C / 8;
+    int ks = 1;
+    while (blocks * ks < 192 && ks < 8 && nchunks % (2 * ks) == 0 && nchunks / (2 * ks) >= 8) ks *= 2;
+    return ks;
+}
+int64_t sr_wino_partial_floats(int64_t B, int64_t C, int64_t N, int64_t H, int64_t W) {
+    const int ks = sr_wino_split(B, C, N, H, W);
+    return ks > 1 ? (int64_t)ks * B * N * H * W : 0;
+}
+
 int sr_wino_conv3x3(float* out, const float* in, const float* wt, int64_t ldw, const float* iscale,
                     const float* oscale, const float* obias, int64_t B, int64_t C, int64_t N, int64_t H, int64_t W,
                     float* u_scratch, hipStream_t st, const WinoNba* nba) {
@@ -505,5 +580,8 @@ int sr_wino_conv3x3(float* out, const float* in, const float* wt, int64_t ldw, c
     p.nz_bstride = nba ? nba->nz_bstride : 0; p.alpha = nba ? nba->alpha : 0.0f; p.gain = nba ? nba->gain : 1.0f;
     p.B = (int)B; p.C = (int)C; p.N = (int)N; p.H = (int)H; p.W = (int)W;
     p.tiles_x = (int)(W / (2 * TW)); p.tiles_y = (int)(H / (2 * TH)); p.tiles_n = (int)(N / NB);
+    p.ks = sr_wino_split(B, C, N, H, W);
+    p.kchunks = (int)(C / 8) / p.ks;
+    p.partial = u_scratch + sr_wino_scratch_floats(C, N);          // behind the U block (sr_conv2d_scratch_floats)
     return launch<8>(p, u_scratch, wt, (int)ldw, st);
 }

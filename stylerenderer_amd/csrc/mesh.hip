@@ -52,7 +52,81 @@ __global__ __launch_bounds__(256) void k_vertex_normals(float* __restrict__ vn, 
     if (norm_out) norm_out[(int64_t)b * nv + vert] = n;
 }
 
+// ---- posed mesh: out[b, i, :] = v[b | 0, i, :] @ M[b] + t[b] (M [3,3] row-major, t [3] or NULL) ------------------------
+// The pose of the latent-inversion loop and of the training loop's random_apply_pose3D is a [nv,3] x [3,3] product:
+// as a library GEMM it is a 16x16-tile kernel of ~150 us at nv = 24 770 (a 3-wide output is all padding) and its
+// backward two more.  One streaming pass here; the gradient of (M, t) is a fixed-order tree sum (deterministic).
+__global__ __launch_bounds__(256) void k_affine3_fwd(float* __restrict__ out, const float* __restrict__ v,
+                                                     const float* __restrict__ m, const float* __restrict__ t,
+                                                     int64_t nv, int64_t v_bstride) {
+    const int b = blockIdx.y;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= nv) return;
+    const float* mb = m + 9 * b;
+    const float* p = v + b * v_bstride + 3 * i;
+    const float x = p[0], y = p[1], z = p[2];
+    float o0 = x * mb[0], o1 = x * mb[1], o2 = x * mb[2];
+    o0 += y * mb[3]; o1 += y * mb[4]; o2 += y * mb[5];
+    o0 += z * mb[6]; o1 += z * mb[7]; o2 += z * mb[8];
+    if (t) { o0 += t[3 * b]; o1 += t[3 * b + 1]; o2 += t[3 * b + 2]; }
+    float* o = out + (b * nv + i) * 3;
+    o[0] = o0; o[1] = o1; o[2] = o2;
+}
+
+// gm[b][j][k] = sum_i v[i][j] g[i][k], gt[b][k] = sum_i g[i][k]: one workgroup per sample, each lane sums a strided
+// subset in index order, then a fixed-order LDS tree — 12 values.
+__global__ __launch_bounds__(1024) void k_affine3_bwd(float* __restrict__ gm, float* __restrict__ gt,
+                                                      const float* __restrict__ v, const float* __restrict__ g,
+                                                      int64_t nv, int64_t v_bstride) {
+    __shared__ float s[12][1024];
+    const int b = blockIdx.x;
+    float a[12];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) a[k] = 0.f;
+    for (int64_t i = threadIdx.x; i < nv; i += 1024) {
+        const float* p = v + b * v_bstride + 3 * i;
+        const float* q = g + (b * nv + i) * 3;
+        const float x = p[0], y = p[1], z = p[2], g0 = q[0], g1 = q[1], g2 = q[2];
+        a[0] += x * g0; a[1] += x * g1; a[2] += x * g2;
+        a[3] += y * g0; a[4] += y * g1; a[5] += y * g2;
+        a[6] += z * g0; a[7] += z * g1; a[8] += z * g2;
+        a[9] += g0; a[10] += g1; a[11] += g2;
+    }
+#pragma unroll
+    for (int k = 0; k < 12; ++k) s[k][threadIdx.x] = a[k];
+    __syncthreads();
+    for (int off = 512; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) {
+#pragma unroll
+            for (int k = 0; k < 12; ++k) s[k][threadIdx.x] += s[k][threadIdx.x + off];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x < 9 && gm) gm[9 * b + threadIdx.x] = s[threadIdx.x][0];
+    if (threadIdx.x >= 9 && threadIdx.x < 12 && gt) gt[3 * b + (threadIdx.x - 9)] = s[threadIdx.x][0];
+}
+
 }  // namespace
+
+extern "C" int sr_affine3_fwd(float* out, const float* v, const float* m, const float* t, int64_t B, int64_t nv,
+                              int64_t v_bstride, sr_stream_t stream) {
+    if (B < 0 || nv < 0) return SR_EINVAL;
+    if (B == 0 || nv == 0) return SR_OK;
+    if (!out || !v || !m) return SR_EINVAL;
+    if (B > 65535) return SR_ERANGE;
+    hipLaunchKernelGGL(k_affine3_fwd, dim3((unsigned)sr_ceil_div(nv, 256), (unsigned)B), dim3(256), 0, sr_stream(stream),
+                       out, v, m, t, nv, v_bstride);
+    return sr_launch_status();
+}
+
+extern "C" int sr_affine3_bwd(float* gm, float* gt, const float* v, const float* g, int64_t B, int64_t nv,
+                              int64_t v_bstride, sr_stream_t stream) {
+    if (B < 0 || nv < 0) return SR_EINVAL;
+    if (B == 0 || (!gm && !gt)) return SR_OK;
+    if (!v || !g) return SR_EINVAL;
+    hipLaunchKernelGGL(k_affine3_bwd, dim3((unsigned)B), dim3(1024), 0, sr_stream(stream), gm, gt, v, g, nv, v_bstride);
+    return sr_launch_status();
+}
 
 extern "C" int sr_vertex_normals_f32(float* vn, float* norm_out, const float* v, const int64_t* tri,
                                      const int32_t* adj_off, const int32_t* adj, int64_t B, int64_t nv, int64_t nf,

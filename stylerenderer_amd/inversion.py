@@ -48,7 +48,19 @@ class LatentInverter:
         groups = [{"params": [self.w], "lr": lr}]
         if optimise_pose:
             groups.append({"params": [self.pose], "lr": pose_lr})
-        self.optim = optim.Adam(groups, betas=(0.9, 0.999), capturable=on_gpu, foreach=on_gpu)
+        if on_gpu:
+            # one sr_adam_flat launch per variable (optim.FlatAdam, the training loop's optimiser) instead of the ~30
+            # multi-tensor passes of torch's capturable foreach Adam: at batch 1 every launch is ~5 us of an 8 ms step
+            from .optim import ALIGN, FlatAdam
+
+            self.optim = None
+            self._adams = []
+            for g_ in groups:
+                p = g_["params"][0]
+                flat_g = torch.zeros((p.numel() + ALIGN - 1) // ALIGN * ALIGN, device=self.device)
+                self._adams.append((p, FlatAdam([p], flat_g, lr=g_["lr"], betas=(0.9, 0.999))))
+        else:
+            self.optim = optim.Adam(groups, betas=(0.9, 0.999))
         self.use_graph = on_gpu if use_graph is None else bool(use_graph)
         self.graph = None
         self.loss_value = torch.zeros((), device=self.device)
@@ -56,10 +68,11 @@ class LatentInverter:
 
     # ---- model ----------------------------------------------------------------------------------------
     def posed_mesh(self):
-        rot = utils_3d.euler_mat(self.pose[:3].view(1, 3), "yxz")[0]                    # [3, 3]
+        rot = utils_3d.euler_mat(self.pose[:3].view(1, 3), "yxz")                       # [1, 3, 3]
         lin = torch.exp(self.pose[6]) * rot
-        v = torch.matmul(self.v0, lin) + self.pose[3:6].view(1, 1, 3)
-        n = torch.matmul(self.n0, rot)
+        # [nv, 3] x [3, 3]: one streaming kernel each (utils_3d.affine3), not a 3-wide library GEMM
+        v = utils_3d.affine3(self.v0, lin, self.pose[3:6].view(1, 3))
+        n = utils_3d.affine3(self.n0, rot)
         return v.contiguous(), n.contiguous(), self.tri
 
     def render(self):
@@ -79,7 +92,13 @@ class LatentInverter:
         img = self.render()
         value = self.loss(img)
         value.backward()
-        self.optim.step()
+        if self.optim is not None:
+            self.optim.step()
+        else:
+            with torch.no_grad():
+                for p, adam in self._adams:
+                    adam.flat_g[:p.numel()].copy_(p.grad.reshape(-1))
+                    adam.step()
         self.loss_value.copy_(value.detach())
         self.image = img.detach()
 

@@ -78,6 +78,59 @@ def random_apply_pose3D(p=[.5, .1, .05, .1, .1, .1, .15], v=None):
     return torch.matmul(v[..., :3].reshape(batch, -1, 3), T[:, :3, :3]) + T[:, :3, 3:].view(-1, 1, 3)
 
 
+class _Affine3(Function):
+    """out[b] = v[b | 0] @ M[b] (+ t[b]) on the device path (csrc/mesh.hip sr_affine3_fwd / _bwd): one streaming pass
+    instead of a 3-wide library GEMM; gradients of M and t by fixed-order sums (deterministic), of v by the same pass
+    with M^T.  First order only (poses are leaves of the loops that use it)."""
+
+    @staticmethod
+    def forward(ctx, v, m, t):
+        vc, mc = v.contiguous(), m.contiguous()
+        tc = t.contiguous() if t is not None else None
+        b, nv = mc.shape[0], vc.shape[-2]
+        out = torch.empty((b, nv, 3), dtype=vc.dtype, device=vc.device)
+        share = vc.dim() == 2 or vc.shape[0] == 1
+        with on_device_of(vc):
+            rc = _lib.lib().sr_affine3_fwd(_lib.ptr(out), _lib.ptr(vc), _lib.ptr(mc), _lib.ptr(tc), b, nv,
+                                           0 if share else nv * 3, stream_of(vc))
+        _lib.check(rc, "sr_affine3_fwd")
+        ctx.save_for_backward(vc, mc)
+        ctx.share, ctx.has_t, ctx.v_shape = share, t is not None, tuple(v.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        vc, mc = ctx.saved_tensors
+        g = g.contiguous()
+        b, nv = mc.shape[0], vc.shape[-2]
+        need_v, need_m, need_t = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.has_t and ctx.needs_input_grad[2]
+        gm = torch.empty_like(mc) if need_m else None
+        gt = torch.empty((b, 3), dtype=g.dtype, device=g.device) if need_t else None
+        gv = None
+        L = _lib.lib()
+        with on_device_of(g):
+            if need_m or need_t:
+                _lib.check(L.sr_affine3_bwd(_lib.ptr(gm), _lib.ptr(gt), _lib.ptr(vc), _lib.ptr(g), b, nv,
+                                            0 if ctx.share else nv * 3, stream_of(g)), "sr_affine3_bwd")
+            if need_v:
+                gv = torch.empty_like(g)
+                mt = mc.transpose(1, 2).contiguous()
+                _lib.check(L.sr_affine3_fwd(_lib.ptr(gv), _lib.ptr(g), _lib.ptr(mt), None, b, nv, nv * 3,
+                                            stream_of(g)), "sr_affine3_fwd")
+                if ctx.share:
+                    gv = gv.sum(0, keepdim=True)
+                gv = gv.reshape(ctx.v_shape)
+        return gv, gm, gt
+
+
+def affine3(v, m, t=None):
+    """v [B or 1, nv, 3] @ m [B, 3, 3] + t [B, 3] (row-vector convention of the reference's pose functions)."""
+    if v.device.type == "cuda" and v.dtype == torch.float32 and m.dim() == 3:
+        return _Affine3.apply(v, m, t)
+    out = torch.matmul(v, m)
+    return out + t.view(-1, 1, 3) if t is not None else out
+
+
 # ---- vertex normals -------------------------------------------------------------------------------
 _ADJ_CACHE = DerivedCache(16)
 

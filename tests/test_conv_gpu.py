@@ -381,7 +381,9 @@ def test_demod_scale_forward_backward(b, ci, co):
 @pytest.mark.parametrize("b,c,n,h,w,scales", [(2, 24, 64, 16, 32, True), (1, 16, 128, 8, 64, False),
                                                (3, 40, 64, 24, 32, True),
                                                (1, 8, 64, 8, 32, True),        # one chunk: first body + tail only
-                                               (2, 512, 64, 8, 32, False)])    # 64 chunks, the largest style row
+                                               (2, 512, 64, 8, 32, False),     # 64 chunks, the largest style row; 4 K slices
+                                               (1, 512, 128, 32, 32, True),    # batch 1 of the inversion loop: 4 K slices
+                                               (1, 128, 64, 8, 32, True)])     # 2 K slices of 8 chunks
 def test_winograd_conv_vs_float64_and_direct(b, c, n, h, w, scales, monkeypatch):
     from stylerenderer_amd.op.conv import conv2d_mfma
 
@@ -403,6 +405,17 @@ def test_winograd_conv_vs_float64_and_direct(b, c, n, h, w, scales, monkeypatch)
     assert float(((direct - ref).abs() / mag).max()) < 2e-6
     assert float(((wino - direct).abs() / mag).max()) < 4e-6
     assert not torch.equal(wino, direct)                 # the two paths really are different kernels
+    # few tiles + long channel loop: K slices (k_conv_wino writes raw slice sums, k_wino_reduce adds them in a fixed
+    # order and applies the epilogue) — same tolerance, run-to-run identical, and a different summation order than the
+    # unsplit kernel (SR_WINO_SPLIT=0)
+    monkeypatch.setenv("SR_WINOGRAD", "1")
+    again = conv2d_mfma(*args, 3, 1, 1).cpu().double()
+    assert torch.equal(again, wino)
+    monkeypatch.setenv("SR_WINO_SPLIT", "0")
+    unsplit = conv2d_mfma(*args, 3, 1, 1).cpu().double()
+    assert float(((unsplit - ref).abs() / mag).max()) < 4e-6
+    if c >= 128:
+        assert not torch.equal(unsplit, wino)
 
 
 # Winograd F(3x3,2x2) weight gradient (csrc/conv_wgrad_wino.hip) vs float64 and vs the direct kernel.
@@ -444,7 +457,8 @@ def test_winograd_wgrad_vs_float64_and_direct(b, c, n, h, w, scales, monkeypatch
 
 
 # ---- conv + noise + bias + LeakyReLU as one node (ConvNBAFn) vs the two separate operators
-@pytest.mark.parametrize("b,c,n,h,w,shared_noise", [(2, 16, 64, 8, 32, False), (3, 24, 128, 16, 32, True)])
+@pytest.mark.parametrize("b,c,n,h,w,shared_noise", [(2, 16, 64, 8, 32, False), (3, 24, 128, 16, 32, True),
+                                                    (1, 128, 64, 8, 32, True)])        # K slices: tail in k_wino_reduce
 def test_conv_nba_node_matches_separate_operators(b, c, n, h, w, shared_noise):
     from stylerenderer_amd.op import conv as cv
     from stylerenderer_amd.op.fused_elem import noise_bias_act

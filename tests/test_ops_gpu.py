@@ -715,3 +715,27 @@ def test_frozen_bias_and_noise_strength_skip_their_reductions_same_input_gradien
         assert a[4] is not None and f[4] is None, kind
         if kind != "act":
             assert a[5] is not None and f[5] is None, kind
+
+
+@pytest.mark.parametrize("shared", [True, False])
+def test_affine3_pose_kernel_vs_matmul(shared):
+    """utils_3d.affine3 (sr_affine3_fwd / _bwd): v @ M + t and its three gradients against the library matmul it
+    replaces (fp32 round-off; the 3x3 / translation gradients are fixed-order sums: two launches agree bit for bit)."""
+    from stylerenderer_amd import synth, utils_3d
+
+    b, nv = 3, 24770
+    v = T(synth.det_normal((1 if shared else b, nv, 3), 11)).requires_grad_()
+    m = T(synth.det_normal((b, 3, 3), 12)).requires_grad_()
+    t = T(synth.det_normal((b, 3), 13)).requires_grad_()
+    go = T(synth.det_normal((b, nv, 3), 14))
+    out = utils_3d.affine3(v, m, t)
+    want = torch.matmul(v, m) + t.view(b, 1, 3)
+    assert out.shape == want.shape and rel_err(out.detach().cpu().numpy(), want.detach().cpu().numpy()) < 1e-6
+    got = torch.autograd.grad(out, [v, m, t], go)
+    ref = torch.autograd.grad(want, [v, m, t], go)
+    for a, r, tol in zip(got, ref, (2e-6, 2e-5, 2e-5)):
+        assert a.shape == r.shape and rel_err(a.cpu().numpy(), r.cpu().numpy()) < tol
+    again = torch.autograd.grad(utils_3d.affine3(v, m, t), [m, t], go)
+    assert torch.equal(again[0], got[1]) and torch.equal(again[1], got[2])
+    out2 = utils_3d.affine3(v, m)                                  # no translation (normals)
+    assert rel_err(out2.detach().cpu().numpy(), torch.matmul(v, m).detach().cpu().numpy()) < 1e-6
