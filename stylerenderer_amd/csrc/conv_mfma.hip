@@ -874,11 +874,14 @@ extern "C" int sr_conv2d_mfma(float* out, const float* in, const float* wt, cons
     bool fused_ok = false;
     {
         const char* e = std::getenv("SR_CONVT_FUSED");
-        // the fused kernel has no split-K: with fewer workgroups than ~a third of the CUs (batch 1 of the inversion
-        // loop at 32^2 / 64^2) each one walks the whole channel loop alone and the per-phase launches, which split K,
-        // are faster (inversion step 7.26 -> 6.98 ms)
+        // the fused kernel has no split-K: when its workgroups cover less than ~3/4 of the CUs AND the channel loop is
+        // long (C > 256: 64 chunks, ~0.38 ms whatever the batch), each one walks the whole loop alone and the per-phase
+        // launches, which split K, are faster — in-graph, scripts/bench_convt_small.py: 32^2 512->512 at batch 1 / 2 / 4
+        // 0.23 / 0.26 / 0.35 ms against 0.38 / 0.39 / 0.40 fused (batch 8: 0.56 against 0.43, fused stays);
+        // 64^2 512->256 at batch 1 / 2 0.26 / 0.33 against 0.39; 128^2 256->128 (32 chunks) is fused from batch 1 on
         const int64_t fused_blocks = (int64_t)(p.IW / TFused::PW) * (p.IH / TFused::PH) * ((p.N + BN - 1) / BN) * p.B;
-        if (!(e && e[0] == '0') && p.IW >= 16 && convt_fused_eligible(p) && (fused_blocks >= 96 || (e && e[0] == '1'))) {
+        const bool fused_pays = fused_blocks >= 192 || p.C <= 256;
+        if (!(e && e[0] == '0') && p.IW >= 16 && convt_fused_eligible(p) && (fused_pays || (e && e[0] == '1'))) {
             for (int i = 0; i < 9; ++i) p.wmap[i] = i;
             const int rc = launch_convt_fused(p, st);
             if (rc != SR_OK) return rc;

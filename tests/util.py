@@ -30,19 +30,23 @@ def rel_err(a, b):
 def check_grad_samples(named_grads, names, values, offsets, tol, scalar_factor=1.0):
     """Sampled entries of every gradient tensor (fixtures written by oracle/make_golden.grad_samples): the error of
     each tensor's samples relative to that tensor's largest sampled magnitude.  Returns the worst ratio.
-    scalar_factor widens the bar for one-element tensors only (a noise strength is ONE sum of up to 2e6 signed terms
-    that cancel to a few percent of their magnitude: its relative error is the summation order's, also between two
-    CPUs running the same code)."""
+    One-element tensors (noise strengths) are measured against the LARGEST of them: each is one sum of up to 2e6
+    signed terms of similar size, and the ones that cancel to a few percent of their terms (|value| 0.1 beside 20-1000
+    for their siblings) carry the summation order's absolute error — also between two CPUs running the same code — at
+    a relative size that says nothing about the kernel.  `scalar_factor` widens their bar further."""
     from stylerenderer_amd import synth
 
     assert sorted(named_grads) == list(names)
     worst = 0.0
+    scalars = [float(np.abs(values[offsets[i]:offsets[i + 1]]).max()) for i, n in enumerate(names)
+               if named_grads[n].numel() == 1]
+    scalar_scale = max(scalars) if scalars else 0.0
     for i, n in enumerate(names):
         want = np.asarray(values[offsets[i]:offsets[i + 1]], np.float64)
         g = named_grads[n].detach().reshape(-1).cpu().numpy().astype(np.float64)
         got = g[synth.sample_index(g.size, 256)]
         assert got.shape == want.shape, n
-        scale = max(float(np.abs(want).max()), 1e-12)
+        scale = max(float(np.abs(want).max()), scalar_scale if g.size == 1 else 0.0, 1e-12)
         err = float(np.abs(got - want).max()) / scale
         bar = tol * (scalar_factor if g.size == 1 else 1.0)
         assert err <= bar, "%s: sampled-gradient error %.3e of the tensor's scale (bar %.1e)" % (n, err, bar)
@@ -81,8 +85,7 @@ def run_generator_with_map_case(gold, tag_size, dev, tol_img, tol_g1, tol_g2, to
                                 retain_graph=True)
     got = {k: x for k, x in zip(params, grads[:-2]) if x is not None}
     assert sorted(k for k, x in zip(params, grads[:-2]) if x is None) == list(gold["unused"])
-    meas["g1"] = check_grad_samples(got, gold["grad_names"], gold["grad_samples"], gold["grad_sample_offsets"], tol_g1,
-                                    scalar_factor=10.0)
+    meas["g1"] = check_grad_samples(got, gold["grad_names"], gold["grad_samples"], gold["grad_sample_offsets"], tol_g1)
     meas["gv"] = rel_err(grads[-2].cpu().numpy(), gold["grad_v"])
     meas["gn"] = rel_err(grads[-1].cpu().numpy(), gold["grad_nrm"])
     assert meas["gv"] < tol_mesh1 and meas["gn"] < tol_mesh1, meas
@@ -97,7 +100,7 @@ def run_generator_with_map_case(gold, tag_size, dev, tol_img, tol_g1, tol_g2, to
     (2.0 * 4 * pen + 0 * img[0, 0, 0, 0]).backward()
     got = {k: p.grad for k, p in g.named_parameters() if p.grad is not None}
     meas["g2"] = check_grad_samples(got, gold["pl_grad_names"], gold["pl_grad_samples"],
-                                    gold["pl_grad_sample_offsets"], tol_g2, scalar_factor=10.0)
+                                    gold["pl_grad_sample_offsets"], tol_g2)
     meas["gv2"] = rel_err(v.grad.cpu().numpy(), gold["pl_grad_v"])
     meas["gn2"] = rel_err(n.grad.cpu().numpy(), gold["pl_grad_nrm"])
     assert meas["gv2"] < tol_mesh2 and meas["gn2"] < tol_mesh2, meas
