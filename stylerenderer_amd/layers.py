@@ -90,6 +90,20 @@ class Blur(nn.Module):
         return upfirdn2d(input, self.kernel, pad=self.pad)
 
 
+_CONST_ROWS = {}
+
+
+def _const_rows(value, b, n, device):
+    """[b, n] tensor filled with `value` (an output scale table of the convolution kernels), made once per shape."""
+    key = (float(value), int(b), int(n), str(device))
+    hit = _CONST_ROWS.get(key)
+    if hit is None:
+        if len(_CONST_ROWS) > 64:
+            _CONST_ROWS.clear()
+        hit = _CONST_ROWS[key] = torch.full((b, n), float(value), dtype=torch.float32, device=device)
+    return hit
+
+
 class EqualConv2d(nn.Module):
     """Plain convolution with equalised learning rate (reference layers.py:204-221)."""
 
@@ -106,19 +120,25 @@ class EqualConv2d(nn.Module):
         return {(3, 1, 1): "c3", (3, 2, 0): "c3s2", (1, 1, 0): "c1", (1, 2, 0): "c1s2"}.get(
             (k, self.stride, self.padding))
 
-    def forward(self, input, with_bias=True):
+    def forward(self, input, with_bias=True, gain=None):
+        """gain (device path, bias-free layers): a constant factor on the output, applied in the convolution's store
+        (its per-(sample, channel) output scale) — ResBlock folds its 1/sqrt(2) in here instead of a separate pass."""
         geom = self._geom()
         bias = self.bias if with_bias else None
         if input.device.type == "cuda" and geom is not None:
             wt, _ = _weight_prep_cached(self, self.weight, self.scale)
-            return _conv.conv2d(input, wt, None, None, bias, geom)
-        return F.conv2d(input, self.weight * self.scale, bias=bias, stride=self.stride,
-                        padding=self.padding)
+            osc = _const_rows(gain, input.shape[0], self.weight.shape[0], input.device) if gain is not None else None
+            assert osc is None or bias is None
+            return _conv.conv2d(input, wt, None, osc, bias, geom)
+        out = F.conv2d(input, self.weight * self.scale, bias=bias, stride=self.stride, padding=self.padding)
+        return out * gain if gain is not None else out
 
-    def forward_stride1(self, input):
+    def forward_stride1(self, input, gain=None):
         """The 1x1 convolution applied to an input that is already decimated (see ConvLayer.forward)."""
         wt, _ = _weight_prep_cached(self, self.weight, self.scale)
-        return _conv.conv2d(input, wt, None, None, self.bias, "c1")
+        osc = _const_rows(gain, input.shape[0], self.weight.shape[0], input.device) if gain is not None else None
+        assert osc is None or self.bias is None
+        return _conv.conv2d(input, wt, None, osc, self.bias, "c1")
 
     def __repr__(self):
         return "%s(%d, %d, %d, stride=%d, padding=%d)" % (
@@ -373,15 +393,21 @@ class ConvLayer(nn.Sequential):
             layers.append(FusedLeakyReLU(out_channel) if bias else ScaledLeakyReLU(0.2))
         super().__init__(*layers)
 
-    def forward(self, input):
+    def forward(self, input, gain=None):
+        """gain (device path only): a constant factor on the layer's output, folded into the activation's gain
+        (sqrt(2) * gain) or, without activation and bias, into the convolution's store."""
         if input.device.type != "cuda" or input.dtype != torch.float32:
-            return super().forward(input)
+            out = super().forward(input)
+            return out * gain if gain is not None else out
         mods = list(self)
         x = input
+        g = 1.0 if gain is None else float(gain)
         if isinstance(mods[0], Blur):
             blur, conv = mods[0], mods[1]
             if conv.weight.shape[2] == 1 and conv.stride == 2 and conv.padding == 0:
                 x = upfirdn2d(x, blur.kernel, down=2, pad=blur.pad)        # blur evaluated at the kept pixels only
+                if len(mods) == 2 and conv.bias is None and gain is not None:
+                    return conv.forward_stride1(x, gain=g)
                 x = conv.forward_stride1(x)
                 mods = mods[2:]
             else:
@@ -398,14 +424,23 @@ class ConvLayer(nn.Sequential):
                     xc = x.contiguous()
                     wt, _ = _weight_prep_cached(conv, conv.weight, conv.scale)
                     if _conv.conv_nba_supported(xc, wt, None):
-                        return _conv.conv2d_nba(xc, wt, None, None, None, None, bias, act.negative_slope, act.scale)
+                        return _conv.conv2d_nba(xc, wt, None, None, None, None, bias, act.negative_slope, act.scale * g)
                 x = conv(x, with_bias=False)
-                return fused_leaky_relu(x, bias, act.negative_slope, act.scale)
+                return fused_leaky_relu(x, bias, act.negative_slope, act.scale * g)
+            if len(mods) == 1 and conv.bias is None and gain is not None and conv._geom() is not None:
+                return conv(x, gain=g)
             x = conv(x)
             mods = mods[1:]
         for m in mods:
             x = m(x)
-        return x
+        return x * g if gain is not None else x
+
+
+RSQRT2 = 1.0 / math.sqrt(2)
+
+
+def _resblock_fold():
+    return os.environ.get("SR_RESBLOCK_FOLD", "1") != "0"
 
 
 class ResBlock(nn.Module):
@@ -425,7 +460,14 @@ class ResBlock(nn.Module):
             # the input feeds conv1 and the (blurred, decimated) skip branch: one node whose backward adds the two
             # input gradients inside the up-sampling FIR kernel of the skip branch (op.upfirdn2d.SkipDown)
             same, down = _skip_down(input, mods[0].kernel, mods[0].pad)
+            if mods[1].bias is None and _resblock_fold():
+                # (a + b) / sqrt(2) = a / sqrt(2) + b / sqrt(2): the factor rides in conv2's activation gain
+                # (sqrt(2) * 1/sqrt(2)) and in the skip convolution's store — one full-size pass (the add) instead
+                # of two, forward and backward
+                return self.conv2(self.conv1(same), gain=RSQRT2) + mods[1].forward_stride1(down, gain=RSQRT2)
             out = self.conv2(self.conv1(same))
             return (out + mods[1].forward_stride1(down)) / math.sqrt(2)
+        if input.device.type == "cuda" and input.dtype == torch.float32 and _resblock_fold():
+            return self.conv2(self.conv1(input), gain=RSQRT2) + self.skip(input, gain=RSQRT2)
         out = self.conv2(self.conv1(input))
         return (out + self.skip(input)) / math.sqrt(2)

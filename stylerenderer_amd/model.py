@@ -301,8 +301,11 @@ class GeneratorWithMap(Generator):
 
     def _synthesis_with_maps(self, latent, noise, vert, attr, tri, return_normals, return_latents):
         out = self.input(latent)
+        # the reference hands the permuted VIEW of the rasterizer output on (model.py:262) — that is what `norm_maps`
+        # returns and what the path-length regulariser differentiates against; the map heads read ONE contiguous NCHW
+        # copy of it (each of their convolutions would otherwise make its own, forward and backward)
         norm_maps = [rasterize(vert, attr, tri, int(out.shape[2]), int(out.shape[3])).permute(0, 3, 1, 2)]
-        maps = self.norm1(norm_maps[-1])
+        maps = self.norm1(norm_maps[-1].contiguous())
         st = self._layer_styles(latent)
         out = self.conv1(out, st[0], maps, noise=noise[0])
         skip = self.to_rgb1(out, st[1])
@@ -312,10 +315,11 @@ class GeneratorWithMap(Generator):
                                                        noise[1::2], noise[2::2], self.to_rgbs):
             norm_maps.append(rasterize(vert, attr, tri, 2 * int(out.shape[2]),
                                        2 * int(out.shape[3])).permute(0, 3, 1, 2))
+            nm = norm_maps[-1].contiguous()
             if two_stage:
-                maps = self.norm_to_style[i](self.norm_to_style[i - 1](norm_maps[-1]))
+                maps = self.norm_to_style[i](self.norm_to_style[i - 1](nm))
             else:
-                maps = self.norm_to_style[i // 2](norm_maps[-1])
+                maps = self.norm_to_style[i // 2](nm)
             # one split (its backward is one cat) instead of two slices, whose backward zero-fills and adds two
             # full-size copies of `maps` — per resolution and per order of differentiation
             maps_up, maps_conv = maps.split([2, maps.shape[1] - 2], 1)
