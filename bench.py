@@ -23,9 +23,12 @@ Prints ONE JSON line on rank 0 with the driver's contract fields plus
                 4 images per GPU, synthetic images + 3DMM-size mesh, lazy R1 / path-length cadence 16 / 4,
                 64 timed iterations), images/s, enqueue time, and for N > 1 the measured 125 MB gradient
                 all-reduce against the xGMI ring bound;
-  rasterizer    BASELINE config[3]: Mtri/s forward and forward+backward, its own HBM roofline and the
-                single-thread C oracle (the reference's CPU rasterizer restated) beside it;
-  inversion     BASELINE config[4]: 400-step latent inversion (generator + rasterizer + LPIPS-shaped metric), steps/s.
+  rasterizer    BASELINE config[3]: Mtri/s forward and forward+backward, its own HBM roofline, the
+                vector-ALU issue roofline that actually bounds it (roofline_valu, from the committed PMC pass) and
+                the single-thread C oracle (the reference's CPU rasterizer restated) beside it;
+  inversion     BASELINE config[4]: 400-step latent inversion (generator + rasterizer + LPIPS metric), steps/s, with a
+                roofline object (executed MFMA flops, launches and microseconds per launch of the replayed step);
+  step_executed_mfma_frac   executed matrix-core flops of the WHOLE headline step / wall time / 157.3 TFLOP/s.
 """
 import argparse
 import json

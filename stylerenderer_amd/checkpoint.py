@@ -92,7 +92,7 @@ def load_checkpoint(path, trainer, map_location="cpu", strict=True):
     """Resume semantics of reference train.py:537-556: every key is optional; `g_ema` falls back to `g`;
     the start iteration comes from the file name unless the checkpoint carries one.
 
-    COLLECTIVE at world size > 1: EVERY rank must call it with the same file (the reference does: train.py:537 runs on
+    COLLECTIVE for a graph_train.GraphedTrainer at world size > 1: EVERY rank must call it with the same file (the reference does: train.py:537 runs on
     all ranks).  A GraphedTrainer drops its captured graphs here and re-captures on the next step(); the warm-up
     iterations of that re-capture issue gradient collectives, so a "rank 0 loads and broadcasts" flow would leave the
     other ranks without matching calls.  The check below turns that mistake into an error (or a hang AT THIS LINE
@@ -134,7 +134,9 @@ def load_checkpoint(path, trainer, map_location="cpu", strict=True):
 def _assert_collective_load(trainer, iteration):
     from . import distributed as sr_dist
 
-    if sr_dist.get_world_size() <= 1:
+    # only a trainer whose next step issues collectives of its own accord (graph_train.GraphedTrainer at world > 1:
+    # the re-capture warm-up) — loading into a plain, non-distributed object on one rank is legitimate
+    if sr_dist.get_world_size() <= 1 or getattr(trainer, "world", 1) <= 1 or not hasattr(trainer, "graphs"):
         return
     dev = getattr(trainer, "device", torch.device("cpu"))
     mine = torch.tensor([float(iteration), -float(iteration)], dtype=torch.float64, device=dev)
