@@ -29,6 +29,9 @@ Prints ONE JSON line on rank 0 with the driver's contract fields plus
   inversion     BASELINE config[4]: 400-step latent inversion (generator + rasterizer + LPIPS metric), steps/s, with a
                 roofline object (executed MFMA flops, launches and microseconds per launch of the replayed step);
   step_executed_mfma_frac   executed matrix-core flops of the WHOLE headline step / wall time / 157.3 TFLOP/s.
+`roofline.traffic`, `mfma_pipe_busy` and the rasterizer's traffic / VALU instruction counts are measured IN this run:
+after the timed steps rank 0 spawns three short `rocprofv3 --pmc` passes (counters only, one TCC counter per pass) over
+a child of this script (`collect_live_pmc`; `--no-pmc` skips them and cites the committed profiles/ summary instead).
 """
 import argparse
 import json
@@ -101,6 +104,10 @@ def parse(argv=None):
     ap.add_argument("--cpu-batch", type=int, default=2)
     ap.add_argument("--cpu-iters", type=int, default=6)
     ap.add_argument("--cpu-threads", type=int, default=32)
+    ap.add_argument("--no-pmc", action="store_true",
+                    help="do not spawn the rocprofv3 --pmc passes that measure HBM traffic / MFMA busy / VALU "
+                         "instructions for the roofline objects (they then cite the committed profiles/ summary)")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--plumbing", action="store_true",
                     help="CPU-only launch check (gloo, tiny model): exercises --gpus N rank spawning without a GPU")
     return ap.parse_args(argv)
@@ -225,6 +232,58 @@ def raster_leg(dev, world, batch=64, res=256, iters=10, cpu_baseline=True):
     return out
 
 
+_LIVE_PMC = {}         # kernel -> {counter: mean per dispatch}, filled by collect_live_pmc() in this run
+
+
+def _short_kernel(name):
+    return name.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0].replace(",", ";")
+
+
+def collect_live_pmc(timeout_s=150):
+    """Hardware counters of THIS run's kernels: three short rocprofv3 --pmc passes (counters only — no trace domains —
+    one TCC counter per pass, as MI355X_MICROARCH.md prescribes) over a child of this very script (2 generator steps +
+    the rasterizer leg).  Fills _LIVE_PMC; returns a note for the JSON line (None when everything worked).  The timed
+    measurements of the parent are finished or not yet started when this runs: nothing overlaps with them."""
+    import csv
+    import glob
+    import shutil
+    import tempfile
+
+    tool = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if tool is None:
+        return "rocprofv3 not found"
+    out = tempfile.mkdtemp(prefix="sr_pmc_", dir="/tmp")
+    child = [sys.executable, os.path.abspath(__file__), "--steps", "2", "--warmup", "1", "--no-train", "--no-inversion",
+             "--no-cpu-baseline", "--pmc-child"]
+    env = dict(os.environ, TMPDIR="/tmp")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    note = None
+    passes = (["FETCH_SIZE"], ["WRITE_SIZE"], ["SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE", "SQ_INSTS_VALU"])
+    acc = {}
+    for i, counters in enumerate(passes):
+        d = os.path.join(out, "p%d" % i)
+        try:
+            subprocess.run([tool, "--pmc"] + counters + ["--output-format", "csv", "-d", d, "-o", "p", "--"] + child,
+                           cwd="/tmp", env=env, timeout=timeout_s, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        except Exception as e:           # noqa: BLE001  (a profiler problem must not take the benchmark down)
+            note = "pmc pass %s failed: %s" % (counters[0], type(e).__name__)
+            continue
+        files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+        if not files:
+            note = "pmc pass %s wrote no counters" % counters[0]
+            continue
+        with open(files[0]) as f:
+            for r in csv.DictReader(f):
+                a = acc.setdefault((_short_kernel(r["Kernel_Name"]), r["Counter_Name"]), [0.0, 0])
+                a[0] += float(r["Counter_Value"])
+                a[1] += 1
+    for (k, c), (v, n) in acc.items():
+        _LIVE_PMC.setdefault(k, {})[c] = v / n
+    shutil.rmtree(out, ignore_errors=True)
+    return note
+
+
 VALU_PEAK_GINST = 1024 * 2.4 / 4.0      # wave64 VALU instructions / ns over 1024 SIMDs at 2.4 GHz, 4 cycles each
 
 
@@ -234,23 +293,28 @@ def valu_roofline(kernel_rows, measured_ms):
     import csv
     import glob
 
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_raster_pmc.csv")))
-    if not files:
-        return None
-    insts, seen = 0.0, 0
-    with open(files[-1]) as f:
-        for r in csv.DictReader(l for l in f if not l.startswith("#")):
-            if r["kernel"] in kernel_rows and r.get("SQ_INSTS_VALU"):
-                insts += float(r["SQ_INSTS_VALU"])
-                seen += 1
+    live = all(k in _LIVE_PMC and "SQ_INSTS_VALU" in _LIVE_PMC[k] for k in kernel_rows)
+    insts, seen, files = 0.0, 0, []
+    if live:
+        insts, seen = sum(_LIVE_PMC[k]["SQ_INSTS_VALU"] for k in kernel_rows), len(kernel_rows)
+    else:
+        files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_raster_pmc.csv")))
+        if not files:
+            return None
+        with open(files[-1]) as f:
+            for r in csv.DictReader(l for l in f if not l.startswith("#")):
+                if r["kernel"] in kernel_rows and r.get("SQ_INSTS_VALU"):
+                    insts += float(r["SQ_INSTS_VALU"])
+                    seen += 1
     if seen != len(kernel_rows) or not measured_ms:
         return None
     floor_ms = insts / (VALU_PEAK_GINST * 1e9) * 1e3
     return {"bound": "valu", "wave_instructions_per_launch": round(insts), "peak": round(VALU_PEAK_GINST, 1),
             "unit": "G wave-inst/s", "achieved": round(insts / (measured_ms * 1e-3) / 1e9, 1),
             "frac": round(floor_ms / measured_ms, 4), "issue_floor_ms": round(floor_ms, 4),
-            "counters_measured_in_this_run": False,
-            "source": "profiles/%s (SQ_INSTS_VALU, separate rocprofv3 --pmc pass)" % os.path.basename(files[-1])}
+            "counters_measured_in_this_run": bool(live),
+            "source": ("rocprofv3 --pmc SQ_INSTS_VALU pass spawned by this run (collect_live_pmc)" if live else
+                       "profiles/%s (SQ_INSTS_VALU, separate rocprofv3 --pmc pass)" % os.path.basename(files[-1]))}
 
 
 def pmc_traffic(kernel_rows):
@@ -264,6 +328,17 @@ def pmc_traffic(kernel_rows):
 
     if isinstance(kernel_rows, str):
         kernel_rows = [kernel_rows]
+    if all(k in _LIVE_PMC and "FETCH_SIZE" in _LIVE_PMC[k] and "WRITE_SIZE" in _LIVE_PMC[k] for k in kernel_rows):
+        # counters of THIS run (collect_live_pmc: separate --pmc passes over a child of this script)
+        total = sum((2.0 * _LIVE_PMC[k]["FETCH_SIZE"] + _LIVE_PMC[k]["WRITE_SIZE"]) * 1024.0 for k in kernel_rows)
+        out = {"traffic": round(total), "traffic_unit": "bytes/launch", "traffic_measured_in_this_run": True,
+               "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes spawned by this run "
+                                 "(2*FETCH_SIZE+WRITE_SIZE, KB)"}
+        c = _LIVE_PMC[kernel_rows[0]]
+        if len(kernel_rows) == 1 and c.get("SQ_VALU_MFMA_BUSY_CYCLES") and c.get("GRBM_GUI_ACTIVE"):
+            out["mfma_pipe_busy"] = round(c["SQ_VALU_MFMA_BUSY_CYCLES"] / (c["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0), 3)
+            out["mfma_pipe_busy_measured_in_this_run"] = True
+        return out
     files = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.csv")) if "raster_pmc" not in f)
     if not files:
         return {}
@@ -679,6 +754,11 @@ def main():
     for p_ in g.parameters():
         p_.grad = None
 
+    pmc_note = None
+    if rank == 0 and world == 1 and not (args.no_pmc or args.pmc_child):
+        # the timed region above is over: counters for the roofline objects below come from short --pmc passes over a
+        # child of this script (never combined with trace domains; the parent's timings are not touched)
+        pmc_note = collect_live_pmc()
     roof, breakdown, step_exec = None, None, None
     if rank == 0:
         # matrix-core flops the WHOLE step executes (every convolution / weight-gradient launch, Winograd launches
@@ -795,7 +875,7 @@ def main():
                        "step": "zero_grad + forward + backward" + (" + DDP all-reduce (RCCL)" if world > 1 else "")},
             "model_flop_frac_of_mfma_peak": round(value / world * FLOP_PER_IMAGE_FWD_BWD / (FP32_MFMA_PEAK_TFLOPS * 1e12), 4),
             "step_executed_mfma_frac": step_exec["frac"] if step_exec else None, "step_executed_mfma": step_exec,
-            "roofline": roof, "cpu_baseline": cpu, "kernel_breakdown": breakdown,
+            "roofline": roof, "cpu_baseline": cpu, "kernel_breakdown": breakdown, "pmc_note": pmc_note,
             "train_step": train_res, "rasterizer": raster, "inversion": inversion_res,
         }
     if world > 1:
