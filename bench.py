@@ -249,6 +249,8 @@ def collect_live_pmc(timeout_s=150):
     import shutil
     import tempfile
 
+    if any(k.startswith(("ROCPROF", "ROCP_", "ROCTRACER")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", ""):
+        return "this run is itself being profiled: no nested --pmc passes"
     tool = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
     if tool is None:
         return "rocprofv3 not found"
