@@ -168,6 +168,13 @@ int sr_affine3_fwd(float* out, const float* v, const float* m, const float* t, i
 int sr_affine3_bwd(float* gm, float* gt, const float* v, const float* g, int64_t B, int64_t nv, int64_t v_bstride,
                    sr_stream_t stream);
 
+/* Pose parameters of the inversion loop, pose = (yaw, pitch, roll, tx, ty, tz, log-scale): rot [3,3] = Rz(roll) Rx(pitch)
+ * Ry(yaw) (utils_3d.euler_mat(angles, "yxz"), row-major), lin = exp(log-scale) * rot; sr_pose_bwd: gradient of the seven
+ * numbers from the gradients of the two matrices (either may be NULL; entries 3..5 are written as 0: the translation's
+ * gradient is sr_affine3_bwd's gt).  One lane each: replaces ~60 one-element tensor-algebra launches per step. */
+int sr_pose_fwd(float* lin, float* rot, const float* pose, sr_stream_t stream);
+int sr_pose_bwd(float* gpose, const float* glin, const float* grot, const float* pose, sr_stream_t stream);
+
 /* Skinny linear algebra of the style path, B = per-GPU batch rows (csrc/style_linear.hip).
  * EqualLinear (reference layers.py:222-248), optionally with the fused leaky-ReLU of the mapping
  * network (act != 0: op/fused_act.py:86-97 semantics, bias inside the activation):

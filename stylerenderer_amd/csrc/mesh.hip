@@ -106,7 +106,78 @@ __global__ __launch_bounds__(1024) void k_affine3_bwd(float* __restrict__ gm, fl
     if (threadIdx.x >= 9 && threadIdx.x < 12 && gt) gt[3 * b + (threadIdx.x - 9)] = s[threadIdx.x][0];
 }
 
+// ---- pose of the latent-inversion loop: (yaw, pitch, roll, tx, ty, tz, log-scale) -> rot = Rz(roll) Rx(pitch) Ry(yaw) ("yxz"
+// order of utils_3d.euler_mat: later axes multiply from the left) and lin = exp(log-scale) * rot, and the gradient of the
+// seven numbers given the gradients of the two matrices.  As tensor algebra this is ~60 launches of one-element kernels
+// per step (sin / cos / cat / view / three 3x3 products and their backward); here one lane each way.
+__device__ __forceinline__ void mat3_mul(const float* a, const float* b, float* o) {      // o = a @ b, row-major
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) o[3 * i + j] = (a[3 * i] * b[j] + a[3 * i + 1] * b[3 + j]) + a[3 * i + 2] * b[6 + j];
+}
+__device__ __forceinline__ void axis_mats(const float* pose, float* ry, float* rx, float* rz, float* dry, float* drx,
+                                          float* drz) {
+    const float c0 = cosf(pose[0]), s0 = sinf(pose[0]), c1 = cosf(pose[1]), s1 = sinf(pose[1]);
+    const float c2 = cosf(pose[2]), s2 = sinf(pose[2]);
+    const float y[9] = {c0, 0.f, s0, 0.f, 1.f, 0.f, -s0, 0.f, c0}, dy[9] = {-s0, 0.f, c0, 0.f, 0.f, 0.f, -c0, 0.f, -s0};
+    const float x[9] = {1.f, 0.f, 0.f, 0.f, c1, -s1, 0.f, s1, c1}, dx[9] = {0.f, 0.f, 0.f, 0.f, -s1, -c1, 0.f, c1, -s1};
+    const float z[9] = {c2, -s2, 0.f, s2, c2, 0.f, 0.f, 0.f, 1.f}, dz[9] = {-s2, -c2, 0.f, c2, -s2, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 9; ++i) { ry[i] = y[i]; rx[i] = x[i]; rz[i] = z[i]; dry[i] = dy[i]; drx[i] = dx[i]; drz[i] = dz[i]; }
+}
+
+__global__ void k_pose_fwd(float* __restrict__ lin, float* __restrict__ rot, const float* __restrict__ pose) {
+    float ry[9], rx[9], rz[9], d0[9], d1[9], d2[9], t[9], r[9];
+    axis_mats(pose, ry, rx, rz, d0, d1, d2);
+    mat3_mul(rx, ry, t);
+    mat3_mul(rz, t, r);
+    const float sc = expf(pose[6]);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) { rot[i] = r[i]; lin[i] = sc * r[i]; }
+}
+
+__global__ void k_pose_bwd(float* __restrict__ gpose, const float* __restrict__ glin, const float* __restrict__ grot,
+                           const float* __restrict__ pose) {
+    float ry[9], rx[9], rz[9], dry[9], drx[9], drz[9], t[9], r[9], u[9], d[9];
+    axis_mats(pose, ry, rx, rz, dry, drx, drz);
+    mat3_mul(rx, ry, t);
+    mat3_mul(rz, t, r);
+    const float sc = expf(pose[6]);
+    float gt[9];                          // dL/dR = grot + sc * glin
+    float gs = 0.f;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        const float gl = glin ? glin[i] : 0.f;
+        gt[i] = (grot ? grot[i] : 0.f) + sc * gl;
+        gs += gl * r[i];
+    }
+    auto dot9 = [&](const float* m) {
+        float a = 0.f;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) a += gt[i] * m[i];
+        return a;
+    };
+    mat3_mul(rx, dry, u); mat3_mul(rz, u, d); gpose[0] = dot9(d);      // d/d yaw:   Rz Rx Ry'
+    mat3_mul(drx, ry, u); mat3_mul(rz, u, d); gpose[1] = dot9(d);      // d/d pitch: Rz Rx' Ry
+    mat3_mul(drz, t, d);                      gpose[2] = dot9(d);      // d/d roll:  Rz' Rx Ry
+    gpose[3] = gpose[4] = gpose[5] = 0.f;                              // (translation: sr_affine3_bwd's gt)
+    gpose[6] = sc * gs;
+}
+
 }  // namespace
+
+extern "C" int sr_pose_fwd(float* lin, float* rot, const float* pose, sr_stream_t stream) {
+    if (!lin || !rot || !pose) return SR_EINVAL;
+    hipLaunchKernelGGL(k_pose_fwd, dim3(1), dim3(1), 0, sr_stream(stream), lin, rot, pose);
+    return sr_launch_status();
+}
+
+extern "C" int sr_pose_bwd(float* gpose, const float* glin, const float* grot, const float* pose, sr_stream_t stream) {
+    if (!gpose || !pose) return SR_EINVAL;
+    hipLaunchKernelGGL(k_pose_bwd, dim3(1), dim3(1), 0, sr_stream(stream), gpose, glin, grot, pose);
+    return sr_launch_status();
+}
 
 extern "C" int sr_affine3_fwd(float* out, const float* v, const float* m, const float* t, int64_t B, int64_t nv,
                               int64_t v_bstride, sr_stream_t stream) {

@@ -68,8 +68,7 @@ class LatentInverter:
 
     # ---- model ----------------------------------------------------------------------------------------
     def posed_mesh(self):
-        rot = utils_3d.euler_mat(self.pose[:3].view(1, 3), "yxz")                       # [1, 3, 3]
-        lin = torch.exp(self.pose[6]) * rot
+        lin, rot = utils_3d.pose_matrices(self.pose)                                    # [1, 3, 3] each
         # [nv, 3] x [3, 3]: one streaming kernel each (utils_3d.affine3), not a 3-wide library GEMM
         v = utils_3d.affine3(self.v0, lin, self.pose[3:6].view(1, 3))
         n = utils_3d.affine3(self.n0, rot)

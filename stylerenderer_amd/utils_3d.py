@@ -123,6 +123,41 @@ class _Affine3(Function):
         return gv, gm, gt
 
 
+class _PoseMatrices(Function):
+    """(lin, rot) [1, 3, 3] from pose [7] on the device path (csrc/mesh.hip sr_pose_fwd / _bwd), see `pose_matrices`."""
+
+    @staticmethod
+    def forward(ctx, pose):
+        pc = pose.contiguous()
+        lin = torch.empty((1, 3, 3), dtype=pc.dtype, device=pc.device)
+        rot = torch.empty_like(lin)
+        with on_device_of(pc):
+            _lib.check(_lib.lib().sr_pose_fwd(_lib.ptr(lin), _lib.ptr(rot), _lib.ptr(pc), stream_of(pc)), "sr_pose_fwd")
+        ctx.save_for_backward(pc)
+        return lin, rot
+
+    @staticmethod
+    def backward(ctx, glin, grot):
+        (pc,) = ctx.saved_tensors
+        gp = torch.empty_like(pc)
+        gl = glin.contiguous() if glin is not None else None
+        gr = grot.contiguous() if grot is not None else None
+        with on_device_of(pc):
+            _lib.check(_lib.lib().sr_pose_bwd(_lib.ptr(gp), _lib.ptr(gl), _lib.ptr(gr), _lib.ptr(pc), stream_of(pc)),
+                       "sr_pose_bwd")
+        return gp
+
+
+def pose_matrices(pose):
+    """pose [7] = (yaw, pitch, roll, tx, ty, tz, log-scale) -> (lin, rot), each [1, 3, 3]: rot = euler_mat(pose[:3],
+    "yxz"), lin = exp(pose[6]) * rot.  Device fp32: one launch forward, one backward (first order); otherwise the
+    tensor algebra it stands for."""
+    if pose.device.type == "cuda" and pose.dtype == torch.float32 and pose.numel() == 7:
+        return _PoseMatrices.apply(pose)
+    rot = euler_mat(pose[:3].view(1, 3), "yxz")
+    return torch.exp(pose[6]) * rot, rot
+
+
 def affine3(v, m, t=None):
     """v [B or 1, nv, 3] @ m [B, 3, 3] + t [B, 3] (row-vector convention of the reference's pose functions)."""
     if v.device.type == "cuda" and v.dtype == torch.float32 and m.dim() == 3:

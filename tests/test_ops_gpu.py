@@ -739,3 +739,23 @@ def test_affine3_pose_kernel_vs_matmul(shared):
     assert torch.equal(again[0], got[1]) and torch.equal(again[1], got[2])
     out2 = utils_3d.affine3(v, m)                                  # no translation (normals)
     assert rel_err(out2.detach().cpu().numpy(), torch.matmul(v, m).detach().cpu().numpy()) < 1e-6
+
+
+def test_pose_matrices_kernel_vs_tensor_algebra():
+    """utils_3d.pose_matrices (sr_pose_fwd / _bwd, one lane each) against euler_mat + exp, values and gradient."""
+    from stylerenderer_amd import utils_3d
+
+    pose = torch.tensor([0.31, -0.12, 0.07, 0.2, -0.1, 0.05, 0.15], device=DEV, requires_grad=True)
+    lin, rot = utils_3d.pose_matrices(pose)
+    ref_rot = utils_3d.euler_mat(pose[:3].view(1, 3), "yxz")
+    ref_lin = torch.exp(pose[6]) * ref_rot
+    assert lin.shape == (1, 3, 3) and rot.shape == (1, 3, 3)
+    assert torch.allclose(rot, ref_rot, atol=2e-7) and torch.allclose(lin, ref_lin, atol=3e-7)
+    gl = torch.randn(1, 3, 3, device=DEV)
+    gr = torch.randn(1, 3, 3, device=DEV)
+    (got,) = torch.autograd.grad((lin * gl).sum() + (rot * gr).sum(), pose)
+    (want,) = torch.autograd.grad((ref_lin * gl).sum() + (ref_rot * gr).sum(), pose)
+    assert torch.allclose(got, want, atol=3e-6), (got, want)
+    (only_rot,) = torch.autograd.grad((utils_3d.pose_matrices(pose)[1] * gr).sum(), pose)
+    (want_rot,) = torch.autograd.grad((utils_3d.euler_mat(pose[:3].view(1, 3), "yxz") * gr).sum(), pose)
+    assert torch.allclose(only_rot, want_rot, atol=3e-6)
