@@ -371,6 +371,20 @@ int sr_conv2d_nba(float* out, const float* in, const float* wt, const float* isc
                   int64_t C, int64_t N, int64_t wt_ld, int64_t H, int64_t W, int64_t noise_bstride, float* scratch,
                   sr_stream_t stream);
 
+/* The same two entry points with a `flags` word.  SR_CONV_U_READY: `scratch` is the buffer an EARLIER call with the same
+ * `wt`, C, N (and the same call geometry) used and nobody has written since — its leading block still holds the
+ * Winograd-domain weights, so their preparation (k_wino_weights, one launch per call) is skipped.  For frozen networks
+ * (latent inversion, sampling): the caller keeps one scratch per (weight, geometry).  Ignored on the direct path. */
+#define SR_CONV_U_READY 1
+int sr_conv2d_mfma_ex(float* out, const float* in, const float* wt, const float* iscale,
+                      const float* oscale, const float* obias, int64_t B, int64_t C, int64_t N,
+                      int64_t wt_ld, int64_t IH, int64_t IW, int64_t OH, int64_t OW, int ksize,
+                      int stride, int pad, int transposed, int flags, float* scratch, sr_stream_t stream);
+int sr_conv2d_nba_ex(float* out, const float* in, const float* wt, const float* iscale, const float* oscale,
+                     const float* noise, const float* noise_w, const float* abias, float alpha, float gain,
+                     int64_t B, int64_t C, int64_t N, int64_t wt_ld, int64_t H, int64_t W, int64_t noise_bstride,
+                     int flags, float* scratch, sr_stream_t stream);
+
 /* Weight gradient of sr_conv2d_mfma (same geometry arguments):
  *   dwt[ky*k+kx][c][n] = sum_{b, pixels} (xscale[b,c] * x[b,c,window]) * (gscale[b,n] * gy[b,n,pixel])
  * x [B,C,IH,IW], gy [B,N,OH,OW], dwt [k*k, C, N]; xscale / gscale may be NULL.  The batch is folded

@@ -29,6 +29,7 @@ SIGNATURES = {
     "sr_noise_bias_act_bwd_dot_scratch_floats": (_l, [_l, _l, _l]),
     "sr_noise_bias_act_bwd_dot": (_i, [_p] * 9 + [_f, _f] + [_l] * 4 + [_p, _p]),
     "sr_conv2d_nba": (_i, [_p] * 8 + [_f, _f] + [_l] * 7 + [_p, _p]),
+    "sr_conv2d_nba_ex": (_i, [_p] * 8 + [_f, _f] + [_l] * 7 + [_i, _p, _p]),
     "sr_noise_bias_act_affine": (_i, [_p] * 4 + [_l] + [_p] * 3 + [_f, _f] + [_l] * 4 + [_p]),
     "sr_noise_bias_act_affine_bwd_scratch_floats": (_l, [_l, _l, _l]),
     "sr_noise_bias_act_affine_bwd": (_i, [_p] * 9 + [_l, _p, _f, _f] + [_l] * 4 + [_p, _p]),
@@ -74,6 +75,7 @@ SIGNATURES = {
     "sr_conv2d_wgrad_mfma": (_i, [_p] * 5 + [_l] * 7 + [_i] * 4 + [_p, _p]),
     "sr_conv2d_scratch_floats": (_l, [_l] * 7 + [_i] * 4),
     "sr_conv2d_mfma": (_i, [_p] * 6 + [_l] * 8 + [_i] * 4 + [_p, _p]),
+    "sr_conv2d_mfma_ex": (_i, [_p] * 6 + [_l] * 8 + [_i] * 5 + [_p, _p]),
     "sr_rasterize_grad_f64": (_i, [_l] * 5 + [_i] * 2 + [_p, _p, _l] + [_p] * 6 + [_l, _l, _p, _p, _d, _p, _p]),
     "sr_pose_fwd": (_i, [_p, _p, _p, _p]),
     "sr_pose_bwd": (_i, [_p, _p, _p, _p, _p]),

@@ -821,10 +821,10 @@ extern "C" int64_t sr_conv2d_scratch_floats(int64_t B, int64_t C, int64_t N, int
     return need;
 }
 
-extern "C" int sr_conv2d_mfma(float* out, const float* in, const float* wt, const float* iscale,
+extern "C" int sr_conv2d_mfma_ex(float* out, const float* in, const float* wt, const float* iscale,
                               const float* oscale, const float* obias, int64_t B, int64_t C,
                               int64_t N, int64_t wt_ld, int64_t IH, int64_t IW, int64_t OH, int64_t OW,
-                              int ksize, int stride, int pad, int transposed, float* scratch,
+                              int ksize, int stride, int pad, int transposed, int flags, float* scratch,
                               sr_stream_t stream) {
     if (B < 0 || C <= 0 || N <= 0 || IH <= 0 || IW <= 0 || OH <= 0 || OW <= 0) return SR_EINVAL;
     if (wt_ld < N || wt_ld % 4 != 0 || (reinterpret_cast<uintptr_t>(wt) & 15)) return SR_EINVAL;
@@ -854,7 +854,8 @@ extern "C" int sr_conv2d_mfma(float* out, const float* in, const float* wt, cons
         int rc;
         if (ksize == 3 && stride == 1 && pad == 1 && scratch && wino_enabled() &&
             sr_wino_eligible(B, C, N, IH, IW, in, out))
-            return sr_wino_conv3x3(out, in, wt, wt_ld, iscale, oscale, obias, B, C, N, IH, IW, scratch, st);
+            return sr_wino_conv3x3(out, in, wt, wt_ld, iscale, oscale, obias, B, C, N, IH, IW, scratch, st, nullptr,
+                                   (flags & SR_CONV_U_READY) != 0);
         if (ksize == 3 && stride == 1) rc = launch_by_patch<1, 3, 3>(p, st);
         else if (ksize == 3 && stride == 2) rc = launch_by_patch<2, 3, 3>(p, st);
         else if (ksize == 1 && stride == 1) rc = launch_by_patch<1, 1, 1>(p, st);
@@ -925,18 +926,36 @@ extern "C" int sr_conv2d_mfma(float* out, const float* in, const float* wt, cons
     return SR_OK;
 }
 
+extern "C" int sr_conv2d_mfma(float* out, const float* in, const float* wt, const float* iscale,
+                              const float* oscale, const float* obias, int64_t B, int64_t C,
+                              int64_t N, int64_t wt_ld, int64_t IH, int64_t IW, int64_t OH, int64_t OW,
+                              int ksize, int stride, int pad, int transposed, float* scratch,
+                              sr_stream_t stream) {
+    return sr_conv2d_mfma_ex(out, in, wt, iscale, oscale, obias, B, C, N, wt_ld, IH, IW, OH, OW, ksize, stride, pad,
+                             transposed, 0, scratch, stream);
+}
+
 // Modulated 3x3 stride-1 convolution with the StyledConv tail fused into the store (Winograd kernel only).
 // SR_EINVAL when the shape is not taken by the Winograd path: the caller then runs sr_conv2d_mfma followed
 // by sr_noise_bias_act.
-extern "C" int sr_conv2d_nba(float* out, const float* in, const float* wt, const float* iscale, const float* oscale,
-                             const float* noise, const float* noise_w, const float* abias, float alpha, float gain,
-                             int64_t B, int64_t C, int64_t N, int64_t wt_ld, int64_t H, int64_t W,
-                             int64_t noise_bstride, float* scratch, sr_stream_t stream) {
+extern "C" int sr_conv2d_nba_ex(float* out, const float* in, const float* wt, const float* iscale, const float* oscale,
+                                const float* noise, const float* noise_w, const float* abias, float alpha, float gain,
+                                int64_t B, int64_t C, int64_t N, int64_t wt_ld, int64_t H, int64_t W,
+                                int64_t noise_bstride, int flags, float* scratch, sr_stream_t stream) {
     if (B < 0 || C <= 0 || N <= 0 || H <= 0 || W <= 0) return SR_EINVAL;
     if (wt_ld < N || wt_ld % 4 != 0 || (reinterpret_cast<uintptr_t>(wt) & 15)) return SR_EINVAL;
     if (B == 0) return SR_OK;
     if (!out || !in || !wt || !scratch || (noise && !noise_w)) return SR_EINVAL;
     if (!wino_enabled() || !sr_wino_eligible(B, C, N, H, W, in, out)) return SR_EINVAL;
     const WinoNba nba{noise, noise_w, abias, noise_bstride, alpha, gain};
-    return sr_wino_conv3x3(out, in, wt, wt_ld, iscale, oscale, nullptr, B, C, N, H, W, scratch, sr_stream(stream), &nba);
+    return sr_wino_conv3x3(out, in, wt, wt_ld, iscale, oscale, nullptr, B, C, N, H, W, scratch, sr_stream(stream), &nba,
+                           (flags & SR_CONV_U_READY) != 0);
+}
+
+extern "C" int sr_conv2d_nba(float* out, const float* in, const float* wt, const float* iscale, const float* oscale,
+                             const float* noise, const float* noise_w, const float* abias, float alpha, float gain,
+                             int64_t B, int64_t C, int64_t N, int64_t wt_ld, int64_t H, int64_t W,
+                             int64_t noise_bstride, float* scratch, sr_stream_t stream) {
+    return sr_conv2d_nba_ex(out, in, wt, iscale, oscale, noise, noise_w, abias, alpha, gain, B, C, N, wt_ld, H, W,
+                            noise_bstride, 0, scratch, stream);
 }

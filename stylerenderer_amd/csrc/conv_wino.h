@@ -42,7 +42,7 @@ int sr_wino_split(int64_t B, int64_t C, int64_t N, int64_t H, int64_t W);
 int64_t sr_wino_partial_floats(int64_t B, int64_t C, int64_t N, int64_t H, int64_t W);
 int sr_wino_conv3x3(float* out, const float* in, const float* wt, int64_t ldw, const float* iscale,
                     const float* oscale, const float* obias, int64_t B, int64_t C, int64_t N, int64_t H, int64_t W,
-                    float* u_scratch, hipStream_t st, const WinoNba* nba = nullptr);
+                    float* u_scratch, hipStream_t st, const WinoNba* nba = nullptr, bool u_ready = false);
 
 // Winograd weight gradient of the same convolution (csrc/conv_wgrad_wino.hip): H % 2 == 0, W % 16 == 0,
 // C % 64 == 0, N % 64 == 0, B <= 32

@@ -511,7 +511,7 @@ __global__ __launch_bounds__(64) void k_wino_weights(float* __restrict__ u, cons
 }
 
 template <int KC>
-int launch(const WinoParams& p, float* u, const float* wt, int ldw, hipStream_t st) {
+int launch(const WinoParams& p, float* u, const float* wt, int ldw, hipStream_t st, bool u_ready) {
     using G = WG<KC>;
     const int lds = (G::STY + p.kchunks * KC) * 4;
     auto kern = k_conv_wino<KC>;
@@ -524,7 +524,8 @@ int launch(const WinoParams& p, float* u, const float* wt, int ldw, hipStream_t 
         }
         configured = true;
     }
-    hipLaunchKernelGGL(k_wino_weights<KC>, dim3(p.N / 64, p.C), dim3(64), 0, st, u, wt, p.C, p.N, ldw);
+    // (u_ready: the caller kept the scratch of an earlier call with the same weights — a frozen network)
+    if (!u_ready) hipLaunchKernelGGL(k_wino_weights<KC>, dim3(p.N / 64, p.C), dim3(64), 0, st, u, wt, p.C, p.N, ldw);
     const int64_t blocks = (int64_t)p.tiles_n * p.tiles_x * p.tiles_y * p.B * p.ks;
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, st, p);
     if (p.ks > 1) {
@@ -572,7 +573,7 @@ int64_t sr_wino_partial_floats(int64_t B, int64_t C, int64_t N, int64_t H, int64
 
 int sr_wino_conv3x3(float* out, const float* in, const float* wt, int64_t ldw, const float* iscale,
                     const float* oscale, const float* obias, int64_t B, int64_t C, int64_t N, int64_t H, int64_t W,
-                    float* u_scratch, hipStream_t st, const WinoNba* nba) {
+                    float* u_scratch, hipStream_t st, const WinoNba* nba, bool u_ready) {
     WinoParams p;
     p.in = in; p.u = u_scratch; p.iscale = iscale; p.oscale = oscale; p.obias = obias; p.out = out;
     p.nba = nba ? 1 : 0;
@@ -583,5 +584,5 @@ int sr_wino_conv3x3(float* out, const float* in, const float* wt, int64_t ldw, c
     p.ks = sr_wino_split(B, C, N, H, W);
     p.kchunks = (int)(C / 8) / p.ks;
     p.partial = u_scratch + sr_wino_scratch_floats(C, N);          // behind the U block (sr_conv2d_scratch_floats)
-    return launch<8>(p, u_scratch, wt, (int)ldw, st);
+    return launch<8>(p, u_scratch, wt, (int)ldw, st, u_ready);
 }

@@ -8,10 +8,12 @@ Low-level operator used by layers.ModulatedConv2d / EqualConv2d for device tenso
 
 It replaces the F.conv2d / F.conv_transpose2d(groups=batch) calls of reference layers.py:301-322.
 """
+import os
+
 import torch
 
 from .. import _lib
-from ._dispatch import on_device_of, require_f32, stream_of
+from ._dispatch import hold_for_capture, on_device_of, require_f32, stream_of
 from . import weight_prep as _wp
 from .fused_elem import rowdot
 
@@ -67,15 +69,36 @@ def conv2d_mfma(x, wt, iscale=None, oscale=None, obias=None, ksize=3, stride=1, 
     flops = 2.0 * b * gh * gw * c * n * ksize * ksize
     L = _lib.lib()
     nscr = L.sr_conv2d_scratch_floats(b, c, n, ih, iw, oh, ow, ksize, stride, pad, int(bool(transposed)))
-    scratch = torch.empty(nscr, dtype=x.dtype, device=x.device) if nscr > 0 else None   # split-K (small maps)
+    scratch, flags = _conv_scratch(wt, nscr, (b, c, n, ih, iw, ksize, stride, pad, bool(transposed)), x)
     with on_device_of(x):
         rc = _timed("conv", (ksize, stride, int(bool(transposed)), b, c, n, gh, gw), flops,
-                    lambda: L.sr_conv2d_mfma(
+                    lambda: L.sr_conv2d_mfma_ex(
                         _lib.ptr(out), _lib.ptr(x), _lib.ptr(wt), _lib.ptr(iscale), _lib.ptr(oscale),
                         _lib.ptr(obias), b, c, n, ldw, ih, iw, oh, ow, ksize, stride, pad,
-                        int(bool(transposed)), _lib.ptr(scratch), stream_of(x)))
+                        int(bool(transposed)), flags, _lib.ptr(scratch), stream_of(x)))
     _lib.check(rc, "sr_conv2d_mfma")
     return out
+
+
+def _conv_scratch(wt, nscr, key, like):
+    """(scratch, flags) of one convolution call.  Weights a frozen network prepared once (`wt._sr_frozen`: latent
+    inversion, the LPIPS trunk) keep ONE scratch per call geometry of the stride-1 3x3 convolution: its leading block
+    holds the Winograd-domain weights, which the second and later calls reuse (SR_CONV_U_READY: one k_wino_weights launch
+    less per convolution and step); the split-K region behind it is rewritten by every call.  The buffer lives as long as
+    the prepared weight (a new weight version makes a new prepared tensor) and as any graph captured over it."""
+    if nscr <= 0:
+        return None, 0
+    if not (getattr(wt, "_sr_frozen", False) and key[5:] == (3, 1, 1, False)) or os.environ.get("SR_U_CACHE", "1") == "0":
+        return torch.empty(nscr, dtype=like.dtype, device=like.device), 0
+    cache = wt.__dict__.setdefault("_sr_scratch", {})
+    k = key + (os.environ.get("SR_WINOGRAD", "1"), os.environ.get("SR_WINO_SPLIT", "1"), wt._version, wt.data_ptr())
+    hit = cache.get(k)
+    if hit is not None and hit.numel() >= nscr:
+        return hold_for_capture(hit), 1
+    if len(cache) >= 6:                      # a handful of geometries per weight (batch sizes of one loop)
+        cache.clear()
+    cache[k] = torch.empty(nscr, dtype=like.dtype, device=like.device)
+    return hold_for_capture(cache[k]), 0
 
 
 def conv2d_wgrad_mfma(x, gy, xscale=None, gscale=None, ksize=3, stride=1, pad=1, transposed=False):
@@ -270,15 +293,15 @@ class ConvNBAFn(torch.autograd.Function):
         out = torch.empty((b, n, h, w), dtype=x.dtype, device=x.device)
         L = _lib.lib()
         nscr = L.sr_conv2d_scratch_floats(b, c, n, h, w, h, w, 3, 1, 1, 0)
-        scratch = torch.empty(max(nscr, 1), dtype=x.dtype, device=x.device)
+        scratch, flags = _conv_scratch(wt if wtp is wt else wtp, max(nscr, 1), (b, c, n, h, w, 3, 1, 1, False), x)
         bstride = 0 if noise is None or noise.numel() == h * w else h * w
         flops = 2.0 * b * h * w * c * n * 9
         with on_device_of(x):
             rc = _timed("conv", (3, 1, 0, b, c, n, h, w), flops,
-                        lambda: L.sr_conv2d_nba(_lib.ptr(out), _lib.ptr(x), _lib.ptr(wtp), _lib.ptr(iscale),
-                                                _lib.ptr(oscale), _lib.ptr(noise), _lib.ptr(noise_w), _lib.ptr(abias),
-                                                float(slope), float(gain), b, c, n, ldw, h, w, bstride,
-                                                _lib.ptr(scratch), stream_of(x)))
+                        lambda: L.sr_conv2d_nba_ex(_lib.ptr(out), _lib.ptr(x), _lib.ptr(wtp), _lib.ptr(iscale),
+                                                   _lib.ptr(oscale), _lib.ptr(noise), _lib.ptr(noise_w), _lib.ptr(abias),
+                                                   float(slope), float(gain), b, c, n, ldw, h, w, bstride, flags,
+                                                   _lib.ptr(scratch), stream_of(x)))
         _lib.check(rc, "sr_conv2d_nba")
         ctx.save_for_backward(x, wt, iscale, oscale, noise, noise_w, abias, out)
         ctx.cfg = (float(slope), float(gain))

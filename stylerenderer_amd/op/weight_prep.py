@@ -166,7 +166,9 @@ def adjoint_cached(wt, flip):
     hit = _FROZEN_ADJ.get(key)
     if hit is None:
         with torch.no_grad():
-            hit = _FROZEN_ADJ.put(key, (_adjoint_launch(wt, flip), wt))
+            adj = _adjoint_launch(wt, flip)
+            adj._sr_frozen = True              # (op.conv keeps the Winograd-domain weights of the data gradient too)
+            hit = _FROZEN_ADJ.put(key, (adj, wt))
     return hit[0]
 
 

@@ -559,3 +559,32 @@ def test_convlayer_shortcuts_equal_the_module_chain(monkeypatch):
         assert rel_err_t(ya, yb) < 2e-6, kw
         for u, v in zip(ga, gb):
             assert rel_err_t(u, v) < 2e-5, kw
+
+
+def test_frozen_weights_keep_their_winograd_domain_weights(monkeypatch):
+    """A prepared weight marked frozen (`_sr_frozen`: latent inversion, LPIPS trunk) keeps one scratch per call geometry;
+    the second and later calls skip k_wino_weights (SR_CONV_U_READY).  Same bits as the uncached call, for the plain and
+    the fused-tail entry point, with K slices too; an in-place change of the weight (version bump) is not served stale."""
+    from stylerenderer_amd.op import conv as cv
+
+    g = torch.Generator().manual_seed(3)
+    for b, c, n, h, w in ((1, 128, 64, 8, 32), (2, 64, 128, 16, 32)):
+        x = torch.randn(b, c, h, w, generator=g).to(DEV)
+        wt = (torch.randn(9, c, n, generator=g) / (3 * c ** 0.5)).to(DEV)
+        isc, osc = torch.randn(b, c, generator=g).to(DEV), torch.randn(b, n, generator=g).to(DEV)
+        monkeypatch.setenv("SR_U_CACHE", "0")
+        want = cv.conv2d_mfma(x, wt, isc, osc, None, 3, 1, 1)
+        monkeypatch.setenv("SR_U_CACHE", "1")
+        wt._sr_frozen = True
+        first = cv.conv2d_mfma(x, wt, isc, osc, None, 3, 1, 1)
+        assert len(wt._sr_scratch) == 1
+        second = cv.conv2d_mfma(x, wt, isc, osc, None, 3, 1, 1)          # U_READY: no weight transform launched
+        assert torch.equal(first, want) and torch.equal(second, want)
+        nz = torch.randn(b, 1, h, w, generator=g).to(DEV)
+        nw, ab = torch.tensor([0.3], device=DEV), torch.randn(n, generator=g).to(DEV)
+        a = cv.ConvNBAFn.apply(x, wt, isc, osc, nz, nw, ab, 0.2, 2 ** 0.5)
+        a2 = cv.ConvNBAFn.apply(x, wt, isc, osc, nz, nw, ab, 0.2, 2 ** 0.5)
+        assert torch.equal(a, a2)
+        wt.mul_(2.0)                                                      # new version: the cached block is not reused
+        doubled = cv.conv2d_mfma(x, wt, isc, osc, None, 3, 1, 1)
+        assert torch.allclose(doubled, 2 * want, rtol=1e-5, atol=1e-6)
