@@ -154,6 +154,8 @@ def test_lost_signal_times_out_and_raises(monkeypatch):
     assert not red.status.any()            # reported once
     # a published epoch releases at once and leaves the status clean
     _lib.check(L.sr_signal_set(red.counters.data_ptr() + 4, red.epoch_dev.data_ptr(), _lib.current_stream()), "set")
+    torch.cuda.synchronize()               # (the two kernels sit on different streams; a cold first launch of the set
+    #                                         kernel — code object load — may take longer than the 0.2 s of this test)
     _lib.check(L.sr_signal_wait_timeout(red.counters.data_ptr() + 4, 1, red.timeout_us, red.status.data_ptr() + 4, 2,
                                         red.comm.cuda_stream), "wait")
     torch.cuda.synchronize()
