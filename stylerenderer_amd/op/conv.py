@@ -85,7 +85,9 @@ def _conv_scratch(wt, nscr, key, like):
     inversion, the LPIPS trunk) keep ONE scratch per call geometry of the stride-1 3x3 convolution: its leading block
     holds the Winograd-domain weights, which the second and later calls reuse (SR_CONV_U_READY: one k_wino_weights launch
     less per convolution and step); the split-K region behind it is rewritten by every call.  The buffer lives as long as
-    the prepared weight (a new weight version makes a new prepared tensor) and as any graph captured over it."""
+    the prepared weight (a new weight version makes a new prepared tensor) and as any graph captured over it.
+    One stream per frozen network: two streams convolving with the same prepared weight and geometry at the same time
+    would share the split-K region (the loops that freeze a network — inversion, sampling — run on one stream)."""
     if nscr <= 0:
         return None, 0
     if not (getattr(wt, "_sr_frozen", False) and key[5:] == (3, 1, 1, False)) or os.environ.get("SR_U_CACHE", "1") == "0":
