@@ -399,9 +399,13 @@ __global__ __launch_bounds__(EB) void k_nba_aff_bwd(float* __restrict__ gx, floa
     }
 }
 
-// out[i] = sum over g (ascending) of part[g * plane + i]
-__global__ __launch_bounds__(EB) void k_plane_sum(float* __restrict__ out, const float* __restrict__ part,
+// out[i] = sum over g (ascending) of part[g * plane + i]; blockIdx.y selects one of two (out, part) pairs, so the two
+// map planes of the StyledMapConv tail are finished by ONE launch
+__global__ __launch_bounds__(EB) void k_plane_sum(float* __restrict__ out0, const float* __restrict__ part0,
+                                                  float* __restrict__ out1, const float* __restrict__ part1,
                                                   int64_t plane, int groups) {
+    float* out = blockIdx.y ? out1 : out0;
+    const float* part = blockIdx.y ? part1 : part0;
     const int64_t i = ((int64_t)blockIdx.x * EB + threadIdx.x) * 4;
     if (i >= plane) return;
     float4 acc = *reinterpret_cast<const float4*>(part + i);
@@ -471,8 +475,7 @@ extern "C" int sr_noise_bias_act_affine_bwd(float* gx, float* gamap, float* gsma
                        noise_bstride, chunks, cg, plane);
     if (groups > 1) {
         const unsigned g1 = (unsigned)sr_ceil_div(plane, EB * 4);
-        hipLaunchKernelGGL(k_plane_sum, dim3(g1), dim3(EB), 0, st, gamap, ga_part, plane, groups);
-        hipLaunchKernelGGL(k_plane_sum, dim3(g1), dim3(EB), 0, st, gsmap, gs_part, plane, groups);
+        hipLaunchKernelGGL(k_plane_sum, dim3(g1, 2), dim3(EB), 0, st, gamap, ga_part, gsmap, gs_part, plane, groups);
     }
     if (gbias) {                                            // (NULL: frozen bias / noise strength)
         hipLaunchKernelGGL(k_nba_finish, dim3((unsigned)c), dim3(64), 0, st, gbias, chan_nw, scratch, n, (int)c,
