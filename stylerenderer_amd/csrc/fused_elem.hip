@@ -286,8 +286,9 @@ extern "C" int sr_noise_bias_act_bwd_dot(float* gx, float* gbias, float* gnoise_
     if (!vec_ok(inner, gx, gy, out, noise) || (noise && noise_bstride % 4 != 0)) return SR_EINVAL;
     const int chunks = (int)sr_ceil_div(inner, ECHUNK);
     hipStream_t st = sr_stream(stream);
-    float* dot_partial = scratch + 2 * n * c * (int64_t)chunks;
-    float* chan_nw = dot_partial + n * c * (int64_t)chunks;
+    float* dot_scratch = scratch + 2 * n * c * (int64_t)chunks;
+    float* chan_nw = dot_scratch + n * c * (int64_t)chunks;
+    float* dot_partial = chunks == 1 ? rowdot : dot_scratch;              // (one chunk: in place, see sr_rowdot)
     hipLaunchKernelGGL(k_nba_bwd<true>, dim3(chunks, (unsigned)(n * c)), dim3(EB), 0, st, gx, scratch, gy, out, noise,
                        alpha, scale, (int)c, inner, noise_bstride, chunks, noise_w, bias, 1.0f / scale,
                        1.0f / (alpha * scale), dot_partial);
@@ -296,7 +297,8 @@ extern "C" int sr_noise_bias_act_bwd_dot(float* gx, float* gbias, float* gnoise_
         if (noise && gnoise_w)
             hipLaunchKernelGGL(k_nba_finish2, dim3(1), dim3(64), 0, st, gnoise_w, chan_nw, (int)c);
     }
-    hipLaunchKernelGGL(k_rowdot_finish, dim3((unsigned)(n * c)), dim3(64), 0, st, rowdot, dot_partial, chunks);
+    if (chunks > 1)
+        hipLaunchKernelGGL(k_rowdot_finish, dim3((unsigned)(n * c)), dim3(64), 0, st, rowdot, dot_partial, chunks);
     return sr_launch_status();
 }
 
@@ -611,14 +613,17 @@ extern "C" int sr_rowdot(float* dots, float* out_scaled, const float* a, const f
     hipStream_t st = sr_stream(stream);
     const int chunks = (int)sr_ceil_div(inner > 0 ? inner : 1, ECHUNK);
     const dim3 grid(chunks, (unsigned)rows);
+    // one chunk per row (maps up to 64^2): the row's single partial sum IS its dot product — written in place, no
+    // finish launch (the finish kernel would add it to zero)
+    float* partial = chunks == 1 ? dots : scratch;
     if (out_scaled) {
-        if (vec) hipLaunchKernelGGL((k_rowdot<true, true>), grid, dim3(EB), 0, st, scratch, out_scaled, a, b, scale, inner, chunks);
-        else hipLaunchKernelGGL((k_rowdot<true, false>), grid, dim3(EB), 0, st, scratch, out_scaled, a, b, scale, inner, chunks);
+        if (vec) hipLaunchKernelGGL((k_rowdot<true, true>), grid, dim3(EB), 0, st, partial, out_scaled, a, b, scale, inner, chunks);
+        else hipLaunchKernelGGL((k_rowdot<true, false>), grid, dim3(EB), 0, st, partial, out_scaled, a, b, scale, inner, chunks);
     } else {
-        if (vec) hipLaunchKernelGGL((k_rowdot<false, true>), grid, dim3(EB), 0, st, scratch, out_scaled, a, b, scale, inner, chunks);
-        else hipLaunchKernelGGL((k_rowdot<false, false>), grid, dim3(EB), 0, st, scratch, out_scaled, a, b, scale, inner, chunks);
+        if (vec) hipLaunchKernelGGL((k_rowdot<false, true>), grid, dim3(EB), 0, st, partial, out_scaled, a, b, scale, inner, chunks);
+        else hipLaunchKernelGGL((k_rowdot<false, false>), grid, dim3(EB), 0, st, partial, out_scaled, a, b, scale, inner, chunks);
     }
-    hipLaunchKernelGGL(k_rowdot_finish, dim3((unsigned)rows), dim3(64), 0, st, dots, scratch, chunks);
+    if (chunks > 1) hipLaunchKernelGGL(k_rowdot_finish, dim3((unsigned)rows), dim3(64), 0, st, dots, scratch, chunks);
     return sr_launch_status();
 }
 
@@ -682,10 +687,10 @@ extern "C" int sr_rowdot_bwd(float* ga, float* gb, float* gs, const float* a, co
     hipStream_t st = sr_stream(stream);
     const int chunks = (int)sr_ceil_div(inner, ECHUNK);
     const dim3 grid(chunks, (unsigned)rows);
-    float* partial = gs ? scratch : nullptr;
+    float* partial = gs ? (chunks == 1 ? gs : scratch) : nullptr;         // (one chunk: in place, see sr_rowdot)
     if (vec) hipLaunchKernelGGL((k_rowdot_bwd<true>), grid, dim3(EB), 0, st, partial, ga, gb, a, b, gd, go, scale, inner, chunks);
     else hipLaunchKernelGGL((k_rowdot_bwd<false>), grid, dim3(EB), 0, st, partial, ga, gb, a, b, gd, go, scale, inner, chunks);
-    if (gs) hipLaunchKernelGGL(k_rowdot_finish, dim3((unsigned)rows), dim3(64), 0, st, gs, scratch, chunks);
+    if (gs && chunks > 1) hipLaunchKernelGGL(k_rowdot_finish, dim3((unsigned)rows), dim3(64), 0, st, gs, scratch, chunks);
     return sr_launch_status();
 }
 
