@@ -786,7 +786,7 @@ __global__ __launch_bounds__(256) void k_smallconv_dx(float* __restrict__ dx, co
 template <int N, int CH>
 __global__ __launch_bounds__(256) void k_smallconv_dw(float* __restrict__ partial, const float* __restrict__ g,
                                                       const float* __restrict__ x, int C, int64_t hw,
-                                                      int chunks) {
+                                                      int chunks, float* __restrict__ dws) {
     __shared__ float lds[CH][4 * SC_MAXN];
     const int64_t row0 = (int64_t)blockIdx.y * CH;   // b * C + c0, CH consecutive channels of one sample
     const int64_t b = row0 / C;
@@ -822,8 +822,10 @@ __global__ __launch_bounds__(256) void k_smallconv_dw(float* __restrict__ partia
     __syncthreads();
     if (threadIdx.x < CH * N) {
         const int k = threadIdx.x / N, j = threadIdx.x % N;
-        partial[((row0 + k) * chunks + blockIdx.x) * N + j] =
-            (lds[k][j * 4] + lds[k][j * 4 + 1]) + (lds[k][j * 4 + 2] + lds[k][j * 4 + 3]);
+        const float r = (lds[k][j * 4] + lds[k][j * 4 + 1]) + (lds[k][j * 4 + 2] + lds[k][j * 4 + 3]);
+        // one chunk per row (maps up to 64^2): this IS the result — stored in the output layout, no finish launch
+        if (dws) dws[(b * N + j) * C + (row0 + k - b * C)] = r;
+        else partial[((row0 + k) * chunks + blockIdx.x) * N + j] = r;
     }
 }
 
@@ -888,25 +890,27 @@ extern "C" int sr_smallconv_dw(float* dws, const float* g, const float* x, int64
     if (!dws || !g || !x || !scratch || !smallconv_ok(B, C, N, hw, g, x) || B * C > 65535) return SR_EINVAL;
     const int chunks = (int)sr_ceil_div(hw, ECHUNK);
     hipStream_t st = sr_stream(stream);
+    float* direct = chunks == 1 ? dws : nullptr;
     if (C % 4 == 0) {
         const dim3 grid((unsigned)chunks, (unsigned)(B * C / 4));
         switch (N) {
-            case 1: hipLaunchKernelGGL((k_smallconv_dw<1, 4>), grid, dim3(256), 0, st, scratch, g, x, (int)C, hw, chunks); break;
-            case 2: hipLaunchKernelGGL((k_smallconv_dw<2, 4>), grid, dim3(256), 0, st, scratch, g, x, (int)C, hw, chunks); break;
-            case 3: hipLaunchKernelGGL((k_smallconv_dw<3, 4>), grid, dim3(256), 0, st, scratch, g, x, (int)C, hw, chunks); break;
-            default: hipLaunchKernelGGL((k_smallconv_dw<4, 4>), grid, dim3(256), 0, st, scratch, g, x, (int)C, hw, chunks); break;
+            case 1: hipLaunchKernelGGL((k_smallconv_dw<1, 4>), grid, dim3(256), 0, st, scratch, g, x, (int)C, hw, chunks, direct); break;
+            case 2: hipLaunchKernelGGL((k_smallconv_dw<2, 4>), grid, dim3(256), 0, st, scratch, g, x, (int)C, hw, chunks, direct); break;
+            case 3: hipLaunchKernelGGL((k_smallconv_dw<3, 4>), grid, dim3(256), 0, st, scratch, g, x, (int)C, hw, chunks, direct); break;
+            default: hipLaunchKernelGGL((k_smallconv_dw<4, 4>), grid, dim3(256), 0, st, scratch, g, x, (int)C, hw, chunks, direct); break;
         }
     } else {
         const dim3 grid((unsigned)chunks, (unsigned)(B * C));
         switch (N) {
-            case 1: hipLaunchKernelGGL((k_smallconv_dw<1, 1>), grid, dim3(256), 0, st, scratch, g, x, (int)C, hw, chunks); break;
-            case 2: hipLaunchKernelGGL((k_smallconv_dw<2, 1>), grid, dim3(256), 0, st, scratch, g, x, (int)C, hw, chunks); break;
-            case 3: hipLaunchKernelGGL((k_smallconv_dw<3, 1>), grid, dim3(256), 0, st, scratch, g, x, (int)C, hw, chunks); break;
-            default: hipLaunchKernelGGL((k_smallconv_dw<4, 1>), grid, dim3(256), 0, st, scratch, g, x, (int)C, hw, chunks); break;
+            case 1: hipLaunchKernelGGL((k_smallconv_dw<1, 1>), grid, dim3(256), 0, st, scratch, g, x, (int)C, hw, chunks, direct); break;
+            case 2: hipLaunchKernelGGL((k_smallconv_dw<2, 1>), grid, dim3(256), 0, st, scratch, g, x, (int)C, hw, chunks, direct); break;
+            case 3: hipLaunchKernelGGL((k_smallconv_dw<3, 1>), grid, dim3(256), 0, st, scratch, g, x, (int)C, hw, chunks, direct); break;
+            default: hipLaunchKernelGGL((k_smallconv_dw<4, 1>), grid, dim3(256), 0, st, scratch, g, x, (int)C, hw, chunks, direct); break;
         }
     }
-    hipLaunchKernelGGL(k_smallconv_dw_finish, dim3((unsigned)(B * C)), dim3(64), 0, st, dws, scratch, (int)C,
-                       (int)N, chunks, B * C);
+    if (chunks > 1)
+        hipLaunchKernelGGL(k_smallconv_dw_finish, dim3((unsigned)(B * C)), dim3(64), 0, st, dws, scratch, (int)C,
+                           (int)N, chunks, B * C);
     return sr_launch_status();
 }
 
