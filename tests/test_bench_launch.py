@@ -57,3 +57,33 @@ def test_world_size_mismatch_is_refused():
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--plumbing", "--gpus", "2"],
                        capture_output=True, text=True, timeout=120, env=env, cwd=ROOT)
     assert p.returncode != 0 and "WORLD_SIZE" in (p.stderr + p.stdout)
+
+
+def test_roofline_objects_prefer_counters_of_this_run():
+    """bench.pmc_traffic / valu_roofline: counters collected by collect_live_pmc (this run's own rocprofv3 --pmc passes)
+    win over the committed summary and are labelled as measured in the run; kernel names are shortened the way
+    scripts/pmc_summary.py does it; 2*FETCH_SIZE + WRITE_SIZE (KB) per launch; VALU issue floor 4 cycles per wave64
+    instruction over 1024 SIMDs at 2.4 GHz."""
+    import importlib
+    import sys
+
+    sys.path.insert(0, ROOT)
+    bench = importlib.import_module("bench")
+    assert bench._short_kernel("void (anonymous namespace)::k_grad_pix<float, 3, false>(long long, long long)") == \
+        "k_grad_pix<float; 3; false>"
+    committed = bench.pmc_traffic("k_conv_wino<8>")
+    assert committed.get("traffic_measured_in_this_run") is False and committed["traffic"] > 0
+    bench._LIVE_PMC.clear()
+    bench._LIVE_PMC["k_conv_wino<8>"] = {"FETCH_SIZE": 100.0, "WRITE_SIZE": 50.0, "SQ_VALU_MFMA_BUSY_CYCLES": 768.0,
+                                         "GRBM_GUI_ACTIVE": 8.0}
+    try:
+        live = bench.pmc_traffic("k_conv_wino<8>")
+        assert live["traffic_measured_in_this_run"] is True and live["traffic"] == round(250.0 * 1024)
+        assert live["mfma_pipe_busy"] == 0.75 and live["mfma_pipe_busy_measured_in_this_run"] is True
+        bench._LIVE_PMC["a"] = {"SQ_INSTS_VALU": 3.0e7}
+        bench._LIVE_PMC["b"] = {"SQ_INSTS_VALU": 1.0e7}
+        v = bench.valu_roofline(["a", "b"], 0.1)
+        assert v["counters_measured_in_this_run"] is True and v["wave_instructions_per_launch"] == 40000000
+        assert abs(v["issue_floor_ms"] - 4.0e7 / (1024 * 2.4e9 / 4) * 1e3) < 1e-4 and abs(v["frac"] - v["issue_floor_ms"] / 0.1) < 1e-3
+    finally:
+        bench._LIVE_PMC.clear()
