@@ -21,10 +21,10 @@ def child():
             y = conv2d_mfma(x, wt, isc, osc, None, 3, 2, 0, True)
         torch.cuda.synchronize()
         t = time.time()
-        for _ in range(5):
+        for _ in range(20):
             y = conv2d_mfma(x, wt, isc, osc, None, 3, 2, 0, True)
         torch.cuda.synchronize()
-        dt = (time.time() - t) / 5
+        dt = (time.time() - t) / 20
         print("%s convT B%d C%d N%d res%d: %.3f ms  %.1f TFLOP/s" % (tag, b, c, n, res, dt * 1e3,
                                                                     2.0 * b * res * res * c * n * 9 / dt / 1e12), flush=True)
 

@@ -59,6 +59,12 @@ struct WgW {
     static constexpr int LDS_FLOATS = 2 * RAW + 2 * OBUF + PAD + 2 * MAX_B * 64;
 };
 
+constexpr int digit_sum(const char (&a)[9]) {
+    int c = 0;
+    for (int i = 0; i < 8; ++i) c += a[i] - '0';
+    return c;
+}
+
 #ifdef WGW_TIMING
 // debug build only (scripts/build_variant.sh): per-workgroup time stamps of wave 0
 __device__ long long g_wgw_stamps[8 * 16384];
@@ -272,73 +278,94 @@ __global__ __launch_bounds__(64 * NW) void k_wgrad_wino(const WgWinoParams p) {
         f2 sv, gv;                        // style / demodulation of this (sample, channel), both halves
     };
     const int t_wr = (wq >> 1) * 512 + (wq & 1) * 256 + lane * 4;
+    // The transform of an item is cut into micro-steps that are pinned to the MFMA slots of a body by the schedule
+    // strings below (one digit = the slot, 0..7, of a micro-step); every schedule produces the same bits.
+    //   input tile  (WGW_VS): load rows 0,1 + style | load rows 2,3 | row stage a | row stage b | column stage of rows
+    //                         0,1 | of rows 2,3 | store positions 0..7 | store positions 8..15
+    //   output tile (WGW_ZS): demodulation | load | row stage | positions 0..7 | their store | positions 8..15 | store
+    // Measured (round 4, scripts/wgw_ablate.sh, 256 -> 256 at 128^2, batch 16): round 3's schedule (VS 01234556, ZS
+    // 0146777, DMA instructions in slots 0..2) 1.381 ms; output-tile transform early 1.31; + both row stages of the input
+    // tile in slot 2 1.30; + DMA instructions in slots 3..5 (behind the transform loads, not beside them) 1.257.  The
+    // same bits every time: only the issue order of one wave's non-MFMA instructions changes.
+#ifndef WGW_VS
+#define WGW_VS "01223345"
+#endif
+#ifndef WGW_ZS
+#define WGW_ZS "0011223"
+#endif
+    constexpr char VS[] = WGW_VS, ZS[] = WGW_ZS;
+    static_assert(sizeof(VS) == 9 && sizeof(ZS) == 8, "schedule strings: 8 and 7 slots");
     auto xf_step = [&](XF& x, int step, const float* rw, int hsel, int b_smp, float* ob) {
         // rw: strip image; hsel: which half of the strip (tiles 4 hsel + wave); ob: operand buffer written
         const float* xr = rw + 1 + lane * (XS * 4) + 3 + 2 * (4 * hsel + wq);
         const float* gr = rw + X_FLOATS + lane * (GS * 4) + 2 * (4 * hsel + wq);
-        if (step == 0) {
-            if (do_v) {
+        const int d = '0' + step;
+        if (do_v) {
+            if (VS[0] == d) {
                 x.P[0] = ld2(xr); x.Q[0] = ld2(xr + 2);
                 x.P[1] = ld2(xr + 24); x.Q[1] = ld2(xr + 26);
                 const float sx = tabx[b_smp * 64 + lane];
                 x.sv.x = x.sv.y = sx;
             }
-            if (do_z) {
-                const float sg = tabg[b_smp * 64 + lane];
-                x.gv.x = x.gv.y = sg;
-            }
-        } else if (step == 1) {
-            if (do_v) {
+            if (VS[1] == d) {
                 x.P[2] = ld2(xr + 48); x.Q[2] = ld2(xr + 50);
                 x.P[3] = ld2(xr + 72); x.Q[3] = ld2(xr + 74);
             }
-            if (do_z) {
-                x.g0 = ld2(gr);
-                x.g1 = ld2(gr + 16);
-            }
-        } else if (step == 2) {
-            if (do_v) {
+            if (VS[2] == d) {
                 x.sp1 = pk_mul(x.P[1], x.sv); x.sp2 = pk_mul(x.P[2], x.sv);
                 x.sq1 = pk_mul(x.Q[1], x.sv); x.sq2 = pk_mul(x.Q[2], x.sv);
                 x.tp[0] = pk_fms(x.P[0], x.sv, x.sp2); x.tq[0] = pk_fms(x.Q[0], x.sv, x.sq2);
             }
-        } else if (step == 3) {
-            if (do_v) {
+            if (VS[3] == d) {
                 x.tp[1] = pk_add(x.sp1, x.sp2); x.tq[1] = pk_add(x.sq1, x.sq2);
                 x.tp[2] = pk_sub(x.sp2, x.sp1); x.tq[2] = pk_sub(x.sq2, x.sq1);
                 x.tp[3] = pk_fnma(x.P[3], x.sv, x.sp1); x.tq[3] = pk_fnma(x.Q[3], x.sv, x.sq1);
             }
-        } else if (step == 4) {
-            if (do_v) {
+            if (VS[4] == d) {
                 x.o01[0] = col01(x.tp[0], x.tq[0]); x.o23[0] = col23(x.tp[0], x.tq[0]);
                 x.o01[1] = col01(x.tp[1], x.tq[1]); x.o23[1] = col23(x.tp[1], x.tq[1]);
             }
-            if (do_z) {
-                x.w0 = pk_mul(x.g0, x.gv); x.w3 = pk_mul(x.g1, x.gv);
-                x.w1 = pk_add(x.w0, x.w3); x.w2 = pk_sub(x.w0, x.w3);
-            }
-        } else if (step == 5) {
-            if (do_v) {
+            if (VS[5] == d) {
                 x.o01[2] = col01(x.tp[2], x.tq[2]); x.o23[2] = col23(x.tp[2], x.tq[2]);
                 x.o01[3] = col01(x.tp[3], x.tq[3]); x.o23[3] = col23(x.tp[3], x.tq[3]);
+            }
+            if (VS[6] == d) {
 #pragma unroll
                 for (int q = 0; q < 2; ++q) st4(ob + t_wr + q * 1024, x.o01[q], x.o23[q]);
             }
-        } else if (step == 6) {
-            if (do_z) {
-                x.z01[0] = z_lo(x.w0, c01); x.z23[0] = z_hi(x.w0, c10);
-                x.z01[1] = z_lo(x.w1, c01); x.z23[1] = z_hi(x.w1, c10);
-            }
-            if (do_v) {
+            if (VS[7] == d) {
 #pragma unroll
                 for (int q = 2; q < 4; ++q) st4(ob + t_wr + q * 1024, x.o01[q], x.o23[q]);
             }
-        } else {
-            if (do_z) {
+        }
+        if (do_z) {
+            if (ZS[0] == d) {
+                const float sg = tabg[b_smp * 64 + lane];
+                x.gv.x = x.gv.y = sg;
+            }
+            if (ZS[1] == d) {
+                x.g0 = ld2(gr);
+                x.g1 = ld2(gr + 16);
+            }
+            if (ZS[2] == d) {
+                x.w0 = pk_mul(x.g0, x.gv); x.w3 = pk_mul(x.g1, x.gv);
+                x.w1 = pk_add(x.w0, x.w3); x.w2 = pk_sub(x.w0, x.w3);
+            }
+            if (ZS[3] == d) {
+                x.z01[0] = z_lo(x.w0, c01); x.z23[0] = z_hi(x.w0, c10);
+                x.z01[1] = z_lo(x.w1, c01); x.z23[1] = z_hi(x.w1, c10);
+            }
+            if (ZS[4] == d) {
+#pragma unroll
+                for (int q = 0; q < 2; ++q) st4(ob + OB + t_wr + q * 1024, x.z01[q], x.z23[q]);
+            }
+            if (ZS[5] == d) {
                 x.z01[2] = z_lo(x.w2, c01); x.z23[2] = z_hi(x.w2, c10);
                 x.z01[3] = z3_lo(x.w3, c01); x.z23[3] = z3_hi(x.w3, c10);
+            }
+            if (ZS[6] == d) {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) st4(ob + OB + t_wr + q * 1024, x.z01[q], x.z23[q]);
+                for (int q = 2; q < 4; ++q) st4(ob + OB + t_wr + q * 1024, x.z01[q], x.z23[q]);
             }
         }
     };
@@ -411,19 +438,42 @@ __global__ __launch_bounds__(64 * NW) void k_wgrad_wino(const WgWinoParams p) {
             av[kp][pq] = ld4(ob_rd + a_rd + pq * 1024 + kp * 512);
             bz[kp][pq] = ld4(ob_rd + b_rd + pq * 1024 + kp * 512);
         };
+        // MFMAs (in sixteenths of the body's 2 NPOS) and DMA instructions per slot: WGW_MS / WGW_DS, one digit per slot
+#ifndef WGW_MS
+#define WGW_MS "22222222"
+#endif
+#ifndef WGW_DS8
+#define WGW_DS8 "00022200"
+#endif
+#ifndef WGW_DS4
+#define WGW_DS4 "00022222"
+#endif
+        constexpr char MS[] = WGW_MS, DS8[] = WGW_DS8, DS4[] = WGW_DS4;
+        static_assert(sizeof(MS) == 9 && sizeof(DS8) == 9 && sizeof(DS4) == 9, "one digit per slot");
+        const char* const DS = NW == 8 ? DS8 : DS4;
+        static_assert(digit_sum(MS) == 16 && digit_sum(DS8) >= WgW<8>::N_DMA && digit_sum(DS4) >= WgW<4>::N_DMA,
+                      "schedule strings: 16 sixteenths of the MFMAs, every DMA instruction of a strip");
+        int m_done = 0, d_done = 0;                                     // (compile-time after unrolling)
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
+            const int m_next = m_done + (MS[s] - '0') * (NPOS / 8);
             if (!FIRST) {
 #pragma unroll
-                for (int u = 0; u < NPOS / 4; ++u) mfma_step((NPOS / 4) * s + u);
+                for (int u = 0; u < 9 * (NPOS / 8); ++u)                  // (fixed bound: unrolls whatever the digits)
+                    if (m_done + u < m_next) mfma_step(m_done + u);
             }
-            if (NW == 4) load_ops(s >> 2, s & 3);                       // the quad this slot has just consumed
-            else if (s & 1) load_ops(s >> 2, (s & 3) >> 1);             // (two slots per quad)
+            // refill the quads whose MFMAs have all been issued (quad g = MFMAs 4g .. 4g + 3 of the body)
+#pragma unroll
+            for (int g = 0; g < NPOS / 2; ++g)
+                if (4 * (g + 1) > m_done && 4 * (g + 1) <= m_next) load_ops(g / (NPOS / 4), g % (NPOS / 4));
+            m_done = m_next;
 #ifndef WGW_NO_DMA
             if (j_par == 1) {
-                if (2 * s < N_DMA) dma1(2 * s);
-                if (2 * s + 1 < N_DMA) dma1(2 * s + 1);
+#pragma unroll
+                for (int u = 0; u < 9; ++u)
+                    if (u < DS[s] - '0' && d_done + u < N_DMA) dma1(d_done + u);
             }
+            d_done += DS[s] - '0';
 #endif
 #ifndef WGW_NO_XFORM
             xf_step(x, s, rw, j_par == 0 ? 1 : 0, b_smp, ob_wr);

@@ -341,27 +341,58 @@ __global__ __launch_bounds__(256) void k_conv_wino(const WinoParams p) {
             }
         };
         // 16 slots of 4 MFMAs; the LDS / VALU / DMA work is pinned between them (sched_barrier: nothing crosses
-        // a slot edge)
+        // a slot edge) by the schedule strings below, one hex digit = the slot of a unit of work:
+        //   WINO_RD  halo rows 0..3 of the transform item          WINO_ST  transform steps 0..3
+        //   WINO_WR  operand stores of result rows 0..3            WINO_L0 / WINO_L1  operand fetches (position pairs
+        //   2i, 2i+1) of the first quad of chunk k / of its second quad (consumed in slots 8+i / in the next body's i)
+        //   WINO_DD  halo DMA instruction pairs 0, 1               WINO_DU  weight DMA instruction pairs 0..3
+        // Every schedule that respects read -> step -> write and "refill after the last use" gives the same bits.
+#ifndef WINO_RD
+// round 3: L0 0123, DD 01, DU 4567 (operand fetches and DMA issue beside the transform's halo reads); round 4
+// (scripts/wino_ablate.sh, 20-launch means, same box): 1.398 / 1.175 / 1.103 ms -> 1.374 / 1.143 / 1.074 at
+// 128 ch 256^2 / 256 ch 128^2 / 512 ch 64^2, batch 16.  Earlier stores (WR 89AB) cost 3 %, later weight DMA (CDEF) 4 %.
+#define WINO_RD "0123"
+#define WINO_ST "4567"
+#define WINO_WR "CDEF"
+#define WINO_L0 "4567"
+#define WINO_L1 "89AB"
+#define WINO_DD "45"
+#define WINO_DU "89AB"
+#endif
+        constexpr char RD[] = WINO_RD, ST[] = WINO_ST, WR[] = WINO_WR, L0[] = WINO_L0, L1[] = WINO_L1, DD[] = WINO_DD,
+                       DU[] = WINO_DU;
+        static_assert(sizeof(RD) == 5 && sizeof(ST) == 5 && sizeof(WR) == 5 && sizeof(L0) == 5 && sizeof(L1) == 5 &&
+                      sizeof(DD) == 3 && sizeof(DU) == 5, "schedule strings");
+        static_assert(G::D_PER_WAVE == 4 && G::U_INSTR / 4 == 8, "4 halo + 8 weight DMA instructions per wave");
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
             const int cq = (s < 8) ? 1 : 0, j = s & 7;
+            const char d = s < 10 ? '0' + s : 'A' + (s - 10);
             if (!(FIRST && s < 8)) {
 #pragma unroll
                 for (int u = 0; u < 4; ++u) mfma_step(cq, 4 * j + u);
             }
-            if (s < 4) { load_ops(0, 2 * s); load_ops(0, 2 * s + 1); }                     // first quad of chunk k
-            if (s >= 8 && s < 12) { load_ops(1, 2 * (s - 8)); load_ops(1, 2 * (s - 8) + 1); }  // second quad (next body)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (L0[i] == d) { load_ops(0, 2 * i); load_ops(0, 2 * i + 1); }            // first quad of chunk k
+                if (L1[i] == d) { load_ops(1, 2 * i); load_ops(1, 2 * i + 1); }            // second quad (next body)
+            }
 #ifndef WINO_NO_DMA
-            // two DMA instructions per slot (4 halo + 8 weight instructions per wave): the halo patch (HBM for the
-            // first output-channel tile that touches it) is in flight 15 slots before the next barrier, the
-            // (L2-resident) weights at least 8
-            if (s < 2) { dma_d1(kd, k & 1, 2 * s); dma_d1(kd, k & 1, 2 * s + 1); }
-            else if (s >= 4 && s < 8) { dma_u1(ku, (k + 1) & 1, 2 * (s - 4)); dma_u1(ku, (k + 1) & 1, 2 * (s - 4) + 1); }
+            // the halo patch (HBM for the first output-channel tile that touches it) has to be in flight long before
+            // the next barrier, the (L2-resident) weights less so
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (i < 2 && DD[i] == d) { dma_d1(kd, k & 1, 2 * i); dma_d1(kd, k & 1, 2 * i + 1); }
+                if (DU[i] == d) { dma_u1(ku, (k + 1) & 1, 2 * i); dma_u1(ku, (k + 1) & 1, 2 * i + 1); }
+            }
 #endif
 #ifndef WINO_NO_XFORM
-            if (s < 4) xf_read(x, d0, s);
-            if (s >= 4 && s < 8) xf_step(x, s - 4, sab);
-            if (s >= 12) xf_write(x, vout, s - 12);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) if (RD[i] == d) xf_read(x, d0, i);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) if (ST[i] == d) xf_step(x, i, sab);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) if (WR[i] == d) xf_write(x, vout, i);
 #endif
             __builtin_amdgcn_sched_barrier(0);
         }
