@@ -458,9 +458,10 @@ def train_leg(dev, rank, world, iters, batch, size=256, plumbing=False):
         # from the backward hooks), a rank that sat it out would leave the others' all-reduces unmatched.  Rank 0 reports.
         from stylerenderer_amd.op import conv as conv_op
 
-        cadence = {"d": 1.0, "r1": 1.0 / 16, "g": 1.0, "path": 1.0 / 4, "d_opt": 1.0 + 1.0 / 16, "g_opt": 1.0 + 1.0 / 4}
+        cadence = {"d": 1.0, "r1": 1.0 / 16, "g": 1.0, "path": 1.0 / 4, "d_opt": 1.0 + 1.0 / 16, "g_opt": 1.0 + 1.0 / 4,
+                   "ema": 1.0}
         phases = {}
-        for name in ("d", "r1", "g", "path", "d_opt", "g_opt"):
+        for name in ("d", "r1", "g", "path", "d_opt", "g_opt", "ema"):
             phases[name] = {"ms_per_replay": round(tr.time_phase(name, 3), 3), "per_iteration": round(cadence[name], 4),
                             "kernel_nodes": getattr(tr.graphs[name], "kernel_nodes", None)}
         for name in ("d", "r1", "g", "path"):

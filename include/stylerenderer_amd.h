@@ -174,6 +174,9 @@ int sr_affine3_bwd(float* gm, float* gt, const float* v, const float* g, int64_t
  * gradient is sr_affine3_bwd's gt).  One lane each: replaces ~60 one-element tensor-algebra launches per step. */
 int sr_pose_fwd(float* lin, float* rot, const float* pose, sr_stream_t stream);
 int sr_pose_bwd(float* gpose, const float* glin, const float* grot, const float* pose, sr_stream_t stream);
+/* B poses at once, forward only: lin [B, 3, 3], rot [B, 3, 3] or NULL, pose [B, 7].  The random poses of the training
+ * loop (reference utils_3d.py:360-376 random_apply_pose3D: euler_mat + scale for a batch of sampled poses). */
+int sr_pose_batch_fwd(float* lin, float* rot, const float* pose, int64_t B, sr_stream_t stream);
 
 /* Skinny linear algebra of the style path, B = per-GPU batch rows (csrc/style_linear.hip).
  * EqualLinear (reference layers.py:222-248), optionally with the fused leaky-ReLU of the mapping

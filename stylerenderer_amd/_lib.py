@@ -79,6 +79,7 @@ SIGNATURES = {
     "sr_rasterize_grad_f64": (_i, [_l] * 5 + [_i] * 2 + [_p, _p, _l] + [_p] * 6 + [_l, _l, _p, _p, _d, _p, _p]),
     "sr_pose_fwd": (_i, [_p, _p, _p, _p]),
     "sr_pose_bwd": (_i, [_p, _p, _p, _p, _p]),
+    "sr_pose_batch_fwd": (_i, [_p, _p, _p, _l, _p]),
     "sr_affine3_fwd": (_i, [_p, _p, _p, _p, _l, _l, _l, _p]),
     "sr_affine3_bwd": (_i, [_p, _p, _p, _p, _l, _l, _l, _p]),
     "sr_signal_bump": (_i, [_p, _p]),

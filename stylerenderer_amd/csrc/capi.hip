@@ -3,7 +3,7 @@
 
 #include "common.h"
 
-extern "C" int sr_abi_version(void) { return 6; }
+extern "C" int sr_abi_version(void) { return 7; }
 
 extern "C" const char* sr_error_string(int code) {
     if (code == SR_OK) return "ok";

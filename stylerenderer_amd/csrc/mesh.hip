@@ -127,14 +127,20 @@ __device__ __forceinline__ void axis_mats(const float* pose, float* ry, float* r
     for (int i = 0; i < 9; ++i) { ry[i] = y[i]; rx[i] = x[i]; rz[i] = z[i]; dry[i] = dy[i]; drx[i] = dx[i]; drz[i] = dz[i]; }
 }
 
-__global__ void k_pose_fwd(float* __restrict__ lin, float* __restrict__ rot, const float* __restrict__ pose) {
+__global__ void k_pose_fwd(float* __restrict__ lin, float* __restrict__ rot, const float* __restrict__ pose, int B) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;          // one pose per thread
+    if (b >= B) return;
+    pose += 7 * b;
     float ry[9], rx[9], rz[9], d0[9], d1[9], d2[9], t[9], r[9];
     axis_mats(pose, ry, rx, rz, d0, d1, d2);
     mat3_mul(rx, ry, t);
     mat3_mul(rz, t, r);
     const float sc = expf(pose[6]);
 #pragma unroll
-    for (int i = 0; i < 9; ++i) { rot[i] = r[i]; lin[i] = sc * r[i]; }
+    for (int i = 0; i < 9; ++i) {
+        if (rot) rot[9 * b + i] = r[i];
+        lin[9 * b + i] = sc * r[i];
+    }
 }
 
 __global__ void k_pose_bwd(float* __restrict__ gpose, const float* __restrict__ glin, const float* __restrict__ grot,
@@ -169,7 +175,16 @@ __global__ void k_pose_bwd(float* __restrict__ gpose, const float* __restrict__ 
 
 extern "C" int sr_pose_fwd(float* lin, float* rot, const float* pose, sr_stream_t stream) {
     if (!lin || !rot || !pose) return SR_EINVAL;
-    hipLaunchKernelGGL(k_pose_fwd, dim3(1), dim3(1), 0, sr_stream(stream), lin, rot, pose);
+    hipLaunchKernelGGL(k_pose_fwd, dim3(1), dim3(1), 0, sr_stream(stream), lin, rot, pose, 1);
+    return sr_launch_status();
+}
+
+extern "C" int sr_pose_batch_fwd(float* lin, float* rot, const float* pose, int64_t B, sr_stream_t stream) {
+    if (B < 0) return SR_EINVAL;
+    if (B == 0) return SR_OK;
+    if (!lin || !pose) return SR_EINVAL;
+    if (B > (1 << 24)) return SR_ERANGE;
+    hipLaunchKernelGGL(k_pose_fwd, dim3((unsigned)sr_ceil_div(B, 64)), dim3(64), 0, sr_stream(stream), lin, rot, pose, (int)B);
     return sr_launch_status();
 }
 

@@ -62,7 +62,10 @@ class LinearMorphableModel(nn.Module):
             self.fc.bias.requires_grad = False
 
     def random_input(self, batch_size=1):
-        return torch.normal(mean=0, std=self.sigma.unsqueeze(0).expand(batch_size, -1))
+        # = torch.normal(mean=0, std=sigma[None].expand(batch, -1)) (reference face_model.py:69-70: same distribution, another draw) without its host-side
+        # check of `std >= 0`, which reads the device and is refused inside a hipGraph capture (graph_train samples the
+        # meshes inside the captured D / G phases)
+        return torch.randn(batch_size, self.sigma.shape[0], device=self.sigma.device, dtype=self.sigma.dtype) * self.sigma
 
     def forward(self, x):
         return torch.reshape(self.fc(x), (-1, self.dim[2] // 3, 3))

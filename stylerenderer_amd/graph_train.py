@@ -109,6 +109,10 @@ class GraphedTrainer(Trainer):
         self.reduce_d = sr_dist.BucketedGradReducer(self.d_params, self.views_d, offs_d, self.flat_d, self.world,
                                                     n_buckets, force=force_collectives)
         self.graphs = {}
+        # a mesh SOURCE handed to step(faces=...) is sampled inside the D and G phases (reference train.py:248-251,
+        # 303-306 draws a fresh batch of meshes in front of each of the two generator passes): ~40 small launches per
+        # iteration that would otherwise run eagerly between two replays, where the host cannot run ahead of the GPU
+        self.face_source = None
 
     # ---- gradient-arrival probes (layout of the flat buffers) -------------------------------------------
     def _probe_g(self):
@@ -170,11 +174,23 @@ class GraphedTrainer(Trainer):
                                                            self.np_rng.rand() < self.args["mixing"]) else n_latent
         self.s_inject[key].fill_(k)
 
+    def _sample_mesh(self, key):
+        if self.face_source is None or not self.use_mesh:
+            return
+        with torch.no_grad():
+            v, nrm, _ = self.face_source.sample(self.batch)
+            self.s_mesh[key][0].copy_(v)
+            self.s_mesh[key][1].copy_(nrm)
+
+    def _phase_ema(self):
+        accumulate(self.g_ema, self.generator, self.accum)
+
     # ---- the four phases (pure device work: these bodies are what the graphs record) ---------------
     def _phase_d(self):
         g, d = self.generator, self.discriminator
         requires_grad(d, True)
         self.reduce_d.begin()
+        self._sample_mesh("d")
         with torch.no_grad():
             fake, _, _ = self._generate(g, self._latents(self.batch), self._mesh_tuple("d"),
                                         inject_index=self.s_inject["d"])
@@ -201,6 +217,7 @@ class GraphedTrainer(Trainer):
         g, d = self.generator, self.discriminator
         requires_grad(d, False)
         self.reduce_g.begin()
+        self._sample_mesh("g")             # the path phase reuses this batch's first meshes (train.py:337-338)
         fake, _, _ = self._generate(g, self._latents(self.batch), self._mesh_tuple("g"),
                                     inject_index=self.s_inject["g"])
         loss = g_nonsaturating_loss(d(fake))
@@ -231,7 +248,7 @@ class GraphedTrainer(Trainer):
     # ---- capture -------------------------------------------------------------------------------------
     def _bodies(self):
         return {"d": self._phase_d, "r1": self._phase_r1, "g": self._phase_g, "path": self._phase_path,
-                "d_opt": self.d_optim.step, "g_opt": self.g_optim.step}
+                "d_opt": self.d_optim.step, "g_opt": self.g_optim.step, "ema": self._phase_ema}
 
     PHASE_REDUCER = {"d": "reduce_d", "r1": "reduce_d", "g": "reduce_g", "path": "reduce_g"}
 
@@ -281,7 +298,7 @@ class GraphedTrainer(Trainer):
         torch.cuda.synchronize()
         self._restore(snap)
         bodies = self._bodies()
-        for name in ("d", "r1", "g", "path", "d_opt", "g_opt"):
+        for name in ("d", "r1", "g", "path", "d_opt", "g_opt", "ema"):
             self.graphs[name] = graphs.capture(bodies[name])     # memset nodes repaired: graphs.py
         torch.cuda.synchronize()
 
@@ -336,6 +353,10 @@ class GraphedTrainer(Trainer):
 
     # ---- one iteration -------------------------------------------------------------------------------
     def step(self, real_img, mesh=None, faces=None, log=True):
+        if faces is not None and self.use_mesh and self.face_source is None and not self.graphs:
+            self.face_source = faces
+        if self.face_source is not None and (mesh is not None or (faces is not None and faces is not self.face_source)):
+            raise RuntimeError("GraphedTrainer: the mesh source is part of the captured phases; it cannot change")
         if not self.graphs and self.capture:
             if self.use_mesh and self.tri is None:
                 self.set_topology(faces.tri if faces is not None else mesh[2])
@@ -359,7 +380,7 @@ class GraphedTrainer(Trainer):
             self._run("path")
             self._run("g_opt")
             ran += ["path", "path_length", "mean_path"]
-        accumulate(self.g_ema, self.generator, self.accum)
+        self._run("ema")
         self.iteration += 1
         return sr_dist.reduce_scalars({k: self.s_loss[k] for k in ran}, to_host=log)
 
@@ -368,6 +389,8 @@ class GraphedTrainer(Trainer):
         if self.use_mesh:
             if self.tri is None:
                 self.set_topology(faces.tri if faces is not None else mesh[2])
+            if self.face_source is not None and mesh is None:
+                return                                    # sampled inside the D / G phases (_sample_mesh)
             for key in ("d", "g"):
                 v, nrm, _ = faces.sample(self.batch) if faces is not None else mesh
                 self.s_mesh[key][0].copy_(v)

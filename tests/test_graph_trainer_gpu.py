@@ -30,8 +30,25 @@ def test_full_size_graphed_iteration_256_and_graph_equals_eager_for_every_phase(
     tr, faces, data = full_size_trainer()
     g0 = tr.g_optim.flat_p.clone()
     d0 = tr.d_optim.flat_p.clone()
+    ema0 = [p.detach().clone() for p in tr.g_ema.parameters()]
     logs = [tr.step(data.batch(4), faces=faces) for _ in range(3)]
-    assert set(tr.graphs) == {"d", "r1", "g", "path", "d_opt", "g_opt"}
+    assert set(tr.graphs) == {"d", "r1", "g", "path", "d_opt", "g_opt", "ema"}
+    # the captured EMA (reference train.py:100-104, once per iteration) is what the eager one computes from here
+    moved = [not torch.equal(a, p.detach()) for a, p in zip(ema0, tr.g_ema.parameters())]
+    assert sum(moved) >= len(moved) - len(tr.frozen)
+    before = [p.detach().clone() for p in tr.g_ema.parameters()]
+    tr.graphs["ema"].replay()
+    replayed = [p.detach().clone() for p in tr.g_ema.parameters()]
+    with torch.no_grad():
+        for p, b in zip(tr.g_ema.parameters(), before):
+            p.copy_(b)
+    train.accumulate(tr.g_ema, tr.generator, tr.accum)
+    assert all(torch.equal(a, p.detach()) for a, p in zip(replayed, tr.g_ema.parameters()))
+    # the meshes are drawn inside the D / G replays (a fresh batch each): the static buffers change without any eager copy
+    m0 = tr.s_mesh["d"][0].clone()
+    tr.graphs["d"].replay()
+    torch.cuda.synchronize()
+    assert not torch.equal(m0, tr.s_mesh["d"][0]) and torch.isfinite(tr.s_mesh["d"][1]).all()
     assert {"d", "g", "r1", "path", "path_length", "mean_path", "real_score", "fake_score"} <= set(logs[0])
     assert "r1" not in logs[1] and "path" not in logs[1]
     for log in logs:

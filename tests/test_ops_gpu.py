@@ -759,3 +759,36 @@ def test_pose_matrices_kernel_vs_tensor_algebra():
     (only_rot,) = torch.autograd.grad((utils_3d.pose_matrices(pose)[1] * gr).sum(), pose)
     (want_rot,) = torch.autograd.grad((utils_3d.euler_mat(pose[:3].view(1, 3), "yxz") * gr).sum(), pose)
     assert torch.allclose(only_rot, want_rot, atol=3e-6)
+
+
+@pytest.mark.gpu
+def test_random_pose_batch_kernel_vs_tensor_algebra():
+    """utils_3d.random_apply_pose3D on the device (sr_pose_batch_fwd + sr_affine3_fwd: two launches, capturable) against
+    the reference's tensor algebra (utils_3d.py:360-376) on the same draw: z = randn * sigma from the same seed."""
+    from stylerenderer_amd import utils_3d
+
+    sig = torch.tensor([.5, .1, .05, .1, .1, .1, .15], device=DEV)
+    for batch, nv in ((1, 17), (4, 1000), (67, 33)):
+        v = torch.randn(batch, nv, 3, device=DEV)
+        torch.manual_seed(11 + batch)
+        got = utils_3d.random_apply_pose3D(p=sig, v=v)
+        torch.manual_seed(11 + batch)
+        z = torch.randn(batch, 7, device=DEV) * sig
+        T = torch.exp(z[:, -1]).view(-1, 1, 1) * utils_3d.euler_mat(z[:, :3], "yxz")
+        want = torch.matmul(v, T) + z[:, 3:6].view(-1, 1, 3)
+        assert got.shape == want.shape and torch.allclose(got, want, atol=3e-6), (got - want).abs().max()
+    # the sampling is capturable: no host read between the draw and the posed vertices
+    g = torch.cuda.CUDAGraph()
+    v = torch.randn(4, 100, 3, device=DEV)
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        utils_3d.random_apply_pose3D(p=sig, v=v)
+    torch.cuda.current_stream().wait_stream(s)
+    with torch.cuda.graph(g):
+        out = utils_3d.random_apply_pose3D(p=sig, v=v)
+    g.replay()
+    first = out.clone()
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.isfinite(out).all() and not torch.equal(first, out)       # a fresh draw per replay

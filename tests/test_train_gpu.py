@@ -79,7 +79,7 @@ def test_graphed_training_iteration(use_mesh):
     before = tr.generator.conv1.conv.weight.detach().clone()
     d_before = tr.discriminator.final_conv[0].weight.detach().clone()
     logs = [tr.step(data.batch(4), faces=faces) for _ in range(5)]
-    assert tr.graphs and set(tr.graphs) == {"d", "r1", "g", "path", "d_opt", "g_opt"}
+    assert tr.graphs and set(tr.graphs) == {"d", "r1", "g", "path", "d_opt", "g_opt", "ema"}
     assert {"d", "g", "r1", "path", "path_length", "mean_path"} <= set(logs[0])
     assert "r1" not in logs[1] and "path" not in logs[1] and "path" in logs[4]
     for log in logs:
