@@ -280,6 +280,10 @@ class BucketedGradReducer:
             self.status = torch.zeros(len(self.buckets), dtype=torch.int32).pin_memory()   # written by a timed-out wait
             self.timeout_us = int(float(os.environ.get("SR_SIGNAL_TIMEOUT_S", "120")) * 1e6)
             self.eager_events = [None] * len(self.buckets)
+            # the words are zeroed on the CURRENT stream and read by wait kernels on the communication stream: without this
+            # edge a wait queued right after construction can run before the fill and read whatever the cached block held
+            # (a previous reducer's epochs: it returns at once — seen as a rare failure of the lost-signal test on a cold box)
+            self.comm.wait_stream(torch.cuda.current_stream(flat.device))
         self.active = False
         self.pending, self.done, self.next_issue = [], [], 0
         self.works = []
