@@ -160,6 +160,65 @@ def grad_samples(named_grads, per_tensor=256):
     return np.concatenate(vals).astype(np.float32), np.asarray(offs, np.int64)
 
 
+# ------------------------------------------------------------------------------- LeakyReLU kink records
+KINK_TAU = 5e-5
+
+
+class KinkRecorder:
+    """Forward hooks on every leaky-ReLU OUTPUT of a reference network (FusedLeakyReLU modules: StyledConv /
+    StyledMapConv / ConvLayer tails; EqualLinear with activation='fused_lrelu').  Any two fp32 implementations put
+    the few pre-activations with |x| ~ 1e-7 on different sides of the kink, which moves every upstream gradient by
+    ~1e-3 of its scale — a property of the activation, not of a kernel.  Per layer the fixture keeps
+      idx   flat indices of the outputs whose pre-activation has |x| < KINK_TAU * max|x| (x rebuilt from the output:
+            y / gain for y > 0, y / (0.2 * gain) otherwise),
+      pos   the reference's side for each of them (y > 0),
+      cnt   the number of positive outputs per channel (int32 [C]),
+    so that a test can (a) put exactly those elements on the reference's side, (b) prove with the per-channel counts
+    that the two sign patterns are then IDENTICAL, and compare the non-linear backward at round-off level.
+    Keys are the names of the modules that own the activation (the product's modules of the same name return the
+    activation output)."""
+
+    def __init__(self, net, ns):
+        self.rec = {}
+        self.hooks = []
+        for name, m in net.named_modules():
+            if isinstance(m, ns.op.FusedLeakyReLU):
+                key = name.rsplit(".", 1)[0]
+            elif isinstance(m, ns.layers.EqualLinear) and m.activation == "fused_lrelu":
+                key = name
+            else:
+                continue
+            self.hooks.append(m.register_forward_hook(lambda mod, inp, out, key=key: self._see(key, out)))
+
+    def _see(self, key, out):
+        y = out.detach()
+        gain = float(2 ** 0.5)
+        x = torch.where(y > 0, y / gain, y / (0.2 * gain))
+        band = KINK_TAU * float(x.abs().max())
+        idx = torch.nonzero(x.reshape(-1).abs() < band).reshape(-1)
+        dims = [d for d in range(y.dim()) if d != 1]
+        assert key not in self.rec, key
+        self.rec[key] = (idx.numpy().astype(np.int32), (y.reshape(-1)[idx] > 0).numpy(),
+                         (y > 0).sum(dims).numpy().astype(np.int32), tuple(y.shape))
+
+    def close(self):
+        for h in self.hooks:
+            h.remove()
+
+    def arrays(self, prefix="kink"):
+        keys = sorted(self.rec)
+        out = {prefix + "_keys": np.array(keys), prefix + "_tau": np.array(KINK_TAU)}
+        for i, k in enumerate(keys):
+            idx, pos, cnt, shape = self.rec[k]
+            out["%s_idx_%d" % (prefix, i)] = idx
+            out["%s_pos_%d" % (prefix, i)] = np.packbits(pos)
+            out["%s_cnt_%d" % (prefix, i)] = cnt
+            out["%s_shape_%d" % (prefix, i)] = np.asarray(shape, np.int64)
+        print("   kink records: %d layers, %d flagged of %d outputs" % (
+            len(keys), sum(len(self.rec[k][0]) for k in keys), sum(int(np.prod(self.rec[k][3])) for k in keys)))
+        return out
+
+
 def gold_generator(ns):
     for tag, size, sdim, nmlp, batch in (("s8", 8, 64, 2, 2), ("s64", 64, 512, 8, 1)):
         g = ns.model.Generator(size, sdim, nmlp)
@@ -292,6 +351,47 @@ def gold_discriminator(ns):
          n_params=np.array(sum(p.numel() for p in d.parameters())))
 
 
+def _disc_case(ns, size, batch=4, sub=1):
+    """Discriminator(size) of the reference (model.py:296-336) at a size where the product runs its big kernels:
+    shared-weight Winograd 3x3 convolutions, the 3x3 stride-2 convolution after Blur pad (2, 2), the decimating FIR +
+    1x1 skip, minibatch-stddev.  Logits; first-order gradients of <logits, 1> w.r.t. every parameter (256 samples
+    each) and the input (every `sub`-th pixel); ONE R1 evaluation the way the step weights it (reference
+    train.py:110-114, 281-289: d_r1_loss -> (r1 / 2 * R1 * d_reg_every + 0 * pred[0]).backward()) with its
+    double-backward parameter gradients; and the kink records of every LeakyReLU (KinkRecorder)."""
+    fn = _reference_train_functions()
+    d = ns.model.Discriminator(size)
+    synth.fill_state_dict(d.state_dict(), salt=61)
+    x = T(dn((batch, 3, size, size), 62 + size)).requires_grad_()
+    kinks = KinkRecorder(d, ns)
+    y = d(x)
+    kinks.close()
+    arrays = {"y": y.detach().numpy(), "n_params": np.array(sum(p.numel() for p in d.parameters())),
+              "sub": np.array(sub)}
+    arrays.update(kinks.arrays())
+    named = dict(d.named_parameters())
+    grads = torch.autograd.grad(y.sum(), list(named.values()) + [x], retain_graph=True)
+    gd = {n: gr for n, gr in zip(named, grads[:-1])}
+    arrays["grad_names"] = np.array(sorted(gd))
+    arrays["grad_samples"], arrays["grad_sample_offsets"] = grad_samples(gd)
+    arrays["gx"] = grads[-1].numpy()[:, :, ::sub, ::sub].copy()
+    # R1: second forward, as the step does (train.py:281-284)
+    xr = x.detach().clone().requires_grad_(True)
+    pred = d(xr)
+    r1 = fn["d_r1_loss"](pred, xr)
+    d.zero_grad()
+    (10.0 / 2 * r1 * 16 + 0 * pred[0]).backward()
+    arrays["r1"] = r1.detach().numpy()
+    g2 = {n: p.grad.clone() for n, p in d.named_parameters() if p.grad is not None}
+    arrays["r1_grad_names"] = np.array(sorted(g2))
+    arrays["r1_grad_samples"], arrays["r1_grad_sample_offsets"] = grad_samples(g2)
+    save("discriminator_s%d" % size, **arrays)
+
+
+def gold_discriminator_big(ns):
+    _disc_case(ns, 64, sub=2)
+    _disc_case(ns, 128, sub=4)
+
+
 def gold_generator_256(ns):
     """The exact network bench.py times (Generator(256, 512, 8), BASELINE config[1]) on one latent: image (0.8 MB)
     and the first-order gradients of a fixed linear functional w.r.t. every parameter (256 samples per tensor) and
@@ -322,9 +422,13 @@ def gold_generator_256(ns):
         # reference's.
         # reference's.  The mapping network (EqualLinear -> fused_leaky_relu, layers.py) keeps the real slope: it is
         # evaluated before the patch, and the synthesis network is entered with input_is_latent=True.
+        kinks = KinkRecorder(g, ns) if slope != 1.0 else None
         w = g.style(T(dn((1, 512), 42)))
         ref_fused.F = types.SimpleNamespace(leaky_relu=lambda x, negative_slope=0.2: x) if slope == 1.0 else real_F
         img, lat = g([w], return_latents=True, input_is_latent=True, noise=_noise_list(g, 4300))
+        if kinks is not None:
+            kinks.close()
+            arrays.update(kinks.arrays())
         if proj is None:
             proj = T(dn(tuple(img.shape), 46))
             arrays.update(image=img.detach().numpy(), latent_row=lat[0, 0].detach().numpy())
@@ -686,10 +790,10 @@ def main():
     os.makedirs(OUT, exist_ok=True)
     ns = ref_shim.load()
     torch.manual_seed(0)
-    which = sys.argv[1:] or ["fused", "ufd", "modconv", "gen", "gen256", "gwm", "disc", "train", "raster", "mesh", "lpips", "contract"]
+    which = sys.argv[1:] or ["fused", "ufd", "modconv", "gen", "gen256", "gwm", "disc", "discbig", "train", "raster", "mesh", "lpips", "contract"]
     table = {"fused": gold_fused_act, "ufd": gold_upfirdn2d, "modconv": gold_modconv,
              "gen": gold_generator, "gen256": gold_generator_256, "gwm": gold_generator_with_map,
-             "disc": gold_discriminator, "train": gold_train_step, "raster": gold_raster, "mesh": gold_mesh, "lpips": gold_lpips,
+             "disc": gold_discriminator, "discbig": gold_discriminator_big, "train": gold_train_step, "raster": gold_raster, "mesh": gold_mesh, "lpips": gold_lpips,
              "contract": gold_state_dict_contract}
     with torch.no_grad():
         pass

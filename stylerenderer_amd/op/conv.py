@@ -322,7 +322,7 @@ class ConvNBAFn(torch.autograd.Function):
             with torch.enable_grad():
                 xa, wa, sa, da, nwa, aba = _aliases(x, wt, iscale, oscale, noise_w, abias)
                 y0 = ConvFn.apply(xa, wa, sa, da, None, "c3")
-                y = _NBA.apply(y0, noise, nwa, aba, slope, gain)
+                y = _NBA.apply(y0, noise, nwa, aba, slope, gain, out.detach())
                 ins = (xa, wa, sa, da, None, nwa, aba)
                 sel = [t for t, nd in zip(ins, needs[:7]) if nd and t is not None]
                 got = iter(torch.autograd.grad(y, sel, gy, create_graph=True, allow_unused=True)) if sel else iter(())
@@ -412,7 +412,7 @@ class UpConvNBAFn(torch.autograd.Function):
             with torch.enable_grad():
                 xa, wa, sa, da, nwa, aba = _aliases(x, wt, iscale, oscale, noise_w, abias)
                 y = ConvFn.apply(xa, wa, sa, da, None, "t3s2")
-                o = _BlurNBA.apply(y, kernel, pad, noise, nwa, aba, slope, gain)
+                o = _BlurNBA.apply(y, kernel, pad, noise, nwa, aba, slope, gain, out.detach())
                 ins = (xa, wa, sa, da, None, None, None, nwa, aba)
                 sel = [t for t, nd in zip(ins, needs[:9]) if nd and t is not None]
                 got = iter(torch.autograd.grad(o, sel, gy, create_graph=True, allow_unused=True)) if sel else iter(())

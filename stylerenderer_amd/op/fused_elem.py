@@ -89,8 +89,11 @@ class _NBABackward(Function):
 
 class _NBA(Function):
     @staticmethod
-    def forward(ctx, x, noise, noise_w, bias, slope, scale):
-        y = _launch_fwd(x, noise, noise_w, bias, None, slope, scale)
+    def forward(ctx, x, noise, noise_w, bias, slope, scale, given=None):
+        """given: the output a fused convolution node already computed for exactly these operands (its recorded
+        backward re-derives the VJP from the separate operators): no launch, and the activation mask of every order
+        of differentiation comes from the ONE tensor the forward pass returned."""
+        y = _launch_fwd(x, noise, noise_w, bias, None, slope, scale) if given is None else given.detach()
         ctx.save_for_backward(y, noise)
         ctx.slope, ctx.scale = slope, scale
         return y
@@ -102,7 +105,7 @@ class _NBA(Function):
         want = bool(needs[3] or (noise is not None and needs[2]))
         gx, gb, gnw = _NBABackward.apply(gy, y, noise, ctx.slope, ctx.scale, want)
         return (gx, None, (gnw if noise is not None and want and needs[2] else None), (gb if want and needs[3] else None),
-                None, None)
+                None, None, None)
 
 
 def noise_bias_act(x, noise, noise_weight, bias, negative_slope=0.2, scale=2 ** 0.5):
@@ -232,19 +235,23 @@ class _BlurNBA(Function):
     backward operators, so gradients of any order stay on the HIP kernels."""
 
     @staticmethod
-    def forward(ctx, x, kernel, pad, noise, noise_w, bias, slope, scale):
+    def forward(ctx, x, kernel, pad, noise, noise_w, bias, slope, scale, given=None):
+        """given: see _NBA.forward."""
         n, c, ih, iw = x.shape
         p0, p1 = pad
         oh, ow = ih + p0 + p1 - 3, iw + p0 + p1 - 3
-        x = x.contiguous()
-        k = kernel.contiguous()
-        y = torch.empty((n, c, oh, ow), dtype=x.dtype, device=x.device)
-        bstride = 0 if noise is None or noise.numel() == oh * ow else oh * ow
-        with on_device_of(x):
-            rc = _lib.lib().sr_blur_noise_bias_act(_lib.ptr(y), _lib.ptr(x), _lib.ptr(k), _lib.ptr(noise),
-                                                   _lib.ptr(noise_w), _lib.ptr(bias), float(slope), float(scale), n,
-                                                   c, ih, iw, oh, ow, p0, p1, bstride, stream_of(x))
-        _lib.check(rc, "sr_blur_noise_bias_act")
+        if given is not None:
+            y = given.detach()
+        else:
+            x = x.contiguous()
+            k = kernel.contiguous()
+            y = torch.empty((n, c, oh, ow), dtype=x.dtype, device=x.device)
+            bstride = 0 if noise is None or noise.numel() == oh * ow else oh * ow
+            with on_device_of(x):
+                rc = _lib.lib().sr_blur_noise_bias_act(_lib.ptr(y), _lib.ptr(x), _lib.ptr(k), _lib.ptr(noise),
+                                                       _lib.ptr(noise_w), _lib.ptr(bias), float(slope), float(scale), n,
+                                                       c, ih, iw, oh, ow, p0, p1, bstride, stream_of(x))
+            _lib.check(rc, "sr_blur_noise_bias_act")
         ctx.save_for_backward(y, noise, kernel)
         ctx.cfg = (slope, scale, p0, p1, tuple(x.shape), (oh, ow))
         return y
@@ -259,7 +266,7 @@ class _BlurNBA(Function):
         g_pad = (3 - p0, in_size[3] - out_size[1] + p0, 3 - p0, in_size[2] - out_size[0] + p0)
         gx = UpFirDn2dBackward.apply(gpre, kernel, flipped(kernel), (1, 1), (1, 1), (p0, p1, p0, p1),
                                      g_pad, in_size, out_size)
-        return gx, None, None, None, (gnw if noise is not None else None), gb, None, None
+        return gx, None, None, None, (gnw if noise is not None else None), gb, None, None, None
 
 
 def blur_noise_bias_act(x, kernel, pad, noise, noise_weight, bias, negative_slope=0.2, scale=2 ** 0.5):

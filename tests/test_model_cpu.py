@@ -156,6 +156,17 @@ def test_discriminator_s16(golden):
     check_grad_samples(got, gold["r1_grad_names"], gold["r1_grad_samples"], gold["r1_grad_sample_offsets"], 4e-6)
 
 
+def test_discriminator_s64_vs_reference(golden):
+    """N1 on CPU tensors at 64^2 (tests/golden/discriminator_s64.npz): logits, first-order gradients, weighted R1 double
+    backward, and the kink records themselves (per-channel positive counts of every LeakyReLU equal the
+    reference's)."""
+    from util import run_discriminator_case
+
+    meas = run_discriminator_case(golden("discriminator_s64"), 64, "cpu", 2e-5, 2e-5, 5e-5)
+    print(meas)
+    assert meas["forced"] == 0, meas
+
+
 def test_generator_with_map_s16_gradients_vs_reference(golden):
     """M7 on CPU tensors: image, normal maps, parameter / mesh gradients and the path-length regulariser over
     [latents] + normal maps (reference model.py:224-295, train.py:118-134, 340-347)."""

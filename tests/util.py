@@ -105,3 +105,103 @@ def run_generator_with_map_case(gold, tag_size, dev, tol_img, tol_g1, tol_g2, to
     meas["gn2"] = rel_err(n.grad.cpu().numpy(), gold["pl_grad_nrm"])
     assert meas["gv2"] < tol_mesh2 and meas["gn2"] < tol_mesh2, meas
     return meas
+
+
+class KinkForcer:
+    """Forward hooks that put the LeakyReLU outputs recorded by oracle/make_golden.KinkRecorder on the REFERENCE's side
+    of the kink and prove that the two sign patterns are then identical.
+
+    For every recorded layer (the module that returns the activation output: StyledConv / StyledMapConv / ConvLayer /
+    EqualLinear) the fixture holds the flat indices of the outputs whose pre-activation is within tau * max|x| of zero
+    in the reference, the reference's side of each, and the per-channel count of positive outputs.  The hook
+      * compares the product's side of the flagged elements with the reference's and — `force` — rewrites the ones
+        that disagree to +-1e-30 (through `.data`: same storage, the value the backward kernels take the mask from;
+        the forward value moves by < tau of the layer's scale at a few dozen elements of 1e7),
+      * then compares the per-channel positive counts: equal counts after forcing = no sign disagreement OUTSIDE the
+        flagged band (a flip there would need an activation error above tau, three orders above the measured one).
+    stats[layer] = (flagged, disagreeing among them, channels whose count still differs)."""
+
+    def __init__(self, net, gold, prefix="kink", force=True):
+        import torch
+
+        self.stats = {}
+        self.hooks = []
+        self.force = force
+        mods = dict(net.named_modules())
+        for i, key in enumerate(str(k) for k in gold[prefix + "_keys"]):
+            idx = torch.from_numpy(gold["%s_idx_%d" % (prefix, i)].astype(np.int64))
+            pos = torch.from_numpy(np.unpackbits(gold["%s_pos_%d" % (prefix, i)])[:idx.numel()].astype(bool))
+            cnt = torch.from_numpy(gold["%s_cnt_%d" % (prefix, i)].astype(np.int64))
+            shape = tuple(int(v) for v in gold["%s_shape_%d" % (prefix, i)])
+            self.hooks.append(mods[key].register_forward_hook(
+                lambda mod, inp, out, a=(key, idx, pos, cnt, shape): self._hook(out, *a)))
+
+    def _hook(self, out, key, idx, pos, cnt, shape):
+        import torch
+
+        y = out.data
+        assert tuple(y.shape) == shape and y.is_contiguous(), (key, tuple(y.shape), shape)
+        flat = y.view(-1)
+        idx, pos, cnt = idx.to(y.device), pos.to(y.device), cnt.to(y.device)
+        dis = (flat[idx] > 0) != pos
+        n_dis = int(dis.sum())
+        if n_dis and self.force:
+            flat[idx[dis]] = torch.where(pos[dis], 1e-30, -1e-30).to(flat.dtype)
+        dims = [d for d in range(y.dim()) if d != 1]
+        bad = int(((y > 0).sum(dims) != cnt).sum())
+        prev = self.stats.get(key, (0, 0, 0))
+        self.stats[key] = (int(idx.numel()), prev[1] + n_dis, prev[2] + bad)
+
+    def close(self):
+        for h in self.hooks:
+            h.remove()
+
+    def disagreements(self):
+        return sum(v[1] for v in self.stats.values())
+
+    def unexplained(self):
+        return {k: v for k, v in self.stats.items() if v[2]}
+
+
+def run_discriminator_case(gold, size, dev, tol_y, tol_g1, tol_g2):
+    """Discriminator(size), batch 4, against tests/golden/discriminator_s<size>.npz (oracle/make_golden._disc_case):
+    logits, first-order gradients (parameters sampled, input sub-sampled), one weighted R1 evaluation (reference
+    train.py:110-114, 281-289) with its double-backward gradients; LeakyReLU kinks controlled by KinkForcer.  On CPU
+    tensors the mask comes from the saved pre-activation, which the hook cannot reach: there a disagreement is only
+    counted (the CPU path is bit-identical to the reference on the authoring host, where the CPU suite runs)."""
+    import torch
+
+    from stylerenderer_amd import model, synth, train
+
+    d = model.Discriminator(size)
+    assert sum(p.numel() for p in d.parameters()) == int(gold["n_params"])
+    synth.fill_state_dict(d.state_dict(), salt=61)
+    d = d.to(dev)
+    sub = int(gold["sub"])
+    x = torch.from_numpy(synth.det_normal((4, 3, size, size), 62 + size)).to(dev).requires_grad_()
+    forcer = KinkForcer(d, gold)
+    y = d(x)
+    meas = {"y": rel_err(y.detach().cpu().numpy(), gold["y"])}
+    assert meas["y"] < tol_y, meas
+    assert not forcer.unexplained(), forcer.unexplained()
+    params = dict(d.named_parameters())
+    grads = torch.autograd.grad(y.sum(), list(params.values()) + [x], retain_graph=True)
+    meas["g1"] = check_grad_samples(dict(zip(params, grads[:-1])), gold["grad_names"], gold["grad_samples"],
+                                    gold["grad_sample_offsets"], tol_g1)
+    meas["gx"] = rel_err(grads[-1].cpu().numpy()[:, :, ::sub, ::sub], gold["gx"])
+    assert meas["gx"] < tol_g1, meas
+    # R1 the way the step evaluates it: a second forward, d_r1_loss, weighted backward (a double backward)
+    xr = x.detach().clone().requires_grad_(True)
+    pred = d(xr)
+    forcer.close()
+    assert not forcer.unexplained(), forcer.unexplained()
+    r1 = train.d_r1_loss(pred, xr)
+    meas["r1"] = abs(float(r1) - float(gold["r1"])) / abs(float(gold["r1"]))
+    assert meas["r1"] < tol_g1, meas
+    d.zero_grad()
+    (10.0 / 2 * r1 * 16 + 0 * pred[0]).backward()
+    got = {n: p.grad for n, p in d.named_parameters() if p.grad is not None}
+    meas["g2"] = check_grad_samples(got, gold["r1_grad_names"], gold["r1_grad_samples"], gold["r1_grad_sample_offsets"],
+                                    tol_g2)
+    meas["forced"] = forcer.disagreements()
+    return meas
