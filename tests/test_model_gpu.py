@@ -150,8 +150,8 @@ def test_generator_256_vs_reference_image_and_gradients(golden):
         5e-5 of the layer's scale of the kink with the reference's side, and the per-channel positive counts
         (oracle/make_golden.KinkRecorder); util.KinkForcer puts the disagreeing ones on the reference's side, asserts
         that no disagreement exists outside that band, and the mask-dependent backward (k_nba_bwd with its rebuilt
-        y0, the fused tails) is then compared at 1e-4 of each tensor's scale — a 1 % error in any mask-dependent path
-        fails (the bar was 2e-2 while the kink was not controlled)."""
+        y0, the fused tails) is then compared at the SAME 2e-5 of each tensor's scale as the linear pass (measured 5.9e-6
+        with 21 of 3.3e7 elements forced; the bar was 2e-2 while the kink was not controlled, measured 6e-3)."""
     from stylerenderer_amd.op import FusedLeakyReLU
     from util import KinkForcer
 
@@ -183,7 +183,7 @@ def test_generator_256_vs_reference_image_and_gradients(golden):
         got = {n: x for n, x in zip(params, grads[:-1]) if x is not None}
         names, vals, offs = gold[prefix + "_names"], gold[prefix + "_samples"], gold[prefix + "_sample_offsets"]
         e_lat = rel_err(grads[-1].cpu().numpy(), gold[prefix + "_latent"])
-        bar = 2e-5 if slope == 1.0 else 1e-4
+        bar = 2e-5
         worst = check_grad_samples(got, names, vals, offs, bar)       # (one-element tensors: vs the largest of them)
         assert e_lat < bar, e_lat
         print("256^2 gradients, slope %.1f: worst sampled %.2e, latent %.2e%s" % (
