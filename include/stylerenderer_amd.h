@@ -122,6 +122,14 @@ int sr_noise_bias_act_affine_bwd2(float* d_gy, float* d_x, float* d_amap, int64_
  * captured in a hipGraph.  All four buffers 16-byte aligned. */
 int sr_adam_flat(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
                  float eps, const float* step, sr_stream_t stream);
+/* Guarded form for data-parallel training: `guard_offs` (host array, <= 16 entries, read at launch time) are positions
+ * of `g` — the first element of every all-reduce bucket.  If any of them is NaN the kernel leaves p / m / v untouched
+ * and stores 1 into `*skipped_host` (pinned host memory, may be NULL).  Together with sr_signal_wait_poison this
+ * turns a lost bucket signal on ONE rank into a refused optimiser step on EVERY rank (the SUM carries the NaN),
+ * where torch DDP's reducer (reference distributed.py:98-105) would raise on the rank that lost it. */
+int sr_adam_flat_guarded(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                         float eps, const float* step, const int64_t* guard_offs, int n_guards,
+                         int32_t* skipped_host, sr_stream_t stream);
 
 /* Row-wise dot products of two [rows, inner] tensors, optionally with a scaled copy in the same
  * sweep: dots[r] = sum_i a[r,i]*b[r,i] ; out_scaled[r,i] = b[r,i]*scale[r] (out_scaled may be NULL).
@@ -274,10 +282,12 @@ int sr_blur_noise_bias_act(float* y, const float* x, const float* k, const float
  * Optional winner map `win` int32 [b,h,w]: id of the triangle that owns the pixel, -1 where uncovered
  * (what sr_rasterize_grad_* walks; index / coeff may then be NULL: the fused autograd path writes
  * 16 B per pixel instead of 48).  Triangles whose bounding box exceeds 64 pixels are walked by the whole
- * workgroup (LDS queue) instead of one lane; optional `big` int32 [1 + 2*b*nf] is the gradient state of the call for
- * sr_rasterize_grad_*: their count, b*nf slots for the flat ids sample * nf + triangle (any order), and b*nf slots
- * for the leader table (smallest row-major pixel each triangle won) that the LDS-tiled forward path fills while it
- * resolves its tiles (the other path leaves them untouched: the gradient pass then builds the table itself). */
+ * workgroup (LDS queue) instead of one lane; optional `big` int32 [2 + 2*b*nf] is the gradient state of the call for
+ * sr_rasterize_grad_*: their count, b*nf slots for the flat ids sample * nf + triangle (any order), b*nf slots
+ * for the leader table (smallest row-major pixel each triangle won) and ONE state word: the LDS-tiled forward path
+ * builds the table while it resolves its tiles and stores 1, the global-key path fills it with INT_MAX and stores 0 —
+ * the gradient pass reads that word on the device and completes the table in place when it is 0 (it never re-derives
+ * which path the forward took). */
 int64_t sr_rasterize_scratch_bytes(int64_t b, int64_t nf, int64_t h, int64_t w, int is_double);
 int sr_rasterize_forward_f32(int64_t b, int64_t nv, int64_t nf, int64_t h, int64_t w, int repeat_v,
                              int repeat_f, int perspective, const float* v, const int64_t* tri,
@@ -379,6 +389,10 @@ int sr_conv2d_nba(float* out, const float* in, const float* wt, const float* isc
  * Winograd-domain weights, so their preparation (k_wino_weights, one launch per call) is skipped.  For frozen networks
  * (latent inversion, sampling): the caller keeps one scratch per (weight, geometry).  Ignored on the direct path. */
 #define SR_CONV_U_READY 1
+/* 1 when a stride-1 3x3 call with these sizes and THESE buffers (16-byte alignment of in / out is part of the rule) is
+ * served by the Winograd kernel, 0 when by the direct one — what a caller that keeps a scratch for SR_CONV_U_READY
+ * must ask before it marks the scratch's weight block as written. */
+int sr_conv2d_uses_winograd(int64_t B, int64_t C, int64_t N, int64_t IH, int64_t IW, const float* in, const float* out);
 int sr_conv2d_mfma_ex(float* out, const float* in, const float* wt, const float* iscale,
                       const float* oscale, const float* obias, int64_t B, int64_t C, int64_t N,
                       int64_t wt_ld, int64_t IH, int64_t IW, int64_t OH, int64_t OW, int ksize,
@@ -419,6 +433,15 @@ int sr_signal_set(uint32_t* word, const uint32_t* epoch, sr_stream_t stream);
 int sr_signal_wait(const uint32_t* counter, uint32_t at_least, sr_stream_t stream);
 int sr_signal_wait_timeout(const uint32_t* counter, uint32_t at_least, uint64_t timeout_us, int32_t* status_host,
                            int32_t code, sr_stream_t stream);
+/* As sr_signal_wait_timeout; on expiry `*poison` (a float of the data the wait guards, may be NULL) is overwritten
+ * with NaN before the kernel returns: what is queued behind the wait then carries a marker that
+ * sr_adam_flat_guarded refuses. */
+int sr_signal_wait_poison(const uint32_t* counter, uint32_t at_least, uint64_t timeout_us, int32_t* status_host,
+                          int32_t code, float* poison, sr_stream_t stream);
+/* sr_signal_set for a word in pinned HOST memory (system-scope store): the host-released mode of the bucketed reducer
+ * polls it from the CPU and queues the collective itself — no kernel ever spins on the communication stream, so the
+ * mode does not depend on the two streams owning separate hardware queues (GPU_MAX_HW_QUEUES). */
+int sr_signal_set_host(uint32_t* word_host, const uint32_t* epoch, sr_stream_t stream);
 
 /* Repairs a captured, not yet instantiated hipGraph_t for the HIP 7.0 runtime PyTorch-ROCm 2.10 bundles: memset nodes
  * replay a corrupted value from the second launch on (torch's multi-block reductions zero their semaphores that way),

@@ -5,8 +5,9 @@ Builds the reference's own CPU rasterizer (op/rasterize.cpp + op/rasterize.h) in
 Only this repo's ``oracle/ref_rasterize_tu.cpp`` is compiled; it #includes the reference
 files through ``-I /root/reference/op``.  No reference source is copied.
 
-Runs only where /root/reference exists (the authoring container).  The GPU box receives
-the prebuilt .so (oracle/_ref/ is git-ignored but not gpurun-ignored).
+Runs only where /root/reference exists (the authoring container).  The built .so stays
+there: oracle/_ref/ is git-ignored AND gpurun-ignored (nothing compiled from
+the reference travels; the GPU box checks against the own C restatement and the fixtures).
 
 The reference's other two native ops (fused_bias_act_kernel.cu, upfirdn2d_kernel.cu) need
 CUDA headers (<cuda.h>, ATen/cuda/CUDAApplyUtils.cuh) and are therefore UNBUILDABLE here;

@@ -36,6 +36,7 @@ SIGNATURES = {
     "sr_noise_bias_act_affine_bwd2_scratch_floats": (_l, [_l, _l, _l]),
     "sr_noise_bias_act_affine_bwd2": (_i, [_p, _p, _p, _l, _p, _p, _l] + [_p] * 6 + [_l, _p, _f, _f] + [_l] * 4 + [_p, _p]),
     "sr_adam_flat": (_i, [_p] * 4 + [_l] + [_f] * 4 + [_p, _p]),
+    "sr_adam_flat_guarded": (_i, [_p] * 4 + [_l] + [_f] * 4 + [_p, ctypes.POINTER(_l), _i, _p, _p]),
     "sr_rowdot_scratch_floats": (_l, [_l, _l]),
     "sr_rowdot": (_i, [_p] * 5 + [_l, _l, _p, _p]),
     "sr_rowdot_bwd": (_i, [_p] * 8 + [_l, _l, _p, _p]),
@@ -75,6 +76,7 @@ SIGNATURES = {
     "sr_conv2d_wgrad_mfma": (_i, [_p] * 5 + [_l] * 7 + [_i] * 4 + [_p, _p]),
     "sr_conv2d_scratch_floats": (_l, [_l] * 7 + [_i] * 4),
     "sr_conv2d_mfma": (_i, [_p] * 6 + [_l] * 8 + [_i] * 4 + [_p, _p]),
+    "sr_conv2d_uses_winograd": (_i, [_l] * 5 + [_p, _p]),
     "sr_conv2d_mfma_ex": (_i, [_p] * 6 + [_l] * 8 + [_i] * 5 + [_p, _p]),
     "sr_rasterize_grad_f64": (_i, [_l] * 5 + [_i] * 2 + [_p, _p, _l] + [_p] * 6 + [_l, _l, _p, _p, _d, _p, _p]),
     "sr_pose_fwd": (_i, [_p, _p, _p, _p]),
@@ -85,7 +87,9 @@ SIGNATURES = {
     "sr_signal_bump": (_i, [_p, _p]),
     "sr_signal_wait": (_i, [_p, ctypes.c_uint32, _p]),
     "sr_signal_set": (_i, [_p, _p, _p]),
+    "sr_signal_set_host": (_i, [_p, _p, _p]),
     "sr_signal_wait_timeout": (_i, [_p, ctypes.c_uint32, ctypes.c_uint64, _p, _i, _p]),
+    "sr_signal_wait_poison": (_i, [_p, ctypes.c_uint32, ctypes.c_uint64, _p, _i, _p, _p]),
     "sr_graph_replace_memset_nodes": (_i, [_p, ctypes.POINTER(_i)]),
     "sr_graph_node_count": (_i, [_p, ctypes.POINTER(_i), ctypes.POINTER(_i)]),
 }

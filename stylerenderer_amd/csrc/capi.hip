@@ -3,7 +3,7 @@
 
 #include "common.h"
 
-extern "C" int sr_abi_version(void) { return 7; }
+extern "C" int sr_abi_version(void) { return 8; }
 
 extern "C" const char* sr_error_string(int code) {
     if (code == SR_OK) return "ok";
@@ -38,16 +38,32 @@ __global__ void k_signal_set(unsigned* word, const unsigned* epoch) {
                        __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// The word lives in pinned HOST memory (the host-released mode of the bucketed reducer polls it from the CPU instead
+// of spinning a kernel on the communication stream).  The node runs after everything captured before it (graph
+// dependency: those kernels' end-of-kernel release has made the bucket visible device-wide), so the store itself needs
+// no fence — a release at system scope would write back this XCD's whole L2 for nothing.
+__global__ void k_signal_set_host(unsigned* word, const unsigned* epoch) {
+    __hip_atomic_store(word, __hip_atomic_load(epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // timeout_ticks in 100 MHz wall-clock ticks (0: wait for ever).  On expiry the kernel stores `code` into *status (pinned
 // host memory, system scope) and RETURNS: what is queued behind it runs on unfinished data, but the host finds the code
 // at its next check and raises instead of the job sitting in a silent device-side spin until an outer limit kills it.
+// `poison` (sr_signal_wait_poison): a float of the data the wait guards (the first element of the all-reduce bucket);
+// on expiry it is overwritten with NaN BEFORE the kernel returns, so the collective queued behind the wait spreads the
+// NaN to every rank and the guarded Adam step (sr_adam_flat_guarded) refuses the update everywhere.
 __global__ void k_signal_wait(const unsigned* counter, unsigned at_least, unsigned long long timeout_ticks, int* status,
-                              int code) {
+                              int code, float* poison) {
     const unsigned long long t0 = wall_clock64();
     // signed distance: correct across the 2^32 wrap of a word that only ever grows
     while ((int)(__hip_atomic_load(counter, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - at_least) < 0) {
         __builtin_amdgcn_s_sleep(16);
         if (timeout_ticks && wall_clock64() - t0 > timeout_ticks) {
+            if (poison) {
+                *poison = __builtin_nanf("");
+                __threadfence();
+            }
             if (status) __hip_atomic_store(status, code, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
             return;
         }
@@ -68,9 +84,16 @@ extern "C" int sr_signal_set(uint32_t* word, const uint32_t* epoch, sr_stream_t 
     return sr_launch_status();
 }
 
+extern "C" int sr_signal_set_host(uint32_t* word_host, const uint32_t* epoch, sr_stream_t stream) {
+    if (!word_host || !epoch) return SR_EINVAL;
+    hipLaunchKernelGGL(k_signal_set_host, dim3(1), dim3(1), 0, sr_stream(stream), word_host, epoch);
+    return sr_launch_status();
+}
+
 extern "C" int sr_signal_wait(const uint32_t* counter, uint32_t at_least, sr_stream_t stream) {
     if (!counter) return SR_EINVAL;
-    hipLaunchKernelGGL(k_signal_wait, dim3(1), dim3(1), 0, sr_stream(stream), counter, at_least, 0ull, (int*)nullptr, 0);
+    hipLaunchKernelGGL(k_signal_wait, dim3(1), dim3(1), 0, sr_stream(stream), counter, at_least, 0ull, (int*)nullptr, 0,
+                       (float*)nullptr);
     return sr_launch_status();
 }
 
@@ -78,7 +101,15 @@ extern "C" int sr_signal_wait_timeout(const uint32_t* counter, uint32_t at_least
                                       int32_t* status_host, int32_t code, sr_stream_t stream) {
     if (!counter) return SR_EINVAL;
     hipLaunchKernelGGL(k_signal_wait, dim3(1), dim3(1), 0, sr_stream(stream), counter, at_least,
-                       (unsigned long long)timeout_us * 100ull, status_host, code);
+                       (unsigned long long)timeout_us * 100ull, status_host, code, (float*)nullptr);
+    return sr_launch_status();
+}
+
+extern "C" int sr_signal_wait_poison(const uint32_t* counter, uint32_t at_least, uint64_t timeout_us,
+                                     int32_t* status_host, int32_t code, float* poison, sr_stream_t stream) {
+    if (!counter) return SR_EINVAL;
+    hipLaunchKernelGGL(k_signal_wait, dim3(1), dim3(1), 0, sr_stream(stream), counter, at_least,
+                       (unsigned long long)timeout_us * 100ull, status_host, code, poison);
     return sr_launch_status();
 }
 

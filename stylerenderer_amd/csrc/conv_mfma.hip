@@ -821,6 +821,13 @@ extern "C" int64_t sr_conv2d_scratch_floats(int64_t B, int64_t C, int64_t N, int
     return need;
 }
 
+// 1 when a stride-1 3x3 convolution call with these sizes AND these buffers runs the Winograd kernel (and therefore
+// writes / reads the Winograd-domain weights at the head of its scratch), 0 when it takes the direct kernel.
+extern "C" int sr_conv2d_uses_winograd(int64_t B, int64_t C, int64_t N, int64_t IH, int64_t IW, const float* in,
+                                       const float* out) {
+    return (wino_enabled() && sr_wino_eligible(B, C, N, IH, IW, in, out)) ? 1 : 0;
+}
+
 extern "C" int sr_conv2d_mfma_ex(float* out, const float* in, const float* wt, const float* iscale,
                               const float* oscale, const float* obias, int64_t B, int64_t C,
                               int64_t N, int64_t wt_ld, int64_t IH, int64_t IW, int64_t OH, int64_t OW,

@@ -921,12 +921,34 @@ extern "C" int sr_smallconv_dw(float* dws, const float* g, const float* x, int64
 //     m = m + (g - m) * (1 - b1);  v = b2 * v + (1 - b2) * g * g;
 //     p = p - (lr / (1 - b1^t)) * m / (sqrt(v) / sqrt(1 - b2^t) + eps)
 // `step` is a device scalar holding t (already incremented by the caller), so the launch is graph-capturable.
+// Guarded form (sr_adam_flat_guarded): `guards` are positions of the gradient buffer (the first element of every
+// all-reduce bucket).  A device-side wait for a bucket's signal that times out stores NaN there before its all-reduce
+// runs (sr_signal_wait_poison), the SUM carries it to every rank, and every workgroup of this kernel on every rank
+// then leaves WITHOUT touching p / m / v; `skipped` (pinned host word) is raised for the host's next check.  No rank
+// ever applies a half-written gradient.
 namespace {
+
+struct AdamGuards {
+    int n;
+    long long off[16];
+};
 
 __global__ __launch_bounds__(EB) void k_adam_flat(float* __restrict__ p, const float* __restrict__ g,
                                                   float* __restrict__ m, float* __restrict__ v, int64_t n4,
                                                   int64_t n, float lr, float b1, float b2, float eps,
-                                                  const float* __restrict__ step) {
+                                                  const float* __restrict__ step, AdamGuards guards, int* skipped) {
+    if (guards.n) {
+        bool bad = false;
+        for (int i = 0; i < guards.n; ++i) {
+            const float x = g[guards.off[i]];
+            bad = bad || (x != x);
+        }
+        if (bad) {
+            if (skipped && blockIdx.x == 0 && threadIdx.x == 0)
+                __hip_atomic_store(skipped, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            return;
+        }
+    }
     const float t = step[0];
     const float bc1 = 1.0f - powf(b1, t);
     const float bc2s = sqrtf(1.0f - powf(b2, t));
@@ -968,7 +990,28 @@ extern "C" int sr_adam_flat(float* p, const float* g, float* m, float* v, int64_
     if (!p || !g || !m || !v || !step) return SR_EINVAL;
     if (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) return SR_EINVAL;
     const int64_t n4 = n / 4;
+    AdamGuards none;
+    none.n = 0;
     hipLaunchKernelGGL(k_adam_flat, dim3(sr_stream_grid(n4 > 0 ? n4 : 1, EB)), dim3(EB), 0, sr_stream(stream), p, g, m, v,
-                       n4, n, lr, beta1, beta2, eps, step);
+                       n4, n, lr, beta1, beta2, eps, step, none, (int*)nullptr);
+    return sr_launch_status();
+}
+
+extern "C" int sr_adam_flat_guarded(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
+                                    float beta2, float eps, const float* step, const int64_t* guard_offs, int n_guards,
+                                    int32_t* skipped_host, sr_stream_t stream) {
+    if (n < 0 || n_guards < 0 || n_guards > 16 || (n_guards > 0 && !guard_offs)) return SR_EINVAL;
+    if (n == 0) return SR_OK;
+    if (!p || !g || !m || !v || !step) return SR_EINVAL;
+    if (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) return SR_EINVAL;
+    AdamGuards gd;
+    gd.n = n_guards;
+    for (int i = 0; i < n_guards; ++i) {
+        if (guard_offs[i] < 0 || guard_offs[i] >= n) return SR_EINVAL;
+        gd.off[i] = guard_offs[i];
+    }
+    const int64_t n4 = n / 4;
+    hipLaunchKernelGGL(k_adam_flat, dim3(sr_stream_grid(n4 > 0 ? n4 : 1, EB)), dim3(EB), 0, sr_stream(stream), p, g, m, v,
+                       n4, n, lr, beta1, beta2, eps, step, gd, skipped_host);
     return sr_launch_status();
 }

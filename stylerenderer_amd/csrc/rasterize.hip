@@ -321,11 +321,19 @@ SR_HD bool load_tri(Tri<R>& t, const R* __restrict__ vs,
     return true;
 }
 
+// (also resets the gradient state of the call when there is one: the big-triangle counter, the leader table — left
+// EMPTY by this path — and the state word that tells the gradient pass so: 0 = table filled but not built)
 __global__ __launch_bounds__(256) void k_fill_u64(unsigned long long* p, unsigned long long v,
-                                                  long long n, int* counter) {
-    if (counter && blockIdx.x == 0 && threadIdx.x == 0) *counter = 0;
+                                                  long long n, int* counter, int* first, long long n_first) {
+    if (counter && blockIdx.x == 0 && threadIdx.x == 0) {
+        *counter = 0;
+        if (first) first[n_first] = 0;
+    }
     const long long stride = (long long)gridDim.x * blockDim.x;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) p[i] = v;
+    if (first)
+        for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n_first; i += stride)
+            first[i] = 0x7FFFFFFF;
 }
 __global__ __launch_bounds__(256) void k_fill_u32(unsigned* p, unsigned v, long long n) {
     const long long stride = (long long)gridDim.x * blockDim.x;
@@ -596,11 +604,15 @@ __device__ __forceinline__ bool load_tri32(Tri<float>& t, const float* __restric
     return true;
 }
 
-// (also resets the gradient state of the call when there is one: the big-triangle counter and the leader table
-// `first`, which k_tile_raster fills while it resolves its tiles)
+// (also resets the gradient state of the call when there is one: the big-triangle counter, the leader table
+// `first`, which k_tile_raster fills while it resolves its tiles, and the state word behind it: 1 = table built by the
+// forward pass)
 __global__ __launch_bounds__(256) void k_tile_zero(unsigned* __restrict__ p, long long n, int* __restrict__ big,
                                                    int* __restrict__ first, long long n_first) {
-    if (big && blockIdx.x == 0 && threadIdx.x == 0) *big = 0;
+    if (big && blockIdx.x == 0 && threadIdx.x == 0) {
+        *big = 0;
+        if (first) first[n_first] = 1;
+    }
     const long long stride = (long long)gridDim.x * 256;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) p[i] = 0u;
     if (first)
@@ -1341,8 +1353,13 @@ __global__ __launch_bounds__(256) void k_grad_big(long long nv, long long nf, lo
 // over the image restricted to a triangle's box IS box order, so that pixel is the triangle's leader.
 // A pixel whose left or upper neighbour was won by the same triangle cannot be the minimum and skips the atomic
 // (most of a triangle's pixels: the table sees little more than one update per visible triangle).
+// `built` (the state word the forward pass left behind the table): non-zero = the tiled forward has already built
+// the table, every workgroup leaves at once.  The decision is the FORWARD's record, not a predicate re-evaluated at
+// backward time (environment flips, a different heuristic input: the table would be read uninitialised).
 __global__ __launch_bounds__(256) void k_first_pix(long long total, long long hw, long long w, long long nf,
-                                                   const int* __restrict__ win, int* __restrict__ first) {
+                                                   const int* __restrict__ win, int* __restrict__ first,
+                                                   const int* __restrict__ built) {
+    if (*built) return;
     const long long g = (long long)blockIdx.x * 256 + threadIdx.x;
     if (g >= total) return;
     const int ti = win[g];
@@ -1618,7 +1635,7 @@ int forward_tiled<float>(long long b, long long nv, long long nf, long long hres
     unsigned* wide_cnt = tile_cnt + b * ntile;
     unsigned* tile_list = wide_cnt + b;
     unsigned* wide_list = tile_list + b * ntile * TILE_CAP;
-    // gradient state: big = [count | b * nf big-triangle ids | b * nf leader table]
+    // gradient state: big = [count | b * nf big-triangle ids | b * nf leader table | state word]
     int* first = (big && win) ? big + 1 + b * nf : nullptr;
     hipLaunchKernelGGL(k_tile_zero, dim3(sr_stream_grid(first ? b * nf : b * ntile + b, 256)), dim3(256), 0, st, tile_cnt,
                        b * ntile + b, big, first, b * nf);
@@ -1663,7 +1680,8 @@ int forward_impl(long long b, long long nv, long long nf, long long h, long long
     unsigned* tmin = reinterpret_cast<unsigned*>(keys + npix);
     const bool is64 = sizeof(R) == 8;
     hipLaunchKernelGGL(k_fill_u64, dim3(sr_stream_grid(npix, 256)), dim3(256), 0, st, keys,
-                       is64 ? key_init_f64() : key_init_f32(), npix, big);
+                       is64 ? key_init_f64() : key_init_f32(), npix, big, (big && win) ? big + 1 + b * nf : nullptr,
+                       b * nf);
     if (is64)
         hipLaunchKernelGGL(k_fill_u32, dim3(sr_stream_grid(npix, 256)), dim3(256), 0, st, tmin,
                            0xFFFFFFFFu, npix);
@@ -1732,19 +1750,15 @@ int grad_impl(long long b, long long nv, long long nf, long long h, long long w,
     if (b * h * w >= 0x7FFFFFFFLL) return SR_ERANGE;
     // (records: 24 floats each, so the two tables behind them stay 8-byte aligned)
     unsigned long long* valid = reinterpret_cast<unsigned long long*>(tg + b * nf * grad_row_floats());
-    const int* first = reinterpret_cast<int*>(valid + (b * nf + 63) / 64 + 1);
-
-    // leaders of all triangles, once per call (the attribute-channel chunks below share them).  The tiled forward
-    // (same predicate, same call geometry) has already left them behind the big-triangle list of its gradient state.
-    if (b * nf > 0 && tiled_ok<R>(b, nf, h, w)) {
-        first = big + 1 + b * nf;
-    } else if (b * nf > 0) {
-        int* mine = reinterpret_cast<int*>(valid + (b * nf + 63) / 64 + 1);
-        hipLaunchKernelGGL(k_fill_u32, dim3(sr_stream_grid(b * nf, 256)), dim3(256), 0, st,
-                           reinterpret_cast<unsigned*>(mine), 0x7FFFFFFFu, b * nf);
+    // leaders of all triangles, once per call (the attribute-channel chunks below share them): the table behind the
+    // big-triangle list of the forward call's gradient state.  The tiled forward has built it (state word 1); the
+    // global-key forward has only filled it (state word 0) and k_first_pix completes it here, in place (idempotent: a
+    // second backward over the same state repeats the same integer minima).  Which of the two happened is read from
+    // the state the FORWARD wrote, on the device — never re-derived from tiled_ok() at backward time.
+    int* first = const_cast<int*>(big) + 1 + b * nf;
+    if (b * nf > 0)
         hipLaunchKernelGGL(k_first_pix, dim3((unsigned)sr_ceil_div(b * h * w, 256)), dim3(256), 0, st, b * h * w, h * w, w,
-                           nf, win, mine);
-    }
+                           nf, win, first, first + b * nf);
     // attribute channels in chunks of <= 4 register accumulators; the vertex gradient rides with chunk 0
     for (long long ch0 = 0; ch0 < (grad_tex ? tex_c : 1); ch0 += 4) {
         const long long ct = tex_c - ch0 < 4 ? tex_c - ch0 : 4;

@@ -239,9 +239,30 @@ class BucketedGradReducer:
     current stream (CPU: the caller) wait for all reductions — it sits in front of the optimiser step.
 
     No RCCL call is captured into a graph.  n_buckets = 1 degenerates to "reduce after the backward" and then uses
-    FlatGradReducer (autotuned all-reduce vs reduce-scatter + all-gather); SR_GRAD_OVERLAP=0 selects that."""
+    FlatGradReducer (autotuned all-reduce vs reduce-scatter + all-gather); SR_GRAD_OVERLAP=0 selects that.
 
-    def __init__(self, params, views, offs, flat, world=None, n_buckets=4, force=False):
+    Two ways to release a bucket of a REPLAYED backward (`self.release`; eager passes use events):
+      "device"  the one-lane wait kernel above spins at the head of the communication stream.  It needs the
+                communication stream and the replaying stream on DIFFERENT hardware queues: if HIP multiplexes them
+                onto one (GPU_MAX_HW_QUEUES, other streams of the process) the waiter can sit in front of the signal it
+                waits for and only its timeout ends the stall.
+      "host"    the signal node stores the epoch into PINNED HOST memory (sr_signal_set_host); `issue_all()` polls
+                the word from the CPU and queues the bucket's collective when it arrives — nothing spins on the device,
+                no assumption about queues; the host no longer runs ahead of the replay (the optimiser graph is
+                launched when the last bucket is out: ~0.1 ms of launch latency per phase).
+    SR_GRAD_OVERLAP=device|host forces one; otherwise the constructor PROBES the assumption — a wait queued on the
+    communication stream BEFORE the kernel that releases it is queued on the current stream; released within
+    microseconds on separate queues, timed out (0.5 s) on a shared one — and picks "host" when the probe fails.
+    The two modes move the same bytes through the same collectives and give bit-identical results.
+
+    A device-side wait that times out must not let the step continue (its all-reduce used to run on a
+    half-written bucket, the optimiser graph was replayed on it, peers never noticed): the wait overwrites the bucket's
+    first element with NaN before it returns (sr_signal_wait_poison), the SUM carries the NaN to every rank, and the
+    Adam step of an optimiser attached with `guard(optimiser)` refuses the update on every rank
+    (sr_adam_flat_guarded) and raises its pinned `skipped` word, which `check()` turns into an exception on every
+    rank at its next arm() / wait()."""
+
+    def __init__(self, params, views, offs, flat, world=None, n_buckets=4, force=False, release=None):
         from . import _lib
 
         self.params, self.views, self.flat = list(params), list(views), flat
@@ -274,23 +295,65 @@ class BucketedGradReducer:
             # on runs its wait kernel BEHIND the whole replay — correct, but nothing overlaps (seen when earlier streams
             # of the process had shifted the round-robin).  High-priority streams get queues of their own.
             self.comm = torch.cuda.Stream(device=flat.device, priority=-1)
-            self.counters = torch.zeros(len(self.buckets), dtype=torch.int32, device=flat.device)
+            self.timeout_us = int(float(os.environ.get("SR_SIGNAL_TIMEOUT_S", "120")) * 1e6)
+            want = release or os.environ.get("SR_GRAD_OVERLAP", "auto")
+            self.release_probe = None
+            if want in ("device", "host"):
+                self.release = want
+            else:
+                self.release_probe = self._queues_independent()
+                self.release = "device" if self.release_probe["independent"] else "host"
+            if self.release == "host":
+                self.counters = torch.zeros(len(self.buckets), dtype=torch.int32).pin_memory()
+                self._words = self.counters.numpy()        # the same pinned words, read without a tensor op
+            else:
+                self.counters = torch.zeros(len(self.buckets), dtype=torch.int32, device=flat.device)
             self.epoch = 0                               # replays announced so far (arm())
             self.epoch_dev = torch.zeros(1, dtype=torch.int32, device=flat.device)
             self.status = torch.zeros(len(self.buckets), dtype=torch.int32).pin_memory()   # written by a timed-out wait
-            self.timeout_us = int(float(os.environ.get("SR_SIGNAL_TIMEOUT_S", "120")) * 1e6)
             self.eager_events = [None] * len(self.buckets)
             # the words are zeroed on the CURRENT stream and read by wait kernels on the communication stream: without this
             # edge a wait queued right after construction can run before the fill and read whatever the cached block held
             # (a previous reducer's epochs: it returns at once — seen as a rare failure of the lost-signal test on a cold box)
             self.comm.wait_stream(torch.cuda.current_stream(flat.device))
         self.active = False
+        self.guarded = []                # pinned `skipped` words of the optimisers attached with guard()
         self.pending, self.done, self.next_issue = [], [], 0
         self.works = []
         self.log = []                    # ("flush" | "issue", bucket, time.perf_counter()) of the last eager pass
         self.stamp = None                # optional callable -> float (tests); perf_counter by default
         self._handles = [p.register_post_accumulate_grad_hook(lambda p, i=i: self._arrived(i))
                          for i, p in enumerate(self.params)]
+
+    def _queues_independent(self, timeout_s=0.5):
+        """Does a kernel spinning at the head of the communication stream leave the current stream running?  The wait
+        is queued FIRST, the kernel that releases it afterwards on the current stream — the order that deadlocks when
+        both streams feed one hardware queue.  Both kernels are launched once before (code-object load)."""
+        import time
+
+        L, dev = self._lib.lib(), self.flat.device
+        cur = torch.cuda.current_stream(dev)
+        word = torch.zeros(2, dtype=torch.int32, device=dev)
+        one = torch.ones(1, dtype=torch.int32, device=dev)
+        status = torch.zeros(1, dtype=torch.int32).pin_memory()
+        self._lib.check(L.sr_signal_set(word.data_ptr() + 4, one.data_ptr(), cur.cuda_stream), "sr_signal_set")
+        self.comm.wait_stream(cur)
+        self._lib.check(L.sr_signal_wait_timeout(word.data_ptr() + 4, 1, 0, None, 0, self.comm.cuda_stream),
+                        "sr_signal_wait_timeout")
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        self._lib.check(L.sr_signal_wait_timeout(word.data_ptr(), 1, int(timeout_s * 1e6), status.data_ptr(), 1,
+                                                 self.comm.cuda_stream), "sr_signal_wait_timeout")
+        self._lib.check(L.sr_signal_set(word.data_ptr(), one.data_ptr(), cur.cuda_stream), "sr_signal_set")
+        torch.cuda.synchronize(dev)
+        return {"independent": not bool(status.any()), "ms": round((time.perf_counter() - t0) * 1e3, 3)}
+
+    def guard(self, optimiser):
+        """The optimiser that consumes this buffer refuses a step whose buckets carry the NaN marker of a timed-out
+        wait (optim.FlatAdam.set_guards); check() raises when it did."""
+        if self.enabled and hasattr(optimiser, "set_guards"):
+            self.guarded.append(optimiser.set_guards([b["lo"] for b in self.buckets]))
+        return optimiser
 
     # ---- one backward ---------------------------------------------------------------------------------------
     def begin(self):
@@ -337,8 +400,9 @@ class BucketedGradReducer:
         if self.is_cuda:
             stream = torch.cuda.current_stream(self.flat.device)      # the producing stream (autograd thread: the op's)
             if self._capturing():
-                self._lib.check(self._lib.lib().sr_signal_set(self.counters.data_ptr() + 4 * b,
-                                                              self.epoch_dev.data_ptr(), stream.cuda_stream),
+                L = self._lib.lib()
+                set_word = L.sr_signal_set_host if self.release == "host" else L.sr_signal_set
+                self._lib.check(set_word(self.counters.data_ptr() + 4 * b, self.epoch_dev.data_ptr(), stream.cuda_stream),
                                 "sr_signal_set")
                 return                               # issued by issue_all() after every replay
             ev = torch.cuda.Event()
@@ -356,10 +420,14 @@ class BucketedGradReducer:
         piece = self.flat[bk["lo"]:bk["hi"]]
         self.log.append(("issue", b, self._now()))
         if self.is_cuda:
-            if replay:
-                self._lib.check(self._lib.lib().sr_signal_wait_timeout(
+            if replay and self.release == "host":
+                self._host_wait(b)                   # returns when the replay has passed the bucket's signal node
+            elif replay:
+                # (on expiry: NaN into the bucket's first element, see the class docstring)
+                self._lib.check(self._lib.lib().sr_signal_wait_poison(
                     self.counters.data_ptr() + 4 * b, self.epoch & 0xFFFFFFFF, self.timeout_us,
-                    self.status.data_ptr() + 4 * b, b + 1, self.comm.cuda_stream), "sr_signal_wait_timeout")
+                    self.status.data_ptr() + 4 * b, b + 1, self.flat.data_ptr() + 4 * bk["lo"],
+                    self.comm.cuda_stream), "sr_signal_wait_poison")
             else:
                 self.comm.wait_event(self.eager_events[b])
             with torch.cuda.stream(self.comm):
@@ -373,6 +441,24 @@ class BucketedGradReducer:
         else:
             self.works.append((dist.all_reduce(piece, op=dist.ReduceOp.SUM, async_op=True), piece))
 
+    def _host_wait(self, b):
+        """Host-released mode: poll the bucket's pinned word until the replay's signal node has stored this epoch.
+        A signal that does not come within SR_SIGNAL_TIMEOUT_S raises HERE, before the collective is queued."""
+        import time
+
+        want = self.epoch & 0xFFFFFFFF
+        t0 = time.perf_counter()
+        spins = 0
+        while ((int(self._words[b]) - want) & 0xFFFFFFFF) >= 0x80000000:
+            spins += 1
+            if spins & 0x3FF == 0:
+                if time.perf_counter() - t0 > self.timeout_us / 1e6:
+                    raise RuntimeError("BucketedGradReducer (host release): the signal of bucket %d (of %d) was not "
+                                       "published within %.0f s at epoch %d on rank %d — the replay that should produce "
+                                       "it did not run or did not finish; the bucket is NOT reduced" % (
+                                           b, len(self.buckets), self.timeout_us / 1e6, self.epoch, get_rank()))
+                time.sleep(0)
+
     def finish(self):
         """End of the backward: buckets with parameters the phase did not reach are completed (zeros) and signalled."""
         for b in range(len(self.buckets)):
@@ -382,7 +468,20 @@ class BucketedGradReducer:
 
     # ---- around a replay / before the optimiser ----------------------------------------------------------------
     def check(self):
-        """Raises when a device-side wait gave up (its bucket's signal node never ran within SR_SIGNAL_TIMEOUT_S)."""
+        """Raises when a device-side wait gave up (its bucket's signal node never ran within SR_SIGNAL_TIMEOUT_S), or
+        when a guarded optimiser refused a step because a bucket carried the NaN marker of such a wait — on this rank
+        or, through the all-reduce, on a peer."""
+        if self.enabled and any(bool(w.any()) for w in self.guarded):
+            for w in self.guarded:
+                w.zero_()
+            lost = [int(x) - 1 for x in self.status.tolist() if x] if self.is_cuda else []
+            if self.is_cuda:
+                self.status.zero_()
+            raise RuntimeError("BucketedGradReducer: the optimiser step after epoch %d was REFUSED on rank %d: a gradient "
+                               "bucket carried NaN at its guard position (%s) — parameters and moments are unchanged" % (
+                                   self.epoch if self.is_cuda else -1, get_rank(),
+                                   "this rank's wait for bucket(s) %s timed out" % lost if lost else
+                                   "a peer rank's bucket wait timed out, or the gradients themselves are NaN"))
         if self.enabled and self.is_cuda and bool(self.status.any()):
             stuck = [int(x) - 1 for x in self.status.tolist() if x]
             self.status.zero_()
@@ -447,4 +546,7 @@ class BucketedGradReducer:
         mb = [round((b["hi"] - b["lo"]) * 4 / 1e6, 1) for b in self.buckets]
         mode = "off" if not self.enabled else ("after-backward (%s)" % self.single.mode if self.single is not None
                                                else "overlapped, %d buckets" % len(self.buckets))
-        return {"mode": mode, "bucket_MB": mb}
+        extra = {}
+        if self.enabled and self.is_cuda:
+            extra = {"release": self.release, "release_probe": self.release_probe}
+        return {"mode": mode, "bucket_MB": mb, **extra}

@@ -108,6 +108,16 @@ class GraphedTrainer(Trainer):
                                                     n_buckets, force=force_collectives)
         self.reduce_d = sr_dist.BucketedGradReducer(self.d_params, self.views_d, offs_d, self.flat_d, self.world,
                                                     n_buckets, force=force_collectives)
+        # a bucket wait that times out marks its bucket; the Adam step of the buffer then refuses the update on every rank
+        self.reduce_g.guard(self.g_optim)
+        self.reduce_d.guard(self.d_optim)
+        # the three networks are rewritten by REPLAYED graphs from here on (Adam, EMA): replays do not bump tensor versions,
+        # so version-keyed frozen caches would go stale — op.weight_prep.freeze_prepared_weights refuses these modules
+        # (sample / invert from copy.deepcopy(trainer.g_ema))
+        from .op.weight_prep import GRAPH_WRITTEN
+
+        for net in (self.generator, self.discriminator, self.g_ema):
+            GRAPH_WRITTEN.add(net)
         self.graphs = {}
         # a mesh SOURCE handed to step(faces=...) is sampled inside the D and G phases (reference train.py:248-251,
         # 303-306 draws a fresh batch of meshes in front of each of the two generator passes): ~40 small launches per

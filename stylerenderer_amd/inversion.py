@@ -22,6 +22,25 @@ from torch import optim
 from . import graphs, utils_3d
 
 
+class _FlatAdamSet:
+    """The per-variable optim.FlatAdam instances of the device path behind torch.optim's two calls (scripts and callers
+    written against `inverter.optim.step()` keep working: ADVICE r4)."""
+
+    def __init__(self, adams):
+        self.adams = adams
+
+    @torch.no_grad()
+    def step(self):
+        for p, adam in self.adams:
+            if p.grad is not None:
+                adam.flat_g[:p.numel()].copy_(p.grad.reshape(-1))
+                adam.step()
+
+    def zero_grad(self, set_to_none=True):
+        for p, _ in self.adams:
+            p.grad = None
+
+
 class LatentInverter:
     def __init__(self, generator, perceptual, target, mesh, lr=0.05, pose_lr=0.01, pixel_weight=1.0, noise=None,
                  n_mean_latent=4096, use_graph=None, optimise_pose=True):
@@ -53,13 +72,14 @@ class LatentInverter:
             # multi-tensor passes of torch's capturable foreach Adam: at batch 1 every launch is ~5 us of an 8 ms step
             from .optim import ALIGN, FlatAdam
 
-            self.optim = None
             self._adams = []
             for g_ in groups:
                 p = g_["params"][0]
                 flat_g = torch.zeros((p.numel() + ALIGN - 1) // ALIGN * ALIGN, device=self.device)
                 self._adams.append((p, FlatAdam([p], flat_g, lr=g_["lr"], betas=(0.9, 0.999))))
+            self.optim = _FlatAdamSet(self._adams)       # `.optim.step()` / `.zero_grad()` like torch's optimiser
         else:
+            self._adams = None
             self.optim = optim.Adam(groups, betas=(0.9, 0.999))
         self.use_graph = on_gpu if use_graph is None else bool(use_graph)
         self.graph = None
@@ -91,13 +111,7 @@ class LatentInverter:
         img = self.render()
         value = self.loss(img)
         value.backward()
-        if self.optim is not None:
-            self.optim.step()
-        else:
-            with torch.no_grad():
-                for p, adam in self._adams:
-                    adam.flat_g[:p.numel()].copy_(p.grad.reshape(-1))
-                    adam.step()
+        self.optim.step()
         self.loss_value.copy_(value.detach())
         self.image = img.detach()
 

@@ -28,6 +28,7 @@ from .op.style_bank import StylePack
 from .op.upfirdn2d import skip_down as _skip_down
 from .op.weight_prep import weight_prep as _weight_prep
 from .op.weight_prep import weight_prep_cached as _weight_prep_cached
+from .op._dispatch import strict_native as _strict_native
 
 
 def _fused_tails():
@@ -94,14 +95,17 @@ _CONST_ROWS = {}
 
 
 def _const_rows(value, b, n, device):
-    """[b, n] tensor filled with `value` (an output scale table of the convolution kernels), made once per shape."""
+    """[b, n] tensor filled with `value` (an output scale table of the convolution kernels), made once per shape and
+    NEVER dropped: captured phases bake its address into their hipGraph (a size-triggered clear() freed
+    tables that replays still read).  A few KB per (value, batch, channels) — the set is bounded by the layer shapes of
+    the networks in the process."""
+    from .op._dispatch import hold_for_capture
+
     key = (float(value), int(b), int(n), str(device))
     hit = _CONST_ROWS.get(key)
     if hit is None:
-        if len(_CONST_ROWS) > 64:
-            _CONST_ROWS.clear()
         hit = _CONST_ROWS[key] = torch.full((b, n), float(value), dtype=torch.float32, device=device)
-    return hit
+    return hold_for_capture(hit)
 
 
 class EqualConv2d(nn.Module):
@@ -130,6 +134,10 @@ class EqualConv2d(nn.Module):
             osc = _const_rows(gain, input.shape[0], self.weight.shape[0], input.device) if gain is not None else None
             assert osc is None or bias is None
             return _conv.conv2d(input, wt, None, osc, bias, geom)
+        if input.device.type == "cuda" and _strict_native():
+            raise RuntimeError("SR_STRICT_NATIVE: EqualConv2d(k=%d, stride=%d, padding=%d) is outside the MFMA kernels' "
+                               "geometries {3x3 s1 p1, 3x3 s2 p0, 1x1 s1, 1x1 s2} and would run on MIOpen"
+                               % (self.weight.shape[2], self.stride, self.padding))
         out = F.conv2d(input, self.weight * self.scale, bias=bias, stride=self.stride, padding=self.padding)
         return out * gain if gain is not None else out
 
@@ -160,6 +168,9 @@ class EqualLinear(nn.Module):
             # device tensors: one launch (scale, bias and the mapping network's leaky-ReLU fused)
             return _style.equal_linear(input, self.weight, self.bias, self.scale, self.lr_mul,
                                        self.activation == "fused_lrelu")
+        if input.device.type == "cuda" and self.activation in (None, "fused_lrelu") and _strict_native():
+            raise RuntimeError("SR_STRICT_NATIVE: EqualLinear input %s (stride %s) is outside sr_linear_fwd and would "
+                               "run on rocBLAS" % (tuple(input.shape), tuple(input.stride())))
         if self.activation == "fused_lrelu":
             out = F.linear(input, self.weight * self.scale)
             return fused_leaky_relu(out, self.bias * self.lr_mul)
@@ -239,6 +250,9 @@ class ModulatedConv2d(nn.Module):
             if _style.demod_supported(s, wsq):
                 d = _style.demod_scale(s, wsq, self.eps)                 # [B, Co]
             else:
+                if _strict_native():
+                    raise RuntimeError("SR_STRICT_NATIVE: demodulation of shape %s x %s is outside sr_demod_fwd and would "
+                                       "run on rocBLAS" % (tuple(s.shape), tuple(wsq.shape)))
                 d = torch.rsqrt(torch.matmul(s * s, wsq) + self.eps)
         return wt, wsq, d
 

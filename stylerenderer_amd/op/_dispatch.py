@@ -32,6 +32,15 @@ def stream_of(t):
     return _lib.current_stream(t.device)
 
 
+def strict_native():
+    """SR_STRICT_NATIVE=1 (set by tests/conftest.py for the GPU suite and by bench.py): a device tensor that would
+    leave this library's kernels for a MIOpen / rocBLAS fallback raises instead — the fallbacks exist for shapes the
+    generator / discriminator never produce, and a benchmark or parity run must not take one silently."""
+    import os
+
+    return os.environ.get("SR_STRICT_NATIVE", "0") == "1"
+
+
 def _capturing():
     return torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()
 

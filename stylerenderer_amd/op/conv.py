@@ -69,7 +69,7 @@ def conv2d_mfma(x, wt, iscale=None, oscale=None, obias=None, ksize=3, stride=1, 
     flops = 2.0 * b * gh * gw * c * n * ksize * ksize
     L = _lib.lib()
     nscr = L.sr_conv2d_scratch_floats(b, c, n, ih, iw, oh, ow, ksize, stride, pad, int(bool(transposed)))
-    scratch, flags = _conv_scratch(wt, nscr, (b, c, n, ih, iw, ksize, stride, pad, bool(transposed)), x)
+    scratch, flags, entry = _conv_scratch(wt, nscr, (b, c, n, ih, iw, ksize, stride, pad, bool(transposed)), x)
     with on_device_of(x):
         rc = _timed("conv", (ksize, stride, int(bool(transposed)), b, c, n, gh, gw), flops,
                     lambda: L.sr_conv2d_mfma_ex(
@@ -77,30 +77,55 @@ def conv2d_mfma(x, wt, iscale=None, oscale=None, obias=None, ksize=3, stride=1, 
                         _lib.ptr(obias), b, c, n, ldw, ih, iw, oh, ow, ksize, stride, pad,
                         int(bool(transposed)), flags, _lib.ptr(scratch), stream_of(x)))
     _lib.check(rc, "sr_conv2d_mfma")
+    _scratch_written(entry, b, c, n, ih, iw, x, out)
     return out
 
 
+class _Scratch:
+    """One persistent scratch of a frozen weight: `ready` says that its leading block HOLDS the Winograd-domain weights —
+    set only after a call that (a) was executed, not merely recorded into a graph under capture, and (b) was served by
+    the Winograd kernel for its actual buffers (sr_conv2d_uses_winograd: 16-byte alignment of input / output is part of
+    the rule; a misaligned first call runs the direct kernel and writes no weights).  ADVICE r4: the entry used to count
+    as ready from its creation."""
+    __slots__ = ("buf", "ready")
+
+    def __init__(self, buf):
+        self.buf, self.ready = buf, False
+
+
 def _conv_scratch(wt, nscr, key, like):
-    """(scratch, flags) of one convolution call.  Weights a frozen network prepared once (`wt._sr_frozen`: latent
+    """(scratch, flags, entry) of one convolution call.  Weights a frozen network prepared once (`wt._sr_frozen`: latent
     inversion, the LPIPS trunk) keep ONE scratch per call geometry of the stride-1 3x3 convolution: its leading block
-    holds the Winograd-domain weights, which the second and later calls reuse (SR_CONV_U_READY: one k_wino_weights launch
-    less per convolution and step); the split-K region behind it is rewritten by every call.  The buffer lives as long as
-    the prepared weight (a new weight version makes a new prepared tensor) and as any graph captured over it.
+    holds the Winograd-domain weights, which later calls reuse (SR_CONV_U_READY: one k_wino_weights launch less per
+    convolution and step) once a call has really written them (`_Scratch.ready`, `_scratch_written`); the split-K
+    region behind it is rewritten by every call.  The buffer lives as long as the prepared weight (a new weight
+    version makes a new prepared tensor) and as any graph captured over it.
     One stream per frozen network: two streams convolving with the same prepared weight and geometry at the same time
     would share the split-K region (the loops that freeze a network — inversion, sampling — run on one stream)."""
     if nscr <= 0:
-        return None, 0
+        return None, 0, None
     if not (getattr(wt, "_sr_frozen", False) and key[5:] == (3, 1, 1, False)) or os.environ.get("SR_U_CACHE", "1") == "0":
-        return torch.empty(nscr, dtype=like.dtype, device=like.device), 0
+        return torch.empty(nscr, dtype=like.dtype, device=like.device), 0, None
     cache = wt.__dict__.setdefault("_sr_scratch", {})
     k = key + (os.environ.get("SR_WINOGRAD", "1"), os.environ.get("SR_WINO_SPLIT", "1"), wt._version, wt.data_ptr())
     hit = cache.get(k)
-    if hit is not None and hit.numel() >= nscr:
-        return hold_for_capture(hit), 1
-    if len(cache) >= 6:                      # a handful of geometries per weight (batch sizes of one loop)
-        cache.clear()
-    cache[k] = torch.empty(nscr, dtype=like.dtype, device=like.device)
-    return hold_for_capture(cache[k]), 0
+    if hit is None or hit.buf.numel() < nscr:
+        if len(cache) >= 6:                      # a handful of geometries per weight (batch sizes of one loop)
+            cache.clear()
+        hit = cache[k] = _Scratch(torch.empty(nscr, dtype=like.dtype, device=like.device))
+    hold_for_capture(hit.buf)
+    return hit.buf, (1 if hit.ready else 0), hit
+
+
+def _scratch_written(entry, b, c, n, h, w, x, out):
+    """After a successful launch: the entry's weight block is valid from now on iff this call was executed (not
+    captured) and took the Winograd kernel."""
+    if entry is None or entry.ready:
+        return
+    if x.is_cuda and torch.cuda.is_current_stream_capturing():
+        return
+    if _lib.lib().sr_conv2d_uses_winograd(b, c, n, h, w, _lib.ptr(x), _lib.ptr(out)):
+        entry.ready = True
 
 
 def conv2d_wgrad_mfma(x, gy, xscale=None, gscale=None, ksize=3, stride=1, pad=1, transposed=False):
@@ -295,7 +320,7 @@ class ConvNBAFn(torch.autograd.Function):
         out = torch.empty((b, n, h, w), dtype=x.dtype, device=x.device)
         L = _lib.lib()
         nscr = L.sr_conv2d_scratch_floats(b, c, n, h, w, h, w, 3, 1, 1, 0)
-        scratch, flags = _conv_scratch(wt if wtp is wt else wtp, max(nscr, 1), (b, c, n, h, w, 3, 1, 1, False), x)
+        scratch, flags, entry = _conv_scratch(wt if wtp is wt else wtp, max(nscr, 1), (b, c, n, h, w, 3, 1, 1, False), x)
         bstride = 0 if noise is None or noise.numel() == h * w else h * w
         flops = 2.0 * b * h * w * c * n * 9
         with on_device_of(x):
@@ -305,6 +330,7 @@ class ConvNBAFn(torch.autograd.Function):
                                                    float(slope), float(gain), b, c, n, ldw, h, w, bstride, flags,
                                                    _lib.ptr(scratch), stream_of(x)))
         _lib.check(rc, "sr_conv2d_nba")
+        _scratch_written(entry, b, c, n, h, w, x, out)
         ctx.save_for_backward(x, wt, iscale, oscale, noise, noise_w, abias, out)
         ctx.cfg = (float(slope), float(gain))
         ctx.frozen = bool(getattr(wt, "_sr_frozen", False))

@@ -93,8 +93,8 @@ def _forward_impl(vertices, triangles, height, width, perspective, eps, tex=None
     coeff = torch.empty((b, h, w, 3), dtype=dt, device=dev) if want_index else None
     zbuf = torch.empty((b, h, w), dtype=dt, device=dev) if want_z else None
     win = torch.empty((b, h, w), dtype=torch.int32, device=dev) if want_win else None
-    # gradient state: [count | big-triangle ids b*nf | leader table b*nf] (include/stylerenderer_amd.h)
-    big = torch.empty(1 + 2 * b * nf, dtype=torch.int32, device=dev) if want_win else None
+    # gradient state: [count | big-triangle ids b*nf | leader table b*nf | state word] (include/stylerenderer_amd.h)
+    big = torch.empty(2 + 2 * b * nf, dtype=torch.int32, device=dev) if want_win else None
     attr, tex_c, tex_flat = None, 0, None
     if tex is not None:
         tex_c = 1 if tex.dim() == vertices.dim() - 1 else int(tex.shape[-1])

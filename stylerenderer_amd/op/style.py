@@ -13,6 +13,7 @@ from torch.autograd import Function
 from torch.nn import functional as F
 
 from .. import _lib
+from . import smallmm as _mm
 from ._dispatch import on_device_of, stream_of
 
 LRELU_SLOPE = 0.2
@@ -27,7 +28,9 @@ def linear_supported(x, weight):
 
 
 def _linear_composite(x, weight, bias, wscale, bscale, act):
-    t = F.linear(x, weight * wscale)
+    """The defining algebra of `_Linear` for its RECORDED backward; the product runs on op.smallmm (this library's
+    kernels, closed under differentiation), not on F.linear / rocBLAS."""
+    t = _mm.mm_nt(x, weight) * wscale
     if bias is not None:
         t = t + bias * bscale
     return F.leaky_relu(t, LRELU_SLOPE) * LRELU_GAIN if act else t
@@ -102,7 +105,8 @@ def demod_supported(s, wsq):
 
 
 def _demod_composite(s, wsq, eps):
-    return torch.rsqrt(torch.matmul(s * s, wsq) + eps)
+    """The defining algebra of `_Demod` for its RECORDED backward (op.smallmm instead of torch.matmul)."""
+    return torch.rsqrt(_mm.mm_nn(s * s, wsq) + eps)
 
 
 class _Demod(Function):

@@ -9,6 +9,8 @@ layers.py:298-300 rewritten as rsqrt(style^2 @ wsq + eps).  One launch replaces 
 permute+copy sequence per layer and step, one more its whole backward.  Both are differentiable to
 any order: the second-order formulas (path-length regulariser only) are plain tensor algebra.
 """
+import weakref
+
 import torch
 from torch.autograd import Function
 
@@ -107,11 +109,21 @@ def weight_prep(weight, scale, want_sq=False):
 _FROZEN_ADJ = None
 
 
+# networks whose parameters a replayed hipGraph rewrites (graph_train.GraphedTrainer registers its three); a WeakSet of the
+# module OBJECTS, so copy.deepcopy(net) is not a member
+GRAPH_WRITTEN = weakref.WeakSet()
+
+
 def freeze_prepared_weights(net, flag=True):
     """Marks every convolution of `net` whose weights the caller guarantees not to change behind torch's back (in-place
     torch ops bump the version and refresh the cache): their tap-major weights, demodulation matrices and
     data-gradient adjoints are prepared once instead of per call (k_wprep / k_wadjoint: ~90 launches per inversion
     step at batch 1, where every launch is ~5 us of a 10 ms step)."""
+    if flag and net in GRAPH_WRITTEN:
+        raise RuntimeError("freeze_prepared_weights: this network's parameters are rewritten by a replayed hipGraph "
+                           "(GraphedTrainer's EMA / optimiser graphs) — replays do not bump tensor versions, so every "
+                           "version-keyed cache (prepared weights, adjoints, Winograd-domain weights) would serve stale "
+                           "values.  Freeze a copy: copy.deepcopy(trainer.g_ema)")
     for m in net.modules():
         m._frozen_weights = bool(flag)          # read by weight_prep_cached through layers.*Conv2d
     return net

@@ -52,12 +52,40 @@ class FlatAdam:
                 p.data = view                      # the module now reads its weights out of the flat buffer
         self.param_groups = [{"params": self.params, "lr": float(lr), "betas": (float(betas[0]), float(betas[1])),
                               "eps": float(eps), "weight_decay": 0, "amsgrad": False}]
+        self.guards = None               # set_guards(): positions of flat_grad that must not be NaN for a step to apply
+        self.skipped = None
+
+    def set_guards(self, offsets):
+        """Data-parallel training: `offsets` = the first element of every all-reduce bucket of the gradient buffer.
+        A step whose gradient carries NaN at one of them is REFUSED on the device (p / m / v untouched) and
+        `self.skipped` (pinned host word) is raised — see sr_adam_flat_guarded and distributed.BucketedGradReducer:
+        a bucket signal lost on one rank becomes a refused step on every rank instead of an update with a half-written
+        gradient."""
+        import ctypes
+
+        offsets = [int(o) for o in offsets][:16]
+        self.guards = (ctypes.c_int64 * len(offsets))(*offsets)
+        if self.flat_p.device.type == "cuda":
+            self.skipped = torch.zeros(1, dtype=torch.int32).pin_memory()
+        else:
+            self.skipped = torch.zeros(1, dtype=torch.int32)
+        return self.skipped
 
     def step(self):
         g = self.param_groups[0]
         self.step_t.add_(1.0)
         if self.flat_p.device.type != "cuda":
+            if self.guards is not None and bool(torch.isnan(self.flat_g[list(self.guards)]).any()):
+                self.skipped.fill_(1)
+                return
             return self._step_host(g)
+        if self.guards is not None:
+            rc = _lib.lib().sr_adam_flat_guarded(self.flat_p.data_ptr(), self.flat_g.data_ptr(), self.m.data_ptr(),
+                                                 self.v.data_ptr(), self.total, g["lr"], g["betas"][0], g["betas"][1],
+                                                 g["eps"], self.step_t.data_ptr(), self.guards, len(self.guards),
+                                                 self.skipped.data_ptr(), _lib.current_stream(self.flat_p.device))
+            _lib.check(rc, "sr_adam_flat_guarded")
+            return
         rc = _lib.lib().sr_adam_flat(self.flat_p.data_ptr(), self.flat_g.data_ptr(), self.m.data_ptr(),
                                      self.v.data_ptr(), self.total, g["lr"], g["betas"][0], g["betas"][1], g["eps"],
                                      self.step_t.data_ptr(), _lib.current_stream(self.flat_p.device))

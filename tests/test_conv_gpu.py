@@ -588,3 +588,56 @@ def test_frozen_weights_keep_their_winograd_domain_weights(monkeypatch):
         wt.mul_(2.0)                                                      # new version: the cached block is not reused
         doubled = cv.conv2d_mfma(x, wt, isc, osc, None, 3, 1, 1)
         assert torch.allclose(doubled, 2 * want, rtol=1e-5, atol=1e-6)
+
+
+def test_frozen_weight_scratch_counts_as_written_only_after_an_executed_winograd_call(monkeypatch):
+    """the persistent scratch of a frozen weight was marked "Winograd-domain weights present" when it was
+    CREATED.  Two first calls leave the block unwritten: one that is only recorded into a graph under capture, and one
+    whose input is not 16-byte aligned (the direct kernel serves it).  The next eager, aligned call must still run the
+    weight transform — same bits as the uncached call; and once the block really is written, later calls reuse it."""
+    from stylerenderer_amd.op import conv as cv
+
+    monkeypatch.setenv("SR_U_CACHE", "1")
+    g = torch.Generator().manual_seed(5)
+    b, c, n, h, w = 1, 64, 64, 8, 32
+    x = torch.randn(b, c, h, w, generator=g).to(DEV)
+    isc, osc = torch.randn(b, c, generator=g).to(DEV), torch.randn(b, n, generator=g).to(DEV)
+
+    def weight():
+        wt = (torch.randn(9, c, n, generator=torch.Generator().manual_seed(9)) / (3 * c ** 0.5)).to(DEV)
+        monkeypatch.setenv("SR_U_CACHE", "0")
+        want = cv.conv2d_mfma(x, wt, isc, osc, None, 3, 1, 1)
+        monkeypatch.setenv("SR_U_CACHE", "1")
+        wt._sr_frozen = True
+        return wt, want
+
+    # (a) first call under capture: recorded, not executed
+    wt, want = weight()
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(graph, stream=side):
+            captured = cv.conv2d_mfma(x, wt, isc, osc, None, 3, 1, 1)
+    torch.cuda.current_stream().wait_stream(side)
+    (entry,) = wt._sr_scratch.values()
+    assert not entry.ready
+    entry.buf.fill_(float("nan"))                       # whatever the fresh allocation held
+    eager = cv.conv2d_mfma(x, wt, isc, osc, None, 3, 1, 1)
+    assert torch.equal(eager, want) and entry.ready
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(captured, want)
+    # (b) first call on a misaligned input view: the direct kernel, no weight block written
+    wt, want = weight()
+    pad = torch.zeros(x.numel() + 1, device=DEV)
+    xm = pad[1:].view_as(x)
+    xm.copy_(x)
+    assert xm.data_ptr() % 16 != 0
+    direct = cv.conv2d_mfma(xm, wt, isc, osc, None, 3, 1, 1)
+    (entry,) = wt._sr_scratch.values()
+    assert not entry.ready and rel_err_t(direct, want) < 2e-6
+    entry.buf.fill_(float("nan"))
+    assert torch.equal(cv.conv2d_mfma(x, wt, isc, osc, None, 3, 1, 1), want) and entry.ready
+    assert torch.equal(cv.conv2d_mfma(x, wt, isc, osc, None, 3, 1, 1), want)          # reused now

@@ -189,3 +189,34 @@ def test_eager_graphed_trainer_single_process_trains_and_arrival_layout_is_a_per
     log = tr.step(train.SyntheticImages(8, SIZE, "cpu").batch(BATCH), mesh=mesh)
     assert all(np.isfinite(v) for v in log.values()) and not torch.equal(before, tr.g_optim.flat_p)
     assert tr.reduce_g.describe()["mode"] == "off"                    # one rank: nothing to reduce
+
+
+def test_guarded_flat_adam_refuses_a_marked_gradient_on_cpu():
+    """optim.FlatAdam.set_guards + BucketedGradReducer.guard on CPU tensors (the host arithmetic of sr_adam_flat_guarded):
+    NaN at a bucket's first element = the marker a timed-out bucket wait leaves (through the all-reduce, on every rank):
+    the step is refused, parameters and moments stay, and the reducer's check() raises once."""
+    import pytest
+    import torch
+
+    from stylerenderer_amd import distributed as sr_dist
+    from stylerenderer_amd.optim import FlatAdam
+
+    ps = [torch.nn.Parameter(torch.randn(64)) for _ in range(4)]
+    flat = torch.ones(4 * 64)
+    offs = [0, 64, 128, 192]
+    views = [flat[i * 64:(i + 1) * 64] for i in range(4)]
+    red = sr_dist.BucketedGradReducer(ps, views, offs, flat, world=1, n_buckets=2, force=True)
+    opt = red.guard(FlatAdam(ps, flat, lr=0.1, offs=offs))
+    assert list(opt.guards) == [b["lo"] for b in red.buckets]
+    opt.step()
+    red.check()
+    p1, m1, t1 = opt.flat_p.clone(), opt.m.clone(), float(opt.step_t)
+    flat[red.buckets[1]["lo"]] = float("nan")
+    opt.step()
+    assert torch.equal(opt.flat_p, p1) and torch.equal(opt.m, m1) and float(opt.step_t) == t1 + 1
+    with pytest.raises(RuntimeError, match="REFUSED"):
+        red.check()
+    red.check()
+    flat.fill_(1.0)
+    opt.step()
+    assert not torch.equal(opt.flat_p, p1)

@@ -177,3 +177,123 @@ def test_lost_signal_times_out_and_raises(monkeypatch):
                                         red.comm.cuda_stream), "wait")
     torch.cuda.synchronize()
     red.check()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def test_overlap_modes_under_constrained_hardware_queues():
+    """The device-released overlap spins a one-lane kernel at the head of the communication stream; that is only safe
+    while the communication stream and the replaying stream own different hardware queues.  The
+    reducer therefore probes the assumption when it is built and falls back to the host-released mode.  Here the whole
+    overlapped iteration runs in a process of its own (HIP reads GPU_MAX_HW_QUEUES at start-up) with 1, 2 and 4
+    hardware queues, and with each mode forced: every run must FINISH (no 120 s signal timeout — the subprocess limit is
+    far below it), stay finite, report a mode consistent with its probe, and land on the same parameters bit for bit
+    (one rank: the all-reduce is the identity, so the two modes and every queue count agree exactly)."""
+    import json
+    import subprocess
+    import sys
+
+    child = os.path.join(os.path.dirname(os.path.abspath(__file__)), "overlap_child.py")
+    runs = []
+    for hwq, forced in (("1", None), ("2", None), ("4", None), (None, "host"), (None, "device")):
+        env = dict(os.environ)
+        env.pop("GPU_MAX_HW_QUEUES", None)
+        env.pop("SR_GRAD_OVERLAP", None)
+        env["SR_SIGNAL_TIMEOUT_S"] = "20"
+        if hwq:
+            env["GPU_MAX_HW_QUEUES"] = hwq
+        if forced:
+            env["SR_GRAD_OVERLAP"] = forced
+        out = subprocess.run([sys.executable, child, str(_free_port())], env=env, capture_output=True, text=True,
+                             timeout=150)
+        assert out.returncode == 0, (hwq, forced, out.stdout[-2000:], out.stderr[-3000:])
+        line = [ln for ln in out.stdout.splitlines() if ln.startswith("CHILD ")][-1]
+        r = json.loads(line[6:])
+        print(hwq, forced, r["release"], r["probe"], r["overlap"]["bucket_done_ms_after_replay_end"])
+        assert r["finite"]
+        if forced:
+            assert r["release"] == forced and r["probe"] is None
+        else:
+            assert r["release"] == ("device" if r["probe"]["independent"] else "host"), r
+        runs.append(r)
+    assert len({r["digest"] for r in runs}) == 1, [(r["hw_queues"], r["forced"], r["release"], r["digest"][:12]) for r in runs]
+
+
+def test_timed_out_wait_poisons_the_bucket_and_the_guarded_step_is_refused(one_rank_group, monkeypatch):
+    """after a wait gave up, the queued all-reduce ran on a half-written bucket and the optimiser graph was
+    replayed on it.  Now the timed-out wait overwrites the bucket's first element with NaN (every rank receives it
+    through the SUM), the guarded Adam step leaves parameters and moments untouched and raises its pinned word, and
+    check() raises — also on a rank whose own waits were fine (simulated: NaN at a guard position without a status)."""
+    from stylerenderer_amd import _lib
+    from stylerenderer_amd import distributed as sr_dist
+    from stylerenderer_amd.optim import FlatAdam
+
+    monkeypatch.setenv("SR_SIGNAL_TIMEOUT_S", "0.2")
+    ps = [torch.nn.Parameter(torch.randn(64, device=DEV)) for _ in range(4)]
+    flat = torch.ones(4 * 64, device=DEV)
+    offs = [0, 64, 128, 192]
+    views = [flat[i * 64:(i + 1) * 64] for i in range(4)]
+    red = sr_dist.BucketedGradReducer(ps, views, offs, flat, world=1, n_buckets=2, force=True, release="device")
+    opt = red.guard(FlatAdam(ps, flat, lr=0.1, offs=offs))
+    assert len(opt.guards) == 2 and list(opt.guards) == [b["lo"] for b in red.buckets]
+    opt.step()                                         # a clean gradient: applied
+    torch.cuda.synchronize()
+    red.check()
+    p1, m1 = opt.flat_p.clone(), opt.m.clone()
+    red.arm()                                          # epoch 1 announced, but nothing publishes it
+    red._issue(1, replay=True)                         # wait (times out) + all-reduce of bucket 1 on the comm stream
+    red.wait()
+    opt.step()
+    torch.cuda.synchronize()
+    assert torch.isnan(flat[red.buckets[1]["lo"]]) and torch.isfinite(flat[:red.buckets[1]["lo"]]).all()
+    assert torch.equal(opt.flat_p, p1) and torch.equal(opt.m, m1)          # the step was refused on the device
+    with pytest.raises(RuntimeError, match=r"REFUSED.*bucket\(s\) \[1\] timed out"):
+        red.check()
+    red.check()                                        # reported once
+    # a peer's marker (NaN arrives through the all-reduce, this rank's own status is clean)
+    flat.fill_(1.0)
+    flat[red.buckets[0]["lo"]] = float("nan")
+    opt.step()
+    torch.cuda.synchronize()
+    assert torch.equal(opt.flat_p, p1)
+    with pytest.raises(RuntimeError, match="REFUSED.*peer"):
+        red.check()
+    flat.fill_(1.0)
+    opt.step()
+    torch.cuda.synchronize()
+    red.check()
+    assert not torch.equal(opt.flat_p, p1)
+
+
+def test_host_released_overlap_orders_buckets_before_the_replay_ends(one_rank_group, monkeypatch):
+    """SR_GRAD_OVERLAP=host at full size: signal nodes store the epoch into pinned host words, issue_all() polls them
+    and queues each collective when its bucket is complete — no kernel spins on the communication stream.  Same
+    trajectory as the run without collectives, bit for bit; bucket 0 of the D phase is still reduced long before the
+    replay ends."""
+    monkeypatch.setenv("SR_GRAD_OVERLAP", "host")
+    a, faces, data = full_size_trainer(force_collectives=True)
+    monkeypatch.delenv("SR_GRAD_OVERLAP")
+    b, _, _ = full_size_trainer()
+    assert a.reduce_d.release == "host" and not a.reduce_d.counters.is_cuda and a.reduce_d.counters.is_pinned()
+    batches = [data.batch(4) for _ in range(2)]
+    for tr in (a, b):
+        torch.manual_seed(123)
+        tr.np_rng = np.random.RandomState(5)
+        meshes = [tuple(t.clone() for t in faces.sample(4)) for _ in range(2)]
+        torch.manual_seed(321)
+        tr.logs = [tr.step(x, mesh=m) for x, m in zip(batches, meshes)]
+    assert torch.equal(a.g_optim.flat_p, b.g_optim.flat_p) and torch.equal(a.d_optim.flat_p, b.d_optim.flat_p)
+    assert a.logs == b.logs
+    tries = [a.measure_overlap("d") for _ in range(3)]
+    print("host-released overlap", tries)
+    for t in tries:
+        done = t["bucket_done_ms_after_replay_end"]
+        assert len(done) == 4 and done == sorted(done) and t["release"] == "host"
+    assert any(t["bucket_done_ms_after_replay_end"][0] < -0.25 * t["replay_ms"] for t in tries), tries
+    assert a.reduce_d.counters.tolist() == [a.reduce_d.epoch] * 4

@@ -345,6 +345,34 @@ def test_rasterize_large_triangles_forward_and_gradients(c, raster_path):
     assert np.abs(got[0][1].cpu().numpy() - wt).max() <= 5e-6 * np.abs(wt).max()
 
 
+@pytest.mark.parametrize("fwd,bwd", [("1", "0"), ("0", "1")])
+def test_rasterize_gradient_follows_the_forward_record_not_the_environment(fwd, bwd, monkeypatch):
+    """the gradient pass used to re-evaluate tiled_ok() (SR_RASTER_TILED + a size heuristic) to decide
+    where the leader table lives; a different answer at backward time read a never-initialised table.  The forward now
+    leaves a state word behind the table (1 = built by the tiled path, 0 = filled only) and the gradient pass reads IT
+    on the device: flipping the environment between forward and backward changes nothing, bit for bit."""
+    import stylerenderer_amd.op as op
+    from stylerenderer_amd import synth
+
+    v0, tri = synth.uv_ellipsoid(20, 18)
+    vh = synth.random_poses(v0, 3, seed=9)
+    nh = synth.vertex_normals(vh, tri)
+    go = T(synth.det_normal((3, 64, 64, 3), 78))
+    res = {}
+    for tag, (e_f, e_b) in {"same": (fwd, fwd), "flipped": (fwd, bwd)}.items():
+        v, n = T(vh).requires_grad_(), T(nh).requires_grad_()
+        monkeypatch.setenv("SR_RASTER_TILED", e_f)
+        out = op.rasterize(v, n, T(tri), 64)
+        monkeypatch.setenv("SR_RASTER_TILED", e_b)
+        res[tag] = torch.autograd.grad(out, [v, n], go, retain_graph=True)
+        again = torch.autograd.grad(out, [v, n], go)                  # a second backward over the same state
+        assert torch.equal(again[0], res[tag][0]) and torch.equal(again[1], res[tag][1])
+    assert torch.equal(res["same"][0], res["flipped"][0]) and torch.equal(res["same"][1], res["flipped"][1])
+    wv, wt = _oracle_grads(vh, nh, tri, go.cpu().numpy(), 64)
+    assert np.abs(res["flipped"][0].cpu().numpy() - wv).max() <= 2e-5 * np.abs(wv).max()
+    assert np.abs(res["flipped"][1].cpu().numpy() - wt).max() <= 2e-6 * np.abs(wt).max()
+
+
 def test_rasterize_gradients_misc():
     """No-channel attributes, per-sample topology [b, nf, 3], only one of the two gradients requested, a
     triangle with a repeated vertex id and out-of-range ids (skipped like the reference does)."""
