@@ -281,10 +281,15 @@ def test_full_gradient_tensors_gpu_vs_own_cpu_path(size, batch, slope, tol):
                                     ("up", dict(in_channel=8, out_channel=6, kernel_size=3, style_dim=16, upsample=True)),
                                     ("rgb", dict(in_channel=8, out_channel=3, kernel_size=1, style_dim=16,
                                                  demodulate=False))])
-def test_modulated_conv_layer_vs_reference_gradients(golden, tag, kw):
+def test_modulated_conv_layer_vs_reference_gradients(golden, tag, kw, monkeypatch):
     """layers.ModulatedConv2d on the HIP path against the reference layer's output and ALL its gradients (input,
-    style, weight, modulation weight / bias), full tensors (tests/golden/modconv.npz).  Measured <= 3.2e-7."""
+    style, weight, modulation weight / bias), full tensors (tests/golden/modconv.npz).  Measured <= 3.2e-7.
+    (SURVEY 8(c)'s fixture has 6 output channels: the convolution kernels take it, the [2, 8] x [8, 6] demodulation
+    product is outside sr_demod_fwd's 4-column granularity and runs on the library — the one shape of the suite that
+    needs SR_STRICT_NATIVE off; no layer of G / D has a channel count that is not a multiple of 4.)"""
     from stylerenderer_amd import layers
+
+    monkeypatch.setenv("SR_STRICT_NATIVE", "0")
 
     gold = golden("modconv")
     m = layers.ModulatedConv2d(**kw)
