@@ -1,0 +1,78 @@
+#!/usr/bin/env python3
+"""GPU box: the split-bf16 spike (csrc/conv_wgrad_bf16x3.hip, SR_CONV_SPLIT_BF16=1) against the exact-fp32 MFMA weight
+gradient of the 1x1 convolution on the discriminator's skip-convolution shapes: milliseconds, TFLOP/s-equivalent
+(direct-convolution flops / time) and the error of both against float64, as a histogram of |error| / sum |a||b|.
+Writes markdown to stdout (profiles/r05_split_bf16.md)."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from stylerenderer_amd.op.conv import conv2d_wgrad_mfma  # noqa: E402
+
+DEV = "cuda"
+
+
+def timed(fn, reps=20):
+    fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+def main():
+    g = torch.Generator().manual_seed(1)
+    rows, hist = [], {}
+    edges = [0, 1e-8, 3e-8, 1e-7, 3e-7, 1e-6, 2e-6, 1e-5, 1.0]
+    for b, c, n, res in ((16, 128, 256, 128), (16, 256, 512, 64), (16, 512, 512, 32), (8, 128, 256, 128), (8, 256, 512, 64),
+                         (16, 3, 128, 256), (16, 512, 512, 64)):
+        x = torch.randn(b, c, res, res, generator=g).to(DEV)
+        gy = torch.randn(b, n, res, res, generator=g).to(DEV)
+        xs, gs = torch.randn(b, c, generator=g).to(DEV), torch.randn(b, n, generator=g).to(DEV)
+        flops = 2.0 * b * res * res * c * n
+        out = {}
+        for mode in ("0", "1"):
+            os.environ["SR_CONV_SPLIT_BF16"] = mode
+            out[mode] = conv2d_wgrad_mfma(x, gy, xs, gs, 1, 1, 0)
+            ms = timed(lambda: conv2d_wgrad_mfma(x, gy, xs, gs, 1, 1, 0))
+            out[mode + "ms"] = ms
+        # float64 reference on a channel sub-block (the full product is 1e12 flops in fp64)
+        cu, cv = min(c, 64), min(n, 64)
+        xd = (x[:, :cu].double() * xs[:, :cu].double()[:, :, None, None]).flatten(2)
+        gd = (gy[:, :cv].double() * gs[:, :cv].double()[:, :, None, None]).flatten(2)
+        want = torch.einsum("bcp,bnp->cn", xd, gd)
+        mag = torch.einsum("bcp,bnp->cn", xd.abs(), gd.abs())
+        errs = {}
+        for mode in ("0", "1"):
+            e = ((out[mode][0, :cu, :cv].double() - want).abs() / mag).flatten().cpu().numpy()
+            errs[mode] = e
+            h = hist.setdefault(mode, np.zeros(len(edges) - 1, np.int64))
+            h += np.histogram(e, bins=edges)[0]
+        rows.append((b, c, n, res, out["0ms"], flops / out["0ms"] / 1e9, out["1ms"], flops / out["1ms"] / 1e9,
+                     out["0ms"] / out["1ms"], errs["0"].max(), np.sqrt((errs["0"] ** 2).mean()), errs["1"].max(),
+                     np.sqrt((errs["1"] ** 2).mean())))
+    print("# Split-bf16 spike: 1x1 weight gradient, exact-fp32 MFMA (`k_wgrad_mfma<1,1,1,...>`) vs three-way bf16 split "
+          "(`k_wgrad1_bf16x3`), both incl. their `k_wgrad_reduce`\n")
+    print("| B | Cin | Cout | map | fp32 MFMA ms | TFLOP/s | split-bf16 ms | TFLOP/s-equivalent | speed-up | fp32 max err | "
+          "fp32 rms | split max err | split rms |")
+    print("|---|---|---|---|---|---|---|---|---|---|---|---|---|")
+    for r in rows:
+        print("| %d | %d | %d | %d^2 | %.4f | %.1f | %.4f | %.1f | **%.2fx** | %.2e | %.2e | %.2e | %.2e |" % r)
+    print("\nErrors are |result - float64| / sum |a||b| over a 64 x 64 channel block of every shape (the bar of "
+          "tests/test_conv_gpu.py is 2e-6).\n")
+    print("| |error| / sum|a||b| | " + " | ".join("< %g" % e for e in edges[1:]) + " |")
+    print("|---|" + "---|" * (len(edges) - 1))
+    for mode, name in (("0", "exact-fp32 MFMA"), ("1", "split-bf16 (6 products)")):
+        print("| %s | " % name + " | ".join(str(int(v)) for v in hist[mode]) + " |")
+
+
+if __name__ == "__main__":
+    main()

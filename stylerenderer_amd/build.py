@@ -39,6 +39,7 @@ SOURCES = [
     ("conv_wino.hip", []),
     ("conv_wgrad_wino.hip", []),
     ("conv_wgrad_mfma.hip", []),
+    ("conv_wgrad_bf16x3.hip", []),
 ]
 
 

@@ -1,0 +1,264 @@
+// SPIKE (opt-in, SR_CONV_SPLIT_BF16=1): weight gradient of the 1x1 convolution on the BF16 matrix cores with fp32-level
+// accuracy — every fp32 operand is split into three bf16 pieces and six of the nine cross products are accumulated in
+// fp32.
+//
+//   D[u][v] = sum_{b, p} (uscale[b,u] * U[b,u,p]) * (vscale[b,v] * V[b,v,p])        U = x, V = dL/dy, p = pixel
+//
+// Why this kernel: the bf16 MFMA (v_mfma_f32_32x32x16_bf16, 16x the rate of v_mfma_f32_32x32x2_f32) wants EIGHT
+// consecutive k per lane.  In NCHW the contiguous dimension is the pixel — which is the K dimension of a weight
+// gradient, for both operands; the forward / data-gradient convolutions contract over channels (stride H*W) and would
+// need a channel-packed activation layout first.  The 1x1 weight gradient (the discriminator's skip convolutions and
+// its first layer) is the product's direct kernel where the operand fetch is a plain 32-byte LDS read.
+//
+// Split (exact): a = h1 + h2 + h3 with h1 = bf16(a), h2 = bf16(a - h1), h3 = a - h1 - h2 (8 + 8 + 8 significand bits:
+// both subtractions are exact in fp32 and the last remainder has at most 8 significant bits).  a*b = sum_{i,j} ai*bj;
+// the three terms with i + j >= 5 are below 2^-24 |a*b| and dropped: six bf16 MFMAs (192 matrix-pipe cycles per 32x32
+// tile and 16 k) instead of eight fp32 MFMAs (512 cycles) — 2.67x fewer, paid for with ~5.5 VALU operations per
+// operand element for the split.  Products of bf16 pairs are exact in the fp32 accumulator's input precision, the
+// accumulation is fp32 like the fp32 MFMA's: the result differs from the fp32 kernel's by the dropped terms and the
+// summation order only (tests/test_conv_gpu.py holds it to the SAME 2e-6 * sum|a*b| bar).
+//
+// Tiling: workgroup = 128 (u) x 128 (v) channels, 4 waves of 64 x 64 (2 x 2 MFMA tiles), K chunks of 32 pixels of one
+// sample, staged through registers into double-buffered LDS (row pitch 36 floats: the eight lanes of a ds_read_b128
+// phase hit 32 distinct banks), scales multiplied at staging.  72 KB of LDS: two workgroups per CU.  K slices write
+// partial slabs in k_wgrad_mfma's layout; k_wgrad_reduce (conv_wgrad_mfma.hip) sums them in a fixed order.
+#include "common.h"
+#include "conv_wgrad_bf16x3.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+
+constexpr int UT = 128, VT = 128, KC = 32, PITCH = 36, THREADS = 256;
+constexpr int TILE = UT * PITCH;               // floats of one operand tile
+constexpr int BUF = 2 * TILE;                  // U tile + V tile
+constexpr int LDS_BYTES = 2 * BUF * 4;         // double buffered: 73 728 B
+static_assert(2 * LDS_BYTES <= 160 * 1024, "two workgroups per CU");
+
+struct P3 {
+    const float* U;
+    const float* V;
+    const float* uscale;
+    const float* vscale;
+    float* partial;            // [ks][UP][VP]
+    int B, CU, CV, HW;
+    int cps;                   // chunks per sample = ceil(HW / KC)
+    int nchunk, per_slice;
+    int tiles_u, tiles_v, UP, VP;
+};
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+struct Split3 {
+    u32x4 h1, h2, h3;          // 8 bf16 each (bit patterns, two per dword: element 2i in the low half)
+};
+
+// two floats -> one dword of two round-to-nearest bf16 (v_cvt_pk_bf16_f32)
+__device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {
+    const f32x2 v = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+}
+__device__ __forceinline__ float bf16_lo(unsigned pk) { return __builtin_bit_cast(float, pk << 16); }
+__device__ __forceinline__ float bf16_hi(unsigned pk) { return __builtin_bit_cast(float, pk & 0xFFFF0000u); }
+
+// a pair of floats -> its three bf16 pieces (see the header: exact three-way split): 11 VALU operations per pair
+__device__ __forceinline__ void split2(float x0, float x1, unsigned& p1, unsigned& p2, unsigned& p3) {
+    p1 = pack_bf16(x0, x1);
+    const float r0 = x0 - bf16_lo(p1), r1 = x1 - bf16_hi(p1);
+    p2 = pack_bf16(r0, r1);
+    const float q0 = r0 - bf16_lo(p2), q1 = r1 - bf16_hi(p2);
+    p3 = pack_bf16(q0, q1);
+}
+
+__device__ __forceinline__ Split3 split8(const float4 lo, const float4 hi) {
+    unsigned a0, a1, a2, a3, b0, b1, b2, b3, c0, c1, c2, c3;
+    split2(lo.x, lo.y, a0, b0, c0);
+    split2(lo.z, lo.w, a1, b1, c1);
+    split2(hi.x, hi.y, a2, b2, c2);
+    split2(hi.z, hi.w, a3, b3, c3);
+    Split3 s;
+    s.h1 = u32x4{a0, a1, a2, a3};
+    s.h2 = u32x4{b0, b1, b2, b3};
+    s.h3 = u32x4{c0, c1, c2, c3};
+    return s;
+}
+
+__device__ __forceinline__ f32x16 mma(const u32x4 a, const u32x4 b, const f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+__global__ __launch_bounds__(THREADS, 2) void k_wgrad1_bf16x3(const P3 p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int bid = blockIdx.x;
+    const int tile_uv = bid % (p.tiles_u * p.tiles_v);
+    const int slice = bid / (p.tiles_u * p.tiles_v);
+    const int u0 = (tile_uv / p.tiles_v) * UT, v0 = (tile_uv % p.tiles_v) * VT;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = lane >> 5, l31 = lane & 31;
+    const int wu = wave >> 1, wv = wave & 1;
+
+    const int first = slice * p.per_slice;
+    int last = first + p.per_slice;
+    if (last > p.nchunk) last = p.nchunk;
+
+    // staging role of this thread: 4 float4 of the U tile and 4 of the V tile per chunk
+    //   item i: row = (tid + 256 i) / 8, quad = (tid + 256 i) % 8
+    const int srow = tid >> 3, squad = tid & 7;          // rows srow + 32 i
+    float4 stU0, stU1, stU2, stU3, stV0, stV1, stV2, stV3;
+    // every load is unconditional (clamped address): a load under a per-lane condition becomes an exec-masked branch
+    auto load_one = [&](const float* __restrict__ base, const float* __restrict__ scale, int C, int row, int b, int p0,
+                        bool pok) -> float4 {
+        const int rc = row < C ? row : C - 1;
+        const int pc = pok ? p0 : 0;
+        float4 a = *reinterpret_cast<const float4*>(base + ((int64_t)b * C + rc) * p.HW + pc);
+        float sc = scale ? scale[(int64_t)b * C + rc] : 1.0f;
+        sc = (pok && row < C) ? sc : 0.0f;
+        a.x *= sc; a.y *= sc; a.z *= sc; a.w *= sc;
+        return a;
+    };
+    auto load_chunk = [&](int chunk) {
+        const int b = chunk / p.cps, p0 = (chunk - b * p.cps) * KC + 4 * squad;
+        const bool pok = p0 < p.HW;
+        stU0 = load_one(p.U, p.uscale, p.CU, u0 + srow, b, p0, pok);
+        stU1 = load_one(p.U, p.uscale, p.CU, u0 + srow + 32, b, p0, pok);
+        stU2 = load_one(p.U, p.uscale, p.CU, u0 + srow + 64, b, p0, pok);
+        stU3 = load_one(p.U, p.uscale, p.CU, u0 + srow + 96, b, p0, pok);
+        stV0 = load_one(p.V, p.vscale, p.CV, v0 + srow, b, p0, pok);
+        stV1 = load_one(p.V, p.vscale, p.CV, v0 + srow + 32, b, p0, pok);
+        stV2 = load_one(p.V, p.vscale, p.CV, v0 + srow + 64, b, p0, pok);
+        stV3 = load_one(p.V, p.vscale, p.CV, v0 + srow + 96, b, p0, pok);
+    };
+    auto store_chunk = [&](float* dst) {
+        float* d = dst + srow * PITCH + 4 * squad;
+        *reinterpret_cast<float4*>(d) = stU0;
+        *reinterpret_cast<float4*>(d + 32 * PITCH) = stU1;
+        *reinterpret_cast<float4*>(d + 64 * PITCH) = stU2;
+        *reinterpret_cast<float4*>(d + 96 * PITCH) = stU3;
+        *reinterpret_cast<float4*>(d + TILE) = stV0;
+        *reinterpret_cast<float4*>(d + TILE + 32 * PITCH) = stV1;
+        *reinterpret_cast<float4*>(d + TILE + 64 * PITCH) = stV2;
+        *reinterpret_cast<float4*>(d + TILE + 96 * PITCH) = stV3;
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    if (first < last) {
+        load_chunk(first);
+        store_chunk(smem);
+    }
+    int buf = 0;
+    for (int chunk = first; chunk < last; ++chunk) {
+        __syncthreads();                                   // buffer `buf` written; the other one no longer read
+        const bool more = chunk + 1 < last;
+        if (more) load_chunk(chunk + 1);                   // global loads fly under the MFMA block below
+        const float* sU = smem + buf * BUF;
+        const float* sV = sU + TILE;
+#pragma unroll
+        for (int s = 0; s < KC / 16; ++s) {
+            const int kofs = 16 * s + 8 * half;
+            Split3 a[2], b[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const float* pa = sU + (wu * 64 + i * 32 + l31) * PITCH + kofs;
+                a[i] = split8(*reinterpret_cast<const float4*>(pa), *reinterpret_cast<const float4*>(pa + 4));
+                const float* pb = sV + (wv * 64 + i * 32 + l31) * PITCH + kofs;
+                b[i] = split8(*reinterpret_cast<const float4*>(pb), *reinterpret_cast<const float4*>(pb + 4));
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    // small terms first
+                    acc[i][j] = mma(a[i].h3, b[j].h1, acc[i][j]);
+                    acc[i][j] = mma(a[i].h1, b[j].h3, acc[i][j]);
+                    acc[i][j] = mma(a[i].h2, b[j].h2, acc[i][j]);
+                    acc[i][j] = mma(a[i].h2, b[j].h1, acc[i][j]);
+                    acc[i][j] = mma(a[i].h1, b[j].h2, acc[i][j]);
+                    acc[i][j] = mma(a[i].h1, b[j].h1, acc[i][j]);
+                }
+        }
+        if (more) store_chunk(smem + (buf ^ 1) * BUF);
+        buf ^= 1;
+    }
+
+    // partial[slice][u][v]; C/D layout: column (v) = lane & 31, row (u) = (r & 3) + 8 (r >> 2) + 4 half
+    float* dst = p.partial + (int64_t)slice * p.UP * p.VP;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int u = u0 + wu * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                const int v = v0 + wv * 64 + j * 32 + l31;
+                dst[(int64_t)u * p.VP + v] = acc[i][j][r];
+            }
+}
+
+}  // namespace
+
+bool sr_wgrad_bf16x3_enabled() {
+    const char* e = std::getenv("SR_CONV_SPLIT_BF16");
+    return e && e[0] == '1';
+}
+
+bool sr_wgrad_bf16x3_eligible(int64_t B, int64_t CU, int64_t CV, int64_t HW, const void* u, const void* v) {
+    return B > 0 && CU > 0 && CV > 0 && HW > 0 && HW % 4 == 0 && B * CU * HW < (1LL << 31) && B * CV * HW < (1LL << 31) &&
+           ((reinterpret_cast<uintptr_t>(u) | reinterpret_cast<uintptr_t>(v)) & 15) == 0;
+}
+
+static void plan3(int64_t B, int64_t CU, int64_t CV, int64_t HW, P3& p) {
+    p.tiles_u = (int)sr_ceil_div(CU, UT);
+    p.tiles_v = (int)sr_ceil_div(CV, VT);
+    p.UP = p.tiles_u * UT;
+    p.VP = p.tiles_v * VT;
+    p.cps = (int)sr_ceil_div(HW, KC);
+    p.nchunk = (int)(B * p.cps);
+    const int tiles_uv = p.tiles_u * p.tiles_v;
+    int ks = (2 * SR_NUM_CU + tiles_uv - 1) / tiles_uv;          // two workgroups per CU
+    if (ks > p.nchunk) ks = p.nchunk;
+    if (ks < 1) ks = 1;
+    p.per_slice = (p.nchunk + ks - 1) / ks;
+}
+
+int sr_wgrad_bf16x3_slices(int64_t B, int64_t CU, int64_t CV, int64_t HW) {
+    P3 p;
+    plan3(B, CU, CV, HW, p);
+    return (p.nchunk + p.per_slice - 1) / p.per_slice;
+}
+
+int64_t sr_wgrad_bf16x3_scratch_floats(int64_t B, int64_t CU, int64_t CV, int64_t HW) {
+    P3 p;
+    plan3(B, CU, CV, HW, p);
+    return (int64_t)sr_wgrad_bf16x3_slices(B, CU, CV, HW) * p.UP * p.VP + 4;
+}
+
+// Launches the partial-slab kernel; returns the number of slices and the padded extents for the caller's reduce.
+int sr_wgrad_bf16x3_launch(const float* U, const float* V, const float* uscale, const float* vscale, float* partial,
+                           int64_t B, int64_t CU, int64_t CV, int64_t HW, int* ks, int* UP, int* VP, hipStream_t st) {
+    P3 p;
+    plan3(B, CU, CV, HW, p);
+    p.U = U; p.V = V; p.uscale = uscale; p.vscale = vscale; p.partial = partial;
+    p.B = (int)B; p.CU = (int)CU; p.CV = (int)CV; p.HW = (int)HW;
+    *ks = (p.nchunk + p.per_slice - 1) / p.per_slice;
+    *UP = p.UP;
+    *VP = p.VP;
+    static bool configured = false;
+    if (!configured) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_wgrad1_bf16x3), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  LDS_BYTES);
+        configured = true;
+    }
+    hipLaunchKernelGGL(k_wgrad1_bf16x3, dim3((unsigned)(p.tiles_u * p.tiles_v * *ks)), dim3(THREADS), LDS_BYTES, st, p);
+    return sr_launch_status();
+}

@@ -28,6 +28,7 @@
 // The modulation scales are fetched per patch as two small LDS rows and multiplied onto the
 // operands after the ds_read (never onto freshly loaded registers: no wait on memory in the loop).
 #include "common.h"
+#include "conv_wgrad_bf16x3.h"
 #include "conv_wino.h"
 
 #include <cstdlib>
@@ -597,6 +598,10 @@ extern "C" int64_t sr_conv2d_wgrad_scratch_floats(int64_t B, int64_t C, int64_t 
         const int64_t w = sr_wgrad_wino_scratch_floats(B, C, N, IH, IW);
         need = need > w ? need : w;
     }
+    if (!transposed && ksize == 1 && stride == 1 && sr_wgrad_bf16x3_enabled()) {
+        const int64_t w = sr_wgrad_bf16x3_scratch_floats(B, C, N, IH * IW);
+        need = need > w ? need : w;
+    }
     return need;
 }
 
@@ -613,6 +618,21 @@ extern "C" int sr_conv2d_wgrad_mfma(float* dwt, const float* x, const float* gy,
     if (!transposed && ksize == 3 && stride == 1 && pad == 1 && wgrad_wino_enabled() &&
         sr_wgrad_wino_eligible(B, C, N, IH, IW, x, gy))
         return sr_wgrad_wino_3x3(dwt, x, gy, xscale, gscale, B, C, N, IH, IW, scratch, st);
+    if (!transposed && ksize == 1 && stride == 1 && pad == 0 && B > 0 && sr_wgrad_bf16x3_enabled() &&
+        sr_wgrad_bf16x3_eligible(B, C, N, IH * IW, x, gy)) {
+        // opt-in spike (SR_CONV_SPLIT_BF16=1): split-bf16 matrix path, same partial-slab layout and reduce
+        int ks3 = 0, UP3 = 0, VP3 = 0;
+        const int rc3 = sr_wgrad_bf16x3_launch(x, gy, xscale, gscale, scratch, B, C, N, IH * IW, &ks3, &UP3, &VP3, st);
+        if (rc3 != SR_OK) return rc3;
+        ReduceParams r;
+        r.partial = scratch; r.out = dwt;
+        r.ks = ks3; r.nt = 1; r.UP = UP3; r.VP = VP3; r.CU = CUc; r.CV = CVc;
+        r.slab = C * N; r.su = N; r.sv = 1;
+        for (int t = 0; t < 9; ++t) r.tmap[t] = t;
+        const int64_t total = (int64_t)CUc * CVc;
+        hipLaunchKernelGGL(k_wgrad_reduce, dim3(sr_stream_grid(total, 256)), dim3(256), 0, st, r);
+        return sr_launch_status();
+    }
     const Plan pl = make_plan(is, (int)B, CUc, CVc, GH, GW);
     WgradParams p;
     p.U = transposed ? gy : x;

@@ -1360,15 +1360,18 @@ __global__ __launch_bounds__(256) void k_first_pix(long long total, long long hw
                                                    const int* __restrict__ win, int* __restrict__ first,
                                                    const int* __restrict__ built) {
     if (*built) return;
-    const long long g = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (g >= total) return;
-    const int ti = win[g];
-    if (ti < 0) return;
-    const long long s = g / hw, pix = g - s * hw;
-    const long long x = pix % w;
-    if (x > 0 && win[g - 1] == ti) return;
-    if (pix >= w && win[g - w] == ti) return;
-    atomicMin(&first[s * nf + ti], (int)pix);                    // integer minimum: order independent
+    // grid-stride: the launch is capped at a few thousand workgroups, so that the common case (table already built by
+    // the tiled forward: every workgroup leaves at the line above) costs ~1 us instead of retiring b*h*w/256 of them
+    const long long stride = (long long)gridDim.x * 256;
+    for (long long g = (long long)blockIdx.x * 256 + threadIdx.x; g < total; g += stride) {
+        const int ti = win[g];
+        if (ti < 0) continue;
+        const long long s = g / hw, pix = g - s * hw;
+        const long long x = pix % w;
+        if (x > 0 && win[g - 1] == ti) continue;
+        if (pix >= w && win[g - w] == ti) continue;
+        atomicMin(&first[s * nf + ti], (int)pix);                // integer minimum: order independent
+    }
 }
 
 // Small triangles: one lane per (sample, TRIANGLE).  The leader table says in ONE coalesced load whether the triangle
@@ -1757,8 +1760,8 @@ int grad_impl(long long b, long long nv, long long nf, long long h, long long w,
     // the state the FORWARD wrote, on the device — never re-derived from tiled_ok() at backward time.
     int* first = const_cast<int*>(big) + 1 + b * nf;
     if (b * nf > 0)
-        hipLaunchKernelGGL(k_first_pix, dim3((unsigned)sr_ceil_div(b * h * w, 256)), dim3(256), 0, st, b * h * w, h * w, w,
-                           nf, win, first, first + b * nf);
+        hipLaunchKernelGGL(k_first_pix, dim3((unsigned)std::min<long long>(sr_ceil_div(b * h * w, 256), 1024)), dim3(256), 0,
+                           st, b * h * w, h * w, w, nf, win, first, first + b * nf);
     // attribute channels in chunks of <= 4 register accumulators; the vertex gradient rides with chunk 0
     for (long long ch0 = 0; ch0 < (grad_tex ? tex_c : 1); ch0 += 4) {
         const long long ct = tex_c - ch0 < 4 ? tex_c - ch0 : 4;

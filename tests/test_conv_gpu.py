@@ -641,3 +641,39 @@ def test_frozen_weight_scratch_counts_as_written_only_after_an_executed_winograd
     entry.buf.fill_(float("nan"))
     assert torch.equal(cv.conv2d_mfma(x, wt, isc, osc, None, 3, 1, 1), want) and entry.ready
     assert torch.equal(cv.conv2d_mfma(x, wt, isc, osc, None, 3, 1, 1), want)          # reused now
+
+
+@pytest.mark.parametrize("case", [(2, 8, 3, 8, 8), (2, 16, 5, 32, 32), (3, 130, 70, 20, 12), (2, 256, 512, 64, 64),
+                                  (5, 128, 256, 16, 24)])
+@pytest.mark.parametrize("scaled", [True, False])
+def test_split_bf16_wgrad_1x1_holds_the_fp32_bar(case, scaled, monkeypatch):
+    """SPIKE, opt-in (SR_CONV_SPLIT_BF16=1): the 1x1 weight gradient on the bf16 matrix cores with every fp32 operand
+    split into three bf16 pieces and six cross products accumulated in fp32 (csrc/conv_wgrad_bf16x3.hip).  Held to the
+    SAME bound as the exact-fp32 convolution kernels above — |error| < 2e-6 * sum |a| |b| against float64 — channel
+    tails, ragged last chunk (H*W not a multiple of 32), with and without the modulation scales; and it must not be
+    worse than the fp32-MFMA kernel by more than 2x on the same inputs."""
+    from stylerenderer_amd.op.conv import conv2d_wgrad_mfma
+
+    b, c, n, h, w = case
+    g = torch.Generator().manual_seed(b * 31 + c + n + h)
+    x = torch.randn(b, c, h, w, generator=g)
+    gy = torch.randn(b, n, h, w, generator=g)
+    xs = torch.randn(b, c, generator=g) if scaled else None
+    gs = torch.randn(b, n, generator=g) if scaled else None
+    xd = x.double() * (xs.double()[:, :, None, None] if scaled else 1.0)
+    gd = gy.double() * (gs.double()[:, :, None, None] if scaled else 1.0)
+    want = torch.einsum("bcp,bnp->cn", xd.flatten(2), gd.flatten(2))[None]            # [1, C, N]
+    mag = torch.einsum("bcp,bnp->cn", xd.abs().flatten(2), gd.abs().flatten(2))[None]
+    dev = lambda t: None if t is None else t.to(DEV)  # noqa: E731
+    monkeypatch.setenv("SR_CONV_SPLIT_BF16", "0")
+    exact = conv2d_wgrad_mfma(dev(x), dev(gy), dev(xs), dev(gs), 1, 1, 0)
+    monkeypatch.setenv("SR_CONV_SPLIT_BF16", "1")
+    split = conv2d_wgrad_mfma(dev(x), dev(gy), dev(xs), dev(gs), 1, 1, 0)
+    again = conv2d_wgrad_mfma(dev(x), dev(gy), dev(xs), dev(gs), 1, 1, 0)
+    assert split.shape == want.shape and torch.equal(split, again)                     # deterministic
+    e_split = float(((split.cpu().double() - want).abs() / (mag + 1e-30)).max())
+    e_exact = float(((exact.cpu().double() - want).abs() / (mag + 1e-30)).max())
+    print(case, scaled, "split-bf16 %.2e, fp32 MFMA %.2e of sum|a||b|" % (e_split, e_exact))
+    assert e_split < 2e-6, (e_split, e_exact)
+    assert e_split < 2 * e_exact + 1e-7, (e_split, e_exact)
+    assert not torch.equal(split, exact) or c * n < 64                                 # the other kernel really ran
