@@ -108,6 +108,8 @@ def parse(argv=None):
     ap.add_argument("--no-pmc", action="store_true",
                     help="do not spawn the rocprofv3 --pmc passes that measure HBM traffic / MFMA busy / VALU "
                          "instructions for the roofline objects (they then cite the committed profiles/ summary)")
+    ap.add_argument("--no-split-bf16", action="store_true",
+                    help="skip the secondary timing of the step with SR_CONV_SPLIT_BF16=1 (opt-in split-bf16 weight gradients)")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--plumbing", action="store_true",
                     help="CPU-only launch check (gloo, tiny model): exercises --gpus N rank spawning without a GPU")
@@ -257,7 +259,7 @@ def collect_live_pmc(timeout_s=150):
         return "rocprofv3 not found"
     out = tempfile.mkdtemp(prefix="sr_pmc_", dir="/tmp")
     child = [sys.executable, os.path.abspath(__file__), "--steps", "2", "--warmup", "1", "--no-train", "--no-inversion",
-             "--no-cpu-baseline", "--pmc-child"]
+             "--no-cpu-baseline", "--no-split-bf16", "--pmc-child"]
     env = dict(os.environ, TMPDIR="/tmp")
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
         env.pop(k, None)
@@ -777,6 +779,27 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     prof, conv_op.PROFILE = conv_op.PROFILE, None
+    # ---- secondary, opt-in arithmetic (NOT the headline): the same step with the stride-2 / 1x1 weight gradients on the
+    # bf16 matrix cores, every fp32 operand split into three bf16 pieces (csrc/conv_wgrad_bf16x3.hip; error table in
+    # profiles/r05_split_bf16.md: at or below the exact-fp32 MFMA kernels' under the same 2e-6 * sum|a||b| bar)
+    split_res = None
+    if world == 1 and not args.no_split_bf16:
+        os.environ["SR_CONV_SPLIT_BF16"] = "1"
+        try:
+            for _ in range(2):
+                step()
+            fence()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                step()
+            fence()
+            dt = time.perf_counter() - t1
+            split_res = {"value": round(args.batch * args.steps / dt, 2), "unit": "images/s",
+                         "ms_per_step": round(dt / args.steps * 1e3, 3), "dtype": "f32 operands split into 3 x bf16, six "
+                         "bf16-MFMA products, fp32 accumulation (weight gradients of the stride-2 3x3 and 1x1 layers only)",
+                         "opt_in": "SR_CONV_SPLIT_BF16=1", "speedup_vs_headline": round(elapsed / dt, 4)}
+        finally:
+            os.environ["SR_CONV_SPLIT_BF16"] = "0"
     per_rank_ms = [round(elapsed / args.steps * 1e3, 3)]
     if world > 1:
         mine = torch.zeros(world, device=dev, dtype=torch.float64)
@@ -924,6 +947,7 @@ def main():
             "model_flop_frac_of_mfma_peak": round(value / world * FLOP_PER_IMAGE_FWD_BWD / (FP32_MFMA_PEAK_TFLOPS * 1e12), 4),
             "step_executed_mfma_frac": step_exec["frac"] if step_exec else None, "step_executed_mfma": step_exec,
             "roofline": roof, "cpu_baseline": cpu, "kernel_breakdown": breakdown, "pmc_note": pmc_note,
+            "split_bf16_variant": split_res,
             "train_step": train_res, "rasterizer": raster, "inversion": inversion_res,
         }
     if world > 1:

@@ -29,6 +29,8 @@ def timed(fn, reps=20):
 
 
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "s2only":
+        return stride2(reps=3, shapes=((16, 256, 128, 128, True), (16, 512, 256, 64, True)))
     g = torch.Generator().manual_seed(1)
     rows, hist = [], {}
     edges = [0, 1e-8, 3e-8, 1e-7, 3e-7, 1e-6, 2e-6, 1e-5, 1.0]
@@ -72,6 +74,38 @@ def main():
     print("|---|" + "---|" * (len(edges) - 1))
     for mode, name in (("0", "exact-fp32 MFMA"), ("1", "split-bf16 (6 products)")):
         print("| %s | " % name + " | ".join(str(int(v)) for v in hist[mode]) + " |")
+    stride2()
+
+
+def stride2(reps=20, shapes=None):
+    """The stride-2 3x3 weight gradient of the up- / down-sampling layers (k_wgrad_s2_dma vs k_wgrad_s2_bf16x3)."""
+    g = torch.Generator().manual_seed(2)
+    rows = []
+    # (B, C, N, res, transposed): headline up-sampling layers, the training step's batch, the discriminator's c3s2
+    for b, c, n, res, tr in shapes or ((16, 256, 128, 128, True), (16, 512, 256, 64, True), (16, 512, 512, 32, True),
+                                       (4, 256, 128, 128, True), (4, 512, 256, 64, True), (8, 128, 256, 257, False),
+                                       (8, 256, 512, 129, False)):
+        out = 2 * res + 1 if tr else (res - 3) // 2 + 1
+        x = torch.randn(b, c, res, res, generator=g).to(DEV)
+        gy = torch.randn(b, n, out, out, generator=g).to(DEV)
+        xs, gs = torch.randn(b, c, generator=g).to(DEV), torch.randn(b, n, generator=g).to(DEV)
+        grid = res if tr else out
+        flops = 2.0 * b * grid * grid * c * n * 9
+        ms, res_t = {}, {}
+        for mode in ("0", "1"):
+            os.environ["SR_CONV_SPLIT_BF16"] = mode
+            res_t[mode] = conv2d_wgrad_mfma(x, gy, xs, gs, 3, 2, 0, tr)
+            ms[mode] = timed(lambda: conv2d_wgrad_mfma(x, gy, xs, gs, 3, 2, 0, tr), reps)
+        diff = float((res_t["1"] - res_t["0"]).abs().max() / res_t["0"].abs().max())
+        rows.append((b, c, n, res, "transposed" if tr else "strided", ms["0"], flops / ms["0"] / 1e9, ms["1"],
+                     flops / ms["1"] / 1e9, ms["0"] / ms["1"], diff))
+    print("\n# Stride-2 3x3 weight gradient: `k_wgrad_s2_dma` (exact fp32 MFMA) vs `k_wgrad_s2_bf16x3`, both incl. "
+          "`k_wgrad_reduce`\n")
+    print("| B | Cin | Cout | input | kind | fp32 MFMA ms | TFLOP/s | split-bf16 ms | TFLOP/s-equivalent | speed-up | "
+          "max |split - fp32| / max |fp32| |")
+    print("|---|---|---|---|---|---|---|---|---|---|---|")
+    for r in rows:
+        print("| %d | %d | %d | %d^2 | %s | %.4f | %.1f | %.4f | %.1f | **%.2fx** | %.1e |" % r)
 
 
 if __name__ == "__main__":

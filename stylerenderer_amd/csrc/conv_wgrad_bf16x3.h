@@ -10,3 +10,10 @@ bool sr_wgrad_bf16x3_eligible(int64_t B, int64_t CU, int64_t CV, int64_t HW, con
 int64_t sr_wgrad_bf16x3_scratch_floats(int64_t B, int64_t CU, int64_t CV, int64_t HW);
 int sr_wgrad_bf16x3_launch(const float* U, const float* V, const float* uscale, const float* vscale, float* partial,
                            int64_t B, int64_t CU, int64_t CV, int64_t HW, int* ks, int* UP, int* VP, hipStream_t st);
+
+bool sr_wgrad_s2_bf16x3_eligible(int64_t B, int64_t CU, int64_t CV, int64_t UH, int64_t UW, int64_t GH, int64_t GW,
+                                 const void* v);
+int64_t sr_wgrad_s2_bf16x3_scratch_floats(int64_t B, int64_t CU, int64_t CV, int64_t GH, int64_t GW);
+int sr_wgrad_s2_bf16x3_launch(const float* U, const float* V, const float* uscale, const float* vscale, float* partial,
+                              int64_t B, int64_t CU, int64_t CV, int64_t UH, int64_t UW, int64_t GH, int64_t GW, int* ks,
+                              int* UP, int* VP, hipStream_t st);

@@ -31,11 +31,13 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 
+namespace s1 {
 constexpr int UT = 128, VT = 128, KC = 32, PITCH = 36, THREADS = 256;
 constexpr int TILE = UT * PITCH;               // floats of one operand tile
 constexpr int BUF = 2 * TILE;                  // U tile + V tile
 constexpr int LDS_BYTES = 2 * BUF * 4;         // double buffered: 73 728 B
 static_assert(2 * LDS_BYTES <= 160 * 1024, "two workgroups per CU");
+}  // namespace s1
 
 struct P3 {
     const float* U;
@@ -90,7 +92,8 @@ __device__ __forceinline__ f32x16 mma(const u32x4 a, const u32x4 b, const f32x16
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
-__global__ __launch_bounds__(THREADS, 2) void k_wgrad1_bf16x3(const P3 p) {
+__global__ __launch_bounds__(s1::THREADS, 2) void k_wgrad1_bf16x3(const P3 p) {
+    using namespace s1;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int bid = blockIdx.x;
     const int tile_uv = bid % (p.tiles_u * p.tiles_v);
@@ -174,18 +177,14 @@ __global__ __launch_bounds__(THREADS, 2) void k_wgrad1_bf16x3(const P3 p) {
                 const float* pb = sV + (wv * 64 + i * 32 + l31) * PITCH + kofs;
                 b[i] = split8(*reinterpret_cast<const float4*>(pb), *reinterpret_cast<const float4*>(pb + 4));
             }
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    // small terms first
-                    acc[i][j] = mma(a[i].h3, b[j].h1, acc[i][j]);
-                    acc[i][j] = mma(a[i].h1, b[j].h3, acc[i][j]);
-                    acc[i][j] = mma(a[i].h2, b[j].h2, acc[i][j]);
-                    acc[i][j] = mma(a[i].h2, b[j].h1, acc[i][j]);
-                    acc[i][j] = mma(a[i].h1, b[j].h2, acc[i][j]);
-                    acc[i][j] = mma(a[i].h1, b[j].h1, acc[i][j]);
-                }
+            // term by term over the four tiles: consecutive MFMAs never accumulate into the same registers
+#define SR_TERM(HA, HB)                                      \
+    acc[0][0] = mma(a[0].HA, b[0].HB, acc[0][0]);            \
+    acc[0][1] = mma(a[0].HA, b[1].HB, acc[0][1]);            \
+    acc[1][0] = mma(a[1].HA, b[0].HB, acc[1][0]);            \
+    acc[1][1] = mma(a[1].HA, b[1].HB, acc[1][1]);
+            SR_TERM(h3, h1) SR_TERM(h1, h3) SR_TERM(h2, h2) SR_TERM(h2, h1) SR_TERM(h1, h2) SR_TERM(h1, h1)
+#undef SR_TERM
         }
         if (more) store_chunk(smem + (buf ^ 1) * BUF);
         buf ^= 1;
@@ -205,6 +204,203 @@ __global__ __launch_bounds__(THREADS, 2) void k_wgrad1_bf16x3(const P3 p) {
             }
 }
 
+
+// ---- stride-2 3x3 weight gradient (the up- / down-sampling convolutions), split-bf16 ---------------------------------
+//   D[tap][u][v] = sum_{b, j, i} (us[b,u] U[b,u,2j+ky,2i+kx]) * (vs[b,v] V[b,v,j,i])       tap = 3 ky + kx
+// U has 2G + 1 pixels per side (pad-0 stride-2 layers: windows never leave the image), V lives on the G x G grid.
+// K = pixels again: V is read as it lies.  Of U, the 8 grid positions i .. i+7 of a lane touch the 17 consecutive
+// columns 2i .. 2i+16 of window row 2j + ky, and the three kx variants are the even columns, the odd columns and the
+// even columns shifted by one.  The staging writes every window row DE-INTERLEAVED into LDS (even columns | odd
+// columns: a different LDS address per lane, free), so that kx = 0 and kx = 1 are plain 32-byte reads whose split
+// pieces already are MFMA fragments, and kx = 2 is kx = 0's pieces moved by one bf16 (4 v_perm per piece).
+// Tile: workgroup = 64 (u) x 128 (v) channels, 8 waves of 32 x 32 x 9 taps (144 accumulator registers: TWO waves per
+// SIMD, so one wave's operand preparation — ~380 VALU operations per 16 k — runs under the other's 54 MFMAs).
+// K chunk = 32 grid positions of one grid row: U patch [64][3 rows][33 even | 32 odd] + V [128][32], staged through
+// registers, double buffered (152 KB).  v1 of this kernel (4 waves of 32 x 64, one wave per SIMD, interleaved rows +
+// 108 v_perm per k-step) ran at 1.15-1.29x the fp32 kernel: the compiler serialises preparation and MFMAs at 490
+// registers.
+namespace s2 {
+constexpr int UT = 64, VT = 128, KC = 32, THREADS = 512, NWAVE = 8;
+constexpr int PU = 76;                       // U row pitch: 3 * 76 = 228 = 4 (mod 32) floats between channels
+constexpr int ODD = 36;                      // odd columns start here inside a row (evens: 0 .. 32)
+constexpr int UCH = 3 * PU;                  // floats per U channel
+constexpr int PV = 36;
+constexpr int OFF_V = UT * UCH;              // 14 592
+constexpr int BUF = OFF_V + VT * PV;         // 19 200 floats
+constexpr int LDS_BYTES = 2 * BUF * 4;       // 153 600
+static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
+constexpr int U_ITEMS = UT * 3 / NWAVE;      // (channel, row) pairs per wave: 24, one 64-column load each
+constexpr int V_ITEMS = VT * KC / 4 / THREADS;   // float4 per thread: 2
+}  // namespace s2
+
+struct P9 {
+    const float* U;
+    const float* V;
+    const float* uscale;
+    const float* vscale;
+    float* partial;            // [ks][9][UP][VP]
+    int B, CU, CV, UH, UW, GH, GW;
+    int segs;                  // chunks per grid row = GW / 32
+    int nchunk, per_slice;
+    int tiles_u, tiles_v, UP, VP;
+};
+
+// (hi half of a, lo half of b): the bf16 pair that straddles two packed dwords
+__device__ __forceinline__ unsigned perm_mid(unsigned a, unsigned b) { return __builtin_amdgcn_perm(b, a, 0x05040302u); }
+
+__device__ __forceinline__ u32x4 shift1(const u32x4 d, unsigned d4) {
+    return u32x4{perm_mid(d.x, d.y), perm_mid(d.y, d.z), perm_mid(d.z, d.w), perm_mid(d.w, d4)};
+}
+
+__global__ __launch_bounds__(512) void k_wgrad_s2_bf16x3(const P9 p) {
+    using namespace s2;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int bid = blockIdx.x;
+    const int tile_uv = bid % (p.tiles_u * p.tiles_v);
+    const int slice = bid / (p.tiles_u * p.tiles_v);
+    const int u0 = (tile_uv / p.tiles_v) * UT, v0 = (tile_uv % p.tiles_v) * VT;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = lane >> 5, l31 = lane & 31;
+    const int wu = wave >> 2, wv = wave & 3;
+
+    const int first = slice * p.per_slice;
+    int last = first + p.per_slice;
+    if (last > p.nchunk) last = p.nchunk;
+    const int plane_u = p.UH * p.UW, plane_v = p.GH * p.GW;
+
+    // ---- staging (whole channel tiles only: CU % 64 == 0, CV % 128 == 0 — see sr_wgrad_s2_bf16x3_eligible).
+    // U: wave w stages channels 8 w .. 8 w + 7, three rows each, 64 columns per load (24 loads of one dword per lane;
+    // the per-item address is ONE running VGPR offset — 24 scalar bases per call site would not fit the SGPR file), and
+    // thread t < 192 the 65th column of (channel t / 3, row t % 3).  Column c lands at c / 2 (even) or ODD + c / 2.
+    // V: thread t stages float4 (row, quad) = ((t + 512 k) / 8, (t + 512 k) % 8).
+    float stU[U_ITEMS], stU65 = 0.0f;
+    float4 stV[V_ITEMS];
+    const int d_row = p.UW, d_ch = plane_u - 2 * p.UW;
+    const int t65 = tid < UT * 3 ? tid : 0;
+    const int off65 = (t65 / 3) * plane_u + (t65 % 3) * p.UW + 64;
+    const int offv0 = (tid >> 3) * plane_v + 4 * (tid & 7);
+    const int lds_col = (lane & 1) ? ODD + (lane >> 1) : (lane >> 1);
+    auto load_chunk = [&](int chunk) {
+        const int seg = chunk % p.segs;
+        const int j = (chunk / p.segs) % p.GH;
+        const int b = chunk / (p.segs * p.GH);
+        const int i0 = seg * KC;
+        const float* ub = p.U + ((int64_t)b * p.CU + u0) * plane_u + (2 * j) * p.UW + 2 * i0;
+        const float* usb = p.uscale ? p.uscale + (int64_t)b * p.CU + u0 : nullptr;
+        int off = wave * 8 * plane_u + lane;
+        float scu[8], sc65 = 1.0f;                                           // wave-uniform scales: scalar loads, ONE branch
+#pragma unroll
+        for (int c = 0; c < 8; ++c) scu[c] = 1.0f;
+        if (usb) {
+#pragma unroll
+            for (int c = 0; c < 8; ++c) scu[c] = usb[wave * 8 + c];
+            sc65 = usb[t65 / 3];
+        }
+#pragma unroll
+        for (int k = 0; k < U_ITEMS; ++k) {
+            stU[k] = ub[off] * scu[k / 3];
+            off += (k % 3 == 2) ? d_ch : d_row;
+        }
+        stU65 = ub[off65] * sc65;
+        const float* vb = p.V + ((int64_t)b * p.CV + v0) * plane_v + j * p.GW + i0;
+        const float* vsb = p.vscale ? p.vscale + (int64_t)b * p.CV + v0 : nullptr;
+        int offv = offv0;
+        float scv[V_ITEMS];
+#pragma unroll
+        for (int k = 0; k < V_ITEMS; ++k) scv[k] = 1.0f;
+        if (vsb) {
+#pragma unroll
+            for (int k = 0; k < V_ITEMS; ++k) scv[k] = vsb[(tid >> 3) + 64 * k];
+        }
+#pragma unroll
+        for (int k = 0; k < V_ITEMS; ++k) {
+            float4 val = *reinterpret_cast<const float4*>(vb + offv);
+            val.x *= scv[k]; val.y *= scv[k]; val.z *= scv[k]; val.w *= scv[k];
+            stV[k] = val;
+            offv += 64 * plane_v;
+        }
+    };
+    auto store_chunk = [&](float* dst) {
+        float* du = dst + wave * 8 * UCH + lds_col;
+#pragma unroll
+        for (int k = 0; k < U_ITEMS; ++k) du[(k / 3) * UCH + (k % 3) * PU] = stU[k];
+        if (tid < UT * 3) dst[(t65 / 3) * UCH + (t65 % 3) * PU + 32] = stU65;       // column 64 = even #32
+        float* dv = dst + OFF_V + (tid >> 3) * PV + 4 * (tid & 7);
+#pragma unroll
+        for (int k = 0; k < V_ITEMS; ++k) *reinterpret_cast<float4*>(dv + 64 * k * PV) = stV[k];
+    };
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+
+    if (first < last) {
+        load_chunk(first);
+        store_chunk(smem);
+    }
+    int buf = 0;
+    for (int chunk = first; chunk < last; ++chunk) {
+        __syncthreads();
+        const bool more = chunk + 1 < last;
+        if (more) load_chunk(chunk + 1);
+        const float* sU = smem + buf * BUF + (wu * 32 + l31) * UCH;
+        const float* sV = smem + buf * BUF + OFF_V + (wv * 32 + l31) * PV;
+#pragma unroll 1
+        for (int s = 0; s < KC / 16; ++s) {
+            const int kofs = 16 * s + 8 * half;
+            const float* pb = sV + kofs;
+            const Split3 bf = split8(*reinterpret_cast<const float4*>(pb), *reinterpret_cast<const float4*>(pb + 4));
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                const float* pe = sU + ky * PU + kofs;                       // even columns e[kofs .. kofs + 8]
+                const float* po = pe + ODD;                                  // odd columns  o[kofs .. kofs + 7]
+                const Split3 ev = split8(*reinterpret_cast<const float4*>(pe), *reinterpret_cast<const float4*>(pe + 4));
+                const Split3 od = split8(*reinterpret_cast<const float4*>(po), *reinterpret_cast<const float4*>(po + 4));
+                unsigned e8a, e8b, e8c;
+                split2(pe[8], 0.0f, e8a, e8b, e8c);
+                const u32x4 s1 = shift1(ev.h1, e8a), s2v = shift1(ev.h2, e8b), s3 = shift1(ev.h3, e8c);
+                // the three taps of the row take turns: consecutive MFMAs never accumulate into the same registers (a
+                // chain of six dependent MFMAs per tap stalls on the 8-pass result latency: SQ_WAIT_INST_ANY 38 %)
+                const int t0 = ky * 3;
+                acc[t0] = mma(ev.h3, bf.h1, acc[t0]);
+                acc[t0 + 1] = mma(od.h3, bf.h1, acc[t0 + 1]);
+                acc[t0 + 2] = mma(s3, bf.h1, acc[t0 + 2]);
+                acc[t0] = mma(ev.h1, bf.h3, acc[t0]);
+                acc[t0 + 1] = mma(od.h1, bf.h3, acc[t0 + 1]);
+                acc[t0 + 2] = mma(s1, bf.h3, acc[t0 + 2]);
+                acc[t0] = mma(ev.h2, bf.h2, acc[t0]);
+                acc[t0 + 1] = mma(od.h2, bf.h2, acc[t0 + 1]);
+                acc[t0 + 2] = mma(s2v, bf.h2, acc[t0 + 2]);
+                acc[t0] = mma(ev.h2, bf.h1, acc[t0]);
+                acc[t0 + 1] = mma(od.h2, bf.h1, acc[t0 + 1]);
+                acc[t0 + 2] = mma(s2v, bf.h1, acc[t0 + 2]);
+                acc[t0] = mma(ev.h1, bf.h2, acc[t0]);
+                acc[t0 + 1] = mma(od.h1, bf.h2, acc[t0 + 1]);
+                acc[t0 + 2] = mma(s1, bf.h2, acc[t0 + 2]);
+                acc[t0] = mma(ev.h1, bf.h1, acc[t0]);
+                acc[t0 + 1] = mma(od.h1, bf.h1, acc[t0 + 1]);
+                acc[t0 + 2] = mma(s1, bf.h1, acc[t0 + 2]);
+            }
+        }
+        if (more) store_chunk(smem + (buf ^ 1) * BUF);
+        buf ^= 1;
+    }
+
+    // partial[slice][tap][u][v]
+    float* dst = p.partial + (int64_t)slice * 9 * p.UP * p.VP;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int u = u0 + wu * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            const int v = v0 + wv * 32 + l31;
+            dst[((int64_t)t * p.UP + u) * p.VP + v] = acc[t][r];
+        }
+}
+
 }  // namespace
 
 bool sr_wgrad_bf16x3_enabled() {
@@ -218,11 +414,11 @@ bool sr_wgrad_bf16x3_eligible(int64_t B, int64_t CU, int64_t CV, int64_t HW, con
 }
 
 static void plan3(int64_t B, int64_t CU, int64_t CV, int64_t HW, P3& p) {
-    p.tiles_u = (int)sr_ceil_div(CU, UT);
-    p.tiles_v = (int)sr_ceil_div(CV, VT);
-    p.UP = p.tiles_u * UT;
-    p.VP = p.tiles_v * VT;
-    p.cps = (int)sr_ceil_div(HW, KC);
+    p.tiles_u = (int)sr_ceil_div(CU, s1::UT);
+    p.tiles_v = (int)sr_ceil_div(CV, s1::VT);
+    p.UP = p.tiles_u * s1::UT;
+    p.VP = p.tiles_v * s1::VT;
+    p.cps = (int)sr_ceil_div(HW, s1::KC);
     p.nchunk = (int)(B * p.cps);
     const int tiles_uv = p.tiles_u * p.tiles_v;
     int ks = (2 * SR_NUM_CU + tiles_uv - 1) / tiles_uv;          // two workgroups per CU
@@ -256,9 +452,59 @@ int sr_wgrad_bf16x3_launch(const float* U, const float* V, const float* uscale, 
     static bool configured = false;
     if (!configured) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_wgrad1_bf16x3), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  LDS_BYTES);
+                                  s1::LDS_BYTES);
         configured = true;
     }
-    hipLaunchKernelGGL(k_wgrad1_bf16x3, dim3((unsigned)(p.tiles_u * p.tiles_v * *ks)), dim3(THREADS), LDS_BYTES, st, p);
+    hipLaunchKernelGGL(k_wgrad1_bf16x3, dim3((unsigned)(p.tiles_u * p.tiles_v * *ks)), dim3(s1::THREADS), s1::LDS_BYTES, st, p);
+    return sr_launch_status();
+}
+
+// ---- stride-2 3x3 -----------------------------------------------------------------------------------------------
+bool sr_wgrad_s2_bf16x3_eligible(int64_t B, int64_t CU, int64_t CV, int64_t UH, int64_t UW, int64_t GH, int64_t GW,
+                                 const void* v) {
+    return B > 0 && GW % s2::KC == 0 && CU % s2::UT == 0 && CV % s2::VT == 0 && UH == 2 * GH + 1 && UW == 2 * GW + 1 &&
+           B * CU * UH * UW < (1LL << 31) && B * CV * GH * GW < (1LL << 31) && (reinterpret_cast<uintptr_t>(v) & 15) == 0;
+}
+
+static void plan9(int64_t B, int64_t CU, int64_t CV, int64_t GH, int64_t GW, P9& p) {
+    p.tiles_u = (int)sr_ceil_div(CU, s2::UT);
+    p.tiles_v = (int)sr_ceil_div(CV, s2::VT);
+    p.UP = p.tiles_u * s2::UT;
+    p.VP = p.tiles_v * s2::VT;
+    p.segs = (int)(GW / s2::KC);
+    p.nchunk = (int)(B * GH * p.segs);
+    const int tiles_uv = p.tiles_u * p.tiles_v;
+    int ks = (SR_NUM_CU + tiles_uv - 1) / tiles_uv;              // one workgroup per CU
+    if (ks > p.nchunk) ks = p.nchunk;
+    if (ks < 1) ks = 1;
+    p.per_slice = (p.nchunk + ks - 1) / ks;
+}
+
+int64_t sr_wgrad_s2_bf16x3_scratch_floats(int64_t B, int64_t CU, int64_t CV, int64_t GH, int64_t GW) {
+    if (GW % s2::KC != 0 || CU % s2::UT != 0 || CV % s2::VT != 0) return 0;
+    P9 p;
+    plan9(B, CU, CV, GH, GW, p);
+    const int ks = (p.nchunk + p.per_slice - 1) / p.per_slice;
+    return (int64_t)ks * 9 * p.UP * p.VP + 4;
+}
+
+int sr_wgrad_s2_bf16x3_launch(const float* U, const float* V, const float* uscale, const float* vscale, float* partial,
+                              int64_t B, int64_t CU, int64_t CV, int64_t UH, int64_t UW, int64_t GH, int64_t GW, int* ks,
+                              int* UP, int* VP, hipStream_t st) {
+    P9 p;
+    plan9(B, CU, CV, GH, GW, p);
+    p.U = U; p.V = V; p.uscale = uscale; p.vscale = vscale; p.partial = partial;
+    p.B = (int)B; p.CU = (int)CU; p.CV = (int)CV; p.UH = (int)UH; p.UW = (int)UW; p.GH = (int)GH; p.GW = (int)GW;
+    *ks = (p.nchunk + p.per_slice - 1) / p.per_slice;
+    *UP = p.UP;
+    *VP = p.VP;
+    static bool configured = false;
+    if (!configured) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_wgrad_s2_bf16x3),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, s2::LDS_BYTES);
+        configured = true;
+    }
+    hipLaunchKernelGGL(k_wgrad_s2_bf16x3, dim3((unsigned)(p.tiles_u * p.tiles_v * *ks)), dim3(s2::THREADS), s2::LDS_BYTES,
+                       st, p);
     return sr_launch_status();
 }

@@ -602,6 +602,10 @@ extern "C" int64_t sr_conv2d_wgrad_scratch_floats(int64_t B, int64_t C, int64_t 
         const int64_t w = sr_wgrad_bf16x3_scratch_floats(B, C, N, IH * IW);
         need = need > w ? need : w;
     }
+    if (ksize == 3 && stride == 2 && sr_wgrad_bf16x3_enabled()) {
+        const int64_t w = sr_wgrad_s2_bf16x3_scratch_floats(B, CUc, CVc, GH, GW);
+        need = need > w ? need : w;
+    }
     return need;
 }
 
@@ -630,6 +634,25 @@ extern "C" int sr_conv2d_wgrad_mfma(float* dwt, const float* x, const float* gy,
         r.slab = C * N; r.su = N; r.sv = 1;
         for (int t = 0; t < 9; ++t) r.tmap[t] = t;
         const int64_t total = (int64_t)CUc * CVc;
+        hipLaunchKernelGGL(k_wgrad_reduce, dim3(sr_stream_grid(total, 256)), dim3(256), 0, st, r);
+        return sr_launch_status();
+    }
+    if (ksize == 3 && is == 2 && pad == 0 && sr_wgrad_bf16x3_enabled() &&
+        sr_wgrad_s2_bf16x3_eligible(B, CUc, CVc, UH, UW, GH, GW, transposed ? x : gy)) {
+        // opt-in spike (SR_CONV_SPLIT_BF16=1): the up- / down-sampling layers' weight gradient on the bf16 matrix cores
+        int ks3 = 0, UP3 = 0, VP3 = 0;
+        const int rc3 = sr_wgrad_s2_bf16x3_launch(transposed ? gy : x, transposed ? x : gy, transposed ? gscale : xscale,
+                                                  transposed ? xscale : gscale, scratch, B, CUc, CVc, UH, UW, GH, GW, &ks3,
+                                                  &UP3, &VP3, st);
+        if (rc3 != SR_OK) return rc3;
+        ReduceParams r;
+        r.partial = scratch; r.out = dwt;
+        r.ks = ks3; r.nt = 9; r.UP = UP3; r.VP = VP3; r.CU = CUc; r.CV = CVc;
+        r.slab = C * N;
+        r.su = transposed ? 1 : N;
+        r.sv = transposed ? N : 1;
+        for (int t = 0; t < 9; ++t) r.tmap[t] = t;
+        const int64_t total = (int64_t)9 * CUc * CVc;
         hipLaunchKernelGGL(k_wgrad_reduce, dim3(sr_stream_grid(total, 256)), dim3(256), 0, st, r);
         return sr_launch_status();
     }

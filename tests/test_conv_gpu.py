@@ -677,3 +677,48 @@ def test_split_bf16_wgrad_1x1_holds_the_fp32_bar(case, scaled, monkeypatch):
     assert e_split < 2e-6, (e_split, e_exact)
     assert e_split < 2 * e_exact + 1e-7, (e_split, e_exact)
     assert not torch.equal(split, exact) or c * n < 64                                 # the other kernel really ran
+
+
+@pytest.mark.parametrize("case", [(2, 128, 64, 32, True), (3, 256, 128, 64, True), (2, 64, 128, 65, False),
+                                  (1, 128, 256, 129, False), (2, 128, 64, 16, True)])
+@pytest.mark.parametrize("scaled", [True, False])
+def test_split_bf16_wgrad_stride2_holds_the_fp32_bar(case, scaled, monkeypatch):
+    """SPIKE, opt-in (SR_CONV_SPLIT_BF16=1): the stride-2 3x3 weight gradient (up-sampling transposed convolution and
+    down-sampling convolution) on the bf16 matrix cores, three-way split, six products (k_wgrad_s2_bf16x3: the 17 window
+    columns of a lane are split once and the even / odd / shifted-even tap fragments assembled with v_perm).  Same bound
+    as the exact-fp32 kernels — |error| < 2e-6 * sum |a||b| against float64 autograd — for both geometries; the last
+    case (16-wide grid) is not eligible and must fall through to the fp32 kernel bit for bit."""
+    from stylerenderer_amd.op.conv import conv2d_wgrad_mfma
+
+    b, c, n, res, tr = case
+    g = torch.Generator().manual_seed(b * 131 + c + n + res)
+    x = torch.randn(b, c, res, res, generator=g)
+    wshape = (c, n, 3, 3) if tr else (n, c, 3, 3)
+    isc = torch.randn(b, c, generator=g) if scaled else None
+    osc = torch.randn(b, n, generator=g) if scaled else None
+
+    def grad_of(xx, ii, oo, gg):
+        wgt = torch.zeros(wshape, dtype=torch.float64, requires_grad=True)
+        y = ref_conv(xx, wgt, ii, oo, None, 2, 0, tr)
+        (gw,) = torch.autograd.grad(y, wgt, gg.double())
+        return to_taps(gw, tr), y.shape
+
+    out = 2 * res + 1 if tr else (res - 3) // 2 + 1
+    gy = torch.randn(b, n, out, out, generator=g)
+    want, _ = grad_of(x, isc, osc, gy)
+    mag, _ = grad_of(x.abs(), isc.abs() if scaled else None, osc.abs() if scaled else None, gy.abs())
+    dev = lambda t: None if t is None else t.to(DEV)  # noqa: E731
+    monkeypatch.setenv("SR_CONV_SPLIT_BF16", "0")
+    exact = conv2d_wgrad_mfma(dev(x), dev(gy), dev(isc), dev(osc), 3, 2, 0, tr)
+    monkeypatch.setenv("SR_CONV_SPLIT_BF16", "1")
+    split = conv2d_wgrad_mfma(dev(x), dev(gy), dev(isc), dev(osc), 3, 2, 0, tr)
+    again = conv2d_wgrad_mfma(dev(x), dev(gy), dev(isc), dev(osc), 3, 2, 0, tr)
+    assert split.shape == want.shape and torch.equal(split, again)
+    e_split = float(((split.cpu().double() - want).abs() / (mag + 1e-30)).max())
+    e_exact = float(((exact.cpu().double() - want).abs() / (mag + 1e-30)).max())
+    print(case, scaled, "split-bf16 %.2e, fp32 MFMA %.2e of sum|a||b|" % (e_split, e_exact))
+    assert e_split < 2e-6, (e_split, e_exact)
+    if res == 16:
+        assert torch.equal(split, exact)                       # not eligible: the fp32 kernel served it
+    else:
+        assert e_split < 2 * e_exact + 1e-7 and not torch.equal(split, exact)
