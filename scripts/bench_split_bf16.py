@@ -31,6 +31,8 @@ def timed(fn, reps=20):
 def main():
     if len(sys.argv) > 1 and sys.argv[1] == "s2only":
         return stride2(reps=3, shapes=((16, 256, 128, 128, True), (16, 512, 256, 64, True)))
+    if len(sys.argv) > 1 and sys.argv[1] == "convonly":
+        return conv_s2(reps=3, shapes=((16, 128, 256, 257), (16, 256, 512, 129)))
     g = torch.Generator().manual_seed(1)
     rows, hist = [], {}
     edges = [0, 1e-8, 3e-8, 1e-7, 3e-7, 1e-6, 2e-6, 1e-5, 1.0]
@@ -75,6 +77,36 @@ def main():
     for mode, name in (("0", "exact-fp32 MFMA"), ("1", "split-bf16 (6 products)")):
         print("| %s | " % name + " | ".join(str(int(v)) for v in hist[mode]) + " |")
     stride2()
+    conv_s2()
+
+
+def conv_s2(reps=20, shapes=None):
+    """The stride-2 3x3 convolution itself (k_conv_mfma<2,3,3,...> vs k_split_w_s2 + k_conv_s2_bf16x3)."""
+    from stylerenderer_amd.op.conv import conv2d_mfma
+
+    g = torch.Generator().manual_seed(3)
+    rows = []
+    # (B, Cin, Cout, input): data gradient of the headline's up-sampling layers, the discriminator's down-sampling ones
+    for b, c, n, res in shapes or ((16, 128, 256, 257), (16, 256, 512, 129), (16, 512, 512, 65), (4, 128, 256, 257),
+                                   (8, 128, 256, 257), (8, 256, 512, 129)):
+        out = (res - 3) // 2 + 1
+        x = torch.randn(b, c, res, res, generator=g).to(DEV)
+        wt = (torch.randn(9, c, n, generator=g) / (3 * c ** 0.5)).to(DEV)
+        isc, osc = torch.randn(b, c, generator=g).to(DEV), torch.randn(b, n, generator=g).to(DEV)
+        flops = 2.0 * b * out * out * c * n * 9
+        ms, res_t = {}, {}
+        for mode in ("0", "1"):
+            os.environ["SR_CONV_SPLIT_BF16"] = mode
+            res_t[mode] = conv2d_mfma(x, wt, isc, osc, None, 3, 2, 0, False)
+            ms[mode] = timed(lambda: conv2d_mfma(x, wt, isc, osc, None, 3, 2, 0, False), reps)
+        diff = float((res_t["1"] - res_t["0"]).abs().max() / res_t["0"].abs().max())
+        rows.append((b, c, n, res, ms["0"], flops / ms["0"] / 1e9, ms["1"], flops / ms["1"] / 1e9, ms["0"] / ms["1"], diff))
+    print("\n# Stride-2 3x3 convolution: `k_conv_mfma<2,3,3,...>` (exact fp32 MFMA) vs `k_split_w_s2` + `k_conv_s2_bf16x3`\n")
+    print("| B | Cin | Cout | input | fp32 MFMA ms | TFLOP/s | split-bf16 ms | TFLOP/s-equivalent | speed-up | "
+          "max |split - fp32| / max |fp32| |")
+    print("|---|---|---|---|---|---|---|---|---|---|")
+    for r in rows:
+        print("| %d | %d | %d | %d^2 | %.4f | %.1f | %.4f | %.1f | **%.2fx** | %.1e |" % r)
 
 
 def stride2(reps=20, shapes=None):

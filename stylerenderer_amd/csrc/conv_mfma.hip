@@ -35,6 +35,8 @@
 // The stride-1 3x3 case of maps >= 32 wide is normally taken by the Winograd kernel (conv_wino.hip);
 // this file then serves the strided / transposed / 1x1 / small-map launches and SR_WINOGRAD=0.
 #include "common.h"
+#include "conv_s2_bf16x3.h"
+#include "conv_wgrad_bf16x3.h"
 #include "conv_wino.h"
 
 #include <cstdlib>
@@ -807,6 +809,11 @@ extern "C" int64_t sr_conv2d_scratch_floats(int64_t B, int64_t C, int64_t N, int
     };
     if (!transposed) {
         consider(OH, OW);
+        if (ksize == 3 && stride == 2 && pad == 0 && sr_wgrad_bf16x3_enabled() &&
+            sr_conv_s2_bf16x3_eligible(B, C, N, IH, IW, OH, OW)) {
+            const int64_t w = sr_conv_s2_bf16x3_scratch_floats(C, N);
+            need = need > w ? need : w;
+        }
         if (ksize == 3 && stride == 1 && pad == 1 && wino_enabled() &&
             sr_wino_eligible(B, C, N, IH, IW, nullptr, nullptr)) {
             const int64_t w = sr_wino_scratch_floats(C, N) + sr_wino_partial_floats(B, C, N, IH, IW);
@@ -863,6 +870,11 @@ extern "C" int sr_conv2d_mfma_ex(float* out, const float* in, const float* wt, c
             sr_wino_eligible(B, C, N, IH, IW, in, out))
             return sr_wino_conv3x3(out, in, wt, wt_ld, iscale, oscale, obias, B, C, N, IH, IW, scratch, st, nullptr,
                                    (flags & SR_CONV_U_READY) != 0);
+        if (ksize == 3 && stride == 2 && pad == 0 && scratch && sr_wgrad_bf16x3_enabled() &&
+            sr_conv_s2_bf16x3_eligible(B, C, N, IH, IW, OH, OW))
+            // opt-in spike (SR_CONV_SPLIT_BF16=1): split-bf16 matrix path for the down-sampling convolution and the
+            // data gradient of the up-sampling one
+            return sr_conv_s2_bf16x3_launch(out, in, wt, wt_ld, iscale, oscale, obias, B, C, N, IH, IW, OH, OW, scratch, st);
         if (ksize == 3 && stride == 1) rc = launch_by_patch<1, 3, 3>(p, st);
         else if (ksize == 3 && stride == 2) rc = launch_by_patch<2, 3, 3>(p, st);
         else if (ksize == 1 && stride == 1) rc = launch_by_patch<1, 1, 1>(p, st);

@@ -112,39 +112,41 @@ __global__ __launch_bounds__(s1::THREADS, 2) void k_wgrad1_bf16x3(const P3 p) {
     //   item i: row = (tid + 256 i) / 8, quad = (tid + 256 i) % 8
     const int srow = tid >> 3, squad = tid & 7;          // rows srow + 32 i
     float4 stU0, stU1, stU2, stU3, stV0, stV1, stV2, stV3;
-    // every load is unconditional (clamped address): a load under a per-lane condition becomes an exec-masked branch
+    float scU0, scU1, scU2, scU3, scV0, scV1, scV2, scV3;
+    // Every load is unconditional (clamped address: a load under a per-lane condition becomes an exec-masked branch) and
+    // NOTHING is computed on the loaded values here: the scale is multiplied on when the chunk is written to LDS, after
+    // the MFMA block — arithmetic at load time makes the compiler wait for the loads (vmcnt) in front of the MFMAs.
     auto load_one = [&](const float* __restrict__ base, const float* __restrict__ scale, int C, int row, int b, int p0,
-                        bool pok) -> float4 {
+                        bool pok, float& sc) -> float4 {
         const int rc = row < C ? row : C - 1;
         const int pc = pok ? p0 : 0;
-        float4 a = *reinterpret_cast<const float4*>(base + ((int64_t)b * C + rc) * p.HW + pc);
-        float sc = scale ? scale[(int64_t)b * C + rc] : 1.0f;
+        sc = scale ? scale[(int64_t)b * C + rc] : 1.0f;
         sc = (pok && row < C) ? sc : 0.0f;
-        a.x *= sc; a.y *= sc; a.z *= sc; a.w *= sc;
-        return a;
+        return *reinterpret_cast<const float4*>(base + ((int64_t)b * C + rc) * p.HW + pc);
     };
     auto load_chunk = [&](int chunk) {
         const int b = chunk / p.cps, p0 = (chunk - b * p.cps) * KC + 4 * squad;
         const bool pok = p0 < p.HW;
-        stU0 = load_one(p.U, p.uscale, p.CU, u0 + srow, b, p0, pok);
-        stU1 = load_one(p.U, p.uscale, p.CU, u0 + srow + 32, b, p0, pok);
-        stU2 = load_one(p.U, p.uscale, p.CU, u0 + srow + 64, b, p0, pok);
-        stU3 = load_one(p.U, p.uscale, p.CU, u0 + srow + 96, b, p0, pok);
-        stV0 = load_one(p.V, p.vscale, p.CV, v0 + srow, b, p0, pok);
-        stV1 = load_one(p.V, p.vscale, p.CV, v0 + srow + 32, b, p0, pok);
-        stV2 = load_one(p.V, p.vscale, p.CV, v0 + srow + 64, b, p0, pok);
-        stV3 = load_one(p.V, p.vscale, p.CV, v0 + srow + 96, b, p0, pok);
+        stU0 = load_one(p.U, p.uscale, p.CU, u0 + srow, b, p0, pok, scU0);
+        stU1 = load_one(p.U, p.uscale, p.CU, u0 + srow + 32, b, p0, pok, scU1);
+        stU2 = load_one(p.U, p.uscale, p.CU, u0 + srow + 64, b, p0, pok, scU2);
+        stU3 = load_one(p.U, p.uscale, p.CU, u0 + srow + 96, b, p0, pok, scU3);
+        stV0 = load_one(p.V, p.vscale, p.CV, v0 + srow, b, p0, pok, scV0);
+        stV1 = load_one(p.V, p.vscale, p.CV, v0 + srow + 32, b, p0, pok, scV1);
+        stV2 = load_one(p.V, p.vscale, p.CV, v0 + srow + 64, b, p0, pok, scV2);
+        stV3 = load_one(p.V, p.vscale, p.CV, v0 + srow + 96, b, p0, pok, scV3);
     };
+    auto scaled = [](float4 a, float sc) { a.x *= sc; a.y *= sc; a.z *= sc; a.w *= sc; return a; };
     auto store_chunk = [&](float* dst) {
         float* d = dst + srow * PITCH + 4 * squad;
-        *reinterpret_cast<float4*>(d) = stU0;
-        *reinterpret_cast<float4*>(d + 32 * PITCH) = stU1;
-        *reinterpret_cast<float4*>(d + 64 * PITCH) = stU2;
-        *reinterpret_cast<float4*>(d + 96 * PITCH) = stU3;
-        *reinterpret_cast<float4*>(d + TILE) = stV0;
-        *reinterpret_cast<float4*>(d + TILE + 32 * PITCH) = stV1;
-        *reinterpret_cast<float4*>(d + TILE + 64 * PITCH) = stV2;
-        *reinterpret_cast<float4*>(d + TILE + 96 * PITCH) = stV3;
+        *reinterpret_cast<float4*>(d) = scaled(stU0, scU0);
+        *reinterpret_cast<float4*>(d + 32 * PITCH) = scaled(stU1, scU1);
+        *reinterpret_cast<float4*>(d + 64 * PITCH) = scaled(stU2, scU2);
+        *reinterpret_cast<float4*>(d + 96 * PITCH) = scaled(stU3, scU3);
+        *reinterpret_cast<float4*>(d + TILE) = scaled(stV0, scV0);
+        *reinterpret_cast<float4*>(d + TILE + 32 * PITCH) = scaled(stV1, scV1);
+        *reinterpret_cast<float4*>(d + TILE + 64 * PITCH) = scaled(stV2, scV2);
+        *reinterpret_cast<float4*>(d + TILE + 96 * PITCH) = scaled(stV3, scV3);
     };
 
     f32x16 acc[2][2];
@@ -162,8 +164,10 @@ __global__ __launch_bounds__(s1::THREADS, 2) void k_wgrad1_bf16x3(const P3 p) {
     int buf = 0;
     for (int chunk = first; chunk < last; ++chunk) {
         __syncthreads();                                   // buffer `buf` written; the other one no longer read
-        const bool more = chunk + 1 < last;
-        if (more) load_chunk(chunk + 1);                   // global loads fly under the MFMA block below
+        // branch-free staging stream (a branch makes the compiler's vmcnt bookkeeping conservative): after the last chunk
+        // it re-stages that chunk into the idle buffer.  The loads are pinned here, their consumers behind the MFMAs.
+        load_chunk(chunk + 1 < last ? chunk + 1 : chunk);   // global loads fly under the MFMA block below
+        __builtin_amdgcn_sched_barrier(0);
         const float* sU = smem + buf * BUF;
         const float* sV = sU + TILE;
 #pragma unroll
@@ -186,7 +190,8 @@ __global__ __launch_bounds__(s1::THREADS, 2) void k_wgrad1_bf16x3(const P3 p) {
             SR_TERM(h3, h1) SR_TERM(h1, h3) SR_TERM(h2, h2) SR_TERM(h2, h1) SR_TERM(h1, h2) SR_TERM(h1, h1)
 #undef SR_TERM
         }
-        if (more) store_chunk(smem + (buf ^ 1) * BUF);
+        __builtin_amdgcn_sched_barrier(0);
+        store_chunk(smem + (buf ^ 1) * BUF);
         buf ^= 1;
     }
 
@@ -274,7 +279,7 @@ __global__ __launch_bounds__(512) void k_wgrad_s2_bf16x3(const P9 p) {
     // the per-item address is ONE running VGPR offset — 24 scalar bases per call site would not fit the SGPR file), and
     // thread t < 192 the 65th column of (channel t / 3, row t % 3).  Column c lands at c / 2 (even) or ODD + c / 2.
     // V: thread t stages float4 (row, quad) = ((t + 512 k) / 8, (t + 512 k) % 8).
-    float stU[U_ITEMS], stU65 = 0.0f;
+    float stU[U_ITEMS], stU65 = 0.0f, sc65 = 1.0f, scv[V_ITEMS];
     float4 stV[V_ITEMS];
     const int d_row = p.UW, d_ch = plane_u - 2 * p.UW;
     const int t65 = tid < UT * 3 ? tid : 0;
@@ -289,24 +294,18 @@ __global__ __launch_bounds__(512) void k_wgrad_s2_bf16x3(const P9 p) {
         const float* ub = p.U + ((int64_t)b * p.CU + u0) * plane_u + (2 * j) * p.UW + 2 * i0;
         const float* usb = p.uscale ? p.uscale + (int64_t)b * p.CU + u0 : nullptr;
         int off = wave * 8 * plane_u + lane;
-        float scu[8], sc65 = 1.0f;                                           // wave-uniform scales: scalar loads, ONE branch
-#pragma unroll
-        for (int c = 0; c < 8; ++c) scu[c] = 1.0f;
-        if (usb) {
-#pragma unroll
-            for (int c = 0; c < 8; ++c) scu[c] = usb[wave * 8 + c];
-            sc65 = usb[t65 / 3];
-        }
+        // raw loads only: the scales are multiplied on in store_chunk, after the MFMA block (arithmetic here would make
+        // the compiler drain vmcnt in front of the MFMAs: the global-load latency of every chunk exposed)
+        sc65 = usb ? usb[t65 / 3] : 1.0f;
 #pragma unroll
         for (int k = 0; k < U_ITEMS; ++k) {
-            stU[k] = ub[off] * scu[k / 3];
+            stU[k] = ub[off];
             off += (k % 3 == 2) ? d_ch : d_row;
         }
-        stU65 = ub[off65] * sc65;
+        stU65 = ub[off65];
         const float* vb = p.V + ((int64_t)b * p.CV + v0) * plane_v + j * p.GW + i0;
         const float* vsb = p.vscale ? p.vscale + (int64_t)b * p.CV + v0 : nullptr;
         int offv = offv0;
-        float scv[V_ITEMS];
 #pragma unroll
         for (int k = 0; k < V_ITEMS; ++k) scv[k] = 1.0f;
         if (vsb) {
@@ -315,20 +314,32 @@ __global__ __launch_bounds__(512) void k_wgrad_s2_bf16x3(const P9 p) {
         }
 #pragma unroll
         for (int k = 0; k < V_ITEMS; ++k) {
-            float4 val = *reinterpret_cast<const float4*>(vb + offv);
-            val.x *= scv[k]; val.y *= scv[k]; val.z *= scv[k]; val.w *= scv[k];
-            stV[k] = val;
+            stV[k] = *reinterpret_cast<const float4*>(vb + offv);
             offv += 64 * plane_v;
         }
     };
-    auto store_chunk = [&](float* dst) {
+    auto store_chunk = [&](float* dst, int chunk) {
+        // the wave-uniform U scales are (scalar-)loaded here, not kept in registers across the MFMA block
+        const int b = chunk / (p.segs * p.GH);
+        float scu[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) scu[c] = 1.0f;
+        if (p.uscale) {
+            const float* usb = p.uscale + (int64_t)b * p.CU + u0 + wave * 8;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) scu[c] = usb[c];
+        }
         float* du = dst + wave * 8 * UCH + lds_col;
 #pragma unroll
-        for (int k = 0; k < U_ITEMS; ++k) du[(k / 3) * UCH + (k % 3) * PU] = stU[k];
-        if (tid < UT * 3) dst[(t65 / 3) * UCH + (t65 % 3) * PU + 32] = stU65;       // column 64 = even #32
+        for (int k = 0; k < U_ITEMS; ++k) du[(k / 3) * UCH + (k % 3) * PU] = stU[k] * scu[k / 3];
+        if (tid < UT * 3) dst[(t65 / 3) * UCH + (t65 % 3) * PU + 32] = stU65 * sc65;       // column 64 = even #32
         float* dv = dst + OFF_V + (tid >> 3) * PV + 4 * (tid & 7);
 #pragma unroll
-        for (int k = 0; k < V_ITEMS; ++k) *reinterpret_cast<float4*>(dv + 64 * k * PV) = stV[k];
+        for (int k = 0; k < V_ITEMS; ++k) {
+            float4 val = stV[k];
+            val.x *= scv[k]; val.y *= scv[k]; val.z *= scv[k]; val.w *= scv[k];
+            *reinterpret_cast<float4*>(dv + 64 * k * PV) = val;
+        }
     };
 
     f32x16 acc[9];
@@ -339,13 +350,14 @@ __global__ __launch_bounds__(512) void k_wgrad_s2_bf16x3(const P9 p) {
 
     if (first < last) {
         load_chunk(first);
-        store_chunk(smem);
+        store_chunk(smem, first);
     }
     int buf = 0;
     for (int chunk = first; chunk < last; ++chunk) {
         __syncthreads();
-        const bool more = chunk + 1 < last;
-        if (more) load_chunk(chunk + 1);
+        const int cn = chunk + 1 < last ? chunk + 1 : chunk;          // branch-free: the last chunk is re-staged
+        load_chunk(cn);
+        __builtin_amdgcn_sched_barrier(0);
         const float* sU = smem + buf * BUF + (wu * 32 + l31) * UCH;
         const float* sV = smem + buf * BUF + OFF_V + (wv * 32 + l31) * PV;
 #pragma unroll 1
@@ -385,7 +397,8 @@ __global__ __launch_bounds__(512) void k_wgrad_s2_bf16x3(const P9 p) {
                 acc[t0 + 2] = mma(s1, bf.h1, acc[t0 + 2]);
             }
         }
-        if (more) store_chunk(smem + (buf ^ 1) * BUF);
+        __builtin_amdgcn_sched_barrier(0);
+        store_chunk(smem + (buf ^ 1) * BUF, cn);
         buf ^= 1;
     }
 

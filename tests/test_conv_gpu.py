@@ -722,3 +722,41 @@ def test_split_bf16_wgrad_stride2_holds_the_fp32_bar(case, scaled, monkeypatch):
         assert torch.equal(split, exact)                       # not eligible: the fp32 kernel served it
     else:
         assert e_split < 2 * e_exact + 1e-7 and not torch.equal(split, exact)
+
+
+@pytest.mark.parametrize("case", [(2, 16, 128, 65), (1, 64, 256, 129), (3, 8, 128, 65), (2, 16, 64, 65)])
+@pytest.mark.parametrize("scaled", [True, False])
+def test_split_bf16_conv_stride2_holds_the_fp32_bar(case, scaled, monkeypatch):
+    """SPIKE, opt-in (SR_CONV_SPLIT_BF16=1): the stride-2 3x3 convolution (down-sampling layers, data gradient of the
+    up-sampling ones) on the bf16 matrix cores: weights split once per call (k_split_w_s2), the input window split in
+    the loop (k_conv_s2_bf16x3).  Same bound as the exact-fp32 kernel — |error| < 2e-6 * sum |a||b| against float64 —
+    with input / output scales and bias; the last case (64 output channels) is not eligible and falls through."""
+    from stylerenderer_amd.op.conv import conv2d_mfma
+
+    b, c, n, res = case
+    g = torch.Generator().manual_seed(b * 77 + c + n + res)
+    x = torch.randn(b, c, res, res, generator=g)
+    wgt = torch.randn(n, c, 3, 3, generator=g)
+    isc = torch.randn(b, c, generator=g) if scaled else None
+    osc = torch.randn(b, n, generator=g) if scaled else None
+    bias = torch.randn(n, generator=g) if scaled else None
+    want = ref_conv(x, wgt, isc, osc, bias, 2, 0, False)
+    absx = x.abs().double() * (isc.abs().double()[:, :, None, None] if scaled else 1.0)
+    mag = F.conv2d(absx, wgt.abs().double(), stride=2)
+    if scaled:
+        mag = mag * osc.abs().double()[:, :, None, None] + bias.abs().double()[None, :, None, None]
+    dev = lambda t: None if t is None else t.to(DEV)  # noqa: E731
+    monkeypatch.setenv("SR_CONV_SPLIT_BF16", "0")
+    exact = conv2d_mfma(dev(x), dev(to_taps(wgt, False)), dev(isc), dev(osc), dev(bias), 3, 2, 0, False)
+    monkeypatch.setenv("SR_CONV_SPLIT_BF16", "1")
+    split = conv2d_mfma(dev(x), dev(to_taps(wgt, False)), dev(isc), dev(osc), dev(bias), 3, 2, 0, False)
+    again = conv2d_mfma(dev(x), dev(to_taps(wgt, False)), dev(isc), dev(osc), dev(bias), 3, 2, 0, False)
+    assert split.shape == want.shape and torch.equal(split, again)
+    e_split = float(((split.cpu().double() - want).abs() / (mag + 1e-30)).max())
+    e_exact = float(((exact.cpu().double() - want).abs() / (mag + 1e-30)).max())
+    print(case, scaled, "split-bf16 %.2e, fp32 MFMA %.2e of sum|a||b|" % (e_split, e_exact))
+    assert e_split < 2e-6, (e_split, e_exact)
+    if n % 128:
+        assert torch.equal(split, exact)
+    else:
+        assert e_split < 2 * e_exact + 1e-7 and not torch.equal(split, exact)
