@@ -31,6 +31,8 @@ def timed(fn, reps=20):
 def main():
     if len(sys.argv) > 1 and sys.argv[1] == "s2only":
         return stride2(reps=3, shapes=((16, 256, 128, 128, True), (16, 512, 256, 64, True)))
+    if len(sys.argv) > 1 and sys.argv[1] == "tonly":
+        return conv_t(reps=5)
     if len(sys.argv) > 1 and sys.argv[1] == "convonly":
         return conv_s2(reps=3, shapes=((16, 128, 256, 257), (16, 256, 512, 129)))
     g = torch.Generator().manual_seed(1)
@@ -78,6 +80,35 @@ def main():
         print("| %s | " % name + " | ".join(str(int(v)) for v in hist[mode]) + " |")
     stride2()
     conv_s2()
+    conv_t()
+
+
+def conv_t(reps=20, shapes=None):
+    """The stride-2 transposed 3x3 convolution (k_convt_fused + strips vs k_split_w_t + k_convt_bf16x3 + strips)."""
+    from stylerenderer_amd.op.conv import conv2d_mfma
+
+    g = torch.Generator().manual_seed(4)
+    rows = []
+    for b, c, n, res in shapes or ((16, 256, 128, 128), (16, 512, 256, 64), (16, 512, 512, 32), (4, 256, 128, 128),
+                                   (4, 512, 256, 64)):
+        x = torch.randn(b, c, res, res, generator=g).to(DEV)
+        wt = (torch.randn(9, c, n, generator=g) / (3 * c ** 0.5)).to(DEV)
+        isc, osc = torch.randn(b, c, generator=g).to(DEV), torch.randn(b, n, generator=g).to(DEV)
+        flops = 2.0 * b * res * res * c * n * 9
+        ms, res_t = {}, {}
+        for mode in ("0", "1"):
+            os.environ["SR_CONV_SPLIT_BF16"] = mode
+            res_t[mode] = conv2d_mfma(x, wt, isc, osc, None, 3, 2, 0, True)
+            ms[mode] = timed(lambda: conv2d_mfma(x, wt, isc, osc, None, 3, 2, 0, True), reps)
+        diff = float((res_t["1"] - res_t["0"]).abs().max() / res_t["0"].abs().max())
+        rows.append((b, c, n, res, ms["0"], flops / ms["0"] / 1e9, ms["1"], flops / ms["1"] / 1e9, ms["0"] / ms["1"], diff))
+    print("\n# Stride-2 transposed 3x3 convolution: `k_convt_fused` (exact fp32 MFMA) vs `k_split_w_t` + `k_convt_bf16x3`, "
+          "both incl. the fp32 border strips\n")
+    print("| B | Cin | Cout | input | fp32 MFMA ms | TFLOP/s | split-bf16 ms | TFLOP/s-equivalent | speed-up | "
+          "max |split - fp32| / max |fp32| |")
+    print("|---|---|---|---|---|---|---|---|---|---|")
+    for r in rows:
+        print("| %d | %d | %d | %d^2 | %.4f | %.1f | %.4f | %.1f | **%.2fx** | %.1e |" % r)
 
 
 def conv_s2(reps=20, shapes=None):

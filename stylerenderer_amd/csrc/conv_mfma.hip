@@ -824,6 +824,10 @@ extern "C" int64_t sr_conv2d_scratch_floats(int64_t B, int64_t C, int64_t N, int
         consider(IH, IW);
         consider(1, IW + 1);
         consider(IH, 1);
+        if (ksize == 3 && stride == 2 && pad == 0 && sr_wgrad_bf16x3_enabled() && sr_convt_bf16x3_eligible(B, C, N, IH, IW)) {
+            const int64_t w = sr_convt_bf16x3_scratch_floats(C, N);
+            need = need > w ? need : w;
+        }
     }
     return need;
 }
@@ -901,7 +905,13 @@ extern "C" int sr_conv2d_mfma_ex(float* out, const float* in, const float* wt, c
         // 64^2 512->256 at batch 1 / 2 0.26 / 0.33 against 0.39; 128^2 256->128 (32 chunks) is fused from batch 1 on
         const int64_t fused_blocks = (int64_t)(p.IW / TFused::PW) * (p.IH / TFused::PH) * ((p.N + BN - 1) / BN) * p.B;
         const bool fused_pays = fused_blocks >= 192 || p.C <= 256;
-        if (!(e && e[0] == '0') && p.IW >= 16 && convt_fused_eligible(p) && (fused_pays || (e && e[0] == '1'))) {
+        if (scratch && sr_wgrad_bf16x3_enabled() && sr_convt_bf16x3_eligible(B, C, N, IH, IW)) {
+            // opt-in spike (SR_CONV_SPLIT_BF16=1): the interior of the map on the bf16 matrix cores (three-way operand
+            // split); the border strips below stay on the exact-fp32 kernels
+            const int rc = sr_convt_bf16x3_launch(out, in, wt, wt_ld, iscale, oscale, obias, B, C, N, IH, IW, scratch, st);
+            if (rc != SR_OK) return rc;
+            fused_ok = true;
+        } else if (!(e && e[0] == '0') && p.IW >= 16 && convt_fused_eligible(p) && (fused_pays || (e && e[0] == '1'))) {
             for (int i = 0; i < 9; ++i) p.wmap[i] = i;
             const int rc = launch_convt_fused(p, st);
             if (rc != SR_OK) return rc;

@@ -240,6 +240,196 @@ __global__ __launch_bounds__(THREADS, 2) void k_conv_s2_bf16x3(const PS2 p) {
         }
 }
 
+
+// ---- stride-2 TRANSPOSED 3x3 convolution (the up-sampling layers' forward), interior of the map ----------------------
+//   out[b,n,2j+ky,2i+kx] += oscale[b,n] * W[ky][kx][c][n] * (iscale[b,c] * in[b,c,j,i])
+// As four output phases of the grid point (a, b) = (oy >> 1, ox >> 1):
+//   (0,0): in(a,b) W00 + in(a-1,b) W20 + in(a,b-1) W02 + in(a-1,b-1) W22      (0,1): in(a,b) W01 + in(a-1,b) W21
+//   (1,0): in(a,b) W10 + in(a,b-1) W12                                         (1,1): in(a,b) W11
+// Only FOUR input shifts feed all nine taps, so a k step pairs (shift, tap) couples of the SAME phase on the two lane
+// halves: {S00 W00 | S10 W20}, {S01 W02 | S11 W22} -> (0,0); {S00 W01 | S10 W21} -> (0,1); {S00 W10 | S01 W12} -> (1,0);
+// {S00 W11 | zero} -> (1,1): five groups of six products, three operand splits per lane.  Interior only (a < IH,
+// b < IW): the last output row / column stay with the fp32 strip launches of conv_mfma.hip.
+// Tile: workgroup = 64 output channels x (4 x 32) grid points, wave = one grid row: 4 phases x 2 channel blocks = 8
+// accumulator tiles; K chunk = 8 input channels (weights 27 KB by LDS-DMA + a 5 x 33 patch per channel), one buffer,
+// several workgroups per CU.
+namespace tc {
+constexpr int NT = 64, KC = 8, THREADS = 256;
+constexpr int PXT = 36, XCH = 5 * PXT;           // patch: 5 rows (a0 - 1 .. a0 + 3) x 33 columns (b0 - 1 .. b0 + 31)
+constexpr int X_FLOATS = KC * XCH;               // 1 440
+constexpr int W_TAP = 3 * 2 * 32 * 4;            // dwords per tap: 3 pieces x 2 channel blocks x 32 lanes x 16 B
+constexpr int W_DWORDS = 9 * W_TAP;              // 6 912 dwords = 27 648 B
+constexpr int LDS_BYTES = (W_DWORDS + X_FLOATS) * 4;
+constexpr int W_INSTR = W_DWORDS / 256;          // 27
+constexpr int X_ITEMS = KC * 5 / 4;              // (channel, row) pairs per wave: 10
+}  // namespace tc
+
+__global__ __launch_bounds__(256) void k_split_w_t(unsigned* __restrict__ wb, const float* __restrict__ wt, int C, int N,
+                                                   int ldw, int tiles_n) {
+    const int64_t total = (int64_t)(C / tc::KC) * tiles_n * 9 * 2 * 32;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int l31 = (int)(i & 31), nb = (int)((i >> 5) & 1);
+        int64_t r = i >> 6;
+        const int tap = (int)(r % 9);
+        r /= 9;
+        const int tn = (int)(r % tiles_n), g = (int)(r / tiles_n);
+        const int n = tn * tc::NT + nb * 32 + l31;
+        float x[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x[j] = n < N ? wt[((int64_t)tap * C + g * tc::KC + j) * ldw + n] : 0.0f;
+        u32x4 h1, h2, h3;
+        split8(x, h1, h2, h3);
+        unsigned* dst = wb + ((int64_t)(g * tiles_n + tn) * 9 + tap) * tc::W_TAP + (nb * 32 + l31) * 4;
+        *reinterpret_cast<u32x4*>(dst) = h1;
+        *reinterpret_cast<u32x4*>(dst + 2 * 32 * 4) = h2;
+        *reinterpret_cast<u32x4*>(dst + 2 * 2 * 32 * 4) = h3;
+    }
+}
+
+__global__ __launch_bounds__(256, 2) void k_convt_bf16x3(const PS2 p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned smem[];
+    int bid = blockIdx.x;
+    const int tn = bid % p.tiles_n;
+    bid /= p.tiles_n;
+    const int tx = bid % p.tiles_x;
+    bid /= p.tiles_x;
+    const int ty = bid % p.tiles_y, b = bid / p.tiles_y;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = lane >> 5, l31 = lane & 31;
+    const int a0 = ty * 4, b0 = tx * 32, n0 = tn * tc::NT;
+    const int plane_in = p.IH * p.IW;
+    const int nchunk = p.C / tc::KC;
+    typedef const float __attribute__((address_space(4)))* cptr_t;
+
+    const unsigned* wsrc = p.wb + (int64_t)tn * tc::W_DWORDS + lane * 4;
+    const int64_t w_chunk = (int64_t)p.tiles_n * tc::W_DWORDS;
+    const float* isb = p.iscale ? p.iscale + (int64_t)b * p.C : nullptr;
+    float* sXw = reinterpret_cast<float*>(smem + tc::W_DWORDS);
+    // patch staging: wave w stages channels 2 w, 2 w + 1, five rows each; lane = patch column (33 used).  Row a0 - 1 + r,
+    // column b0 - 1 + lane: zero outside the image (top row / left column of the map), clamped address.
+    const int col = b0 - 1 + lane;
+    const bool col_ok = lane < 33 && col >= 0;
+    const int colc = col_ok ? col : 0;
+    int xoff[5];
+    bool xok[5];
+#pragma unroll
+    for (int r = 0; r < 5; ++r) {
+        const int row = a0 - 1 + r;
+        xok[r] = col_ok && row >= 0;
+        xoff[r] = (row >= 0 ? row : 0) * p.IW + colc;
+    }
+    const float* xin = p.in + (int64_t)b * p.C * plane_in;
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int ph = 0; ph < 4; ++ph)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[ph][i][r] = 0.0f;
+
+    for (int g = 0; g < nchunk; ++g) {
+        __syncthreads();              // every wave is done reading the buffer
+        {
+            const unsigned* src = wsrc + g * w_chunk;
+#pragma unroll
+            for (int i = 0; i < tc::W_INSTR / 4; ++i) {
+                const int j = wave + 4 * i;
+                __builtin_amdgcn_global_load_lds((gptr_t)(src + j * 256), (lptr_t)(smem + j * 256), 16, 0, 0);
+            }
+            if (wave < tc::W_INSTR % 4) {
+                const int j = wave + 4 * (tc::W_INSTR / 4);
+                __builtin_amdgcn_global_load_lds((gptr_t)(src + j * 256), (lptr_t)(smem + j * 256), 16, 0, 0);
+            }
+            float sc0 = 1.0f, sc1 = 1.0f;
+            if (isb) {
+                const cptr_t c = (cptr_t)(isb + g * tc::KC + 2 * wave);
+                sc0 = c[0];
+                sc1 = c[1];
+            }
+            const float* xw = xin + (int64_t)(g * tc::KC + 2 * wave) * plane_in;
+            float stX[tc::X_ITEMS];
+#pragma unroll
+            for (int k = 0; k < tc::X_ITEMS; ++k) stX[k] = xw[(k / 5) * plane_in + xoff[k % 5]];
+            if (lane < 33) {
+                float* dw = sXw + (2 * wave) * tc::XCH + lane;
+#pragma unroll
+                for (int k = 0; k < tc::X_ITEMS; ++k)
+                    dw[(k / 5) * tc::XCH + (k % 5) * tc::PXT] = xok[k % 5] ? stX[k] * (k < 5 ? sc0 : sc1) : 0.0f;
+            }
+        }
+        __syncthreads();              // chunk complete (the barrier drains this wave's DMA)
+        const unsigned* sW = smem;
+        // grid point (a0 + wave, b0 + l31) sits at patch (row wave + 1, column l31 + 1)
+        const float* sX = sXw + (wave + 1) * tc::PXT + l31 + 1;
+        // operands of this lane: half 0 -> S00, S01 ; half 1 -> S10, S11, S01  (S_dy_dx = in(a - dy, b - dx))
+        const float* p0 = half ? sX - tc::PXT : sX;            // S00 | S10
+        const float* p1 = half ? sX - tc::PXT - 1 : sX - 1;    // S01 | S11
+        const float* p2 = sX - 1;                          // (half 1 of group 4) S01
+        float x0[8], x1[8], x2[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            x0[c] = p0[c * tc::XCH];
+            x1[c] = p1[c * tc::XCH];
+            x2[c] = half ? p2[c * tc::XCH] : p0[c * tc::XCH];
+        }
+        u32x4 f0[3], f1[3], f2[3], f3[3];
+        split8(x0, f0[0], f0[1], f0[2]);                    // group 1, 3: S00 | S10
+        split8(x1, f1[0], f1[1], f1[2]);                    // group 2:    S01 | S11
+        split8(x2, f2[0], f2[1], f2[2]);                    // group 4:    S00 | S01
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {                       // group 5:    S00 | zero
+            f3[k].x = half ? 0u : f0[k].x; f3[k].y = half ? 0u : f0[k].y;
+            f3[k].z = half ? 0u : f0[k].z; f3[k].w = half ? 0u : f0[k].w;
+        }
+        // weight fragments of group q: tap TA[q] on half 0, TB[q] on half 1
+        auto group = [&](int ph, const u32x4 (&bf)[3], int ta, int tb) {
+            const unsigned* pw = sW + (half ? tb : ta) * tc::W_TAP + l31 * 4;
+            u32x4 w1[2], w2[2], w3[2];
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb) {
+                w1[nb] = *reinterpret_cast<const u32x4*>(pw + nb * 128);
+                w2[nb] = *reinterpret_cast<const u32x4*>(pw + 256 + nb * 128);
+                w3[nb] = *reinterpret_cast<const u32x4*>(pw + 512 + nb * 128);
+            }
+#define SR_TERM(A, Bv) acc[ph][0] = mma(A[0], Bv, acc[ph][0]); acc[ph][1] = mma(A[1], Bv, acc[ph][1]);
+            SR_TERM(w3, bf[0]) SR_TERM(w1, bf[2]) SR_TERM(w2, bf[1]) SR_TERM(w2, bf[0]) SR_TERM(w1, bf[1]) SR_TERM(w1, bf[0])
+#undef SR_TERM
+        };
+        // taps: index ky * 3 + kx
+        group(0, f0, 0, 6);        // (0,0): S00 W00 | S10 W20
+        group(1, f0, 1, 7);        // (0,1): S00 W01 | S10 W21
+        group(0, f1, 2, 8);        // (0,0): S01 W02 | S11 W22
+        group(2, f2, 3, 5);        // (1,0): S00 W10 | S01 W12
+        group(3, f3, 4, 4);        // (1,1): S00 W11 | zero
+    }
+
+    // epilogue: grid point (a, b) -> outputs (2a + py, 2b + px); C/D layout column = lane & 31 (grid column)
+    const int a = a0 + wave, bcol = b0 + l31;
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int nu = n0 + nb * 32 + (r & 3) + 8 * (r >> 2);
+            const int n = nu + 4 * half;
+            float s = 1.0f, bi = 0.0f;
+            if (p.oscale) {
+                const cptr_t os = (cptr_t)(p.oscale + (int64_t)b * p.N + nu);
+                s = half ? os[4] : os[0];
+            }
+            if (p.obias) {
+                const cptr_t ob = (cptr_t)(p.obias + nu);
+                bi = half ? ob[4] : ob[0];
+            }
+            float* o = p.out + (((int64_t)b * p.N + n) * p.OH + 2 * a) * p.OW + 2 * bcol;
+            o[0] = acc[0][nb][r] * s + bi;
+            o[1] = acc[1][nb][r] * s + bi;
+            o[p.OW] = acc[2][nb][r] * s + bi;
+            o[p.OW + 1] = acc[3][nb][r] * s + bi;
+        }
+}
+
 }  // namespace
 
 bool sr_conv_s2_bf16x3_eligible(int64_t B, int64_t C, int64_t N, int64_t IH, int64_t IW, int64_t OH, int64_t OW) {
@@ -271,5 +461,34 @@ int sr_conv_s2_bf16x3_launch(float* out, const float* in, const float* wt, int64
     }
     hipLaunchKernelGGL(k_conv_s2_bf16x3, dim3((unsigned)(B * p.tiles_y * p.tiles_x * tiles_n)), dim3(THREADS), LDS_BYTES, st,
                        p);
+    return sr_launch_status();
+}
+
+// ---- transposed --------------------------------------------------------------------------------------------------
+bool sr_convt_bf16x3_eligible(int64_t B, int64_t C, int64_t N, int64_t IH, int64_t IW) {
+    return B > 0 && C % tc::KC == 0 && N % tc::NT == 0 && IW % 32 == 0 && IH % 4 == 0 &&
+           B * C * IH * IW < (1LL << 31) && B * N * (2 * IH + 1) * (2 * IW + 1) < (1LL << 31);
+}
+
+int64_t sr_convt_bf16x3_scratch_floats(int64_t C, int64_t N) {
+    return (C / tc::KC) * (N / tc::NT) * (int64_t)tc::W_DWORDS + 4;
+}
+
+// interior of the map only (grid points a < IH, b < IW, all four phases); the caller runs the border strips
+int sr_convt_bf16x3_launch(float* out, const float* in, const float* wt, int64_t ldw, const float* iscale,
+                           const float* oscale, const float* obias, int64_t B, int64_t C, int64_t N, int64_t IH,
+                           int64_t IW, float* scratch, hipStream_t st) {
+    unsigned* wb = reinterpret_cast<unsigned*>(scratch);
+    const int tiles_n = (int)(N / tc::NT);
+    const int64_t items = (C / tc::KC) * tiles_n * 9 * 2 * 32;
+    hipLaunchKernelGGL(k_split_w_t, dim3(sr_stream_grid(items, 256)), dim3(256), 0, st, wb, wt, (int)C, (int)N, (int)ldw,
+                       tiles_n);
+    PS2 p;
+    p.in = in; p.wb = wb; p.iscale = iscale; p.oscale = oscale; p.obias = obias; p.out = out;
+    p.B = (int)B; p.C = (int)C; p.N = (int)N; p.IH = (int)IH; p.IW = (int)IW; p.OH = (int)(2 * IH + 1);
+    p.OW = (int)(2 * IW + 1);
+    p.tiles_x = (int)(IW / 32); p.tiles_y = (int)(IH / 4); p.tiles_n = tiles_n;
+    hipLaunchKernelGGL(k_convt_bf16x3, dim3((unsigned)(B * p.tiles_y * p.tiles_x * tiles_n)), dim3(tc::THREADS),
+                       tc::LDS_BYTES, st, p);
     return sr_launch_status();
 }

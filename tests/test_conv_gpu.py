@@ -760,3 +760,41 @@ def test_split_bf16_conv_stride2_holds_the_fp32_bar(case, scaled, monkeypatch):
         assert torch.equal(split, exact)
     else:
         assert e_split < 2 * e_exact + 1e-7 and not torch.equal(split, exact)
+
+
+@pytest.mark.parametrize("case", [(2, 16, 64, 32), (1, 64, 128, 64), (3, 8, 64, 32), (2, 16, 32, 32)])
+@pytest.mark.parametrize("scaled", [True, False])
+def test_split_bf16_transposed_conv_holds_the_fp32_bar(case, scaled, monkeypatch):
+    """SPIKE, opt-in (SR_CONV_SPLIT_BF16=1): the stride-2 transposed 3x3 convolution (forward of the up-sampling
+    layers): interior of the map on the bf16 matrix cores (k_split_w_t + k_convt_bf16x3: four input shifts feed the nine
+    taps, five paired k groups), border row / column on the exact strips.  Same |error| < 2e-6 * sum |a||b| bound
+    against float64 over the WHOLE output incl. the seams; the 32-channel case is not eligible and falls through."""
+    from stylerenderer_amd.op.conv import conv2d_mfma
+
+    b, c, n, res = case
+    g = torch.Generator().manual_seed(b * 55 + c + n + res)
+    x = torch.randn(b, c, res, res, generator=g)
+    wgt = torch.randn(c, n, 3, 3, generator=g)
+    isc = torch.randn(b, c, generator=g) if scaled else None
+    osc = torch.randn(b, n, generator=g) if scaled else None
+    bias = torch.randn(n, generator=g) if scaled else None
+    want = ref_conv(x, wgt, isc, osc, bias, 2, 0, True)
+    absx = x.abs().double() * (isc.abs().double()[:, :, None, None] if scaled else 1.0)
+    mag = F.conv_transpose2d(absx, wgt.abs().double(), stride=2)
+    if scaled:
+        mag = mag * osc.abs().double()[:, :, None, None] + bias.abs().double()[None, :, None, None]
+    dev = lambda t: None if t is None else t.to(DEV)  # noqa: E731
+    monkeypatch.setenv("SR_CONV_SPLIT_BF16", "0")
+    exact = conv2d_mfma(dev(x), dev(to_taps(wgt, True)), dev(isc), dev(osc), dev(bias), 3, 2, 0, True)
+    monkeypatch.setenv("SR_CONV_SPLIT_BF16", "1")
+    split = conv2d_mfma(dev(x), dev(to_taps(wgt, True)), dev(isc), dev(osc), dev(bias), 3, 2, 0, True)
+    again = conv2d_mfma(dev(x), dev(to_taps(wgt, True)), dev(isc), dev(osc), dev(bias), 3, 2, 0, True)
+    assert split.shape == want.shape and torch.equal(split, again)
+    e_split = float(((split.cpu().double() - want).abs() / (mag + 1e-30)).max())
+    e_exact = float(((exact.cpu().double() - want).abs() / (mag + 1e-30)).max())
+    print(case, scaled, "split-bf16 %.2e, fp32 MFMA %.2e of sum|a||b|" % (e_split, e_exact))
+    assert e_split < 2e-6, (e_split, e_exact)
+    if n % 64:
+        assert torch.equal(split, exact)
+    else:
+        assert e_split < 2 * e_exact + 1e-7 and not torch.equal(split, exact)
