@@ -254,19 +254,21 @@ __global__ __launch_bounds__(THREADS, 2) void k_conv_s2_bf16x3(const PS2 p) {
 // accumulator tiles; K chunk = 8 input channels (weights 27 KB by LDS-DMA + a 5 x 33 patch per channel), one buffer,
 // several workgroups per CU.
 namespace tc {
-constexpr int NT = 64, KC = 8, THREADS = 256;
+constexpr int NT = 64, KC = 16, THREADS = 256;   // KC: channels per chunk = two 8-channel weight blocks
 constexpr int PXT = 36, XCH = 5 * PXT;           // patch: 5 rows (a0 - 1 .. a0 + 3) x 33 columns (b0 - 1 .. b0 + 31)
-constexpr int X_FLOATS = KC * XCH;               // 1 440
+constexpr int X_FLOATS = KC * XCH;               // 2 880
 constexpr int W_TAP = 3 * 2 * 32 * 4;            // dwords per tap: 3 pieces x 2 channel blocks x 32 lanes x 16 B
-constexpr int W_DWORDS = 9 * W_TAP;              // 6 912 dwords = 27 648 B
-constexpr int LDS_BYTES = (W_DWORDS + X_FLOATS) * 4;
-constexpr int W_INSTR = W_DWORDS / 256;          // 27
-constexpr int X_ITEMS = KC * 5 / 4;              // (channel, row) pairs per wave: 10
+constexpr int W_BLOCK = 9 * W_TAP;               // 6 912 dwords = 27 648 B per 8 input channels
+constexpr int W_DWORDS = (KC / 8) * W_BLOCK;     // per chunk
+constexpr int LDS_BYTES = (W_DWORDS + X_FLOATS) * 4;     // 66 816: two workgroups per CU
+static_assert(2 * LDS_BYTES <= 160 * 1024, "two workgroups per CU");
+constexpr int W_INSTR = W_BLOCK / 256;           // 27 DMA instructions per 8-channel block
+constexpr int X_ITEMS = KC * 5 / 4;              // (channel, row) pairs per wave: 20
 }  // namespace tc
 
 __global__ __launch_bounds__(256) void k_split_w_t(unsigned* __restrict__ wb, const float* __restrict__ wt, int C, int N,
                                                    int ldw, int tiles_n) {
-    const int64_t total = (int64_t)(C / tc::KC) * tiles_n * 9 * 2 * 32;
+    const int64_t total = (int64_t)(C / 8) * tiles_n * 9 * 2 * 32;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
         const int l31 = (int)(i & 31), nb = (int)((i >> 5) & 1);
         int64_t r = i >> 6;
@@ -276,7 +278,7 @@ __global__ __launch_bounds__(256) void k_split_w_t(unsigned* __restrict__ wb, co
         const int n = tn * tc::NT + nb * 32 + l31;
         float x[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) x[j] = n < N ? wt[((int64_t)tap * C + g * tc::KC + j) * ldw + n] : 0.0f;
+        for (int j = 0; j < 8; ++j) x[j] = n < N ? wt[((int64_t)tap * C + g * 8 + j) * ldw + n] : 0.0f;
         u32x4 h1, h2, h3;
         split8(x, h1, h2, h3);
         unsigned* dst = wb + ((int64_t)(g * tiles_n + tn) * 9 + tap) * tc::W_TAP + (nb * 32 + l31) * 4;
@@ -302,11 +304,11 @@ __global__ __launch_bounds__(256, 2) void k_convt_bf16x3(const PS2 p) {
     const int nchunk = p.C / tc::KC;
     typedef const float __attribute__((address_space(4)))* cptr_t;
 
-    const unsigned* wsrc = p.wb + (int64_t)tn * tc::W_DWORDS + lane * 4;
-    const int64_t w_chunk = (int64_t)p.tiles_n * tc::W_DWORDS;
+    const unsigned* wsrc = p.wb + (int64_t)tn * tc::W_BLOCK + lane * 4;
+    const int64_t w_block = (int64_t)p.tiles_n * tc::W_BLOCK;      // between consecutive 8-channel blocks
     const float* isb = p.iscale ? p.iscale + (int64_t)b * p.C : nullptr;
     float* sXw = reinterpret_cast<float*>(smem + tc::W_DWORDS);
-    // patch staging: wave w stages channels 2 w, 2 w + 1, five rows each; lane = patch column (33 used).  Row a0 - 1 + r,
+    // patch staging: wave w stages channels 4 w .. 4 w + 3, five rows each; lane = patch column (33 used).  Row a0 - 1 + r,
     // column b0 - 1 + lane: zero outside the image (top row / left column of the map), clamped address.
     const int col = b0 - 1 + lane;
     const bool col_ok = lane < 33 && col >= 0;
@@ -332,37 +334,42 @@ __global__ __launch_bounds__(256, 2) void k_convt_bf16x3(const PS2 p) {
     for (int g = 0; g < nchunk; ++g) {
         __syncthreads();              // every wave is done reading the buffer
         {
-            const unsigned* src = wsrc + g * w_chunk;
 #pragma unroll
-            for (int i = 0; i < tc::W_INSTR / 4; ++i) {
-                const int j = wave + 4 * i;
-                __builtin_amdgcn_global_load_lds((gptr_t)(src + j * 256), (lptr_t)(smem + j * 256), 16, 0, 0);
+            for (int q = 0; q < tc::KC / 8; ++q) {
+                const unsigned* src = wsrc + (int64_t)(g * (tc::KC / 8) + q) * w_block;
+                unsigned* dst = smem + q * tc::W_BLOCK;
+#pragma unroll
+                for (int i = 0; i < tc::W_INSTR / 4; ++i) {
+                    const int j = wave + 4 * i;
+                    __builtin_amdgcn_global_load_lds((gptr_t)(src + j * 256), (lptr_t)(dst + j * 256), 16, 0, 0);
+                }
+                if (wave < tc::W_INSTR % 4) {
+                    const int j = wave + 4 * (tc::W_INSTR / 4);
+                    __builtin_amdgcn_global_load_lds((gptr_t)(src + j * 256), (lptr_t)(dst + j * 256), 16, 0, 0);
+                }
             }
-            if (wave < tc::W_INSTR % 4) {
-                const int j = wave + 4 * (tc::W_INSTR / 4);
-                __builtin_amdgcn_global_load_lds((gptr_t)(src + j * 256), (lptr_t)(smem + j * 256), 16, 0, 0);
-            }
-            float sc0 = 1.0f, sc1 = 1.0f;
+            float sc[4] = {1.0f, 1.0f, 1.0f, 1.0f};
             if (isb) {
-                const cptr_t c = (cptr_t)(isb + g * tc::KC + 2 * wave);
-                sc0 = c[0];
-                sc1 = c[1];
+                const cptr_t c = (cptr_t)(isb + g * tc::KC + 4 * wave);
+                sc[0] = c[0]; sc[1] = c[1]; sc[2] = c[2]; sc[3] = c[3];
             }
-            const float* xw = xin + (int64_t)(g * tc::KC + 2 * wave) * plane_in;
+            const float* xw = xin + (int64_t)(g * tc::KC + 4 * wave) * plane_in;
             float stX[tc::X_ITEMS];
 #pragma unroll
             for (int k = 0; k < tc::X_ITEMS; ++k) stX[k] = xw[(k / 5) * plane_in + xoff[k % 5]];
             if (lane < 33) {
-                float* dw = sXw + (2 * wave) * tc::XCH + lane;
+                float* dw = sXw + (4 * wave) * tc::XCH + lane;
 #pragma unroll
                 for (int k = 0; k < tc::X_ITEMS; ++k)
-                    dw[(k / 5) * tc::XCH + (k % 5) * tc::PXT] = xok[k % 5] ? stX[k] * (k < 5 ? sc0 : sc1) : 0.0f;
+                    dw[(k / 5) * tc::XCH + (k % 5) * tc::PXT] = xok[k % 5] ? stX[k] * sc[k / 5] : 0.0f;
             }
         }
         __syncthreads();              // chunk complete (the barrier drains this wave's DMA)
-        const unsigned* sW = smem;
+#pragma unroll
+        for (int q = 0; q < tc::KC / 8; ++q) {
+        const unsigned* sW = smem + q * tc::W_BLOCK;
         // grid point (a0 + wave, b0 + l31) sits at patch (row wave + 1, column l31 + 1)
-        const float* sX = sXw + (wave + 1) * tc::PXT + l31 + 1;
+        const float* sX = sXw + q * 8 * tc::XCH + (wave + 1) * tc::PXT + l31 + 1;
         // operands of this lane: half 0 -> S00, S01 ; half 1 -> S10, S11, S01  (S_dy_dx = in(a - dy, b - dx))
         const float* p0 = half ? sX - tc::PXT : sX;            // S00 | S10
         const float* p1 = half ? sX - tc::PXT - 1 : sX - 1;    // S01 | S11
@@ -403,6 +410,7 @@ __global__ __launch_bounds__(256, 2) void k_convt_bf16x3(const PS2 p) {
         group(0, f1, 2, 8);        // (0,0): S01 W02 | S11 W22
         group(2, f2, 3, 5);        // (1,0): S00 W10 | S01 W12
         group(3, f3, 4, 4);        // (1,1): S00 W11 | zero
+        }
     }
 
     // epilogue: grid point (a, b) -> outputs (2a + py, 2b + px); C/D layout column = lane & 31 (grid column)
@@ -471,7 +479,7 @@ bool sr_convt_bf16x3_eligible(int64_t B, int64_t C, int64_t N, int64_t IH, int64
 }
 
 int64_t sr_convt_bf16x3_scratch_floats(int64_t C, int64_t N) {
-    return (C / tc::KC) * (N / tc::NT) * (int64_t)tc::W_DWORDS + 4;
+    return (C / 8) * (N / tc::NT) * (int64_t)tc::W_BLOCK + 4;
 }
 
 // interior of the map only (grid points a < IH, b < IW, all four phases); the caller runs the border strips
@@ -480,7 +488,7 @@ int sr_convt_bf16x3_launch(float* out, const float* in, const float* wt, int64_t
                            int64_t IW, float* scratch, hipStream_t st) {
     unsigned* wb = reinterpret_cast<unsigned*>(scratch);
     const int tiles_n = (int)(N / tc::NT);
-    const int64_t items = (C / tc::KC) * tiles_n * 9 * 2 * 32;
+    const int64_t items = (C / 8) * tiles_n * 9 * 2 * 32;
     hipLaunchKernelGGL(k_split_w_t, dim3(sr_stream_grid(items, 256)), dim3(256), 0, st, wb, wt, (int)C, (int)N, (int)ldw,
                        tiles_n);
     PS2 p;
@@ -488,6 +496,12 @@ int sr_convt_bf16x3_launch(float* out, const float* in, const float* wt, int64_t
     p.B = (int)B; p.C = (int)C; p.N = (int)N; p.IH = (int)IH; p.IW = (int)IW; p.OH = (int)(2 * IH + 1);
     p.OW = (int)(2 * IW + 1);
     p.tiles_x = (int)(IW / 32); p.tiles_y = (int)(IH / 4); p.tiles_n = tiles_n;
+    static bool configured = false;
+    if (!configured) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_convt_bf16x3), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  tc::LDS_BYTES);
+        configured = true;
+    }
     hipLaunchKernelGGL(k_convt_bf16x3, dim3((unsigned)(B * p.tiles_y * p.tiles_x * tiles_n)), dim3(tc::THREADS),
                        tc::LDS_BYTES, st, p);
     return sr_launch_status();
