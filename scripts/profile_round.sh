@@ -8,7 +8,7 @@ root=$(pwd)
 out=$root/gpurun_out/prof_$tag
 mkdir -p $out
 export TMPDIR=/tmp
-BENCH="python $root/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-train --no-inversion --no-pmc"
+BENCH="python $root/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-train --no-inversion --no-pmc --no-split-bf16"
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -o $tag -- $BENCH > $out/trace.log 2>&1
 # PMC passes: never combined with the trace domains, one TCC counter per pass
