@@ -1759,7 +1759,11 @@ int grad_impl(long long b, long long nv, long long nf, long long h, long long w,
     // second backward over the same state repeats the same integer minima).  Which of the two happened is read from
     // the state the FORWARD wrote, on the device — never re-derived from tiled_ok() at backward time.
     int* first = const_cast<int*>(big) + 1 + b * nf;
+#ifndef SR_ABL_NOFIRST      // (ablation build: timing of the gate itself; only valid after a tiled forward)
     if (b * nf > 0)
+#else
+    if (false)
+#endif
         hipLaunchKernelGGL(k_first_pix, dim3((unsigned)std::min<long long>(sr_ceil_div(b * h * w, 256), 1024)), dim3(256), 0,
                            st, b * h * w, h * w, w, nf, win, first, first + b * nf);
     // attribute channels in chunks of <= 4 register accumulators; the vertex gradient rides with chunk 0
