@@ -352,6 +352,9 @@ class BucketedGradReducer:
         """The optimiser that consumes this buffer refuses a step whose buckets carry the NaN marker of a timed-out
         wait (optim.FlatAdam.set_guards); check() raises when it did."""
         if self.enabled and hasattr(optimiser, "set_guards"):
+            if len(self.buckets) > 16:
+                raise RuntimeError("BucketedGradReducer.guard: sr_adam_flat_guarded takes at most 16 guard positions "
+                                   "(%d buckets; SR_GRAD_BUCKETS <= 16)" % len(self.buckets))
             self.guarded.append(optimiser.set_guards([b["lo"] for b in self.buckets]))
         return optimiser
 

@@ -63,7 +63,9 @@ class FlatAdam:
         gradient."""
         import ctypes
 
-        offsets = [int(o) for o in offsets][:16]
+        offsets = [int(o) for o in offsets]
+        if len(offsets) > 16:
+            raise ValueError("FlatAdam.set_guards: at most 16 guard positions")
         self.guards = (ctypes.c_int64 * len(offsets))(*offsets)
         if self.flat_p.device.type == "cuda":
             self.skipped = torch.zeros(1, dtype=torch.int32).pin_memory()
