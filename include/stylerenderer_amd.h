@@ -265,6 +265,21 @@ int sr_blur_noise_bias_act(float* y, const float* x, const float* k, const float
                            const float* bias, float alpha, float gain, int64_t n, int64_t c, int in_h, int in_w,
                            int out_h, int out_w, int pad0, int pad1, int64_t noise_bstride, sr_stream_t stream);
 
+/* First-order backward of sr_blur_noise_bias_act in ONE pass (the gradient of reference layers.py:194-203 + model.py:26-32
+ * taken together): gx = blur^T(lrelu'(y) * gy * gain) [n, c, out_h, out_w], gbias [c] = sum lrelu'(y) gy gain, gnoise_w [1]
+ * = the same sum weighted with the noise (both NULL when bias / noise strength are frozen), rowdot [n * c] = the sum
+ * weighted with the pre-activation value rebuilt from y (the demodulation gradient of the convolution in front, see
+ * sr_noise_bias_act_bwd_dot).  gy, y [n, c, in_h, in_w] = the forward's OUTPUT extent, out = in + 3 - 2 pad0 its input
+ * extent (pad0 = the forward's symmetric padding); k_flipped = the forward taps flipped in both axes (what sr_upfirdn2d
+ * takes for the gradient of a blur).  gx is bit-identical to sr_noise_bias_act_bwd followed by sr_upfirdn2d; the three
+ * sums are deterministic (per-workgroup partials added in a fixed order) but associate differently from
+ * sr_noise_bias_act_bwd_dot.  scratch: sr_blur_nba_bwd_scratch_floats floats. */
+int64_t sr_blur_nba_bwd_scratch_floats(int64_t n, int64_t c, int out_h, int out_w);
+int sr_blur_nba_bwd(float* gx, float* gbias, float* gnoise_w, float* rowdot, const float* gy, const float* y,
+                    const float* k_flipped, const float* noise, const float* noise_w, const float* bias, float alpha,
+                    float gain, int64_t n, int64_t c, int in_h, int in_w, int out_h, int out_w, int pad0,
+                    int64_t noise_bstride, float* scratch, sr_stream_t stream);
+
 
 /* ---------------------------------------------------------------------------------------
  * 3DMM triangle rasterizer (z-buffered, deterministic; results equal the reference's

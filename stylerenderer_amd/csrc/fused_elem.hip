@@ -268,6 +268,20 @@ extern "C" int sr_noise_bias_act_bwd(float* gx, float* gbias, float* gnoise_w, c
     return sr_launch_status();
 }
 
+// The three finish launches behind a pass that left per-workgroup partials in the layout of k_nba_bwd<true>
+// (csrc/upfirdn2d.hip k_fir4_nba_bwd shares them): gbias NULL = frozen parameters, rowdot NULL = one chunk (written in
+// place by the producer).
+int sr_nba_finish_launch(float* gbias, float* gnoise_w, float* rowdot, const float* partial, const float* dot_partial,
+                         float* chan_nw, int64_t n, int64_t c, int chunks, bool has_noise, hipStream_t st) {
+    if (gbias) {
+        hipLaunchKernelGGL(k_nba_finish, dim3((unsigned)c), dim3(64), 0, st, gbias, chan_nw, partial, n, (int)c, chunks);
+        if (has_noise && gnoise_w)
+            hipLaunchKernelGGL(k_nba_finish2, dim3(1), dim3(64), 0, st, gnoise_w, chan_nw, (int)c);
+    }
+    if (rowdot) hipLaunchKernelGGL(k_rowdot_finish, dim3((unsigned)(n * c)), dim3(64), 0, st, rowdot, dot_partial, chunks);
+    return sr_launch_status();
+}
+
 extern "C" int64_t sr_noise_bias_act_bwd_dot_scratch_floats(int64_t n, int64_t c, int64_t inner) {
     if (n <= 0 || c <= 0 || inner <= 0) return 3;
     return 3 * n * c * sr_ceil_div(inner, ECHUNK) + c + 2;      // partial pairs + row-dot partials + channel shares

@@ -15,6 +15,8 @@
 // (-ffp-contract=off), the order the oracle (oracle/ops_np.py) fixes, so HIP == oracle bitwise.
 #include "common.h"
 
+#include <cstdlib>
+
 namespace {
 
 struct UfdParams {
@@ -71,6 +73,74 @@ constexpr int T_OH = 32, T_OW = 64, T_K = 4;
 constexpr int T_IH = T_OH + T_K - 1;        // 35
 constexpr int T_IW = T_OW + T_K - 1;        // 67
 constexpr int T_LD = 68;                    // LDS row pitch (floats), multiple of 4
+// Aligned staging (ALN): when the input rows are 16-byte aligned (in_w % 4 == 0, aligned base) and the window starts two
+// columns left of a tile boundary (pad_x0 == 2: the gradient of the up-sampling layers' blur, the blur in front of the
+// discriminator's stride-2 convolutions), the window is widened to start FOUR columns left — 72 columns = 18 aligned
+// 16-byte groups per row, 630 vector loads per tile instead of 2 380 scalar ones with their index arithmetic; the FIR then
+// reads its 8-float window at column lx + 2 (8-byte aligned: four ds_read_b64).
+constexpr int A_LD = 72, A_G = A_LD / 4;    // pitch / 16-byte groups per row of the widened window
+
+typedef const float __attribute__((address_space(4)))* cptr_t;
+
+// The sixteen taps are wave-uniform: scalar loads into SGPRs (constant address space) instead of sixteen vector registers
+// per lane — with the row-sliding window below the kernels fit 64 registers (eight waves per SIMD).
+#define FIR4_LOAD_TAPS(kf, k)                                   \
+    float kf[16];                                               \
+    {                                                           \
+        const cptr_t kc_ = (cptr_t)(uintptr_t)(k);              \
+        _Pragma("unroll") for (int i_ = 0; i_ < 16; ++i_) kf[i_] = kc_[15 - i_];   /* flipped */ \
+    }
+
+// 2 x 4 outputs per lane from rows ly .. ly+4 of the staged tile.  Row t is tap row ky = t of output row 0 and ky = t - 1
+// of output row 1: walking t upwards visits every accumulator's taps ky-major then kx — the bit-exact order of the
+// oracle (multiply and add separate) — with one 8-float window row live at a time.
+template <int LD, int COFF>
+__device__ __forceinline__ void fir4_rows(const float* s_in, const float (&kf)[16], int lx, int ly, float (&acc)[2][4]) {
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[r][c] = 0.0f;
+#pragma unroll
+    for (int t = 0; t < 5; ++t) {
+        float win[8];
+        const float* row = s_in + (ly + t) * LD + lx + COFF;
+        if (COFF % 4 == 0) {
+            const float4 a = *reinterpret_cast<const float4*>(row);
+            const float4 b = *reinterpret_cast<const float4*>(row + 4);
+            win[0] = a.x; win[1] = a.y; win[2] = a.z; win[3] = a.w;
+            win[4] = b.x; win[5] = b.y; win[6] = b.z; win[7] = b.w;
+        } else {
+#pragma unroll
+            for (int h = 0; h < 4; ++h) {
+                const float2 a = *reinterpret_cast<const float2*>(row + 2 * h);
+                win[2 * h] = a.x;
+                win[2 * h + 1] = a.y;
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int ky = t - r;
+            if (ky < 0 || ky > 3) continue;
+#pragma unroll
+            for (int kx = 0; kx < 4; ++kx)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const float prod = win[c + kx] * kf[ky * 4 + kx];
+                    acc[r][c] = acc[r][c] + prod;
+                }
+        }
+    }
+}
+
+__device__ __forceinline__ void fir4_store_row(float* q, int ox, int out_w, const float (&v)[4]) {
+    if (ox + 3 < out_w && ((reinterpret_cast<uintptr_t>(q) & 15) == 0)) {
+        *reinterpret_cast<float4*>(q) = make_float4(v[0], v[1], v[2], v[3]);
+    } else {
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            if (ox + c < out_w) q[c] = v[c];
+    }
+}
 
 // NBA: the StyledConv tail (reference model.py:26-32: NoiseInjection + FusedLeakyReLU) applied to the
 // blurred value before it is stored — y = lrelu((f + nw * noise[b, p]) + bias[c]) * gain, the same
@@ -84,14 +154,14 @@ struct FirNba {
     float alpha, gain;
 };
 
-template <bool NBA>
+template <bool NBA, bool ALN>
 __global__ __launch_bounds__(256) void k_fir4_tile(float* __restrict__ out,
                                                    const float* __restrict__ x,
                                                    const float* __restrict__ k, int in_h, int in_w,
                                                    int out_h, int out_w, int pad_x0, int pad_y0,
                                                    int tiles_x, int tiles_y, FirNba nba) {
-    __shared__ __attribute__((aligned(16))) float s_in[T_IH * T_LD];
-    __shared__ float s_k[16];
+    constexpr int LD = ALN ? A_LD : T_LD;
+    __shared__ __attribute__((aligned(16))) float s_in[T_IH * LD];
     int bid = blockIdx.x;
     const int tx_i = bid % tiles_x;
     bid /= tiles_x;
@@ -100,65 +170,53 @@ __global__ __launch_bounds__(256) void k_fir4_tile(float* __restrict__ out,
     const int oy0 = ty_i * T_OH, ox0 = tx_i * T_OW;
     const int iy0 = oy0 - pad_y0, ix0 = ox0 - pad_x0;
     const float* src = x + plane * (int64_t)in_h * in_w;
+    FIR4_LOAD_TAPS(kf, k)
 
-    if (threadIdx.x < 16) {
-        const int ky = threadIdx.x >> 2, kx = threadIdx.x & 3;
-        s_k[threadIdx.x] = k[(3 - ky) * 4 + (3 - kx)];
-    }
-    // stage the halo tile: consecutive lanes read consecutive columns of one row (coalesced).  All ten
-    // loads of a lane are issued before the first LDS write (unconditional loads from clamped addresses,
-    // masked afterwards): one memory round trip per tile instead of ten dependent ones.
-    constexpr int T_STAGE = (T_IH * T_LD + 255) / 256;
-    float stage[T_STAGE];
+    if (ALN) {
+        // (pad_x0 == 2) window columns ox0 - 4 .. ox0 + 67 as 18 aligned groups per row; a group is inside or outside
+        constexpr int NG = T_IH * A_G, ST = (NG + 255) / 256;
+        float4 stage[ST];
 #pragma unroll
-    for (int k = 0; k < T_STAGE; ++k) {
-        const int i = threadIdx.x + 256 * k;
-        const int r = i / T_LD, c = i - r * T_LD;
-        const int gy = iy0 + r, gx = ix0 + c;
-        const bool ok = i < T_IH * T_LD && c < T_IW && gy >= 0 && gy < in_h && gx >= 0 && gx < in_w;
-        const float v = src[ok ? (int64_t)gy * in_w + gx : 0];
-        stage[k] = ok ? v : 0.0f;
-    }
+        for (int j = 0; j < ST; ++j) {
+            const int i = threadIdx.x + 256 * j;
+            const int r = i / A_G, g = i - r * A_G;
+            const int gy = iy0 + r, gx = ox0 - 4 + 4 * g;
+            const bool ok = i < NG && gy >= 0 && gy < in_h && gx >= 0 && gx < in_w;
+            const float4 v = *reinterpret_cast<const float4*>(src + (ok ? (int64_t)gy * in_w + gx : 0));
+            stage[j] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
 #pragma unroll
-    for (int k = 0; k < T_STAGE; ++k) {
-        const int i = threadIdx.x + 256 * k;
-        if (i < T_IH * T_LD) s_in[i] = stage[k];
+        for (int j = 0; j < ST; ++j) {
+            const int i = threadIdx.x + 256 * j;
+            if (i < NG) reinterpret_cast<float4*>(s_in)[i] = stage[j];
+        }
+    } else {
+        // stage the halo tile: consecutive lanes read consecutive columns of one row (coalesced).  All ten
+        // loads of a lane are issued before the first LDS write (unconditional loads from clamped addresses,
+        // masked afterwards): one memory round trip per tile instead of ten dependent ones.
+        constexpr int T_STAGE = (T_IH * T_LD + 255) / 256;
+        float stage[T_STAGE];
+#pragma unroll
+        for (int j = 0; j < T_STAGE; ++j) {
+            const int i = threadIdx.x + 256 * j;
+            const int r = i / T_LD, c = i - r * T_LD;
+            const int gy = iy0 + r, gx = ix0 + c;
+            const bool ok = i < T_IH * T_LD && c < T_IW && gy >= 0 && gy < in_h && gx >= 0 && gx < in_w;
+            const float v = src[ok ? (int64_t)gy * in_w + gx : 0];
+            stage[j] = ok ? v : 0.0f;
+        }
+#pragma unroll
+        for (int j = 0; j < T_STAGE; ++j) {
+            const int i = threadIdx.x + 256 * j;
+            if (i < T_IH * T_LD) s_in[i] = stage[j];
+        }
     }
     __syncthreads();
-
-    float kf[16];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) kf[i] = s_k[i];
 
     const int lx = (threadIdx.x & 15) * 4;       // 4 output columns per lane
     const int ly = (threadIdx.x >> 4) * 2;       // 2 output rows per lane
     float acc[2][4];
-#pragma unroll
-    for (int r = 0; r < 2; ++r)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) acc[r][c] = 0.0f;
-
-    // rows ly .. ly+4 of the tile feed the two output rows; for bit-exact ky-major order each
-    // output row walks its own four input rows top to bottom.
-    float win[5][8];
-#pragma unroll
-    for (int r = 0; r < 5; ++r) {
-        const float4 a = *reinterpret_cast<const float4*>(&s_in[(ly + r) * T_LD + lx]);
-        const float4 b = *reinterpret_cast<const float4*>(&s_in[(ly + r) * T_LD + lx + 4]);
-        win[r][0] = a.x; win[r][1] = a.y; win[r][2] = a.z; win[r][3] = a.w;
-        win[r][4] = b.x; win[r][5] = b.y; win[r][6] = b.z; win[r][7] = b.w;
-    }
-#pragma unroll
-    for (int r = 0; r < 2; ++r)
-#pragma unroll
-        for (int ky = 0; ky < 4; ++ky)
-#pragma unroll
-            for (int kx = 0; kx < 4; ++kx)
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const float prod = win[r + ky][c + kx] * kf[ky * 4 + kx];
-                    acc[r][c] = acc[r][c] + prod;
-                }
+    fir4_rows<LD, ALN ? 2 : 0>(s_in, kf, lx, ly, acc);
 
     float* dst = out + plane * (int64_t)out_h * out_w;
     float nw = 0.0f, bb = 0.0f;
@@ -185,14 +243,152 @@ __global__ __launch_bounds__(256) void k_fir4_tile(float* __restrict__ out,
                 acc[r][c] = ((v > 0.0f) ? v : v * nba.alpha) * nba.gain;
             }
         }
-        float* q = dst + (int64_t)oy * out_w + ox;
-        if (ox + 3 < out_w && ((reinterpret_cast<uintptr_t>(q) & 15) == 0)) {
-            *reinterpret_cast<float4*>(q) = make_float4(acc[r][0], acc[r][1], acc[r][2], acc[r][3]);
-        } else {
+        fir4_store_row(dst + (int64_t)oy * out_w + ox, ox, out_w, acc[r]);
+    }
+}
+
+// ------------------------------------------------------------------------------ backward of blur + tail, one pass
+// Gradient of  y = lrelu((blur(x) + w * noise) + bias) * gain  (k_fir4_tile<true>) w.r.t. x, with the reductions of
+// the tail's backward, in ONE pass over the two full-size tensors it needs (gy, y) — the two-kernel form
+// (k_nba_bwd: read gy, y, write gpre;  k_fir4_tile<false>: read gpre, write gx) moves five tensors, this one three.
+// The halo tile of gpre = lrelu'(y) * gy * gain is computed while it is staged (same expression as k_nba_bwd, so gx
+// is bit-identical to the two-kernel form); every gpre element belongs to exactly one tile's "owned" 32 x 64 corner
+// of its 35 x 67 window, where it enters the three sums
+//     sum gpre (bias gradient), sum gpre * noise (noise strength), sum gpre * y0 (demodulation row-dot; y0 = the
+//     pre-activation value of the forward pass rebuilt from y, see k_nba_bwd<true>)
+// as one partial triple per workgroup; the finish kernels of csrc/fused_elem.hip add them in a fixed order.
+struct FirNbaBwd {
+    const float* fw;          // forward output y [planes, in_h, in_w]
+    const float* noise;       // [B or 1, 1, in_h, in_w] or NULL
+    const float* noise_w;     // 1 float (device) when noise != NULL
+    const float* bias;        // [C] or NULL
+    float* partial;           // [planes * tiles] pairs (sum gpre, sum gpre * noise)
+    float* dot_partial;       // [planes * tiles]
+    int64_t noise_bstride;
+    int channels;
+    float alpha, gain, inv_pos, inv_neg;
+};
+
+struct FirSums {
+    float b, n, d;
+};
+
+__device__ __forceinline__ float fir4_gpre(float g, float o, float nzv, bool ok, bool owned, const FirNbaBwd& q, float nw,
+                                           float bb, FirSums& s) {
+    const float v = ok ? ((o > 0.0f) ? g : g * q.alpha) * q.gain : 0.0f;
+    if (owned) {
+        const float y0 = ((o > 0.0f) ? o * q.inv_pos : o * q.inv_neg) - nw * nzv - bb;
+        s.b += v;
+        s.n += v * nzv;
+        s.d += v * y0;
+    }
+    return v;
+}
+
+template <bool ALN>
+__global__ __launch_bounds__(256) void k_fir4_nba_bwd(float* __restrict__ out, const float* __restrict__ gy,
+                                                      const float* __restrict__ k, int in_h, int in_w, int out_h,
+                                                      int out_w, int pad_x0, int pad_y0, int tiles_x, int tiles_y,
+                                                      FirNbaBwd q) {
+    constexpr int LD = ALN ? A_LD : T_LD;
+    __shared__ __attribute__((aligned(16))) float s_in[T_IH * LD];
+    __shared__ float s_red[12];
+    int bid = blockIdx.x;
+    const int tile = bid % (tiles_x * tiles_y);
+    const int tx_i = bid % tiles_x;
+    bid /= tiles_x;
+    const int ty_i = bid % tiles_y;
+    const int64_t plane = bid / tiles_y;
+    const int oy0 = ty_i * T_OH, ox0 = tx_i * T_OW;
+    const int iy0 = oy0 - pad_y0, ix0 = ox0 - pad_x0;
+    const float* src = gy + plane * (int64_t)in_h * in_w;
+    const float* fws = q.fw + plane * (int64_t)in_h * in_w;
+    const int64_t b = plane / q.channels;
+    const float* nz = q.noise ? q.noise + b * q.noise_bstride : nullptr;
+    const float nw = q.noise ? q.noise_w[0] : 0.0f;
+    const float bb = q.bias ? q.bias[plane - b * q.channels] : 0.0f;
+    FIR4_LOAD_TAPS(kf, k)
+
+    FirSums sums{0.0f, 0.0f, 0.0f};
+    if (ALN) {
+        // window columns ox0 - 4 .. ox0 + 67; owned = rows 0..31, window columns 2..65 (image columns ox0 - 2 .. ox0 + 61)
+        constexpr int NG = T_IH * A_G, ST = (NG + 255) / 256;
+        float4 sg[ST], so[ST], sn[ST];
 #pragma unroll
-            for (int c = 0; c < 4; ++c)
-                if (ox + c < out_w) q[c] = acc[r][c];
+        for (int j = 0; j < ST; ++j) {
+            const int i = threadIdx.x + 256 * j;
+            const int r = i / A_G, g = i - r * A_G;
+            const int y = iy0 + r, x = ox0 - 4 + 4 * g;
+            const bool ok = i < NG && y >= 0 && y < in_h && x >= 0 && x < in_w;
+            const int64_t o = ok ? (int64_t)y * in_w + x : 0;
+            sg[j] = *reinterpret_cast<const float4*>(src + o);
+            so[j] = *reinterpret_cast<const float4*>(fws + o);
+            sn[j] = nz ? *reinterpret_cast<const float4*>(nz + o) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
+#pragma unroll
+        for (int j = 0; j < ST; ++j) {
+            const int i = threadIdx.x + 256 * j;
+            const int r = i / A_G, g = i - r * A_G;
+            const int y = iy0 + r, x = ox0 - 4 + 4 * g;
+            const bool ok = i < NG && y >= 0 && y < in_h && x >= 0 && x < in_w;
+            const bool own_r = ok && r < T_OH;
+            const int c0 = 4 * g;
+            float4 v;
+            v.x = fir4_gpre(sg[j].x, so[j].x, sn[j].x, ok, own_r && c0 >= 2 && c0 < 66, q, nw, bb, sums);
+            v.y = fir4_gpre(sg[j].y, so[j].y, sn[j].y, ok, own_r && c0 + 1 >= 2 && c0 + 1 < 66, q, nw, bb, sums);
+            v.z = fir4_gpre(sg[j].z, so[j].z, sn[j].z, ok, own_r && c0 + 2 >= 2 && c0 + 2 < 66, q, nw, bb, sums);
+            v.w = fir4_gpre(sg[j].w, so[j].w, sn[j].w, ok, own_r && c0 + 3 >= 2 && c0 + 3 < 66, q, nw, bb, sums);
+            if (i < NG) reinterpret_cast<float4*>(s_in)[i] = v;
+        }
+    } else {
+        constexpr int T_STAGE = (T_IH * T_LD + 255) / 256;
+        float sg[T_STAGE], so[T_STAGE], sn[T_STAGE];
+#pragma unroll
+        for (int j = 0; j < T_STAGE; ++j) {
+            const int i = threadIdx.x + 256 * j;
+            const int r = i / T_LD, c = i - r * T_LD;
+            const int y = iy0 + r, x = ix0 + c;
+            const bool ok = i < T_IH * T_LD && c < T_IW && y >= 0 && y < in_h && x >= 0 && x < in_w;
+            const int64_t o = ok ? (int64_t)y * in_w + x : 0;
+            sg[j] = src[o];
+            so[j] = fws[o];
+            sn[j] = nz ? nz[o] : 0.0f;
+        }
+#pragma unroll
+        for (int j = 0; j < T_STAGE; ++j) {
+            const int i = threadIdx.x + 256 * j;
+            const int r = i / T_LD, c = i - r * T_LD;
+            const int y = iy0 + r, x = ix0 + c;
+            const bool ok = i < T_IH * T_LD && c < T_IW && y >= 0 && y < in_h && x >= 0 && x < in_w;
+            const float v = fir4_gpre(sg[j], so[j], sn[j], ok, ok && r < T_OH && c < T_OW, q, nw, bb, sums);
+            if (i < T_IH * T_LD) s_in[i] = v;
+        }
+    }
+    sums.b = sr_wave_sum(sums.b);
+    sums.n = sr_wave_sum(sums.n);
+    sums.d = sr_wave_sum(sums.d);
+    {
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        if (lane == 0) { s_red[wave] = sums.b; s_red[4 + wave] = sums.n; s_red[8 + wave] = sums.d; }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int64_t slot = plane * (int64_t)(tiles_x * tiles_y) + tile;
+        q.partial[slot * 2] = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+        q.partial[slot * 2 + 1] = (s_red[4] + s_red[5]) + (s_red[6] + s_red[7]);
+        q.dot_partial[slot] = (s_red[8] + s_red[9]) + (s_red[10] + s_red[11]);
+    }
+
+    const int lx = (threadIdx.x & 15) * 4, ly = (threadIdx.x >> 4) * 2;
+    float acc[2][4];
+    fir4_rows<LD, ALN ? 2 : 0>(s_in, kf, lx, ly, acc);
+    float* dst = out + plane * (int64_t)out_h * out_w;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int oy = oy0 + ly + r;
+        if (oy >= out_h) continue;
+        const int ox = ox0 + lx;
+        fir4_store_row(dst + (int64_t)oy * out_w + ox, ox, out_w, acc[r]);
     }
 }
 
@@ -275,6 +471,15 @@ __global__ __launch_bounds__(256) void k_fir4_resample(float* __restrict__ out, 
         if (ox0 + lx + c < out_w) q[c] = addend ? acc[c] + addend[o + c] : acc[c];
 }
 
+// aligned staging of k_fir4_tile / k_fir4_nba_bwd (see A_LD); SR_FIR_ALIGNED=0 keeps the scalar staging (A/B)
+inline bool fir4_aligned(const float* x, int in_w, int pad_x0) {
+    static const bool enabled = [] {
+        const char* e = std::getenv("SR_FIR_ALIGNED");
+        return !(e && e[0] == '0');
+    }();
+    return enabled && pad_x0 == 2 && in_w % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0;
+}
+
 }  // namespace
 
 extern "C" int sr_upfirdn2d(float* out, const float* x, const float* k, int64_t major, int in_h,
@@ -296,8 +501,12 @@ extern "C" int sr_upfirdn2d(float* out, const float* x, const float* k, int64_t 
         const int tiles_x = (out_w + T_OW - 1) / T_OW, tiles_y = (out_h + T_OH - 1) / T_OH;
         const int64_t blocks = (int64_t)tiles_x * tiles_y * major;
         if (blocks < 0x7FFFFFFFLL) {
-            hipLaunchKernelGGL(k_fir4_tile<false>, dim3((unsigned)blocks), dim3(256), 0, st, out, x, k, in_h, in_w,
-                               out_h, out_w, pad_x0, pad_y0, tiles_x, tiles_y, FirNba{});
+            if (fir4_aligned(x, in_w, pad_x0))
+                hipLaunchKernelGGL((k_fir4_tile<false, true>), dim3((unsigned)blocks), dim3(256), 0, st, out, x, k, in_h,
+                                   in_w, out_h, out_w, pad_x0, pad_y0, tiles_x, tiles_y, FirNba{});
+            else
+                hipLaunchKernelGGL((k_fir4_tile<false, false>), dim3((unsigned)blocks), dim3(256), 0, st, out, x, k, in_h,
+                                   in_w, out_h, out_w, pad_x0, pad_y0, tiles_x, tiles_y, FirNba{});
             return sr_launch_status();
         }
     }
@@ -348,7 +557,60 @@ extern "C" int sr_blur_noise_bias_act(float* y, const float* x, const float* k, 
     const int64_t blocks = (int64_t)tiles_x * tiles_y * n * c;
     if (blocks >= 0x7FFFFFFFLL) return SR_ERANGE;
     const FirNba nba{noise, noise_w, bias, noise_bstride, (int)c, alpha, gain};
-    hipLaunchKernelGGL(k_fir4_tile<true>, dim3((unsigned)blocks), dim3(256), 0, sr_stream(stream), y, x, k, in_h,
-                       in_w, out_h, out_w, pad0, pad0, tiles_x, tiles_y, nba);
+    if (fir4_aligned(x, in_w, pad0))
+        hipLaunchKernelGGL((k_fir4_tile<true, true>), dim3((unsigned)blocks), dim3(256), 0, sr_stream(stream), y, x, k,
+                           in_h, in_w, out_h, out_w, pad0, pad0, tiles_x, tiles_y, nba);
+    else
+        hipLaunchKernelGGL((k_fir4_tile<true, false>), dim3((unsigned)blocks), dim3(256), 0, sr_stream(stream), y, x, k,
+                           in_h, in_w, out_h, out_w, pad0, pad0, tiles_x, tiles_y, nba);
     return sr_launch_status();
+}
+
+// finish kernels of csrc/fused_elem.hip (bias / noise-strength / row-dot partials -> results, fixed order)
+int sr_nba_finish_launch(float* gbias, float* gnoise_w, float* rowdot, const float* partial, const float* dot_partial,
+                         float* chan_nw, int64_t n, int64_t c, int chunks, bool has_noise, hipStream_t st);
+
+extern "C" int64_t sr_blur_nba_bwd_scratch_floats(int64_t n, int64_t c, int out_h, int out_w) {
+    if (n <= 0 || c <= 0 || out_h <= 0 || out_w <= 0) return 3;
+    const int64_t tiles = (int64_t)((out_w + T_OW - 1) / T_OW) * ((out_h + T_OH - 1) / T_OH);
+    return 3 * n * c * tiles + c + 2;
+}
+
+// gx [n, c, out_h, out_w] = blur^T( lrelu'(y) * gy * gain ) with `k` the FORWARD blur kernel and pad0 / pad1 the
+// forward's padding (the gradient pads by 3 - pad0 in front), plus gbias [c], gnoise_w [1] (both optional: NULL = the
+// parameters are frozen) and rowdot [n * c] (see FirNbaBwd).  gy, y: [n, c, in_h, in_w], the forward's OUTPUT extent.
+extern "C" int sr_blur_nba_bwd(float* gx, float* gbias, float* gnoise_w, float* rowdot, const float* gy, const float* y,
+                               const float* k_flipped, const float* noise, const float* noise_w, const float* bias,
+                               float alpha, float gain, int64_t n, int64_t c, int in_h, int in_w, int out_h, int out_w,
+                               int pad0, int64_t noise_bstride, float* scratch, sr_stream_t stream) {
+    if (n < 0 || c < 0 || in_h < 0 || in_w < 0) return SR_EINVAL;
+    // forward: in = out + 2 * pad - 3 with pad0 == pad1 (the up-sampling layers: 257 -> 256, pad 1)
+    if (out_h + 2 * pad0 - 3 != in_h || out_w + 2 * pad0 - 3 != in_w || pad0 < 0 || pad0 > 3) return SR_EINVAL;
+    if (n * c == 0 || in_h == 0 || in_w == 0) return SR_OK;
+    if (!gx || !rowdot || !gy || !y || !k_flipped || !scratch || (noise && !noise_w) || gain == 0.0f || alpha == 0.0f)
+        return SR_EINVAL;
+    const int tiles_x = (out_w + T_OW - 1) / T_OW, tiles_y = (out_h + T_OH - 1) / T_OH;
+    const int chunks = tiles_x * tiles_y;
+    const int64_t blocks = (int64_t)chunks * n * c;
+    if (blocks >= 0x7FFFFFFFLL) return SR_ERANGE;
+    // every gpre element must lie in some tile's owned corner: the tiles start at -gpad and cover chunks * 32 / 64
+    const int gpad = 3 - pad0;
+    if (tiles_y * T_OH - gpad < in_h || tiles_x * T_OW - gpad < in_w) return SR_EINVAL;
+    hipStream_t st = sr_stream(stream);
+    float* dot_partial = scratch + 2 * n * c * (int64_t)chunks;
+    float* chan_nw = dot_partial + n * c * (int64_t)chunks;
+    const FirNbaBwd q{y, noise, noise_w, bias, scratch, chunks == 1 ? rowdot : dot_partial, noise_bstride, (int)c, alpha,
+                      gain, 1.0f / gain, 1.0f / (alpha * gain)};
+    const bool aln = fir4_aligned(gy, in_w, gpad) && (reinterpret_cast<uintptr_t>(y) & 15) == 0 &&
+                     (!noise || ((reinterpret_cast<uintptr_t>(noise) & 15) == 0 && noise_bstride % 4 == 0));
+    if (aln)
+        hipLaunchKernelGGL(k_fir4_nba_bwd<true>, dim3((unsigned)blocks), dim3(256), 0, st, gx, gy, k_flipped, in_h, in_w,
+                           out_h, out_w, gpad, gpad, tiles_x, tiles_y, q);
+    else
+        hipLaunchKernelGGL(k_fir4_nba_bwd<false>, dim3((unsigned)blocks), dim3(256), 0, st, gx, gy, k_flipped, in_h, in_w,
+                           out_h, out_w, gpad, gpad, tiles_x, tiles_y, q);
+    const int rc = sr_launch_status();
+    if (rc != SR_OK) return rc;
+    return sr_nba_finish_launch(gbias, gnoise_w, chunks == 1 ? nullptr : rowdot, scratch, dot_partial, chan_nw, n, c,
+                                chunks, noise != nullptr, st);
 }

@@ -398,6 +398,34 @@ def _nba_bwd_dot(gy, out, noise, noise_w, abias, slope, gain, want_params=True):
     return g, gb, gnw, rdot
 
 
+def _blur_bwd_fused():
+    """SR_BLUR_BWD_FUSED=0: the two-kernel backward of the up-sampling layer's tail (A/B measurements)."""
+    import os
+
+    return os.environ.get("SR_BLUR_BWD_FUSED", "1") != "0"
+
+
+def _blur_nba_bwd(gy, out, k_flipped, p0, shape257, noise, noise_w, abias, slope, gain, want_params=True):
+    """csrc/upfirdn2d.hip k_fir4_nba_bwd: gradient w.r.t. the blur's input plus what `_nba_bwd_dot` returns."""
+    gy = gy.contiguous()
+    b, n, oh, ow = out.shape
+    L = _lib.lib()
+    g257 = torch.empty(shape257, dtype=out.dtype, device=out.device)
+    gb = torch.empty(n if want_params else 0, dtype=out.dtype, device=out.device)
+    gnw = (torch.empty if noise is not None else torch.zeros)(1 if want_params else 0, dtype=out.dtype, device=out.device)
+    rdot = torch.empty((b, n), dtype=out.dtype, device=out.device)
+    scratch = torch.empty(L.sr_blur_nba_bwd_scratch_floats(b, n, shape257[2], shape257[3]), dtype=out.dtype,
+                          device=out.device)
+    bstride = 0 if noise is None or noise.numel() == oh * ow else oh * ow
+    with on_device_of(out):
+        rc = L.sr_blur_nba_bwd(_lib.ptr(g257), _lib.ptr(gb) if want_params else None,
+                               _lib.ptr(gnw) if want_params else None, _lib.ptr(rdot), _lib.ptr(gy), _lib.ptr(out),
+                               _lib.ptr(k_flipped), _lib.ptr(noise), _lib.ptr(noise_w), _lib.ptr(abias), slope, gain, b, n,
+                               oh, ow, shape257[2], shape257[3], p0, bstride, _lib.ptr(scratch), stream_of(out))
+    _lib.check(rc, "sr_blur_nba_bwd")
+    return g257, gb, gnw, rdot
+
+
 def upconv_nba_supported(x, wt, noise, oh, ow):
     b = x.shape[0]
     n = wt.shape[2]
@@ -445,11 +473,17 @@ class UpConvNBAFn(torch.autograd.Function):
                 grads = [next(got) if (nd and t is not None) else None for t, nd in zip(ins, needs[:9])]
             return tuple(grads) + (None, None)
         want_p = bool(needs[8] or (noise is not None and needs[7]))
-        g, gb, gnw, rdot = _nba_bwd_dot(gy, out, noise, noise_w, abias, slope, gain, want_p)
         p0 = pad[0]
         oh, ow = out.shape[2], out.shape[3]
-        g257 = upfirdn2d_op(g.reshape(-1, oh, ow, 1), flipped(kernel), 1, 1, 1, 1, 3 - p0,
-                            shape257[3] - ow + p0, 3 - p0, shape257[2] - oh + p0).view(shape257)
+        if (_blur_bwd_fused() and pad[0] == pad[1] and shape257[2] == oh + 3 - 2 * p0 and shape257[3] == ow + 3 - 2 * p0
+                and tuple(kernel.shape) == (4, 4)):
+            # activation backward, its three reductions and the blur's gradient in one pass over gy and out
+            g257, gb, gnw, rdot = _blur_nba_bwd(gy, out, flipped(kernel), p0, shape257, noise, noise_w, abias, slope,
+                                                gain, want_p)
+        else:
+            g, gb, gnw, rdot = _nba_bwd_dot(gy, out, noise, noise_w, abias, slope, gain, want_p)
+            g257 = upfirdn2d_op(g.reshape(-1, oh, ow, 1), flipped(kernel), 1, 1, 1, 1, 3 - p0,
+                                shape257[3] - ow + p0, 3 - p0, shape257[2] - oh + p0).view(shape257)
         gx = gw = gis = gos = None
         if needs[0] or needs[2]:
             dxu = ConvFn.apply(g257, adjoint_weight(wt, "t3s2", ctx.frozen, ctx.adj), oscale, None, None, "c3s2")

@@ -533,6 +533,41 @@ def test_fused_styledconv_nodes_second_order_with_linked_inputs(up):
     assert rel_err_t(g2_f, g2_u) < 1e-4
 
 
+@pytest.mark.parametrize("b,n,oh,shared,frozen", [(2, 8, 256, False, False), (3, 5, 16, True, False), (1, 6, 64, False, True),
+                                                   (2, 4, 96, None, False)])
+def test_upsampling_tail_backward_in_one_pass_equals_the_two_kernels(b, n, oh, shared, frozen, monkeypatch):
+    """k_fir4_nba_bwd (activation backward + its three reductions + the blur's gradient in one pass over gy and y)
+    against sr_noise_bias_act_bwd_dot followed by sr_upfirdn2d: the 257^2-side gradient bit for bit (same expression
+    for lrelu'(y) * gy * gain, same tap order), the three sums to fp32 round-off of their different association."""
+    from stylerenderer_amd.op import conv as cv
+    from stylerenderer_amd.op.upfirdn2d import flipped, upfirdn2d_op
+
+    g = torch.Generator().manual_seed(5 + oh)
+    mk = lambda *s: torch.randn(*s, generator=g).to(DEV)  # noqa: E731
+    ow = oh
+    gy, out = mk(b, n, oh, ow), mk(b, n, oh, ow)
+    noise = None if shared is None else mk(1 if shared else b, 1, oh, ow)
+    nw, ab = (mk(1) if noise is not None else None), mk(n)
+    k1 = torch.tensor([1.0, 3.0, 3.0, 1.0])
+    kernel = (k1[None, :] * k1[:, None] / 64.0 * 4.0).to(DEV)
+    shape257 = (b, n, oh + 1, ow + 1)
+    want_p = not frozen
+    g257, gb, gnw, rdot = cv._blur_nba_bwd(gy, out, flipped(kernel), 1, shape257, noise, nw, ab, 0.2, 2 ** 0.5, want_p)
+    gm, gb0, gnw0, rdot0 = cv._nba_bwd_dot(gy, out, noise, nw, ab, 0.2, 2 ** 0.5, want_p)
+    g0 = upfirdn2d_op(gm.reshape(-1, oh, ow, 1), flipped(kernel), 1, 1, 1, 1, 2, 2, 2, 2).view(shape257)
+    assert torch.equal(g257, g0)
+    assert rel_err_t(rdot, rdot0) < 2e-6
+    if want_p:
+        assert rel_err_t(gb, gb0) < 2e-6
+        if noise is not None:
+            assert abs(float(gnw) - float(gnw0)) < 2e-6 * float((gm * noise).abs().sum())
+    else:
+        assert gb.numel() == 0 and gnw.numel() == 0
+    # and run-to-run identical
+    again = cv._blur_nba_bwd(gy, out, flipped(kernel), 1, shape257, noise, nw, ab, 0.2, 2 ** 0.5, want_p)
+    assert all(torch.equal(u, v) for u, v in zip(again, (g257, gb, gnw, rdot)))
+
+
 def test_convlayer_shortcuts_equal_the_module_chain(monkeypatch):
     """layers.ConvLayer on device tensors (bias + LeakyReLU in the Winograd store; both biases added once; the skip
     branch's blur evaluated at the kept pixels) against the plain chain Blur -> EqualConv2d(+bias) -> FusedLeakyReLU."""
