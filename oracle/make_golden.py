@@ -444,6 +444,46 @@ def gold_generator_256(ns):
     save("generator_s256", **arrays)
 
 
+def gold_generator_256_b16(ns):
+    """BASELINE config[1] at its REAL batch: Generator(256, 512, 8) on 16 latents through the mapping network (the call
+    bench.py times: `net([z])`), per-sample noise maps [16, 1, h, w] (what noise=None draws, made deterministic).
+    Kept: every 8th pixel of every image at the real slope (196 KB), every 16th of the linear pass, and — with linear activations, so that no kink
+    enters (see gold_generator_256) — 256 samples of the gradient of <img, proj> w.r.t. every parameter (sums over
+    the 16 samples: the batch reduction of every weight-gradient kernel at the benchmark's exact launch shapes) and
+    the gradient w.r.t. the 16 mapped latents w = style(z) (full, 32 KB)."""
+    import types
+
+    b = 16
+    g = ns.model.Generator(256, 512, 8)
+    synth.fill_state_dict(g.state_dict(), salt=41)
+    ref_fused = sys.modules[ns.op.FusedLeakyReLU.__module__]
+    real_F = ref_fused.F
+    z = T(dn((b, 512), 47))
+    noise = [T(dn((b, 1, 2 ** ((i + 5) // 2), 2 ** ((i + 5) // 2)), 4400 + i)) for i in range(g.num_layers)]
+    with torch.no_grad():
+        img, _ = g([z], noise=noise)
+        w = g.style(z)                     # the mapping network keeps its real slope (evaluated before the patch)
+    arrays = {"image_s8": img.numpy()[:, :, ::8, ::8].copy(), "w": w.numpy().copy()}
+    for m in g.modules():
+        if isinstance(m, ns.op.FusedLeakyReLU):
+            m.negative_slope = 1.0
+    w = w.clone().requires_grad_(True)
+    ref_fused.F = types.SimpleNamespace(leaky_relu=lambda x, negative_slope=0.2: x)
+    try:
+        img, _ = g([w], input_is_latent=True, noise=noise)
+        proj = T(dn((b, 3, 32, 32), 48)).repeat_interleave(8, 2).repeat_interleave(8, 3)     # 8x8 blocks: small to rebuild
+        named = dict(g.named_parameters())
+        grads = torch.autograd.grad((img * proj).sum(), list(named.values()) + [w], allow_unused=True)
+    finally:
+        ref_fused.F = real_F
+    arrays["lin_image_s16"] = img.detach().numpy()[:, :, ::16, ::16].copy()
+    gd = {n: gr for n, gr in zip(named, grads[:-1]) if gr is not None}
+    vals, offs = grad_samples(gd)
+    arrays.update(lin_grad_names=np.array(sorted(gd)), lin_grad_samples=vals, lin_grad_sample_offsets=offs,
+                  lin_grad_w=grads[-1].numpy())
+    save("generator_s256_b16", **arrays)
+
+
 def _reference_train_functions(reshape_grads=False):
     """The loss / regulariser / EMA definitions of the reference's train.py (lines 96-145), exec'ed from where the
     file lies: the module as a whole does not parse, these top-level defs do.
@@ -790,9 +830,9 @@ def main():
     os.makedirs(OUT, exist_ok=True)
     ns = ref_shim.load()
     torch.manual_seed(0)
-    which = sys.argv[1:] or ["fused", "ufd", "modconv", "gen", "gen256", "gwm", "disc", "discbig", "train", "raster", "mesh", "lpips", "contract"]
+    which = sys.argv[1:] or ["fused", "ufd", "modconv", "gen", "gen256", "gen256b16", "gwm", "disc", "discbig", "train", "raster", "mesh", "lpips", "contract"]
     table = {"fused": gold_fused_act, "ufd": gold_upfirdn2d, "modconv": gold_modconv,
-             "gen": gold_generator, "gen256": gold_generator_256, "gwm": gold_generator_with_map,
+             "gen": gold_generator, "gen256": gold_generator_256, "gen256b16": gold_generator_256_b16, "gwm": gold_generator_with_map,
              "disc": gold_discriminator, "discbig": gold_discriminator_big, "train": gold_train_step, "raster": gold_raster, "mesh": gold_mesh, "lpips": gold_lpips,
              "contract": gold_state_dict_contract}
     with torch.no_grad():

@@ -190,6 +190,47 @@ def test_generator_256_vs_reference_image_and_gradients(golden):
             slope, worst, e_lat, "" if forcer is None else ", kink elements forced %d" % forcer.disagreements()))
 
 
+def test_generator_256_batch16_vs_reference(golden):
+    """BASELINE config[1] at its real batch against the reference (tests/golden/generator_s256_b16.npz, written by
+    oracle/make_golden.gold_generator_256_b16): Generator(256, 512, 8) on 16 latents through the mapping network with
+    per-sample noise maps — every 8th pixel of all 16 images at the real slope (1e-5), and, with linear activations
+    (no kink enters; the mapping network keeps its slope, as in the B = 1 test), 256 samples of every parameter
+    gradient — each a sum over the 16 samples, i.e. the batch reduction of every weight-gradient kernel at exactly the
+    launch shapes bench.py times — and the full gradient w.r.t. the 16 mapped latents, at the 2e-5 of the B = 1 pin."""
+    from stylerenderer_amd.op import FusedLeakyReLU
+
+    gold = golden("generator_s256_b16")
+    b = 16
+    g = model.Generator(256, 512, 8)
+    synth.fill_state_dict(g.state_dict(), salt=41)
+    g = g.to(DEV)
+    z = T(synth.det_normal((b, 512), 47))
+    noise = [T(synth.det_normal((b, 1, 2 ** ((i + 5) // 2), 2 ** ((i + 5) // 2)), 4400 + i)) for i in range(g.num_layers)]
+    with torch.no_grad():
+        img, _ = g([z], noise=noise)
+        w = g.style(z)
+    e_img = rel_err(img.cpu().numpy()[:, :, ::8, ::8], gold["image_s8"])
+    e_w = rel_err(w.cpu().numpy(), gold["w"])
+    assert e_img < 1e-5 and e_w < 1e-5, (e_img, e_w)
+    del img
+    for m in g.modules():
+        if isinstance(m, FusedLeakyReLU):
+            m.negative_slope = 1.0
+    w = T(gold["w"]).requires_grad_(True)
+    img, _ = g([w], input_is_latent=True, noise=noise)
+    e_lin = rel_err(img.detach().cpu().numpy()[:, :, ::16, ::16], gold["lin_image_s16"])
+    assert e_lin < 1e-5, e_lin
+    proj = T(synth.det_normal((b, 3, 32, 32), 48)).repeat_interleave(8, 2).repeat_interleave(8, 3)
+    params = dict(g.named_parameters())
+    grads = torch.autograd.grad((img * proj).sum(), list(params.values()) + [w], allow_unused=True)
+    got = {n: x for n, x in zip(params, grads[:-1]) if x is not None}
+    worst = check_grad_samples(got, gold["lin_grad_names"], gold["lin_grad_samples"], gold["lin_grad_sample_offsets"], 2e-5)
+    e_gw = rel_err(grads[-1].cpu().numpy(), gold["lin_grad_w"])
+    assert e_gw < 2e-5, e_gw
+    print("256^2 B=16: image %.2e, w %.2e, linear image %.2e, worst sampled gradient %.2e, latent gradient %.2e" % (
+        e_img, e_w, e_lin, worst, e_gw))
+
+
 @pytest.mark.parametrize("size", [64, 128])
 def test_discriminator_big_vs_reference(golden, size):
     """N1 at sizes where the big kernels run (reference model.py:296-336, layers.py:341-391): D(64) / D(128), batch 4,
