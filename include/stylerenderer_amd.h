@@ -408,6 +408,26 @@ int sr_conv2d_nba(float* out, const float* in, const float* wt, const float* isc
  * served by the Winograd kernel, 0 when by the direct one — what a caller that keeps a scratch for SR_CONV_U_READY
  * must ask before it marks the scratch's weight block as written. */
 int sr_conv2d_uses_winograd(int64_t B, int64_t C, int64_t N, int64_t IH, int64_t IW, const float* in, const float* out);
+
+/* Generic-geometry convolution (csrc/conv_generic.hip): any kernel extent kh x kw, stride (sy, sx) and zero padding
+ * (py, px), dilation 1, one group, weights in the reference's layout [N, C, kh, kw] — what the reference's EqualConv2d
+ * (layers.py:204-221: F.conv2d with any kernel_size / stride / padding) and ModulatedConv2d with kernel_size other than
+ * 1 or 3 (layers.py:259-323, F.conv2d / F.conv_transpose2d) reach outside the matrix-core geometries above; replaces the
+ * MIOpen call a device tensor would otherwise make.  Direct fp32 kernels, fixed summation order.
+ *   sr_conv2d_generic        y [B,N,OH,OW] = conv(x [B,C,IH,IW], w) (+ bias[N] or NULL); OH = (IH + 2 py - kh) / sy + 1
+ *   sr_conv2d_generic_dgrad  dx [B,C,IH,IW] = its gradient w.r.t. x for g [B,N,OH,OW]; ALSO F.conv_transpose2d(g, w,
+ *                            stride, padding) as a forward operator (w then reads [in = N, out = C, kh, kw])
+ *   sr_conv2d_generic_wgrad  dw [N,C,kh,kw] = its gradient w.r.t. w
+ * SR_EINVAL when (OH, OW) is not the convolution's extent for (IH, IW); SR_ERANGE past 65535 (sample, channel) planes. */
+int sr_conv2d_generic(float* y, const float* x, const float* w, const float* bias, int64_t B, int64_t C, int64_t N,
+                      int64_t IH, int64_t IW, int64_t OH, int64_t OW, int kh, int kw, int sy, int sx, int py, int px,
+                      sr_stream_t stream);
+int sr_conv2d_generic_dgrad(float* dx, const float* g, const float* w, int64_t B, int64_t C, int64_t N, int64_t IH,
+                            int64_t IW, int64_t OH, int64_t OW, int kh, int kw, int sy, int sx, int py, int px,
+                            sr_stream_t stream);
+int sr_conv2d_generic_wgrad(float* dw, const float* x, const float* g, int64_t B, int64_t C, int64_t N, int64_t IH,
+                            int64_t IW, int64_t OH, int64_t OW, int kh, int kw, int sy, int sx, int py, int px,
+                            sr_stream_t stream);
 int sr_conv2d_mfma_ex(float* out, const float* in, const float* wt, const float* iscale,
                       const float* oscale, const float* obias, int64_t B, int64_t C, int64_t N,
                       int64_t wt_ld, int64_t IH, int64_t IW, int64_t OH, int64_t OW, int ksize,

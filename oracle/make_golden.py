@@ -130,6 +130,37 @@ def gold_modconv(ns):
     save("modconv", **out)
 
 
+def gold_conv_generic(ns):
+    """The reference's layers at geometries outside {3x3 s1 p1, 3x3 s2 p0, 1x1}: ModulatedConv2d with kernel_size 5
+    (plain, up-sampling, down-sampling) and 7 (up-sampling: its blur CROPS, pad (-1, -1)), EqualConv2d 5x5 p2, 4x4 s2
+    p1, 3x3 p0, 2x2 s3 — output and all gradients (input, style, every parameter), full tensors."""
+    out = {}
+    L = ns.layers
+    for tag, kw in [("m5", dict(kernel_size=5)), ("m5up", dict(kernel_size=5, upsample=True)),
+                    ("m5down", dict(kernel_size=5, downsample=True)), ("m7up", dict(kernel_size=7, upsample=True)),
+                    ("m5nodemod", dict(kernel_size=5, demodulate=False))]:
+        m = L.ModulatedConv2d(in_channel=8, out_channel=12, style_dim=16, **kw)
+        synth.fill_state_dict(m.state_dict(), salt=35)
+        x, s = dn((2, 8, 10, 10), 36), dn((2, 16), 37)
+        xt, st = T(x).requires_grad_(), T(s).requires_grad_()
+        y = m(xt, st)
+        gy = dn(tuple(y.shape), 38)
+        grads = torch.autograd.grad(y, [xt, st, m.weight, m.modulation.weight, m.modulation.bias], T(gy))
+        out.update({tag + "_y": y.detach().numpy(), tag + "_gx": grads[0].numpy(), tag + "_gs": grads[1].numpy(),
+                    tag + "_gw": grads[2].numpy(), tag + "_gmw": grads[3].numpy(), tag + "_gmb": grads[4].numpy()})
+    for tag, (k, st_, pd) in [("e5", (5, 1, 2)), ("e4s2", (4, 2, 1)), ("e3p0", (3, 1, 0)), ("e2s3", (2, 3, 0))]:
+        m = L.EqualConv2d(6, 10, k, stride=st_, padding=pd)
+        synth.fill_state_dict(m.state_dict(), salt=39)
+        x = dn((3, 6, 11, 13), 40)
+        xt = T(x).requires_grad_()
+        y = m(xt)
+        gy = dn(tuple(y.shape), 41)
+        grads = torch.autograd.grad(y, [xt, m.weight, m.bias], T(gy))
+        out.update({tag + "_y": y.detach().numpy(), tag + "_gx": grads[0].numpy(), tag + "_gw": grads[1].numpy(),
+                    tag + "_gb": grads[2].numpy()})
+    save("conv_generic", **out)
+
+
 # ------------------------------------------------------------------------------- generator
 def _noise_list(g, key):
     noises = []
@@ -830,8 +861,8 @@ def main():
     os.makedirs(OUT, exist_ok=True)
     ns = ref_shim.load()
     torch.manual_seed(0)
-    which = sys.argv[1:] or ["fused", "ufd", "modconv", "gen", "gen256", "gen256b16", "gwm", "disc", "discbig", "train", "raster", "mesh", "lpips", "contract"]
-    table = {"fused": gold_fused_act, "ufd": gold_upfirdn2d, "modconv": gold_modconv,
+    which = sys.argv[1:] or ["fused", "ufd", "modconv", "convgeneric", "gen", "gen256", "gen256b16", "gwm", "disc", "discbig", "train", "raster", "mesh", "lpips", "contract"]
+    table = {"fused": gold_fused_act, "ufd": gold_upfirdn2d, "modconv": gold_modconv, "convgeneric": gold_conv_generic,
              "gen": gold_generator, "gen256": gold_generator_256, "gen256b16": gold_generator_256_b16, "gwm": gold_generator_with_map,
              "disc": gold_discriminator, "discbig": gold_discriminator_big, "train": gold_train_step, "raster": gold_raster, "mesh": gold_mesh, "lpips": gold_lpips,
              "contract": gold_state_dict_contract}

@@ -61,6 +61,9 @@ SIGNATURES = {
     "sr_upfirdn2d": (_i, [_p, _p, _p, _l] + [_i] * 14 + [_p]),
     "sr_upsample2_add": (_i, [_p] * 4 + [_l] + [_i] * 6 + [_p]),
     "sr_blur_noise_bias_act": (_i, [_p] * 6 + [_f, _f, _l, _l] + [_i] * 6 + [_l, _p]),
+    "sr_conv2d_generic": (_i, [_p] * 4 + [_l] * 7 + [_i] * 6 + [_p]),
+    "sr_conv2d_generic_dgrad": (_i, [_p] * 3 + [_l] * 7 + [_i] * 6 + [_p]),
+    "sr_conv2d_generic_wgrad": (_i, [_p] * 3 + [_l] * 7 + [_i] * 6 + [_p]),
     "sr_blur_nba_bwd_scratch_floats": (_l, [_l, _l, _i, _i]),
     "sr_blur_nba_bwd": (_i, [_p] * 10 + [_f, _f, _l, _l] + [_i] * 5 + [_l, _p, _p]),
     "sr_rasterize_scratch_bytes": (_l, [_l, _l, _l, _l, _i]),

@@ -41,6 +41,7 @@ SOURCES = [
     ("conv_wgrad_mfma.hip", []),
     ("conv_wgrad_bf16x3.hip", []),
     ("conv_s2_bf16x3.hip", []),
+    ("conv_generic.hip", []),
 ]
 
 

@@ -22,6 +22,7 @@ from torch.nn import functional as F
 
 from .op import FusedLeakyReLU, fused_leaky_relu, upfirdn2d
 from .op import conv as _conv
+from .op import conv_generic as _convg
 from .op import smallconv as _smallconv
 from .op import style as _style
 from .op.style_bank import StylePack
@@ -134,10 +135,13 @@ class EqualConv2d(nn.Module):
             osc = _const_rows(gain, input.shape[0], self.weight.shape[0], input.device) if gain is not None else None
             assert osc is None or bias is None
             return _conv.conv2d(input, wt, None, osc, bias, geom)
+        if input.device.type == "cuda" and _convg.supported(input, self.weight):
+            # any other kernel extent / stride / padding (reference layers.py:204-221): the direct kernels of
+            # csrc/conv_generic.hip, not MIOpen
+            out = _convg.conv2d_generic(input, self.weight * self.scale, bias, self.stride, self.padding)
+            return out * gain if gain is not None else out
         if input.device.type == "cuda" and _strict_native():
-            raise RuntimeError("SR_STRICT_NATIVE: EqualConv2d(k=%d, stride=%d, padding=%d) is outside the MFMA kernels' "
-                               "geometries {3x3 s1 p1, 3x3 s2 p0, 1x1 s1, 1x1 s2} and would run on MIOpen"
-                               % (self.weight.shape[2], self.stride, self.padding))
+            raise RuntimeError("SR_STRICT_NATIVE: EqualConv2d on a %s device tensor would run on MIOpen" % input.dtype)
         out = F.conv2d(input, self.weight * self.scale, bias=bias, stride=self.stride, padding=self.padding)
         return out * gain if gain is not None else out
 
@@ -262,22 +266,42 @@ class ModulatedConv2d(nn.Module):
                 and _smallconv.supported(input, self.out_channel)):
             # ToRGB: <= 4 output channels -> streaming kernels instead of 128-wide MFMA tiles
             return _smallconv.modulated_conv1x1_small(input, self.weight[0, :, :, 0, 0] * self.scale, s)
-        wt, wsq, d = self._prepared(style, s)
         k = self.kernel_size
+        if k not in (1, 3) or ((self.upsample or self.downsample) and k != 3):
+            return self._forward_generic(input, s, skip_blur)
+        wt, wsq, d = self._prepared(style, s)
         if self.upsample:
-            if k != 3:
-                raise RuntimeError("ModulatedConv2d: upsample supports kernel_size 3")
             out = _conv.conv2d(input, wt, s, d, None, "t3s2")
             return out if skip_blur else self.blur(out)      # skip_blur: the caller fuses it (StyledConv)
         if self.downsample:
-            if k != 3:
-                raise RuntimeError("ModulatedConv2d: downsample supports kernel_size 3")
             return _conv.conv2d(self.blur(input), wt, s, d, None, "c3s2")
         if k == 3:
             return _conv.conv2d(input, wt, s, d, None, "c3")
-        if k == 1:
-            return _conv.conv2d(input, wt, s, d, None, "c1")
-        raise RuntimeError("ModulatedConv2d: kernel_size %d is not supported on device" % k)
+        return _conv.conv2d(input, wt, s, d, None, "c1")
+
+    def _forward_generic(self, input, s, skip_blur=False):
+        """Any other kernel_size (reference layers.py:259-323 takes every odd extent, also up- and down-sampling): the
+        shared-weight form  y = d[b, o] * conv(s[b, i] * x, scale * W)  with the modulation and demodulation as
+        element-wise operand scalings around the direct kernels of csrc/conv_generic.hip — no grouped convolution, no
+        MIOpen.  Equal to the reference's per-sample weights: (scale W s) * rsqrt(sum (scale W s)^2 + eps)."""
+        w = self.weight[0] * self.scale                                      # [Co, Ci, k, k]
+        x = input * s[:, :, None, None]
+        d = None
+        if self.demodulate:
+            wsq = w.pow(2).sum((2, 3)).t().contiguous()                      # [Ci, Co]
+            if _style.demod_supported(s, wsq):
+                d = _style.demod_scale(s, wsq, self.eps)                     # [B, Co] (sr_demod_fwd)
+            else:                                                            # (Co % 4 != 0: element-wise, not rocBLAS)
+                d = torch.rsqrt(((s * s)[:, :, None] * wsq[None]).sum(1) + self.eps)
+        if self.upsample:
+            out = _convg.conv_transpose2d_generic(x, w.transpose(0, 1), stride=2, padding=0)
+        elif self.downsample:
+            out = _convg.conv2d_generic(self.blur(x), w, None, 2, 0)
+        else:
+            out = _convg.conv2d_generic(x, w, None, 1, self.padding)
+        if d is not None:
+            out = out * d[:, :, None, None]
+        return self.blur(out) if (self.upsample and not skip_blur) else out
 
     def forward_noise_bias_act(self, input, style, noise, noise_weight, act_bias, negative_slope, act_scale):
         """conv -> noise -> bias -> LeakyReLU of a non-upsampling 3x3 layer as one autograd node (device tensors,

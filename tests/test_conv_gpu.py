@@ -833,3 +833,86 @@ def test_split_bf16_transposed_conv_holds_the_fp32_bar(case, scaled, monkeypatch
         assert torch.equal(split, exact)                        # not eligible: the exact kernels served it
     else:
         assert e_split < 2 * e_exact + 1e-7 and not torch.equal(split, exact)
+
+
+# ------------------------------------------------------------------------------------------------ generic geometry
+GENERIC = [  # B, C, N, H, W, kh, kw, stride, pad
+    (2, 5, 7, 11, 13, 5, 5, 1, 2), (3, 4, 6, 9, 9, 3, 3, 1, 0), (2, 6, 5, 12, 10, 4, 4, 2, 1), (1, 3, 4, 15, 17, 7, 7, 3, 3),
+    (2, 8, 8, 8, 8, 2, 2, 3, 0), (2, 4, 4, 10, 12, 3, 5, (2, 1), (1, 2))]
+
+
+@pytest.mark.parametrize("case", GENERIC)
+def test_generic_convolution_kernels_vs_float64(case):
+    """csrc/conv_generic.hip (any kernel extent / stride / padding — what the reference's EqualConv2d and
+    ModulatedConv2d accept beyond the matrix-core geometries): forward, data gradient, weight gradient and the
+    transposed convolution as a forward operator against float64, |err| <= 2e-6 * sum|a*b|; then a SECOND-order
+    gradient through the three mutually-adjoint Functions (the R1 / path-length pattern) against float64 autograd."""
+    from stylerenderer_amd.op import conv_generic as cg
+
+    b, c, n, h, w, kh, kw, st, pd = case
+    g = torch.Generator().manual_seed(7)
+    x0, w0, b0 = torch.randn(b, c, h, w, generator=g), torch.randn(n, c, kh, kw, generator=g) / (c * kh * kw) ** 0.5, \
+        torch.randn(n, generator=g)
+
+    def run(dev, dt):
+        x, wt, bias = [t.to(dev, dt).requires_grad_(True) for t in (x0, w0, b0)]
+        conv = cg.conv2d_generic if dev == DEV else (lambda a, ww, bb, s, p: F.conv2d(a, ww, bb, stride=s, padding=p))
+        y = conv(x, wt, bias, st, pd)
+        proj = torch.randn(y.shape, generator=torch.Generator().manual_seed(8)).to(dev, dt)
+        gx, gw, gb = torch.autograd.grad((y * proj).sum(), [x, wt, bias], create_graph=True)
+        # second order: gradient of |gx|^2 + |gw|^2 w.r.t. the weights and the projection-free input
+        (hw, hx) = torch.autograd.grad((gx * gx).sum() + (gw * gw).sum(), [wt, x])
+        return [t.detach().double().cpu() for t in (y, gx, gw, gb, hw, hx)]
+
+    got = run(DEV, torch.float32)
+    want = run("cpu", torch.float64)
+    # scale of each result: the same expression on absolute values bounds sum|a*b|
+    ya = F.conv2d(x0.double().abs(), w0.double().abs(), None, stride=st, padding=pd)
+    bound = float(ya.max())
+    for name, a, r in zip(("y", "gx", "gw", "gb", "hw", "hx"), got, want):
+        scale = max(float(r.abs().max()), bound if name == "y" else 0.0)
+        err = float((a - r).abs().max())
+        assert err <= (2e-6 if name in ("y", "gx", "gw") else 2e-5) * scale * (1.0 if name == "y" else 8.0), (name, err, scale)
+    # transposed convolution as a forward operator (the up-sampling ModulatedConv2d)
+    wt_t = torch.randn(c, n, kh, kw, generator=g) / (c * kh * kw) ** 0.5
+    yt = cg.conv_transpose2d_generic(x0.to(DEV), wt_t.to(DEV), stride=st, padding=pd)
+    rt = F.conv_transpose2d(x0.double(), wt_t.double(), stride=st, padding=pd)
+    assert yt.shape == rt.shape
+    assert float((yt.double().cpu() - rt).abs().max()) <= 2e-6 * float(
+        F.conv_transpose2d(x0.double().abs(), wt_t.double().abs(), stride=st, padding=pd).max())
+
+
+def test_generic_geometry_layers_vs_reference(golden):
+    """layers.ModulatedConv2d with kernel_size 5 / 7 (plain, up-sampling incl. the cropping blur, down-sampling, no
+    demodulation) and EqualConv2d 5x5 p2 / 4x4 s2 p1 / 3x3 p0 / 2x2 s3 on device tensors — under SR_STRICT_NATIVE, i.e.
+    without MIOpen / rocBLAS — against the reference's layers (tests/golden/conv_generic.npz): output and every gradient
+    at 2e-6 of the tensor's scale (5e-6 for the parameter gradients of the modulated layers, which pass through the
+    demodulation's cancellation)."""
+    from stylerenderer_amd import layers, synth
+
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)  # noqa: E731
+    rel = lambda a, b: float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))  # noqa: E731
+    gold = golden("conv_generic")
+    for tag, kw in [("m5", dict(kernel_size=5)), ("m5up", dict(kernel_size=5, upsample=True)),
+                    ("m5down", dict(kernel_size=5, downsample=True)), ("m7up", dict(kernel_size=7, upsample=True)),
+                    ("m5nodemod", dict(kernel_size=5, demodulate=False))]:
+        m = layers.ModulatedConv2d(in_channel=8, out_channel=12, style_dim=16, **kw)
+        synth.fill_state_dict(m.state_dict(), salt=35)
+        m = m.to(DEV)
+        x, s = T(synth.det_normal((2, 8, 10, 10), 36)).requires_grad_(), T(synth.det_normal((2, 16), 37)).requires_grad_()
+        y = m(x, s)
+        assert rel(y.detach().cpu().numpy(), gold[tag + "_y"]) < 2e-6, tag
+        gy = T(synth.det_normal(tuple(y.shape), 38))
+        grads = torch.autograd.grad(y, [x, s, m.weight, m.modulation.weight, m.modulation.bias], gy)
+        for a, k in zip(grads, ("gx", "gs", "gw", "gmw", "gmb")):
+            assert rel(a.cpu().numpy(), gold[tag + "_" + k]) < 5e-6, (tag, k)
+    for tag, (k, st, pd) in [("e5", (5, 1, 2)), ("e4s2", (4, 2, 1)), ("e3p0", (3, 1, 0)), ("e2s3", (2, 3, 0))]:
+        m = layers.EqualConv2d(6, 10, k, stride=st, padding=pd)
+        synth.fill_state_dict(m.state_dict(), salt=39)
+        m = m.to(DEV)
+        x = T(synth.det_normal((3, 6, 11, 13), 40)).requires_grad_()
+        y = m(x)
+        assert rel(y.detach().cpu().numpy(), gold[tag + "_y"]) < 2e-6, tag
+        grads = torch.autograd.grad(y, [x, m.weight, m.bias], T(synth.det_normal(tuple(y.shape), 41)))
+        for a, kk in zip(grads, ("gx", "gw", "gb")):
+            assert rel(a.cpu().numpy(), gold[tag + "_" + kk]) < 2e-6, (tag, kk)

@@ -174,3 +174,34 @@ def test_generator_with_map_s16_gradients_vs_reference(golden):
 
     meas = run_generator_with_map_case(golden("generator_map_s16"), 16, "cpu", 5e-5, 1e-5, 1e-4, 2e-5, 2e-4)
     print(meas)
+
+
+def test_generic_geometry_layers_cpu_vs_reference(golden):
+    """The CPU formulation of ModulatedConv2d (kernel_size 5 / 7; plain, up-sampling incl. the cropping blur,
+    down-sampling, no demodulation) and EqualConv2d at geometries outside the matrix-core set against the reference's
+    layers (tests/golden/conv_generic.npz, oracle/make_golden.gold_conv_generic)."""
+    from stylerenderer_amd import layers
+
+    T = torch.from_numpy
+    gold = golden("conv_generic")
+    for tag, kw in [("m5", dict(kernel_size=5)), ("m5up", dict(kernel_size=5, upsample=True)),
+                    ("m5down", dict(kernel_size=5, downsample=True)), ("m7up", dict(kernel_size=7, upsample=True)),
+                    ("m5nodemod", dict(kernel_size=5, demodulate=False))]:
+        m = layers.ModulatedConv2d(in_channel=8, out_channel=12, style_dim=16, **kw)
+        synth.fill_state_dict(m.state_dict(), salt=35)
+        x, s = T(synth.det_normal((2, 8, 10, 10), 36)).requires_grad_(), T(synth.det_normal((2, 16), 37)).requires_grad_()
+        y = m(x, s)
+        assert rel_err(y.detach().numpy(), gold[tag + "_y"]) < 2e-6, tag
+        grads = torch.autograd.grad(y, [x, s, m.weight, m.modulation.weight, m.modulation.bias],
+                                    T(synth.det_normal(tuple(y.shape), 38)))
+        for a, k in zip(grads, ("gx", "gs", "gw", "gmw", "gmb")):
+            assert rel_err(a.numpy(), gold[tag + "_" + k]) < 5e-6, (tag, k)
+    for tag, (k, st, pd) in [("e5", (5, 1, 2)), ("e4s2", (4, 2, 1)), ("e3p0", (3, 1, 0)), ("e2s3", (2, 3, 0))]:
+        m = layers.EqualConv2d(6, 10, k, stride=st, padding=pd)
+        synth.fill_state_dict(m.state_dict(), salt=39)
+        x = T(synth.det_normal((3, 6, 11, 13), 40)).requires_grad_()
+        y = m(x)
+        assert rel_err(y.detach().numpy(), gold[tag + "_y"]) < 2e-6, tag
+        grads = torch.autograd.grad(y, [x, m.weight, m.bias], T(synth.det_normal(tuple(y.shape), 41)))
+        for a, kk in zip(grads, ("gx", "gw", "gb")):
+            assert rel_err(a.numpy(), gold[tag + "_" + kk]) < 2e-6, (tag, kk)
