@@ -302,7 +302,12 @@ int sr_blur_nba_bwd(float* gx, float* gbias, float* gnoise_w, float* rowdot, con
  * for the leader table (smallest row-major pixel each triangle won) and ONE state word: the LDS-tiled forward path
  * builds the table while it resolves its tiles and stores 1, the global-key path fills it with INT_MAX and stores 0 —
  * the gradient pass reads that word on the device and completes the table in place when it is 0 (it never re-derives
- * which path the forward took). */
+ * which path the forward took).
+ * `perspective` is a flags word: bit 0 = perspective projection (the reference's bool), bit 1 = SR_RASTER_CHW: the
+ * interpolated attributes are written channel-major, attr[b,c,h,w] — what the generator's map heads convolve — instead of
+ * the reference's [b,h,w,c] (model.py:262 permutes and every consumer re-lays it out); sr_rasterize_grad_* with the same
+ * bit reads grad_out as [b,c,h,w].  Same values either way. */
+#define SR_RASTER_CHW 2
 int64_t sr_rasterize_scratch_bytes(int64_t b, int64_t nf, int64_t h, int64_t w, int is_double);
 int sr_rasterize_forward_f32(int64_t b, int64_t nv, int64_t nf, int64_t h, int64_t w, int repeat_v,
                              int repeat_f, int perspective, const float* v, const int64_t* tri,

@@ -442,7 +442,7 @@ __global__ __launch_bounds__(256) void k_resolve(long long b, long long nv, long
                                                  long long* __restrict__ index, R* __restrict__ coeff,
                                                  R* __restrict__ zbuf, const R* __restrict__ tex,
                                                  long long tex_c, R* __restrict__ attr,
-                                                 int* __restrict__ win, R eps) {
+                                                 int* __restrict__ win, R eps, bool chw) {
     const long long hw = h * w;
     const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= b * hw) return;
@@ -487,7 +487,7 @@ __global__ __launch_bounds__(256) void k_resolve(long long b, long long nv, long
             const R a1 = tex[i1 * tex_c + ch] * c1;
             const R a2 = tex[i2 * tex_c + ch] * c2;
             const R s01 = a0 + a1;
-            attr[g * tex_c + ch] = s01 + a2;
+            attr[chw ? (s * tex_c + ch) * hw + pix : g * tex_c + ch] = s01 + a2;     // [b,c,h,w] or [b,h,w,c]
         }
     }
 }
@@ -805,7 +805,7 @@ __global__ __launch_bounds__(256) void k_tile_raster(unsigned b, unsigned nv, un
                                                      long long* __restrict__ index, float* __restrict__ coeff,
                                                      float* __restrict__ zbuf, const float* __restrict__ tex,
                                                      int tex_c, float* __restrict__ attr, int* __restrict__ win,
-                                                     int* __restrict__ first, float eps) {
+                                                     int* __restrict__ first, float eps, bool chw) {
     __shared__ unsigned long long s_key[TILE * TILE];
     __shared__ float s_rec[REC_F][256];
     __shared__ int s_box[4][256];          // clipped box x0, y0, width; triangle id
@@ -948,7 +948,7 @@ __global__ __launch_bounds__(256) void k_tile_raster(unsigned b, unsigned nv, un
                 const float a1 = tex[r1 + ch] * c1;
                 const float a2 = tex[r2 + ch] * c2;
                 const float s01 = a0 + a1;
-                attr[g * tex_c + ch] = s01 + a2;
+                attr[chw ? ((size_t)s * tex_c + ch) * hw + (size_t)y * res + x : g * tex_c + ch] = s01 + a2;
             }
         }
     }
@@ -1173,17 +1173,18 @@ __device__ __forceinline__ void grad_pixel(TriAcc<R, CT, PERSP>& acc, const Tri<
                                            R eps, const int* __restrict__ wins, int ti,
                                            const R* __restrict__ gos, const R* __restrict__ tex0,
                                            const R* __restrict__ tex1, const R* __restrict__ tex2,
-                                           int tex_c, int ch0) {
+                                           int tex_c, int ch0, long long gcs) {
     const long long pix = x + (long long)y * w;
     if (pix >= hw || wins[pix] != ti) return;
     R c0, c1, c2, z;
     shade<R>(t, x, y, PERSP, eps, c0, c1, c2, z);        // same bits as k_resolve used for the interpolation
-    const R* go = gos + pix * tex_c;
+    // gcs: channel stride of grad_out — 1 for [b,h,w,c] (pixel stride tex_c), h*w for [b,c,h,w] (pixel stride 1)
+    const R* go = gos + pix * (gcs == 1 ? tex_c : 1);
     acc.n += 1;
 #pragma unroll
     for (int j = 0; j < CT; ++j) {
         if (ch0 + j < tex_c) {
-            const R gch = go[ch0 + j];
+            const R gch = go[(ch0 + j) * gcs];
             acc.gt[j] += gch * c0;
             acc.gt[CT + j] += gch * c1;
             acc.gt[2 * CT + j] += gch * c2;
@@ -1192,7 +1193,7 @@ __device__ __forceinline__ void grad_pixel(TriAcc<R, CT, PERSP>& acc, const Tri<
     if (want_v) {
         R d0 = 0, d1 = 0, d2 = 0;
         for (int ch = 0; ch < tex_c; ++ch) {
-            const R gch = go[ch];
+            const R gch = go[ch * gcs];
             d0 += gch * tex0[ch];
             d1 += gch * tex1[ch];
             d2 += gch * tex2[ch];
@@ -1208,19 +1209,20 @@ template <typename R, int CT, bool PERSP>
 __device__ __forceinline__ void grad_pixel_regs(TriAcc<R, CT, PERSP>& acc, const Tri<R>& t, const JacTri<R, PERSP>& jt,
                                                 bool want_v, int x, int y, long long w, long long hw, long long h_arg,
                                                 R eps, const int* __restrict__ wins, int ti,
-                                                const R* __restrict__ gos, const R (&tx)[3][4], int tex_c, int ch0) {
+                                                const R* __restrict__ gos, const R (&tx)[3][4], int tex_c, int ch0,
+                                                long long gcs) {
     // (the caller walks the pixels of its winner mask: this pixel IS inside the image and won by `ti`)
     const long long pix = x + (long long)y * w;
     R c0, c1, c2, z;
     shade<R>(t, x, y, PERSP, eps, c0, c1, c2, z);
-    const R* go = gos + pix * tex_c;
+    const R* go = gos + pix * (gcs == 1 ? tex_c : 1);
     R gch[4];
-    if (tex_c == 3) {
+    if (tex_c == 3 && gcs == 1) {
         load3<R>(go, gch[0], gch[1], gch[2]);
         gch[3] = (R)0;
     } else {
 #pragma unroll
-        for (int ch = 0; ch < 4; ++ch) gch[ch] = ch < tex_c ? go[ch] : (R)0;
+        for (int ch = 0; ch < 4; ++ch) gch[ch] = ch < tex_c ? go[ch * gcs] : (R)0;
     }
     acc.n += 1;
 #pragma unroll
@@ -1312,7 +1314,7 @@ __global__ __launch_bounds__(256) void k_grad_big(long long nv, long long nf, lo
                                                   const long long* __restrict__ f, const int* __restrict__ win,
                                                   const int* __restrict__ big, const R* __restrict__ grad_out,
                                                   bool want_v, R* __restrict__ tg,
-                                                  R eps) {
+                                                  R eps, bool chw) {
     __shared__ R s_part[4];
     const long long hw = h * w;
     const int count = big[0];
@@ -1338,7 +1340,7 @@ __global__ __launch_bounds__(256) void k_grad_big(long long nv, long long nf, lo
             const int yy = (int)(p / bw);
             grad_pixel<R, CT, PERSP>(acc, t, jt, distinct, t.x0 + (int)(p - (long long)yy * bw), t.y0 + yy, w, hw, h,
                                      eps, win + s * hw, (int)ti, grad_out + s * hw * tex_c, tb + i0 * tex_c,
-                                     tb + i1 * tex_c, tb + i2 * tex_c, tex_c, ch0);
+                                     tb + i1 * tex_c, tb + i2 * tex_c, tex_c, ch0, chw ? hw : 1);
         }
         const R cnt = block_sum_256<R>((R)acc.n, s_part);
 #pragma unroll
@@ -1389,7 +1391,7 @@ __global__ __launch_bounds__(256) void k_grad_pix(long long b, long long nv, lon
                                                   const int* __restrict__ first,
                                                   unsigned long long* __restrict__ valid,
                                                   const R* __restrict__ grad_out, bool want_v,
-                                                  R* __restrict__ tg, R eps) {
+                                                  R* __restrict__ tg, R eps, bool chw) {
     __shared__ int s_row[256], s_pix[256];
     __shared__ int s_cnt[4];
     const long long hw = h * w;
@@ -1507,11 +1509,11 @@ __global__ __launch_bounds__(256) void k_grad_pix(long long b, long long nv, lon
         const int yy = p / bw;
         if (tex_regs)
             grad_pixel_regs<R, CT, PERSP>(acc, t, jt, distinct, t.x0 + (p - yy * bw), t.y0 + yy, w, hw, h, eps, wins, ti,
-                                          grad_out + s * hw * tex_c, tx, tex_c, ch0);
+                                          grad_out + s * hw * tex_c, tx, tex_c, ch0, chw ? hw : 1);
         else
             grad_pixel<R, CT, PERSP>(acc, t, jt, distinct, t.x0 + (p - yy * bw), t.y0 + yy, w, hw, h, eps, wins, ti,
                                      grad_out + s * hw * tex_c, tb + i0 * tex_c, tb + i1 * tex_c, tb + i2 * tex_c, tex_c,
-                                     ch0);
+                                     ch0, chw ? hw : 1);
     }
     store_row<R, CT, PERSP>(acc, tg, row);
 }
@@ -1624,14 +1626,14 @@ inline bool tiled_ok<float>(long long b, long long nf, long long h, long long w)
 
 template <typename R>
 int forward_tiled(long long, long long, long long, long long, int, int, int, const R*, const long long*, long long*, R*,
-                  R*, R, const R*, long long, R*, int*, int*, void*, hipStream_t) {
+                  R*, R, const R*, long long, R*, int*, int*, bool, void*, hipStream_t) {
     return SR_EINVAL;
 }
 template <>
 int forward_tiled<float>(long long b, long long nv, long long nf, long long hres, int repeat_v, int repeat_f,
                          int perspective, const float* v, const long long* tri, long long* index, float* coeff,
                          float* zbuf, float eps, const float* tex, long long tex_c, float* attr, int* win, int* big,
-                         void* work, hipStream_t st) {
+                         bool chw, void* work, hipStream_t st) {
     const int ntx = (int)sr_ceil_div(hres, TILE);
     const long long ntile = (long long)ntx * ntx;
     unsigned* tile_cnt = reinterpret_cast<unsigned*>(work);
@@ -1657,7 +1659,7 @@ int forward_tiled<float>(long long b, long long nv, long long nf, long long hres
                                eps);                                                                                   \
         hipLaunchKernelGGL((k_tile_raster<P>), dim3((unsigned)(b * ntile)), dim3(256), 0, st, (unsigned)b, (unsigned)nv, \
                            (unsigned)nf, (int)hres, repeat_v != 0, repeat_f != 0, v, tri, tile_cnt, tile_list, wide_cnt,  \
-                           wide_list, ntx, index, coeff, zbuf, tex, (int)tex_c, attr, win, first, eps);                 \
+                           wide_list, ntx, index, coeff, zbuf, tex, (int)tex_c, attr, win, first, eps, chw);            \
     } while (0)
     if (perspective) SR_TILE_LAUNCH(true);
     else SR_TILE_LAUNCH(false);
@@ -1675,10 +1677,14 @@ int forward_impl(long long b, long long nv, long long nf, long long h, long long
     if (b == 0) return SR_OK;
     if (!work || (nf > 0 && (!v || !tri))) return SR_EINVAL;
     if (attr && (!tex || tex_c <= 0)) return SR_EINVAL;
+    // `perspective` carries the flags of the call: bit 0 = perspective projection, bit 1 (SR_RASTER_CHW) = attribute
+    // maps channel-major [b, c, h, w] instead of the reference's [b, h, w, c]
+    const bool chw = (perspective & SR_RASTER_CHW) != 0;
+    perspective &= 1;
     const long long npix = b * h * w;
     if (eps < 0) eps = -eps;
     if (tiled_ok<R>(b, nf, h, w)) return forward_tiled(b, nv, nf, h, repeat_v, repeat_f, perspective, v, tri, index, coeff,
-                                                       zbuf, eps, tex, tex_c, attr, win, big, work, st);
+                                                       zbuf, eps, tex, tex_c, attr, win, big, chw, work, st);
     unsigned long long* keys = reinterpret_cast<unsigned long long*>(work);
     unsigned* tmin = reinterpret_cast<unsigned*>(keys + npix);
     const bool is64 = sizeof(R) == 8;
@@ -1703,7 +1709,7 @@ int forward_impl(long long b, long long nv, long long nf, long long h, long long
     }
     hipLaunchKernelGGL((k_resolve<R>), dim3((unsigned)sr_ceil_div(npix, 256)), dim3(256), 0, st, b, nv, nf,
                        h, w, repeat_v != 0, repeat_f != 0, perspective != 0, v, tri, keys, tmin, index,
-                       coeff, zbuf, tex, tex_c, attr, win, eps);
+                       coeff, zbuf, tex, tex_c, attr, win, eps, chw);
     return sr_launch_status();
 }
 
@@ -1727,13 +1733,15 @@ template <typename R, int CT, bool PERSP>
 void grad_launch(long long b, long long nv, long long nf, long long h, long long w, bool repeat_f, const R* v,
                  const R* tex, int tex_c, int ch0, const long long* tri, const int* win, const int* big,
                  const R* grad_out, const int* adj_off, const int* adj, long long off_bs, long long adj_bs,
-                 R* grad_v, R* grad_tex, R eps, R* tg, const int* first, unsigned long long* valid, hipStream_t st) {
+                 R* grad_v, R* grad_tex, R eps, R* tg, const int* first, unsigned long long* valid, bool chw,
+                 hipStream_t st) {
     const bool want_v = grad_v != nullptr && ch0 == 0;
     hipLaunchKernelGGL((k_grad_big<R, CT, PERSP>), dim3(SR_NUM_CU * 2), dim3(256), 0, st, nv, nf, h, w, repeat_f, v,
-                       tex, tex_c, ch0, tri, win, big, grad_out, want_v, tg, eps);
+                       tex, tex_c, ch0, tri, win, big, grad_out, want_v, tg, eps, chw);
     if (b * nf > 0)
         hipLaunchKernelGGL((k_grad_pix<R, CT, PERSP>), dim3((unsigned)sr_ceil_div(b * nf, 256)), dim3(256), 0, st, b,
-                           nv, nf, h, w, repeat_f, v, tex, tex_c, ch0, tri, win, first, valid, grad_out, want_v, tg, eps);
+                           nv, nf, h, w, repeat_f, v, tex, tex_c, ch0, tri, win, first, valid, grad_out, want_v, tg, eps,
+                           chw);
     hipLaunchKernelGGL((k_grad_vert<R, CT, PERSP>), dim3((unsigned)sr_ceil_div(nv, 256), (unsigned)b), dim3(256), 0,
                        st, nv, nf, adj_off, adj, off_bs, adj_bs, tg, valid, tex_c, ch0, grad_v, grad_tex);
 }
@@ -1744,6 +1752,8 @@ int grad_impl(long long b, long long nv, long long nf, long long h, long long w,
               const R* grad_out, const int* adj_off, const int* adj, long long off_bs, long long adj_bs,
               R* grad_v, R* grad_tex, R eps, void* work, hipStream_t st) {
     if (b < 0 || nv < 0 || nf < 0 || h < 0 || w < 0 || tex_c <= 0) return SR_EINVAL;
+    const bool chw = (perspective & SR_RASTER_CHW) != 0;        // grad_out [b, c, h, w] (see forward_impl)
+    perspective &= 1;
     if (b == 0 || nv == 0 || (!grad_v && !grad_tex)) return SR_OK;
     if (b > 65535 || nf >= 0x7FFFFFFFLL / 3 || tex_c > 0x7FFFFFFF) return SR_ERANGE;
     if (!v || !tex || !grad_out || !adj_off || !work || (nf > 0 && (!tri || !adj || !win || !big))) return SR_EINVAL;
@@ -1771,7 +1781,7 @@ int grad_impl(long long b, long long nv, long long nf, long long h, long long w,
         const long long ct = tex_c - ch0 < 4 ? tex_c - ch0 : 4;
 #define SR_GRAD_ARGS                                                                                              \
     b, nv, nf, h, w, repeat_f != 0, v, tex, (int)tex_c, (int)ch0, tri, win, big, grad_out, adj_off, adj, off_bs, \
-        adj_bs, grad_v, grad_tex, eps, tg, first, valid, st
+        adj_bs, grad_v, grad_tex, eps, tg, first, valid, chw, st
 #define SR_GRAD_CASE(CT)                                          \
     do {                                                          \
         if (perspective) grad_launch<R, CT, true>(SR_GRAD_ARGS);  \

@@ -302,9 +302,10 @@ class GeneratorWithMap(Generator):
     def _synthesis_with_maps(self, latent, noise, vert, attr, tri, return_normals, return_latents):
         out = self.input(latent)
         # the reference hands the permuted VIEW of the rasterizer output on (model.py:262) — that is what `norm_maps`
-        # returns and what the path-length regulariser differentiates against; the map heads read ONE contiguous NCHW
-        # copy of it (each of their convolutions would otherwise make its own, forward and backward)
-        norm_maps = [rasterize(vert, attr, tri, int(out.shape[2]), int(out.shape[3])).permute(0, 3, 1, 2)]
+        # returns and what the path-length regulariser differentiates against.  Here the rasterizer writes the maps
+        # channel-major itself (SR_RASTER_CHW: same values, no re-layout pass forward or backward per resolution;
+        # SR_RASTER_NCHW=0 keeps the permuted view + one contiguous copy for the map heads)
+        norm_maps = [_normal_map(vert, attr, tri, int(out.shape[2]), int(out.shape[3]))]
         maps = self.norm1(norm_maps[-1].contiguous())
         st = self._layer_styles(latent)
         out = self.conv1(out, st[0], maps, noise=noise[0])
@@ -313,8 +314,7 @@ class GeneratorWithMap(Generator):
         i, k = 1, 2
         for conv_up, conv, n_up, n_conv, to_rgb in zip(self.convs[::2], self.convs[1::2],
                                                        noise[1::2], noise[2::2], self.to_rgbs):
-            norm_maps.append(rasterize(vert, attr, tri, 2 * int(out.shape[2]),
-                                       2 * int(out.shape[3])).permute(0, 3, 1, 2))
+            norm_maps.append(_normal_map(vert, attr, tri, 2 * int(out.shape[2]), 2 * int(out.shape[3])))
             nm = norm_maps[-1].contiguous()
             if two_stage:
                 maps = self.norm_to_style[i](self.norm_to_style[i - 1](nm))
@@ -329,6 +329,15 @@ class GeneratorWithMap(Generator):
             i += 2
             k += 3
         return skip, (latent if return_latents else None), (norm_maps if return_normals else None)
+
+
+def _normal_map(vert, attr, tri, h, w):
+    """Rasterised vertex attributes as [b, c, h, w] (reference model.py:262: rasterize(...).permute(0, 3, 1, 2))."""
+    import os
+
+    if os.environ.get("SR_RASTER_NCHW", "1") != "0":
+        return rasterize(vert, attr, tri, h, w, channel_major=True)
+    return rasterize(vert, attr, tri, h, w).permute(0, 3, 1, 2)
 
 
 class Discriminator(nn.Module):

@@ -57,8 +57,11 @@ def _suffix(t):
     raise RuntimeError(" type error")
 
 
+SR_RASTER_CHW = 2          # include/stylerenderer_amd.h: attribute maps / their gradient channel-major [b, c, h, w]
+
+
 def _forward_impl(vertices, triangles, height, width, perspective, eps, tex=None, want_z=False,
-                  want_index=True, want_win=False):
+                  want_index=True, want_win=False, chw=False):
     if vertices.device != triangles.device:
         raise RuntimeError(" cuda input error")
     if triangles.dtype != torch.int64:
@@ -86,6 +89,8 @@ def _forward_impl(vertices, triangles, height, width, perspective, eps, tex=None
                 raise RuntimeError(" type error")
             taken = flat[index.view(-1)].view(b, h, w, 3, tex_c) * coeff.unsqueeze(-1)
             attr = (taken[..., 0, :] + taken[..., 1, :]) + taken[..., 2, :]
+            if chw:
+                attr = attr.permute(0, 3, 1, 2).contiguous()
         if rv and rf:
             return index[0], coeff[0], (zbuf[0] if zbuf is not None else None), (attr[0] if attr is not None else None), None
         return index, coeff, zbuf, attr, None
@@ -101,12 +106,12 @@ def _forward_impl(vertices, triangles, height, width, perspective, eps, tex=None
         tex_flat = tex.contiguous().view(-1, tex_c)
         if tex_flat.dtype != dt:
             raise RuntimeError(" type error")
-        attr = torch.empty((b, h, w, tex_c), dtype=dt, device=dev)
+        attr = torch.empty((b, tex_c, h, w) if chw else (b, h, w, tex_c), dtype=dt, device=dev)
     work = torch.empty(L.sr_rasterize_scratch_bytes(b, nf, h, w, int(suf == "f64")), dtype=torch.uint8,
                        device=dev)
     with on_device_of(vertices):
         rc = getattr(L, "sr_rasterize_forward_" + suf)(
-            b, nv, nf, h, w, int(rv), int(rf), int(bool(perspective)), _lib.ptr(vertices),
+            b, nv, nf, h, w, int(rv), int(rf), int(bool(perspective)) | (SR_RASTER_CHW if chw else 0), _lib.ptr(vertices),
             _lib.ptr(triangles), _lib.ptr(index), _lib.ptr(coeff), _lib.ptr(zbuf), abs(float(eps)),
             _lib.ptr(tex_flat), tex_c, _lib.ptr(attr), _lib.ptr(win), _lib.ptr(big), _lib.ptr(work),
             stream_of(vertices))
@@ -203,13 +208,17 @@ def incidence(tri, nv):
 
 class Rasterize(Function):
     @staticmethod
-    def forward(ctx, v, tex, tri, h, w, perspective, eps):
+    def forward(ctx, v, tex, tri, h, w, perspective, eps, chw=False):
+        """chw: the interpolated attributes come back channel-major [b, c, h, w] (and the gradient is taken in that
+        layout) — the layout the generator's map heads convolve; same values as the reference's [b, h, w, c]."""
         v = v.contiguous()
         tri = tri.contiguous()
         on_dev = is_device_tensor(v)
         need_grad = on_dev and (ctx.needs_input_grad[0] or ctx.needs_input_grad[1])
+        chw = bool(chw) and tex.dim() == v.dim()
         ind, coeff, _, out, state = _forward_impl(v, tri, h, w, perspective, eps, tex=tex,
-                                                  want_index=not on_dev, want_win=need_grad)
+                                                  want_index=not on_dev, want_win=need_grad, chw=chw)
+        ctx.chw = chw
         if on_dev:
             win, big = state if state is not None else (None, None)
             ctx.save_for_backward(v, tex, tri, win, big)
@@ -225,9 +234,11 @@ class Rasterize(Function):
     def backward(ctx, grad_out):
         need_v, need_t = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
         if not (need_v or need_t):
-            return (None,) * 7
+            return (None,) * 8
         if not ctx.on_dev:
-            return Rasterize._backward_host(ctx, grad_out, need_v, need_t)
+            if ctx.chw:
+                grad_out = grad_out.permute(0, 2, 3, 1)
+            return Rasterize._backward_host(ctx, grad_out, need_v, need_t) + (None,)
         v, tex, tri, win, big = ctx.saved_tensors
         if v.dim() != 3:
             raise RuntimeError("rasterize backward: batched vertices [b, n, 3] required")
@@ -238,7 +249,7 @@ class Rasterize(Function):
         nf = tri.size(-2)
         h, w = win.shape[-2], win.shape[-1]
         c = 1 if ctx.no_channel else int(tex.shape[-1])
-        go = grad_out.contiguous()
+        go = grad_out.contiguous()                            # [b, h, w, c], or [b, c, h, w] for a chw forward
         tex_c = tex.contiguous()
         if tex_c.dim() < 2 or tex_c.shape[0] != b or tex_c.shape[1] != nv:
             raise RuntimeError("rasterize backward: batched attributes [b, n(, c)] required")
@@ -250,11 +261,12 @@ class Rasterize(Function):
                            device=v.device)
         with on_device_of(v):
             rc = getattr(L, "sr_rasterize_grad_" + suf)(
-                b, nv, nf, h, w, int(tri.dim() == 2), int(bool(ctx.perspective)), _lib.ptr(v), _lib.ptr(tex_c), c,
+                b, nv, nf, h, w, int(tri.dim() == 2), int(bool(ctx.perspective)) | (SR_RASTER_CHW if ctx.chw else 0),
+                _lib.ptr(v), _lib.ptr(tex_c), c,
                 _lib.ptr(tri), _lib.ptr(win), _lib.ptr(big), _lib.ptr(go), _lib.ptr(off), _lib.ptr(adj), off_bs, adj_bs,
                 _lib.ptr(grad_v), _lib.ptr(grad_t), abs(float(ctx.eps)), _lib.ptr(work), stream_of(v))
         _lib.check(rc, "sr_rasterize_grad")
-        return grad_v, grad_t, None, None, None, None, None
+        return grad_v, grad_t, None, None, None, None, None, None
 
     @staticmethod
     def _backward_host(ctx, grad_out, need_v, need_t):
@@ -280,5 +292,7 @@ class Rasterize(Function):
         return grad_v, grad_t, None, None, None, None, None
 
 
-def rasterize(v, tex, tri, h=256, w=0, perspective=False, eps=1e-6):
-    return Rasterize.apply(v, tex, tri, h, w, perspective, eps)
+def rasterize(v, tex, tri, h=256, w=0, perspective=False, eps=1e-6, channel_major=False):
+    """reference op/rasterize.py `rasterize`; channel_major=True returns the interpolated attributes as [b, c, h, w]
+    (= the reference's output .permute(0, 3, 1, 2), contiguous) straight from the kernel."""
+    return Rasterize.apply(v, tex, tri, h, w, perspective, eps, channel_major)

@@ -373,6 +373,39 @@ def test_rasterize_gradient_follows_the_forward_record_not_the_environment(fwd, 
     assert np.abs(res["flipped"][1].cpu().numpy() - wt).max() <= 2e-6 * np.abs(wt).max()
 
 
+@pytest.mark.parametrize("tiled,tex_c,dtype", [("1", 3, "f32"), ("0", 3, "f32"), ("1", 5, "f32"), ("1", 3, "f64")])
+def test_rasterize_channel_major_equals_the_permuted_output(tiled, tex_c, dtype, monkeypatch):
+    """SR_RASTER_CHW (the layout the generator's map heads convolve): attributes written [b, c, h, w] by the kernel and
+    the gradient taken from a [b, c, h, w] cotangent are, bit for bit, the reference layout's permuted — for the
+    LDS-tiled and the global-key forward, three (register path) and five attribute channels, both precisions, and with
+    a triangle large enough for the workgroup-cooperative gradient path."""
+    import stylerenderer_amd.op as op
+    from stylerenderer_amd import synth
+
+    monkeypatch.setenv("SR_RASTER_TILED", tiled)
+    dt = torch.float32 if dtype == "f32" else torch.float64
+    v0, tri = synth.uv_ellipsoid(20, 18)
+    vh = synth.random_poses(v0, 3, seed=19)
+    nv = v0.shape[0]
+    # one screen-filling triangle behind the mesh (the `big` list)
+    vh = np.concatenate([vh, np.tile(np.array([[[-0.9, -0.9, -0.99], [0.9, -0.9, -0.99], [0.0, 0.9, -0.99]]], vh.dtype),
+                                     (3, 1, 1))], 1)
+    tri = np.concatenate([tri, [[nv, nv + 1, nv + 2]]], 0)
+    tex = synth.det_normal((3, nv + 3, tex_c), 79)
+    go = synth.det_normal((3, 64, 64, tex_c), 80)
+    res = {}
+    for chw in (False, True):
+        v, t = T(vh).to(dt).requires_grad_(), T(tex).to(dt).requires_grad_()
+        out = op.rasterize(v, t, T(tri), 64, channel_major=chw)
+        g = T(go).to(dt)
+        grads = torch.autograd.grad(out, [v, t], g.permute(0, 3, 1, 2).contiguous() if chw else g)
+        res[chw] = (out.detach(), grads)
+    assert res[True][0].shape == (3, tex_c, 64, 64) and res[True][0].is_contiguous()
+    assert torch.equal(res[True][0], res[False][0].permute(0, 3, 1, 2))
+    assert torch.equal(res[True][1][0], res[False][1][0]) and torch.equal(res[True][1][1], res[False][1][1])
+    assert float(res[True][1][0].abs().max()) > 0
+
+
 def test_rasterize_gradients_misc():
     """No-channel attributes, per-sample topology [b, nf, 3], only one of the two gradients requested, a
     triangle with a repeated vertex id and out-of-range ids (skipped like the reference does)."""
