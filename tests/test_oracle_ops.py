@@ -57,3 +57,25 @@ def test_modulated_conv(golden, tag):
                                 blur_kernel=ops_np.make_blur_kernel((1, 3, 3, 1), 4.0))
     assert y.shape == g[tag + "_y"].shape
     assert rel_err(y, g[tag + "_y"]) < 5e-6
+
+
+@pytest.mark.parametrize("tag,demod,up", [("m5", True, False), ("m5up", True, True), ("m5nodemod", False, False)])
+def test_modulated_conv_kernel_size_5(golden, tag, demod, up):
+    """The numpy restatement at a kernel size the matrix-core kernels do not take (reference layers.py:259-323 with
+    kernel_size 5: padding 2; up-sampling blur pad (0, 0)) against the reference's layer (conv_generic.npz)."""
+    import torch
+
+    from stylerenderer_amd import synth
+
+    g = golden("conv_generic")
+    ci, co, k = 8, 12, 5
+    sd = {"weight": torch.empty(1, co, ci, k, k), "modulation.weight": torch.empty(ci, 16),
+          "modulation.bias": torch.empty(ci)}
+    synth.fill_state_dict(sd, salt=35)
+    w, mw, mb = (sd[n].numpy() for n in ("weight", "modulation.weight", "modulation.bias"))
+    x, s = synth.det_normal((2, 8, 10, 10), 36), synth.det_normal((2, 16), 37)
+    style = s.astype(np.float64) @ (mw.astype(np.float64).T / np.sqrt(16)) + mb
+    y = ops_np.modulated_conv2d(x, w, style, demodulate=demod, upsample=up,
+                                blur_kernel=ops_np.make_blur_kernel((1, 3, 3, 1), 4.0), blur_pad=(0, 0))
+    assert y.shape == g[tag + "_y"].shape
+    assert rel_err(y, g[tag + "_y"]) < 5e-6
