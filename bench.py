@@ -779,8 +779,8 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     prof, conv_op.PROFILE = conv_op.PROFILE, None
-    # ---- secondary, opt-in arithmetic (NOT the headline): the same step with the stride-2 / 1x1 weight gradients on the
-    # bf16 matrix cores, every fp32 operand split into three bf16 pieces (csrc/conv_wgrad_bf16x3.hip; error table in
+    # ---- secondary, opt-in arithmetic (NOT the headline): the same step with the stride-2 convolutions and the stride-2 /
+    # 1x1 weight gradients on the bf16 matrix cores, every fp32 operand split into three bf16 pieces (csrc/conv_wgrad_bf16x3.hip; error table in
     # profiles/r05_split_bf16.md: at or below the exact-fp32 MFMA kernels' under the same 2e-6 * sum|a||b| bar)
     split_res = None
     if world == 1 and not args.no_split_bf16:
@@ -796,7 +796,7 @@ def main():
             dt = time.perf_counter() - t1
             split_res = {"value": round(args.batch * args.steps / dt, 2), "unit": "images/s",
                          "ms_per_step": round(dt / args.steps * 1e3, 3), "dtype": "f32 operands split into 3 x bf16, six "
-                         "bf16-MFMA products, fp32 accumulation (weight gradients of the stride-2 3x3 and 1x1 layers only)",
+                         "bf16-MFMA products, fp32 accumulation (stride-2 3x3 convolution, its transposed form and the stride-2 / 1x1 weight gradients; the Winograd layers stay exact fp32)",
                          "opt_in": "SR_CONV_SPLIT_BF16=1", "speedup_vs_headline": round(elapsed / dt, 4)}
         finally:
             os.environ["SR_CONV_SPLIT_BF16"] = "0"
