@@ -119,10 +119,20 @@ struct Geo {
 // (image lanes: one plane; style lanes: one float; border / absent-style lanes: 0 from the zero / ones
 // line), i.e. one v_mad_u64_u32 per DMA instruction instead of a dozen selects and scalar branches.  Every
 // instruction issued on the SIMD costs the matrix pipe a slot.
-template <int IS, int TY, int TX, int PW, int PH, int PB, bool V4, bool FAST>
+// TAP9 (1x1 window only): the stride-2 TRANSPOSED 3x3 convolution of a small map as nine shifted 1x1 convolutions in ONE
+// launch.  out[2j + py, 2i + px] = sum over taps (ky, kx) = (py, px) mod 2 of in[j - (ky >> 1), i - (kx >> 1)] * W[ky][kx]:
+// tap (ky, kx) is a 1x1 convolution over the phase grid with the input shifted by (ky >> 1, kx >> 1).  blockIdx
+// enumerates (tap, tile, K slice); every workgroup walks the same K = channels-of-its-slice, so the launch is balanced
+// whatever the phase (the four per-phase launches carry 4 / 2 / 2 / 1 taps) and has 9x the workgroups of one phase —
+// what a 4^2 .. 32^2 map at batch 1 .. 4 needs to fill 256 CUs.  Each workgroup stores its raw sums to
+// partial[slice * 9 + tap] (common (IH+1) x (IW+1) grid); k_convt_tap_reduce adds the taps of each output's phase and
+// the slices in a fixed order and applies scale / bias.  Replaces 8 .. 18 launches per layer (four phases x {interior, two
+// border strips} + their split-K reductions) by two.
+template <int IS, int TY, int TX, int PW, int PH, int PB, bool V4, bool FAST, bool TAP9 = false>
 __global__ __launch_bounds__(256) void k_conv_mfma(const ConvParams p) {
     using G = Geo<IS, TY, TX, PW, PH, PB, V4>;
     static_assert(PW * PH * PB == BM, "patch must hold 128 pixels");
+    static_assert(!TAP9 || (IS == 1 && TY == 1 && TX == 1 && !V4), "tap-split mode is a shifted 1x1 convolution");
     extern __shared__ __attribute__((aligned(16))) float smem[];     // the ONLY LDS object
 
     // ---- tile decode; workgroups that share an input patch (different n tiles) and neighbouring
@@ -132,6 +142,17 @@ __global__ __launch_bounds__(256) void k_conv_mfma(const ConvParams p) {
     {
         const int q = nwg / SR_NUM_XCD, r = nwg % SR_NUM_XCD, xcd = bid % SR_NUM_XCD;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + bid / SR_NUM_XCD;
+    }
+    // geometry of this workgroup: the launch's, or (TAP9) its tap's
+    int tap = 0, g_dy0 = p.dy0, g_dx0 = p.dx0, g_gh = p.GH, g_gw = p.GW, g_ooy = p.ooy, g_oox = p.oox, g_slab = p.wmap[0];
+    if (TAP9) {
+        tap = bid % 9;                      // the nine taps of a tile are neighbours: one input patch in L2
+        bid /= 9;
+        const int ky = tap / 3, kx = tap - 3 * ky;
+        g_dy0 = -(ky >> 1); g_dx0 = -(kx >> 1);
+        g_ooy = ky & 1; g_oox = kx & 1;
+        g_gh = g_ooy ? p.IH : p.IH + 1; g_gw = g_oox ? p.IW : p.IW + 1;
+        g_slab = tap;
     }
     const int n_t = bid % p.tiles_n;
     bid /= p.tiles_n;
@@ -144,7 +165,7 @@ __global__ __launch_bounds__(256) void k_conv_mfma(const ConvParams p) {
     const int c_beg = slice * p.c_per_slice;
     const int c_end = min(p.C, c_beg + p.c_per_slice);
     const int n0 = n_t * BN, gy0 = p.gy_base + ty_i * PH, gx0 = p.gx_base + tx_i * PW, b0 = tb_i * PB;
-    const int iy0 = gy0 * IS + p.dy0, ix0 = gx0 * IS + p.dx0;
+    const int iy0 = gy0 * IS + g_dy0, ix0 = gx0 * IS + g_dx0;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -181,6 +202,7 @@ __global__ __launch_bounds__(256) void k_conv_mfma(const ConvParams p) {
 #pragma unroll
         for (int k = 0; k < G::NT; ++k)
             if (t == k) slab = p.wmap[k];
+        if (TAP9) slab = g_slab;
         w_src[i] = (slab * p.C + c) * p.ldw + col;
     }
     // input: !V4: instruction j moves LDS floats [64 j, 64 j + 64) of the halo image, then the
@@ -374,8 +396,8 @@ __global__ __launch_bounds__(256) void k_conv_mfma(const ConvParams p) {
         const int m = wpx * 64 + pt * 32 + l31;
         const int px = m % PW, py = (m / PW) % PH, pb = m / (PW * PH);
         const int gy = gy0 + py, gx = gx0 + px, b = b0 + pb;
-        if (gy >= p.GH || gx >= p.GW || b >= p.B) continue;
-        const int64_t pix = (int64_t)(gy * p.osy + p.ooy) * p.OW + (gx * p.osx + p.oox);
+        if (gy >= g_gh || gx >= g_gw || b >= p.B) continue;
+        const int64_t pix = (int64_t)(gy * p.osy + g_ooy) * p.OW + (gx * p.osx + g_oox);
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
@@ -383,7 +405,11 @@ __global__ __launch_bounds__(256) void k_conv_mfma(const ConvParams p) {
                 const int n = n0 + wco * 64 + ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
                 if (n < p.N) {
                     float v = acc[ct][pt][r];
-                    if (p.ks > 1) {
+                    if (TAP9) {
+                        // [slice * 9 + tap][b][n][row][col] over the common (IH + 1) x (IW + 1) grid
+                        const int rw = p.GW, rh = p.GH;
+                        p.partial[((((int64_t)slice * 9 + tap) * p.B + b) * p.N + n) * (rh * rw) + gy * rw + gx] = v;
+                    } else if (p.ks > 1) {
                         // compact slab of THIS launch's region: [slice][b][n][row][col]
                         const int rw = p.GW - p.gx_base, rh = p.GH - p.gy_base;
                         p.partial[(((int64_t)slice * p.B + b) * p.N + n) * (rh * rw) +
@@ -398,10 +424,10 @@ __global__ __launch_bounds__(256) void k_conv_mfma(const ConvParams p) {
     }
 }
 
-template <int IS, int TY, int TX, int PW, int PH, int PB, bool V4, bool FAST>
+template <int IS, int TY, int TX, int PW, int PH, int PB, bool V4, bool FAST, bool TAP9 = false>
 int launch_fast(const ConvParams& p, dim3 grid, hipStream_t st) {
     using G = Geo<IS, TY, TX, PW, PH, PB, V4>;
-    auto kern = k_conv_mfma<IS, TY, TX, PW, PH, PB, V4, FAST>;
+    auto kern = k_conv_mfma<IS, TY, TX, PW, PH, PB, V4, FAST, TAP9>;
     static bool configured = false;     // opt in to > 64 KiB of dynamic LDS once per variant
     if (!configured) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -412,12 +438,13 @@ int launch_fast(const ConvParams& p, dim3 grid, hipStream_t st) {
     return sr_launch_status();
 }
 
-template <int IS, int TY, int TX, int PW, int PH, int PB, bool V4>
+template <int IS, int TY, int TX, int PW, int PH, int PB, bool V4, bool TAP9 = false>
 int launch_one(const ConvParams& p, dim3 grid, hipStream_t st) {
     using G = Geo<IS, TY, TX, PW, PH, PB, V4>;
     // no channel tail in any K slice -> chunk-invariant DMA descriptors
-    if (p.C % G::KC == 0 && p.c_per_slice % G::KC == 0) return launch_fast<IS, TY, TX, PW, PH, PB, V4, true>(p, grid, st);
-    return launch_fast<IS, TY, TX, PW, PH, PB, V4, false>(p, grid, st);
+    if (p.C % G::KC == 0 && p.c_per_slice % G::KC == 0)
+        return launch_fast<IS, TY, TX, PW, PH, PB, V4, true, TAP9>(p, grid, st);
+    return launch_fast<IS, TY, TX, PW, PH, PB, V4, false, TAP9>(p, grid, st);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -732,6 +759,94 @@ __global__ __launch_bounds__(256) void k_conv_reduce(const ConvParams p, int rh,
     }
 }
 
+// Tap-split transposed convolution (k_conv_mfma<..., TAP9>): output (Y, X) of phase (Y & 1, X & 1) at grid point
+// (Y >> 1, X >> 1) is the sum of its phase's taps over all K slices, added in a fixed order (slice-major, taps ascending).
+__global__ __launch_bounds__(256) void k_convt_tap_reduce(const ConvParams p) {
+    const int rh = p.GH, rw = p.GW;
+    const int64_t region = (int64_t)rh * rw, plane_out = (int64_t)p.OH * p.OW;
+    const int64_t total = (int64_t)p.B * p.N * plane_out, slab = (int64_t)p.B * p.N * region;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = i / plane_out;
+        const int q = (int)(i - row * plane_out);
+        const int Y = q / p.OW, X = q - Y * p.OW;
+        const int py = Y & 1, px = X & 1;
+        const int64_t at = row * region + (int64_t)(Y >> 1) * rw + (X >> 1);
+        float acc = 0.0f;
+        for (int s = 0; s < p.ks; ++s)
+            for (int ky = py; ky < 3; ky += 2)
+                for (int kx = px; kx < 3; kx += 2) acc += p.partial[((int64_t)s * 9 + ky * 3 + kx) * slab + at];
+        if (p.oscale) acc *= p.oscale[row];
+        if (p.obias) acc += p.obias[row % p.N];
+        p.out[i] = acc;
+    }
+}
+
+// SR_CONVT_TAPS=0 keeps the per-phase launches for small maps (A/B measurements); =1 forces the tap-split form for any size
+int convt_taps_mode() {
+    const char* e = std::getenv("SR_CONVT_TAPS");
+    return !e ? 2 : (e[0] == '0' ? 0 : 1);
+}
+
+// K slices of the tap-split launch: enough workgroups for ~2 per CU (the nine taps already multiply the tiles by 9),
+// >= 32 channels (a multiple of 16) per slice
+void convt_taps_plan(int IH, int IW, int B, int N, int C, int& ks, int& c_per_slice) {
+    int pw, ph, pb;
+    patch_shape(IW + 1, pw, ph, pb);
+    const int64_t blocks = (int64_t)((IW + pw) / pw) * ((IH + ph) / ph) * ((B + pb - 1) / pb) * ((N + BN - 1) / BN) * 9;
+    ks = 1;
+    c_per_slice = (C + 15) / 16 * 16;
+    if (blocks >= 2 * SR_NUM_CU || C < 64) return;
+    int want = (int)((2 * SR_NUM_CU + blocks - 1) / blocks);
+    if (want > 8) want = 8;
+    int per = (C + want - 1) / want;
+    per = (per + 15) / 16 * 16;
+    if (per < 32) per = 32;
+    c_per_slice = per;
+    ks = (C + per - 1) / per;
+}
+
+int64_t convt_taps_floats(int64_t B, int64_t C, int64_t N, int64_t IH, int64_t IW) {
+    int ks, per;
+    convt_taps_plan((int)IH, (int)IW, (int)B, (int)N, (int)C, ks, per);
+    return (int64_t)ks * 9 * B * N * (IH + 1) * (IW + 1);
+}
+
+// Small problems only: measured inside captured graphs (scripts/bench_convt_small.py, profiles/r05_notes.md) the
+// tap-split form wins up to ~10 GFLOP per call (4^2 .. 16^2 maps at batch 4, 32^2 .. 128^2 at batch 1: 0.042 / 0.076 /
+// 0.143 / 0.150 / 0.189 / 0.173 ms against 0.071 / 0.095 / 0.218 / 0.226 / 0.258 / 0.231), ties at ~10 and loses
+// above (its 1x1 workgroups top out at ~40 TFLOP/s; 32^2 at batch 4: 0.475 against 0.352 per-phase).
+bool convt_taps_wanted(int64_t B, int64_t C, int64_t N, int64_t IH, int64_t IW) {
+    const int mode = convt_taps_mode();
+    return mode == 1 || (mode == 2 && 18.0 * (double)B * (double)C * (double)N * (double)IH * (double)IW < 9.0e9);
+}
+
+int launch_convt_taps(ConvParams p, hipStream_t st) {
+    p.GH = p.IH + 1; p.GW = p.IW + 1;                // common grid of the four phases
+    p.gy_base = p.gx_base = 0;
+    p.osy = p.osx = 2; p.ooy = p.oox = 0;
+    p.dy0 = p.dx0 = 0;
+    convt_taps_plan(p.IH, p.IW, p.B, p.N, p.C, p.ks, p.c_per_slice);
+    int pw, ph, pb;
+    patch_shape(p.GW, pw, ph, pb);
+    p.tiles_x = (p.GW + pw - 1) / pw;
+    p.tiles_y = (p.GH + ph - 1) / ph;
+    p.tiles_b = (p.B + pb - 1) / pb;
+    p.tiles_n = (p.N + BN - 1) / BN;
+    const int64_t blocks = (int64_t)p.tiles_x * p.tiles_y * p.tiles_b * p.tiles_n * p.ks * 9;
+    if (blocks > 0x7FFFFFFFLL) return SR_ERANGE;
+    const dim3 grid((unsigned)blocks);
+    int rc;
+    if (pw == 32) rc = launch_one<1, 1, 1, 32, 4, 1, false, true>(p, grid, st);
+    else if (pw == 16) rc = launch_one<1, 1, 1, 16, 8, 1, false, true>(p, grid, st);
+    else if (pw == 8) rc = launch_one<1, 1, 1, 8, 8, 2, false, true>(p, grid, st);
+    else rc = launch_one<1, 1, 1, 4, 4, 8, false, true>(p, grid, st);
+    if (rc != SR_OK) return rc;
+    const int64_t total = (int64_t)p.B * p.N * p.OH * p.OW;
+    hipLaunchKernelGGL(k_convt_tap_reduce, dim3(sr_stream_grid(total, 256)), dim3(256), 0, st, p);
+    return sr_launch_status();
+}
+
 // Winograd F(2x2,3x3) for the stride-1 3x3 convolution (csrc/conv_wino.hip); SR_WINOGRAD=0 keeps the
 // direct implicit GEMM (A/B measurements, exact-fma-chain numerics).
 bool wino_enabled() {
@@ -824,6 +939,10 @@ extern "C" int64_t sr_conv2d_scratch_floats(int64_t B, int64_t C, int64_t N, int
         consider(IH, IW);
         consider(1, IW + 1);
         consider(IH, 1);
+        if (ksize == 3 && stride == 2 && pad == 0 && convt_taps_wanted(B, C, N, IH, IW)) {
+            const int64_t w = convt_taps_floats(B, C, N, IH, IW);
+            need = need > w ? need : w;
+        }
         if (ksize == 3 && stride == 2 && pad == 0 && sr_wgrad_bf16x3_enabled() && sr_convt_bf16x3_eligible(B, C, N, IH, IW)) {
             const int64_t w = sr_convt_bf16x3_scratch_floats(C, N);
             need = need > w ? need : w;
@@ -895,6 +1014,10 @@ extern "C" int sr_conv2d_mfma_ex(float* out, const float* in, const float* wt, c
     // runs as thin strip launches instead of padding every tile row by up to 50 %.
     // interior of the map: all four phases in one workgroup (k_convt_fused); SR_CONVT_FUSED=0 keeps the
     // per-phase launches
+    // small problems: nine shifted 1x1 convolutions in one launch + one reduction (k_conv_mfma<..., TAP9>)
+    if (scratch && convt_taps_wanted(B, C, N, IH, IW) && convt_taps_floats(B, C, N, IH, IW) <= p.partial_floats &&
+        !(sr_wgrad_bf16x3_enabled() && sr_convt_bf16x3_eligible(B, C, N, IH, IW)))
+        return launch_convt_taps(p, st);
     bool fused_ok = false;
     {
         const char* e = std::getenv("SR_CONVT_FUSED");

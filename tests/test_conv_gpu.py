@@ -108,6 +108,36 @@ def test_conv_vs_float64(case, scaled):
     assert float((err / (mag + 1e-30)).max()) < 2e-6
 
 
+TAPS = [(2, 8, 6, 4, 4), (2, 8, 6, 8, 8), (1, 11, 9, 16, 16), (1, 6, 130, 32, 32), (1, 12, 64, 8, 64), (3, 24, 140, 5, 7),
+        (4, 512, 512, 8, 8), (1, 80, 64, 33, 30)]
+
+
+@pytest.mark.parametrize("case", TAPS)
+@pytest.mark.parametrize("mode", ["1", "0"])
+def test_transposed_conv_tap_split_vs_float64(case, mode, monkeypatch):
+    """The stride-2 transposed 3x3 convolution as nine shifted 1x1 convolutions in one launch + one reduction
+    (k_conv_mfma<..., TAP9>, the form small problems take; SR_CONVT_TAPS=1 forces it for every size) and the per-phase
+    launches it replaces (=0), both against float64 at the kernels' 2e-6 * sum|a*b|: odd extents, non-square maps,
+    channel tails (11, 24, 80 input channels), two output-channel tiles, K slices (512 channels at 8^2); deterministic."""
+    from stylerenderer_amd.op.conv import conv2d_mfma
+
+    monkeypatch.setenv("SR_CONVT_TAPS", mode)
+    b, c, n, h, w = case
+    g = torch.Generator().manual_seed(b * 1000 + c * 10 + n + h)
+    x = torch.randn(b, c, h, w, generator=g)
+    wgt = torch.randn(c, n, 3, 3, generator=g)
+    isc, osc, bias = torch.randn(b, c, generator=g), torch.randn(b, n, generator=g), torch.randn(n, generator=g)
+    want = ref_conv(x, wgt, isc, osc, bias, 2, 0, True)
+    got = conv2d_mfma(x.to(DEV), to_taps(wgt, True).to(DEV), isc.to(DEV), osc.to(DEV), bias.to(DEV), 3, 2, 0, True)
+    assert got.shape == want.shape
+    absx = x.abs().double() * isc.abs().double()[:, :, None, None]
+    mag = F.conv_transpose2d(absx, wgt.abs().double(), stride=2) * osc.abs().double()[:, :, None, None] + \
+        bias.abs().double()[None, :, None, None]
+    assert float(((got.cpu().double() - want).abs() / (mag + 1e-30)).max()) < 2e-6
+    again = conv2d_mfma(x.to(DEV), to_taps(wgt, True).to(DEV), isc.to(DEV), osc.to(DEV), bias.to(DEV), 3, 2, 0, True)
+    assert torch.equal(got, again)
+
+
 def test_conv_full_width_layers_spotcheck():
     """Generator-sized layers (512 -> 512 at 16x16, 128 -> 128 at 128x128): compare a strip of
     outputs with float64."""
