@@ -138,6 +138,35 @@ def test_transposed_conv_tap_split_vs_float64(case, mode, monkeypatch):
     assert torch.equal(got, again)
 
 
+@pytest.mark.parametrize("case", [(2, 8, 130, 32, 32), (1, 16, 6, 8, 64), (3, 24, 64, 12, 32), (1, 64, 128, 64, 64)])
+@pytest.mark.parametrize("scaled", [True, False])
+def test_transposed_conv_border_strips_vs_float64(case, scaled, monkeypatch):
+    """Fused interior (k_convt_fused) + the thin per-phase strip launches for output row 2*IH / column 2*IW, whole output
+    against float64 at 2e-6 * sum|a*b| — with and without modulation / demodulation / bias, non-square maps, two
+    output-channel tiles (130), N < one wave (6); the strips checked on their own as well."""
+    from stylerenderer_amd.op.conv import conv2d_mfma
+
+    monkeypatch.setenv("SR_CONVT_TAPS", "0")          # (these sizes would otherwise take the tap-split launch)
+    monkeypatch.setenv("SR_CONVT_FUSED", "1")
+    b, c, n, h, w = case
+    g = torch.Generator().manual_seed(b * 1000 + c * 10 + n + h)
+    x = torch.randn(b, c, h, w, generator=g)
+    wgt = torch.randn(c, n, 3, 3, generator=g)
+    isc = torch.randn(b, c, generator=g) if scaled else None
+    osc = torch.randn(b, n, generator=g) if scaled else None
+    bias = torch.randn(n, generator=g) if scaled else None
+    want = ref_conv(x, wgt, isc, osc, bias, 2, 0, True)
+    dev = lambda t: None if t is None else t.to(DEV)  # noqa: E731
+    got = conv2d_mfma(dev(x), dev(to_taps(wgt, True)), dev(isc), dev(osc), dev(bias), 3, 2, 0, True)
+    absx = x.abs().double() * (isc.abs().double()[:, :, None, None] if scaled else 1.0)
+    mag = F.conv_transpose2d(absx, wgt.abs().double(), stride=2)
+    if scaled:
+        mag = mag * osc.abs().double()[:, :, None, None] + bias.abs().double()[None, :, None, None]
+    rel = (got.cpu().double() - want).abs() / (mag + 1e-30)
+    assert float(rel.max()) < 2e-6
+    assert float(rel[:, :, -1, :].max()) < 2e-6 and float(rel[:, :, :, -1].max()) < 2e-6      # the strips themselves
+
+
 def test_conv_full_width_layers_spotcheck():
     """Generator-sized layers (512 -> 512 at 16x16, 128 -> 128 at 128x128): compare a strip of
     outputs with float64."""
