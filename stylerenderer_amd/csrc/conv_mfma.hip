@@ -76,6 +76,9 @@ struct ConvParams {
     float* partial;
     int64_t partial_floats;
     int ks, c_per_slice;
+    // TAP9 launches: the taps this launch walks are tap_first + i * tap_step, i < tap_count (all nine: 0, 1, 9; the
+    // border strips behind the fused kernel: row 2*IH = taps 6, 7, 8; column 2*IW = taps 2, 5, 8)
+    int tap_first, tap_step, tap_count;
 };
 
 // V4: the halo window starts at a 16-byte aligned column (LEAD extra columns on the left), rows
@@ -145,13 +148,16 @@ __global__ __launch_bounds__(256) void k_conv_mfma(const ConvParams p) {
     }
     // geometry of this workgroup: the launch's, or (TAP9) its tap's
     int tap = 0, g_dy0 = p.dy0, g_dx0 = p.dx0, g_gh = p.GH, g_gw = p.GW, g_ooy = p.ooy, g_oox = p.oox, g_slab = p.wmap[0];
+    int tap_local = 0;
     if (TAP9) {
-        tap = bid % 9;                      // the nine taps of a tile are neighbours: one input patch in L2
-        bid /= 9;
+        tap_local = bid % p.tap_count;      // the taps of a tile are neighbours: one input patch in L2
+        bid /= p.tap_count;
+        tap = p.tap_first + tap_local * p.tap_step;
         const int ky = tap / 3, kx = tap - 3 * ky;
         g_dy0 = -(ky >> 1); g_dx0 = -(kx >> 1);
         g_ooy = ky & 1; g_oox = kx & 1;
-        g_gh = g_ooy ? p.IH : p.IH + 1; g_gw = g_oox ? p.IW : p.IW + 1;
+        // the phase's extent, clipped to the launch's region [gy_base, GH) x [gx_base, GW)
+        g_gh = min(g_ooy ? p.IH : p.IH + 1, p.GH); g_gw = min(g_oox ? p.IW : p.IW + 1, p.GW);
         g_slab = tap;
     }
     const int n_t = bid % p.tiles_n;
@@ -406,9 +412,10 @@ __global__ __launch_bounds__(256) void k_conv_mfma(const ConvParams p) {
                 if (n < p.N) {
                     float v = acc[ct][pt][r];
                     if (TAP9) {
-                        // [slice * 9 + tap][b][n][row][col] over the common (IH + 1) x (IW + 1) grid
-                        const int rw = p.GW, rh = p.GH;
-                        p.partial[((((int64_t)slice * 9 + tap) * p.B + b) * p.N + n) * (rh * rw) + gy * rw + gx] = v;
+                        // [slice * tap_count + tap][b][n][row][col] over the launch's region
+                        const int rw = p.GW - p.gx_base, rh = p.GH - p.gy_base;
+                        p.partial[((((int64_t)slice * p.tap_count + tap_local) * p.B + b) * p.N + n) * (rh * rw) +
+                                  (gy - p.gy_base) * rw + (gx - p.gx_base)] = v;
                     } else if (p.ks > 1) {
                         // compact slab of THIS launch's region: [slice][b][n][row][col]
                         const int rw = p.GW - p.gx_base, rh = p.GH - p.gy_base;
@@ -826,6 +833,7 @@ int launch_convt_taps(ConvParams p, hipStream_t st) {
     p.gy_base = p.gx_base = 0;
     p.osy = p.osx = 2; p.ooy = p.oox = 0;
     p.dy0 = p.dx0 = 0;
+    p.tap_first = 0; p.tap_step = 1; p.tap_count = 9;
     convt_taps_plan(p.IH, p.IW, p.B, p.N, p.C, p.ks, p.c_per_slice);
     int pw, ph, pb;
     patch_shape(p.GW, pw, ph, pb);
@@ -844,6 +852,74 @@ int launch_convt_taps(ConvParams p, hipStream_t st) {
     if (rc != SR_OK) return rc;
     const int64_t total = (int64_t)p.B * p.N * p.OH * p.OW;
     hipLaunchKernelGGL(k_convt_tap_reduce, dim3(sr_stream_grid(total, 256)), dim3(256), 0, st, p);
+    return sr_launch_status();
+}
+
+// Border strips behind the fused kernel (output row 2*IH, column 2*IW) through the same tap machinery: only the taps
+// ky = 2 reach the last row, only kx = 2 the last column — two TAP9 launches of three taps each (32-wide patches along
+// the row, 4 x 4 x 8-sample patches down the column) and one reduction, instead of four thin per-phase launches with a
+// split-K reduction behind each.  partial = [row: 3 x B x N x (IW + 1)] [column: 3 x B x N x IH].
+__global__ __launch_bounds__(256) void k_convt_strip_reduce(const ConvParams p, const float* __restrict__ prow,
+                                                            const float* __restrict__ pcol) {
+    const int rw = p.IW + 1, ch = p.IH, OW = p.OW, OH = p.OH;
+    const int per_row = OW + OH - 1;                                  // strip outputs per (sample, channel)
+    const int64_t planes = (int64_t)p.B * p.N, total = planes * per_row;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = i / per_row;
+        const int q = (int)(i - row * per_row);
+        float acc;
+        int64_t o;
+        if (q < OW) {                                                 // output (2 IH, X = q): taps (2, 0) + (2, 2) | (2, 1)
+            const int g = q >> 1;
+            const float* t = prow + row * rw + g;
+            acc = (q & 1) ? t[planes * rw] : t[0] + t[2 * planes * rw];
+            o = (int64_t)(OH - 1) * OW + q;
+        } else {                                                      // output (Y, 2 IW): taps (0, 2) + (2, 2) | (1, 2)
+            const int Y = q - OW, g = Y >> 1;
+            const float* t = pcol + row * ch + g;
+            acc = (Y & 1) ? t[planes * ch] : ((g < ch ? t[0] : 0.0f) + (g < ch ? t[2 * planes * ch] : 0.0f));
+            o = (int64_t)Y * OW + (OW - 1);
+        }
+        if (p.oscale) acc *= p.oscale[row];
+        if (p.obias) acc += p.obias[row % p.N];
+        p.out[row * (int64_t)OH * OW + o] = acc;
+    }
+}
+
+int64_t convt_strip_floats(int64_t B, int64_t N, int64_t IH, int64_t IW) { return 3 * B * N * (IW + 1 + IH); }
+
+template <int PW, int PH, int PB>
+int launch_strip_part(ConvParams& p, hipStream_t st) {
+    p.tiles_x = (p.GW - p.gx_base + PW - 1) / PW;
+    p.tiles_y = (p.GH - p.gy_base + PH - 1) / PH;
+    p.tiles_b = (p.B + PB - 1) / PB;
+    p.tiles_n = (p.N + BN - 1) / BN;
+    const int64_t blocks = (int64_t)p.tiles_x * p.tiles_y * p.tiles_b * p.tiles_n * p.tap_count;
+    if (blocks > 0x7FFFFFFFLL) return SR_ERANGE;
+    return launch_one<1, 1, 1, PW, PH, PB, false, true>(p, dim3((unsigned)blocks), st);
+}
+
+int launch_convt_strips(ConvParams p, hipStream_t st) {
+    float* prow = p.partial;
+    float* pcol = p.partial + 3 * (int64_t)p.B * p.N * (p.IW + 1);
+    p.osy = p.osx = 2; p.ooy = p.oox = 0;
+    p.dy0 = p.dx0 = 0;
+    p.ks = 1; p.c_per_slice = (p.C + 15) / 16 * 16;
+    // row 2*IH: grid row IH, all IW + 1 grid columns, taps (2, 0) (2, 1) (2, 2)
+    p.gy_base = p.IH; p.GH = p.IH + 1; p.gx_base = 0; p.GW = p.IW + 1;
+    p.tap_first = 6; p.tap_step = 1; p.tap_count = 3;
+    p.partial = prow;
+    int rc = launch_strip_part<32, 4, 1>(p, st);
+    if (rc != SR_OK) return rc;
+    // column 2*IW: grid column IW, grid rows 0 .. IH - 1 (the corner is the row's), taps (0, 2) (1, 2) (2, 2)
+    p.gy_base = 0; p.GH = p.IH; p.gx_base = p.IW; p.GW = p.IW + 1;
+    p.tap_first = 2; p.tap_step = 3; p.tap_count = 3;
+    p.partial = pcol;
+    rc = launch_strip_part<4, 4, 8>(p, st);
+    if (rc != SR_OK) return rc;
+    const int64_t total = (int64_t)p.B * p.N * (p.OW + p.OH - 1);
+    hipLaunchKernelGGL(k_convt_strip_reduce, dim3(sr_stream_grid(total, 256)), dim3(256), 0, st, p, prow, pcol);
     return sr_launch_status();
 }
 
@@ -943,6 +1019,10 @@ extern "C" int64_t sr_conv2d_scratch_floats(int64_t B, int64_t C, int64_t N, int
             const int64_t w = convt_taps_floats(B, C, N, IH, IW);
             need = need > w ? need : w;
         }
+        if (ksize == 3 && stride == 2 && pad == 0) {
+            const int64_t w = convt_strip_floats(B, N, IH, IW);
+            need = need > w ? need : w;
+        }
         if (ksize == 3 && stride == 2 && pad == 0 && sr_wgrad_bf16x3_enabled() && sr_convt_bf16x3_eligible(B, C, N, IH, IW)) {
             const int64_t w = sr_convt_bf16x3_scratch_floats(C, N);
             need = need > w ? need : w;
@@ -980,6 +1060,7 @@ extern "C" int sr_conv2d_mfma_ex(float* out, const float* in, const float* wt, c
     p.partial_floats = scratch ? sr_conv2d_scratch_floats(B, C, N, IH, IW, OH, OW, ksize, stride, pad, transposed) : 0;
     for (int i = 0; i < 9; ++i) p.wmap[i] = 0;
     p.ks = 1; p.c_per_slice = (p.C + 15) / 16 * 16;
+    p.tap_first = 0; p.tap_step = 1; p.tap_count = 9;
     if (!transposed) {
         if (OH != (IH + 2 * pad - ksize) / stride + 1 || OW != (IW + 2 * pad - ksize) / stride + 1)
             return SR_EINVAL;
@@ -1040,6 +1121,12 @@ extern "C" int sr_conv2d_mfma_ex(float* out, const float* in, const float* wt, c
             if (rc != SR_OK) return rc;
             fused_ok = true;
         }
+    }
+    if (fused_ok && scratch && convt_strip_floats(B, N, IH, IW) <= p.partial_floats) {
+        // the interior is done: output row 2*IH and column 2*IW as two three-tap launches + one reduction
+        // (SR_CONVT_STRIPS=0: the four thin per-phase launches and their split-K reductions)
+        const char* e = std::getenv("SR_CONVT_STRIPS");
+        if (!(e && e[0] == '0')) return launch_convt_strips(p, st);
     }
     for (int py = 0; py < 2; ++py)
         for (int px = 0; px < 2; ++px) {
