@@ -91,7 +91,7 @@ struct ConvParams {
 // (lead = 0..3 floats, different per row and channel) and the operand fetch adds that lead back: its value for
 // k-step (channel pair cp, tap row ty) is (L0 + 2 cp + ty) mod 4 with a per-lane constant L0 — four precomputed
 // offsets, selected at compile time in the unrolled loop.  Same 16-byte DMA count as the aligned stride-1 form.
-template <int IS, int TY, int TX, int PW, int PH, int PB, bool V4>
+template <int IS, int TY, int TX, int PW, int PH, int PB, bool V4, bool TAP9 = false>
 struct Geo {
     static constexpr bool ROT = V4 && IS == 2;
     static constexpr int NT = TY * TX;
@@ -99,7 +99,9 @@ struct Geo {
     static constexpr int KC = NT >= 9 ? 4 : (NT >= 4 ? 8 : 16);
     static constexpr int EH = (PH - 1) * IS + TY;
     static constexpr int EW = (PW - 1) * IS + TX;
-    static constexpr int LEAD = (V4 && !ROT) ? (TX > 1 ? 3 : 0) : 0;
+    // TAP9 with 16-byte DMAs: every tap's window starts FOUR columns left of the tile (aligned); the operand fetch adds
+    // 4 + dx0 (dx0 = 0 or -1: the tap's input shift) — one staging layout for all nine taps
+    static constexpr int LEAD = (V4 && !ROT) ? (TAP9 ? 4 : (TX > 1 ? 3 : 0)) : 0;
     static constexpr int EWP = ROT ? (EW + 3 + 3) / 4 * 4
                                    : (V4 ? (LEAD + EW + 3) / 4 * 4 : EW + ((EW % 2 == 0) ? 1 : 0));
     static constexpr int PLANE = PB * EH * EWP;                  // one channel of the chunk
@@ -133,9 +135,9 @@ struct Geo {
 // border strips} + their split-K reductions) by two.
 template <int IS, int TY, int TX, int PW, int PH, int PB, bool V4, bool FAST, bool TAP9 = false>
 __global__ __launch_bounds__(256) void k_conv_mfma(const ConvParams p) {
-    using G = Geo<IS, TY, TX, PW, PH, PB, V4>;
+    using G = Geo<IS, TY, TX, PW, PH, PB, V4, TAP9>;
     static_assert(PW * PH * PB == BM, "patch must hold 128 pixels");
-    static_assert(!TAP9 || (IS == 1 && TY == 1 && TX == 1 && !V4), "tap-split mode is a shifted 1x1 convolution");
+    static_assert(!TAP9 || (IS == 1 && TY == 1 && TX == 1), "tap-split mode is a shifted 1x1 convolution");
     extern __shared__ __attribute__((aligned(16))) float smem[];     // the ONLY LDS object
 
     // ---- tile decode; workgroups that share an input patch (different n tiles) and neighbouring
@@ -186,7 +188,8 @@ __global__ __launch_bounds__(256) void k_conv_mfma(const ConvParams p) {
         a_off[t] = half * BN + wco * 64 + t * 32 + l31;
         const int m = wpx * 64 + t * 32 + l31;
         const int px = m % PW, py = (m / PW) % PH, pb = m / (PW * PH);
-        b_off[t] = G::W_FLOATS + half * G::PLANE + (pb * G::EH + py * IS) * G::EWP + px * IS + G::LEAD;
+        b_off[t] = G::W_FLOATS + half * G::PLANE + (pb * G::EH + py * IS) * G::EWP + px * IS + G::LEAD +
+                   ((TAP9 && V4) ? g_dx0 : 0);
         s_off[t] = G::S_BASE + pb * G::KC + half;                        // style of (sample, channel)
         const int l0 = half + iy0 + py * IS + ix0;
 #pragma unroll
@@ -228,7 +231,7 @@ __global__ __launch_bounds__(256) void k_conv_mfma(const ConvParams p) {
                 const int cola = q % G::EWP, r = (q / G::EWP) % G::EH;
                 pb = q / (G::EWP * G::EH);
                 const int gy = iy0 + r;
-                int gx = ix0 - G::LEAD + cola;
+                int gx = ((TAP9 && V4) ? gx0 : ix0) - G::LEAD + cola;
                 bool ok = gy >= 0 && gy < p.IH && b0 + pb < p.B;
                 if (G::ROT) {
                     // aligned group at or below the window start of this (channel, row); it may run into the
@@ -433,7 +436,7 @@ __global__ __launch_bounds__(256) void k_conv_mfma(const ConvParams p) {
 
 template <int IS, int TY, int TX, int PW, int PH, int PB, bool V4, bool FAST, bool TAP9 = false>
 int launch_fast(const ConvParams& p, dim3 grid, hipStream_t st) {
-    using G = Geo<IS, TY, TX, PW, PH, PB, V4>;
+    using G = Geo<IS, TY, TX, PW, PH, PB, V4, TAP9>;
     auto kern = k_conv_mfma<IS, TY, TX, PW, PH, PB, V4, FAST, TAP9>;
     static bool configured = false;     // opt in to > 64 KiB of dynamic LDS once per variant
     if (!configured) {
@@ -447,7 +450,7 @@ int launch_fast(const ConvParams& p, dim3 grid, hipStream_t st) {
 
 template <int IS, int TY, int TX, int PW, int PH, int PB, bool V4, bool TAP9 = false>
 int launch_one(const ConvParams& p, dim3 grid, hipStream_t st) {
-    using G = Geo<IS, TY, TX, PW, PH, PB, V4>;
+    using G = Geo<IS, TY, TX, PW, PH, PB, V4, TAP9>;
     // no channel tail in any K slice -> chunk-invariant DMA descriptors
     if (p.C % G::KC == 0 && p.c_per_slice % G::KC == 0)
         return launch_fast<IS, TY, TX, PW, PH, PB, V4, true, TAP9>(p, grid, st);
@@ -820,12 +823,20 @@ int64_t convt_taps_floats(int64_t B, int64_t C, int64_t N, int64_t IH, int64_t I
 }
 
 // Small problems only: measured inside captured graphs (scripts/bench_convt_small.py, profiles/r05_notes.md) the
-// tap-split form wins up to ~10 GFLOP per call (4^2 .. 16^2 maps at batch 4, 32^2 .. 128^2 at batch 1: 0.042 / 0.076 /
-// 0.143 / 0.150 / 0.189 / 0.173 ms against 0.071 / 0.095 / 0.218 / 0.226 / 0.258 / 0.231), ties at ~10 and loses
-// above (its 1x1 workgroups top out at ~40 TFLOP/s; 32^2 at batch 4: 0.475 against 0.352 per-phase).
+// tap-split form wins up to ~10 GFLOP per call (4^2 .. 16^2 maps at batch 4, 32^2 .. 128^2 at batch 1: 0.042 / 0.069 /
+// 0.128 / 0.135 / 0.168 / 0.172 ms against 0.071 / 0.095 / 0.218 / 0.226 / 0.258 / 0.231; 32^2 at batch 2 and 16^2 at
+// batch 8, 9.7 GFLOP: 0.241 against 0.259 / 0.270) and loses above (its 1x1 workgroups top out at 45-60 TFLOP/s; 32^2
+// at batch 4: 0.429 against 0.352 per-phase).
 bool convt_taps_wanted(int64_t B, int64_t C, int64_t N, int64_t IH, int64_t IW) {
     const int mode = convt_taps_mode();
-    return mode == 1 || (mode == 2 && 18.0 * (double)B * (double)C * (double)N * (double)IH * (double)IW < 9.0e9);
+    return mode == 1 || (mode == 2 && 18.0 * (double)B * (double)C * (double)N * (double)IH * (double)IW < 1.05e10);
+}
+
+// 16-byte halo DMAs for a tap-split launch: aligned rows and an aligned tile origin (one sample per patch is checked
+// by the caller's choice of the patch shape); SR_CONVT_TAPS_V4=0 keeps the 4-byte form (A/B, tests)
+bool taps_v4(const ConvParams& p) {
+    const char* e = std::getenv("SR_CONVT_TAPS_V4");
+    return !(e && e[0] == '0') && p.IW % 4 == 0 && p.gx_base % 4 == 0 && (reinterpret_cast<uintptr_t>(p.in) & 15) == 0;
 }
 
 int launch_convt_taps(ConvParams p, hipStream_t st) {
@@ -844,9 +855,12 @@ int launch_convt_taps(ConvParams p, hipStream_t st) {
     const int64_t blocks = (int64_t)p.tiles_x * p.tiles_y * p.tiles_b * p.tiles_n * p.ks * 9;
     if (blocks > 0x7FFFFFFFLL) return SR_ERANGE;
     const dim3 grid((unsigned)blocks);
+    const bool v4 = taps_v4(p);
     int rc;
-    if (pw == 32) rc = launch_one<1, 1, 1, 32, 4, 1, false, true>(p, grid, st);
-    else if (pw == 16) rc = launch_one<1, 1, 1, 16, 8, 1, false, true>(p, grid, st);
+    if (pw == 32) rc = v4 ? launch_one<1, 1, 1, 32, 4, 1, true, true>(p, grid, st)
+                          : launch_one<1, 1, 1, 32, 4, 1, false, true>(p, grid, st);
+    else if (pw == 16) rc = v4 ? launch_one<1, 1, 1, 16, 8, 1, true, true>(p, grid, st)
+                               : launch_one<1, 1, 1, 16, 8, 1, false, true>(p, grid, st);
     else if (pw == 8) rc = launch_one<1, 1, 1, 8, 8, 2, false, true>(p, grid, st);
     else rc = launch_one<1, 1, 1, 4, 4, 8, false, true>(p, grid, st);
     if (rc != SR_OK) return rc;
@@ -897,6 +911,7 @@ int launch_strip_part(ConvParams& p, hipStream_t st) {
     p.tiles_n = (p.N + BN - 1) / BN;
     const int64_t blocks = (int64_t)p.tiles_x * p.tiles_y * p.tiles_b * p.tiles_n * p.tap_count;
     if (blocks > 0x7FFFFFFFLL) return SR_ERANGE;
+    if (PB == 1 && taps_v4(p)) return launch_one<1, 1, 1, PW, PH, PB, PB == 1, true>(p, dim3((unsigned)blocks), st);
     return launch_one<1, 1, 1, PW, PH, PB, false, true>(p, dim3((unsigned)blocks), st);
 }
 
