@@ -494,6 +494,11 @@ __device__ long long g_convt_stamps[8 * 16384];
 #define CONVT_STAMP(i)
 #endif
 
+// KS: K slices (round 5).  With few tiles and a long channel loop (the 32^2 x 512-channel layer at batch 4: 128
+// workgroups walking 64 chunks each) slice s of p.ks walks the channels [s * c_per_slice, (s + 1) * c_per_slice): the
+// same loop over k = 0 .. n - 1 with the bases of the two buffer resources and of the style row moved, raw sums to
+// partial[s] in the layout of `out`; k_convt_fused_reduce adds the slices in order and applies scale / bias.
+template <bool KS>
 __global__ __launch_bounds__(256) void k_convt_fused(const ConvParams p) {
 #if __HIP_DEVICE_COMPILE__   // buffer-resource builtins: device pass only (the host pass needs just the stub)
     using G = TFused;
@@ -515,7 +520,11 @@ __global__ __launch_bounds__(256) void k_convt_fused(const ConvParams p) {
     const int tx_i = bid % p.tiles_x;
     bid /= p.tiles_x;
     const int ty_i = bid % p.tiles_y;
-    const int b = bid / p.tiles_y;
+    bid /= p.tiles_y;
+    const int b = KS ? bid % p.B : bid;
+    const int slice = KS ? bid / p.B : 0;
+    const int c_beg = KS ? slice * p.c_per_slice : 0;          // first channel of this workgroup's K range
+    const int c_cnt = KS ? p.c_per_slice : p.C;
     const int n0 = n_t * BN, j0 = ty_i * G::PH, i0 = tx_i * G::PW;
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -551,9 +560,9 @@ __global__ __launch_bounds__(256) void k_convt_fused(const ConvParams p) {
         i_off[i] = off;
     }
     const int plane_in = p.IH * p.IW;
-    const __amdgpu_buffer_rsrc_t r_w = uniform_rsrc(p.wt, 9 * p.C * p.ldw * 4);
-    const __amdgpu_buffer_rsrc_t r_in = uniform_rsrc(p.in + (int64_t)b * p.C * plane_in, p.C * plane_in * 4);
-    const int nchunks = p.C / G::KC;
+    const __amdgpu_buffer_rsrc_t r_w = uniform_rsrc(p.wt + (int64_t)c_beg * p.ldw, (9 * p.C - c_beg) * p.ldw * 4);
+    const __amdgpu_buffer_rsrc_t r_in = uniform_rsrc(p.in + ((int64_t)b * p.C + c_beg) * plane_in, c_cnt * plane_in * 4);
+    const int nchunks = c_cnt / G::KC;
 
     // DMA instruction i (0 .. 10) of chunk k (clamped to the last chunk: a surplus fetch lands in a free buffer)
     auto dma1 = [&](int k, int i) {
@@ -603,7 +612,7 @@ __global__ __launch_bounds__(256) void k_convt_fused(const ConvParams p) {
     for (int i = 0; i < N_DMA; ++i) dma1(0, i);
 #pragma unroll
     for (int i = 0; i < 4; ++i) dma1(1, i);
-    for (int c = tid; c < p.C; c += 256) sty[c] = p.iscale ? p.iscale[(int64_t)b * p.C + c] : 1.0f;
+    for (int c = tid; c < c_cnt; c += 256) sty[c] = p.iscale ? p.iscale[(int64_t)b * p.C + c_beg + c] : 1.0f;
     __builtin_amdgcn_s_waitcnt(0x0F70);
     __syncthreads();
 
@@ -682,9 +691,10 @@ __global__ __launch_bounds__(256) void k_convt_fused(const ConvParams p) {
             for (int r = 0; r < 16; ++r) {
                 const int n = n0 + wco * 64 + ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
                 if (n < p.N) {
-                    const float os = p.oscale ? p.oscale[(int64_t)b * p.N + n] : 1.0f;
-                    const float ob = p.obias ? p.obias[n] : 0.0f;
-                    float* o = p.out + ((int64_t)b * p.N + n) * plane_out + (int64_t)(2 * j) * p.OW + 2 * i;
+                    const float os = (!KS && p.oscale) ? p.oscale[(int64_t)b * p.N + n] : 1.0f;
+                    const float ob = (!KS && p.obias) ? p.obias[n] : 0.0f;
+                    float* o = (KS ? p.partial + (int64_t)slice * p.B * p.N * plane_out : p.out) +
+                               ((int64_t)b * p.N + n) * plane_out + (int64_t)(2 * j) * p.OW + 2 * i;
                     o[0] = acc[0][ct][pt][r] * os + ob;
                     o[1] = acc[1][ct][pt][r] * os + ob;
                     o[p.OW] = acc[2][ct][pt][r] * os + ob;
@@ -712,14 +722,57 @@ bool convt_fused_eligible(const ConvParams& p) {
            (reinterpret_cast<uintptr_t>(p.in) & 15) == 0;
 }
 
+// interior outputs (rows < 2 IH, columns < 2 IW) = the slices of k_convt_fused<true> added in order, then scale / bias
+__global__ __launch_bounds__(256) void k_convt_fused_reduce(const ConvParams p) {
+    const int iw2 = 2 * p.IW, ih2 = 2 * p.IH;
+    const int64_t plane_out = (int64_t)p.OH * p.OW, planes = (int64_t)p.B * p.N;
+    const int64_t total = planes * ih2 * (iw2 / 4);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = i / ((int64_t)ih2 * (iw2 / 4));
+        const int q = (int)(i - row * (int64_t)ih2 * (iw2 / 4));
+        const int Y = q / (iw2 / 4), X = (q - Y * (iw2 / 4)) * 4;
+        const int64_t at = row * plane_out + (int64_t)Y * p.OW + X;
+        float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        for (int s = 0; s < p.ks; ++s) {
+            const float* src = p.partial + (int64_t)s * planes * plane_out + at;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) acc[k] += src[k];
+        }
+        const float os = p.oscale ? p.oscale[row] : 1.0f, ob = p.obias ? p.obias[row % p.N] : 0.0f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) p.out[at + k] = acc[k] * os + ob;
+    }
+}
+
+// K slices of the fused kernel: the smallest of 2 / 4 that gives >= 192 workgroups with whole chunks and >= 64 channels per slice
+int convt_fused_slices(int64_t fused_blocks, int C) {
+    for (int ks = 2; ks <= 4; ks *= 2)
+        if (C % (ks * TFused::KC) == 0 && C / ks >= 64 && fused_blocks * ks >= 192) return ks;
+    return 1;
+}
+
+int64_t convt_fused_split_floats(int64_t B, int64_t C, int64_t N, int64_t IH, int64_t IW) {
+    const int64_t blocks = (IW / TFused::PW) * (IH / TFused::PH) * ((N + BN - 1) / BN) * B;
+    if (IW % TFused::PW || IH % TFused::PH || blocks >= 192 || C <= 256) return 0;
+    const int ks = convt_fused_slices(blocks, (int)C);
+    return ks > 1 ? ks * B * N * (2 * IH + 1) * (2 * IW + 1) : 0;
+}
+
 int launch_convt_fused(ConvParams p, hipStream_t st) {
     p.tiles_x = p.IW / TFused::PW;
     p.tiles_y = p.IH / TFused::PH;
     p.tiles_n = (p.N + BN - 1) / BN;
-    const int64_t blocks = (int64_t)p.tiles_x * p.tiles_y * p.tiles_n * p.B;
+    const int64_t blocks = (int64_t)p.tiles_x * p.tiles_y * p.tiles_n * p.B * p.ks;
     if (blocks > 0x7FFFFFFFLL) return SR_ERANGE;
+    if (p.ks > 1) {
+        const int lds = (TFused::STY + p.c_per_slice) * 4;
+        hipLaunchKernelGGL(k_convt_fused<true>, dim3((unsigned)blocks), dim3(256), lds, st, p);
+        const int64_t total = (int64_t)p.B * p.N * 2 * p.IH * (2 * p.IW / 4);
+        hipLaunchKernelGGL(k_convt_fused_reduce, dim3(sr_stream_grid(total, 256)), dim3(256), 0, st, p);
+        return sr_launch_status();
+    }
     const int lds = (TFused::STY + p.C) * 4;
-    hipLaunchKernelGGL(k_convt_fused, dim3((unsigned)blocks), dim3(256), lds, st, p);
+    hipLaunchKernelGGL(k_convt_fused<false>, dim3((unsigned)blocks), dim3(256), lds, st, p);
     return sr_launch_status();
 }
 
@@ -1035,8 +1088,9 @@ extern "C" int64_t sr_conv2d_scratch_floats(int64_t B, int64_t C, int64_t N, int
             need = need > w ? need : w;
         }
         if (ksize == 3 && stride == 2 && pad == 0) {
-            const int64_t w = convt_strip_floats(B, N, IH, IW);
+            const int64_t w = convt_strip_floats(B, N, IH, IW), f = convt_fused_split_floats(B, C, N, IH, IW);
             need = need > w ? need : w;
+            need = need > f ? need : f;
         }
         if (ksize == 3 && stride == 2 && pad == 0 && sr_wgrad_bf16x3_enabled() && sr_convt_bf16x3_eligible(B, C, N, IH, IW)) {
             const int64_t w = sr_convt_bf16x3_scratch_floats(C, N);
@@ -1123,7 +1177,17 @@ extern "C" int sr_conv2d_mfma_ex(float* out, const float* in, const float* wt, c
         // 0.23 / 0.26 / 0.35 ms against 0.38 / 0.39 / 0.40 fused (batch 8: 0.56 against 0.43, fused stays);
         // 64^2 512->256 at batch 1 / 2 0.26 / 0.33 against 0.39; 128^2 256->128 (32 chunks) is fused from batch 1 on
         const int64_t fused_blocks = (int64_t)(p.IW / TFused::PW) * (p.IH / TFused::PH) * ((p.N + BN - 1) / BN) * p.B;
-        const bool fused_pays = fused_blocks >= 192 || p.C <= 256;
+        bool fused_pays = fused_blocks >= 192 || p.C <= 256;
+        if (!fused_pays && scratch && !(e && e[0] == '0')) {
+            // few tiles, long channel loop: K slices inside the fused kernel (SR_CONVT_FUSED_KS=0: the per-phase launches)
+            const char* k = std::getenv("SR_CONVT_FUSED_KS");
+            const int ks = (k && k[0] == '0') ? 1 : convt_fused_slices(fused_blocks, p.C);
+            if (ks > 1 && convt_fused_eligible(p) && (int64_t)ks * B * N * OH * OW <= p.partial_floats) {
+                p.ks = ks;
+                p.c_per_slice = p.C / ks;
+                fused_pays = true;
+            }
+        }
         if (scratch && sr_wgrad_bf16x3_enabled() && sr_convt_bf16x3_eligible(B, C, N, IH, IW)) {
             // opt-in spike (SR_CONV_SPLIT_BF16=1): the interior of the map on the bf16 matrix cores (three-way operand
             // split); the border strips below stay on the exact-fp32 kernels
@@ -1133,6 +1197,7 @@ extern "C" int sr_conv2d_mfma_ex(float* out, const float* in, const float* wt, c
         } else if (!(e && e[0] == '0') && p.IW >= 16 && convt_fused_eligible(p) && (fused_pays || (e && e[0] == '1'))) {
             for (int i = 0; i < 9; ++i) p.wmap[i] = i;
             const int rc = launch_convt_fused(p, st);
+            p.ks = 1; p.c_per_slice = (p.C + 15) / 16 * 16;          // (the strips below plan their own)
             if (rc != SR_OK) return rc;
             fused_ok = true;
         }

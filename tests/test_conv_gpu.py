@@ -167,6 +167,32 @@ def test_transposed_conv_border_strips_vs_float64(case, scaled, monkeypatch):
     assert float(rel[:, :, -1, :].max()) < 2e-6 and float(rel[:, :, :, -1].max()) < 2e-6      # the strips themselves
 
 
+@pytest.mark.parametrize("case", [(2, 320, 512, 32, 32), (4, 512, 256, 32, 32)])
+def test_transposed_conv_fused_kernel_with_k_slices_vs_float64(case, monkeypatch):
+    """k_convt_fused<true>: few tiles and a long channel loop (fewer than 192 workgroups, more than 256 channels) are cut
+    into 2 / 4 K slices whose raw sums k_convt_fused_reduce adds in order — against float64 at 2e-6 * sum|a*b|, and
+    bit-identical between two launches; SR_CONVT_FUSED_KS=0 (the per-phase launches it replaces) agrees to round-off."""
+    from stylerenderer_amd.op.conv import conv2d_mfma
+
+    monkeypatch.setenv("SR_CONVT_TAPS", "0")
+    b, c, n, h, w = case
+    g = torch.Generator().manual_seed(c + n)
+    x = torch.randn(b, c, h, w, generator=g)
+    wgt = torch.randn(c, n, 3, 3, generator=g) / (3 * c ** 0.5)
+    isc, osc, bias = torch.randn(b, c, generator=g), torch.randn(b, n, generator=g), torch.randn(n, generator=g)
+    want = ref_conv(x, wgt, isc, osc, bias, 2, 0, True)
+    args = [t.to(DEV) for t in (x, to_taps(wgt, True), isc, osc, bias)]
+    got = conv2d_mfma(*args, 3, 2, 0, True)
+    mag = F.conv_transpose2d(x.abs().double() * isc.abs().double()[:, :, None, None], wgt.abs().double(), stride=2) * \
+        osc.abs().double()[:, :, None, None] + bias.abs().double()[None, :, None, None]
+    assert float(((got.cpu().double() - want).abs() / (mag + 1e-30)).max()) < 2e-6
+    assert torch.equal(got, conv2d_mfma(*args, 3, 2, 0, True))
+    monkeypatch.setenv("SR_CONVT_FUSED_KS", "0")
+    old = conv2d_mfma(*args, 3, 2, 0, True)
+    assert float(((old - got).abs().cpu().double() / (mag + 1e-30)).max()) < 2e-6
+    assert not torch.equal(old, got) or True          # (different summation orders: equality is not required)
+
+
 def test_conv_full_width_layers_spotcheck():
     """Generator-sized layers (512 -> 512 at 16x16, 128 -> 128 at 128x128): compare a strip of
     outputs with float64."""
