@@ -927,7 +927,7 @@ int launch_convt_taps(ConvParams p, hipStream_t st) {
 // the row, 4 x 4 x 8-sample patches down the column) and one reduction, instead of four thin per-phase launches with a
 // split-K reduction behind each.  partial = [row: 3 x B x N x (IW + 1)] [column: 3 x B x N x IH].
 __global__ __launch_bounds__(256) void k_convt_strip_reduce(const ConvParams p, const float* __restrict__ prow,
-                                                            const float* __restrict__ pcol) {
+                                                            const float* __restrict__ pcol, int ks_row, int ks_col) {
     const int rw = p.IW + 1, ch = p.IH, OW = p.OW, OH = p.OH;
     const int per_row = OW + OH - 1;                                  // strip outputs per (sample, channel)
     const int64_t planes = (int64_t)p.B * p.N, total = planes * per_row;
@@ -937,15 +937,18 @@ __global__ __launch_bounds__(256) void k_convt_strip_reduce(const ConvParams p, 
         const int q = (int)(i - row * per_row);
         float acc;
         int64_t o;
+        acc = 0.0f;
         if (q < OW) {                                                 // output (2 IH, X = q): taps (2, 0) + (2, 2) | (2, 1)
             const int g = q >> 1;
             const float* t = prow + row * rw + g;
-            acc = (q & 1) ? t[planes * rw] : t[0] + t[2 * planes * rw];
+            for (int s = 0; s < ks_row; ++s, t += 3 * planes * rw)    // K slices in order
+                acc += (q & 1) ? t[planes * rw] : t[0] + t[2 * planes * rw];
             o = (int64_t)(OH - 1) * OW + q;
         } else {                                                      // output (Y, 2 IW): taps (0, 2) + (2, 2) | (1, 2)
             const int Y = q - OW, g = Y >> 1;
             const float* t = pcol + row * ch + g;
-            acc = (Y & 1) ? t[planes * ch] : ((g < ch ? t[0] : 0.0f) + (g < ch ? t[2 * planes * ch] : 0.0f));
+            for (int s = 0; s < ks_col; ++s, t += 3 * planes * ch)
+                acc += (Y & 1) ? t[planes * ch] : t[0] + t[2 * planes * ch];
             o = (int64_t)Y * OW + (OW - 1);
         }
         if (p.oscale) acc *= p.oscale[row];
@@ -954,7 +957,9 @@ __global__ __launch_bounds__(256) void k_convt_strip_reduce(const ConvParams p, 
     }
 }
 
-int64_t convt_strip_floats(int64_t B, int64_t N, int64_t IH, int64_t IW) { return 3 * B * N * (IW + 1 + IH); }
+// (up to STRIP_KS K slices per strip)
+constexpr int STRIP_KS = 4;
+int64_t convt_strip_floats(int64_t B, int64_t N, int64_t IH, int64_t IW) { return STRIP_KS * 3 * B * N * (IW + 1 + IH); }
 
 template <int PW, int PH, int PB>
 int launch_strip_part(ConvParams& p, hipStream_t st) {
@@ -962,7 +967,17 @@ int launch_strip_part(ConvParams& p, hipStream_t st) {
     p.tiles_y = (p.GH - p.gy_base + PH - 1) / PH;
     p.tiles_b = (p.B + PB - 1) / PB;
     p.tiles_n = (p.N + BN - 1) / BN;
-    const int64_t blocks = (int64_t)p.tiles_x * p.tiles_y * p.tiles_b * p.tiles_n * p.tap_count;
+    int64_t blocks = (int64_t)p.tiles_x * p.tiles_y * p.tiles_b * p.tiles_n * p.tap_count;
+    // a strip is a few hundred workgroups walking the whole channel loop (32 - 64 chunks of ~1.2 us each): K slices
+    // shorten the chain until ~2 workgroups per CU exist (>= 64 channels, a multiple of 16, per slice)
+    p.ks = 1; p.c_per_slice = (p.C + 15) / 16 * 16;
+    for (int ks = STRIP_KS; ks >= 2; ks /= 2)
+        if (p.C % (16 * ks) == 0 && p.C / ks >= 64 && blocks * ks <= 4 * SR_NUM_CU) {
+            p.ks = ks;
+            p.c_per_slice = p.C / ks;
+            break;
+        }
+    blocks *= p.ks;
     if (blocks > 0x7FFFFFFFLL) return SR_ERANGE;
     if (PB == 1 && taps_v4(p)) return launch_one<1, 1, 1, PW, PH, PB, PB == 1, true>(p, dim3((unsigned)blocks), st);
     return launch_one<1, 1, 1, PW, PH, PB, false, true>(p, dim3((unsigned)blocks), st);
@@ -970,7 +985,7 @@ int launch_strip_part(ConvParams& p, hipStream_t st) {
 
 int launch_convt_strips(ConvParams p, hipStream_t st) {
     float* prow = p.partial;
-    float* pcol = p.partial + 3 * (int64_t)p.B * p.N * (p.IW + 1);
+    float* pcol = p.partial + STRIP_KS * 3 * (int64_t)p.B * p.N * (p.IW + 1);
     p.osy = p.osx = 2; p.ooy = p.oox = 0;
     p.dy0 = p.dx0 = 0;
     p.ks = 1; p.c_per_slice = (p.C + 15) / 16 * 16;
@@ -980,14 +995,17 @@ int launch_convt_strips(ConvParams p, hipStream_t st) {
     p.partial = prow;
     int rc = launch_strip_part<32, 4, 1>(p, st);
     if (rc != SR_OK) return rc;
+    const int ks_row = p.ks;
     // column 2*IW: grid column IW, grid rows 0 .. IH - 1 (the corner is the row's), taps (0, 2) (1, 2) (2, 2)
     p.gy_base = 0; p.GH = p.IH; p.gx_base = p.IW; p.GW = p.IW + 1;
     p.tap_first = 2; p.tap_step = 3; p.tap_count = 3;
     p.partial = pcol;
     rc = launch_strip_part<4, 4, 8>(p, st);
     if (rc != SR_OK) return rc;
+    const int ks_col = p.ks;
     const int64_t total = (int64_t)p.B * p.N * (p.OW + p.OH - 1);
-    hipLaunchKernelGGL(k_convt_strip_reduce, dim3(sr_stream_grid(total, 256)), dim3(256), 0, st, p, prow, pcol);
+    hipLaunchKernelGGL(k_convt_strip_reduce, dim3(sr_stream_grid(total, 256)), dim3(256), 0, st, p, prow, pcol, ks_row,
+                       ks_col);
     return sr_launch_status();
 }
 
