@@ -399,6 +399,53 @@ class ConstantInput(nn.Module):
         return self.input.repeat(input.shape[0], 1, 1, 1)
 
 
+class _BiasSums(torch.autograd.Function):
+    """conv.bias + activation.bias of MANY layers in one multi-tensor launch (the layers merge the two so that the bias is
+    added once, in the convolution's store or the activation kernel; per layer that was one ~5 us add per forward)."""
+
+    @staticmethod
+    def forward(ctx, *biases):
+        n = len(biases) // 2
+        return tuple(torch._foreach_add(list(biases[:n]), list(biases[n:])))
+
+    @staticmethod
+    def backward(ctx, *grads):
+        return tuple(grads) + tuple(grads)
+
+
+class BiasBank:
+    """`with BiasBank(net):` around a network's forward on device tensors: every ConvLayer with a convolution bias AND an
+    activation bias finds its merged bias prepared (one launch for all of them).  SR_BIAS_BANK=0 disables."""
+
+    def __init__(self, net):
+        self.net = net
+        self.filled = []
+
+    def __enter__(self):
+        if os.environ.get("SR_BIAS_BANK", "1") == "0":
+            return self
+        plan = getattr(self.net, "_bias_plan", None)
+        if plan is None:
+            plan = [m for m in self.net.modules() if isinstance(m, ConvLayer) and m.merged_bias_pair() is not None]
+            self.net._bias_plan = plan
+        pairs = [m.merged_bias_pair() for m in plan]
+        live = [(m, p) for m, p in zip(plan, pairs) if p is not None and p[0].device.type == "cuda"
+                and p[0].dtype == torch.float32]
+        if len(live) < 2:
+            return self
+        sums = _BiasSums.apply(*([p[0] for _, p in live] + [p[1] for _, p in live]))
+        for (m, _), t in zip(live, sums):
+            m._bias_sum = t
+            self.filled.append(m)
+        return self
+
+    def __exit__(self, *exc):
+        for m in self.filled:
+            m._bias_sum = None
+        self.filled = []
+        return False
+
+
 class ConvLayer(nn.Sequential):
     """[Blur] -> EqualConv2d -> [FusedLeakyReLU | ScaledLeakyReLU] (reference layers.py:341-378).
     `activate` is 'lrelu' or anything else for "no activation"; the reference passes False from
@@ -431,6 +478,14 @@ class ConvLayer(nn.Sequential):
             layers.append(FusedLeakyReLU(out_channel) if bias else ScaledLeakyReLU(0.2))
         super().__init__(*layers)
 
+    def merged_bias_pair(self):
+        """(conv.bias, activation.bias) when forward() merges them (device path), else None."""
+        mods = [m for m in self if not isinstance(m, Blur)]
+        if (len(mods) >= 2 and isinstance(mods[0], EqualConv2d) and isinstance(mods[1], FusedLeakyReLU)
+                and mods[0].bias is not None and mods[0]._geom() is not None):
+            return mods[0].bias, mods[1].bias
+        return None
+
     def forward(self, input, gain=None):
         """gain (device path only): a constant factor on the layer's output, folded into the activation's gain
         (sqrt(2) * gain) or, without activation and bias, into the convolution's store."""
@@ -455,7 +510,9 @@ class ConvLayer(nn.Sequential):
             conv = mods[0]
             act = mods[1] if len(mods) > 1 and isinstance(mods[1], FusedLeakyReLU) else None
             if act is not None and conv.bias is not None and conv._geom() is not None:
-                bias = conv.bias + act.bias
+                bias = getattr(self, "_bias_sum", None)            # prepared for the whole network (BiasBank)
+                if bias is None:
+                    bias = conv.bias + act.bias
                 if conv._geom() == "c3" and _fused_tails():
                     # stride-1 3x3 layers of 32^2 .. 256^2 maps: bias + LeakyReLU in the Winograd kernel's store
                     # (the pre-activation tensor is never written or kept for backward)

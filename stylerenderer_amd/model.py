@@ -15,7 +15,7 @@ import numpy as np
 import torch
 from torch import nn
 
-from .layers import (Blur, ConstantInput, ConvLayer, EqualLinear, ModulatedConv2d, NoiseInjection,  # noqa: F401
+from .layers import (BiasBank, Blur, ConstantInput, ConvLayer, EqualLinear, ModulatedConv2d, NoiseInjection,  # noqa: F401
                      PixelNorm, ResBlock, Upsample)
 from .op import FusedLeakyReLU, rasterize
 from .op import smallconv as _smallconv
@@ -207,7 +207,7 @@ class Generator(nn.Module):
                 styles = [self.style(s) for s in styles]
         if noise is None:
             if randomize_noise:
-                noise = [None] * self.num_layers
+                noise = self._draw_noise(styles[0])
             else:
                 noise = [getattr(self.noises, "noise_%d" % i) for i in range(self.num_layers)]
         if truncation < 1 and truncation_latent is not None:
@@ -231,6 +231,24 @@ class Generator(nn.Module):
                 latent = torch.cat([styles[0].unsqueeze(1).repeat(1, inject_index, 1),
                                     styles[1].unsqueeze(1).repeat(1, self.n_latent - inject_index, 1)], 1)
         return latent, noise
+
+    def _draw_noise(self, like):
+        """Fresh per-sample noise maps for every layer (reference layers.py:328-332 draws one per NoiseInjection call):
+        on a device ONE normal_() launch over a flat buffer, the maps are views of it (layer i: [B, 1, 2^r, 2^r] with
+        r = (i + 5) // 2, i.e. 4, 8, 8, 16, 16, ...) — 13 launches less per forward at 256^2.  SR_NOISE_BANK=0, CPU
+        tensors, or a resolution the module was not built for: None per layer (each layer draws its own)."""
+        import os
+
+        if like.device.type != "cuda" or os.environ.get("SR_NOISE_BANK", "1") == "0":
+            return [None] * self.num_layers
+        b = like.shape[0]
+        sizes = [2 ** ((i + 5) // 2) for i in range(self.num_layers)]
+        flat = torch.empty(b * sum(r * r for r in sizes), device=like.device, dtype=torch.float32).normal_()
+        out, off = [], 0
+        for r in sizes:
+            out.append(flat[off:off + b * r * r].view(b, 1, r, r))
+            off += b * r * r
+        return out
 
     def _style_layers(self):
         """[(ModulatedConv2d, latent index)] in the order forward() calls them (reference model.py:172-186: conv1 0,
@@ -296,7 +314,8 @@ class GeneratorWithMap(Generator):
         latent, noise = self._latents(styles, inject_index, truncation, truncation_latent,
                                       input_is_latent, noise, randomize_noise)
         vert, attr, tri = mesh[0], mesh[1], mesh[2]
-        with _weight_bank.Scope(self):          # device tensors: every convolution weight prepared up front
+        # device tensors: every convolution weight and every merged layer bias prepared up front
+        with _weight_bank.Scope(self), BiasBank(self):
             return self._synthesis_with_maps(latent, noise, vert, attr, tri, return_normals, return_latents)
 
     def _synthesis_with_maps(self, latent, noise, vert, attr, tri, return_normals, return_latents):
@@ -360,7 +379,8 @@ class Discriminator(nn.Module):
             EqualLinear(channels[4], 1))
 
     def forward(self, input):
-        with _weight_bank.Scope(self):          # device tensors: every convolution weight prepared up front
+        # device tensors: every convolution weight and every merged layer bias prepared up front
+        with _weight_bank.Scope(self), BiasBank(self):
             return self._forward(input)
 
     def _forward(self, input):
