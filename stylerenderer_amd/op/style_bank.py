@@ -49,7 +49,10 @@ class _Stack0(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
-        return _Unbind0.apply(g)
+        # one re-layout of the stacked gradient when it arrives strided (the modulation weights are consumed transposed:
+        # their gradient is a transposed view, and AccumulateGrad would otherwise clone every layer's slice to meet the
+        # parameter's layout — 15 copies of 1 MB per backward at 256^2)
+        return _Unbind0.apply(g.contiguous())
 
 
 def stack0(ts):
