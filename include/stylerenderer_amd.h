@@ -124,11 +124,13 @@ int sr_adam_flat(float* p, const float* g, float* m, float* v, int64_t n, float 
                  float eps, const float* step, sr_stream_t stream);
 /* Guarded form for data-parallel training: `guard_offs` (host array, <= 16 entries, read at launch time) are positions
  * of `g` — the first element of every all-reduce bucket.  If any of them is NaN the kernel leaves p / m / v untouched
- * and stores 1 into `*skipped_host` (pinned host memory, may be NULL).  Together with sr_signal_wait_poison this
+ * stores 1 into `*skipped_host` (pinned host memory, may be NULL) and takes the caller's increment of `*step` back (a
+ * refused step does not advance the bias correction).  The guard samples only these positions: NaN elsewhere in `g` is
+ * not detected, and a gradient that is legitimately NaN at a guard position refuses the step as well.  Together with sr_signal_wait_poison this
  * turns a lost bucket signal on ONE rank into a refused optimiser step on EVERY rank (the SUM carries the NaN),
  * where torch DDP's reducer (reference distributed.py:98-105) would raise on the rank that lost it. */
 int sr_adam_flat_guarded(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
-                         float eps, const float* step, const int64_t* guard_offs, int n_guards,
+                         float eps, float* step, const int64_t* guard_offs, int n_guards,
                          int32_t* skipped_host, sr_stream_t stream);
 
 /* Row-wise dot products of two [rows, inner] tensors, optionally with a scaled copy in the same

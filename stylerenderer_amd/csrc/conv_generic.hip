@@ -21,10 +21,13 @@ struct GConv {
     int B, C, N, IH, IW, OH, OW, KH, KW, sy, sx, py, px;
 };
 
-// grid (pixel blocks, b * N + n): the weights of a workgroup are wave-uniform (scalar loads), lanes walk output columns
+// grid (pixel blocks, (b * N + n) folded over y and z): the weights of a workgroup are wave-uniform (scalar loads), lanes
+// walk output columns
 __global__ __launch_bounds__(256) void k_gconv_fwd(float* __restrict__ y, const float* __restrict__ x,
                                                    const float* __restrict__ w, const float* __restrict__ bias, GConv p) {
-    const int bn = blockIdx.y, b = bn / p.N, n = bn - b * p.N;
+    const int64_t bn64 = (int64_t)blockIdx.z * gridDim.y + blockIdx.y;
+    if (bn64 >= (int64_t)p.B * p.N) return;
+    const int bn = (int)bn64, b = bn / p.N, n = bn - b * p.N;
     const int64_t opix = (int64_t)p.OH * p.OW;
     const float* wn = w + (int64_t)n * p.C * p.KH * p.KW;
     const float* xb = x + (int64_t)b * p.C * p.IH * p.IW;
@@ -54,7 +57,9 @@ __global__ __launch_bounds__(256) void k_gconv_fwd(float* __restrict__ y, const 
 // oy * sy - py + ky == iy  and  ox * sx - px + kx == ix
 __global__ __launch_bounds__(256) void k_gconv_dgrad(float* __restrict__ dx, const float* __restrict__ g,
                                                      const float* __restrict__ w, GConv p) {
-    const int bc = blockIdx.y, b = bc / p.C, c = bc - b * p.C;
+    const int64_t bc64 = (int64_t)blockIdx.z * gridDim.y + blockIdx.y;
+    if (bc64 >= (int64_t)p.B * p.C) return;
+    const int bc = (int)bc64, b = bc / p.C, c = bc - b * p.C;
     const int64_t ipix = (int64_t)p.IH * p.IW, opix = (int64_t)p.OH * p.OW;
     const int taps = p.KH * p.KW;
     const float* gb = g + (int64_t)b * p.N * opix;
@@ -122,8 +127,15 @@ GConv make(int64_t B, int64_t C, int64_t N, int64_t IH, int64_t IW, int64_t OH, 
 }
 
 bool fits(int64_t B, int64_t C, int64_t N, int64_t IH, int64_t IW, int64_t OH, int64_t OW, int kh, int kw) {
-    return B * C < 65536 && B * N < 65536 && IH * IW < (1LL << 31) && OH * OW < (1LL << 31) && C < (1 << 24) &&
+    return B * C < (1LL << 31) && B * N < (1LL << 31) && IH * IW < (1LL << 31) && OH * OW < (1LL << 31) && C < (1 << 24) &&
            N < (1 << 24) && N * C * kh * kw < (1LL << 31);
+}
+
+// rows = b * channels of the output: folded over grid.y (<= 65535) and grid.z
+dim3 row_grid(int64_t pix, int64_t rows) {
+    const int64_t gx = sr_ceil_div(pix, 256) < 1024 ? sr_ceil_div(pix, 256) : 1024;
+    const int64_t gy = rows < 65535 ? rows : 65535;
+    return dim3((unsigned)gx, (unsigned)gy, (unsigned)sr_ceil_div(rows, gy));
 }
 
 }  // namespace
@@ -137,7 +149,7 @@ extern "C" int sr_conv2d_generic(float* y, const float* x, const float* w, const
     if (B == 0) return SR_OK;
     if (!y || !x || !w) return SR_EINVAL;
     const int64_t opix = OH * OW;
-    const dim3 grid((unsigned)(sr_ceil_div(opix, 256) < 1024 ? sr_ceil_div(opix, 256) : 1024), (unsigned)(B * N));
+    const dim3 grid = row_grid(opix, B * N);
     hipLaunchKernelGGL(k_gconv_fwd, grid, dim3(256), 0, sr_stream(stream), y, x, w, bias, p);
     return sr_launch_status();
 }
@@ -153,7 +165,7 @@ extern "C" int sr_conv2d_generic_dgrad(float* dx, const float* g, const float* w
     if (B == 0) return SR_OK;
     if (!dx || !g || !w) return SR_EINVAL;
     const int64_t ipix = IH * IW;
-    const dim3 grid((unsigned)(sr_ceil_div(ipix, 256) < 1024 ? sr_ceil_div(ipix, 256) : 1024), (unsigned)(B * C));
+    const dim3 grid = row_grid(ipix, B * C);
     hipLaunchKernelGGL(k_gconv_dgrad, grid, dim3(256), 0, sr_stream(stream), dx, g, w, p);
     return sr_launch_status();
 }

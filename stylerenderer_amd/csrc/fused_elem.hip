@@ -950,7 +950,7 @@ struct AdamGuards {
 __global__ __launch_bounds__(EB) void k_adam_flat(float* __restrict__ p, const float* __restrict__ g,
                                                   float* __restrict__ m, float* __restrict__ v, int64_t n4,
                                                   int64_t n, float lr, float b1, float b2, float eps,
-                                                  const float* __restrict__ step, AdamGuards guards, int* skipped) {
+                                                  float* __restrict__ step, AdamGuards guards, int* skipped) {
     if (guards.n) {
         bool bad = false;
         for (int i = 0; i < guards.n; ++i) {
@@ -958,8 +958,12 @@ __global__ __launch_bounds__(EB) void k_adam_flat(float* __restrict__ p, const f
             bad = bad || (x != x);
         }
         if (bad) {
-            if (skipped && blockIdx.x == 0 && threadIdx.x == 0)
-                __hip_atomic_store(skipped, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            // a refused step is no step: the caller advanced the counter in front of this launch, take that back.  Every
+            // workgroup sees the same `bad` (g is read-only here) and leaves before reading step[0]: no race.
+            if (blockIdx.x == 0 && threadIdx.x == 0) {
+                step[0] -= 1.0f;
+                if (skipped) __hip_atomic_store(skipped, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
             return;
         }
     }
@@ -1007,12 +1011,12 @@ extern "C" int sr_adam_flat(float* p, const float* g, float* m, float* v, int64_
     AdamGuards none;
     none.n = 0;
     hipLaunchKernelGGL(k_adam_flat, dim3(sr_stream_grid(n4 > 0 ? n4 : 1, EB)), dim3(EB), 0, sr_stream(stream), p, g, m, v,
-                       n4, n, lr, beta1, beta2, eps, step, none, (int*)nullptr);
+                       n4, n, lr, beta1, beta2, eps, const_cast<float*>(step), none, (int*)nullptr);
     return sr_launch_status();
 }
 
 extern "C" int sr_adam_flat_guarded(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
-                                    float beta2, float eps, const float* step, const int64_t* guard_offs, int n_guards,
+                                    float beta2, float eps, float* step, const int64_t* guard_offs, int n_guards,
                                     int32_t* skipped_host, sr_stream_t stream) {
     if (n < 0 || n_guards < 0 || n_guards > 16 || (n_guards > 0 && !guard_offs)) return SR_EINVAL;
     if (n == 0) return SR_OK;

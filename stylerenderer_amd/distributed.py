@@ -14,10 +14,13 @@ reference serialises the step:
     125 MB of generator gradients overlaps with the remaining backward (ring bound per bucket
     2*(N-1)/N * S / 153 GB/s on the 7-link xGMI mesh).
 """
+import logging
 import os
 
 import torch
 from torch import distributed as dist
+
+_log = logging.getLogger("stylerenderer_amd.distributed")
 
 
 def get_rank():
@@ -303,6 +306,8 @@ class BucketedGradReducer:
             else:
                 self.release_probe = self._queues_independent()
                 self.release = "device" if self.release_probe["independent"] else "host"
+            _log.info("BucketedGradReducer rank %d: %s-released buckets (%s)", get_rank(), self.release,
+                      "forced (release= / SR_GRAD_OVERLAP)" if self.release_probe is None else "queue probe %s" % self.release_probe)
             if self.release == "host":
                 self.counters = torch.zeros(len(self.buckets), dtype=torch.int32).pin_memory()
                 self._words = self.counters.numpy()        # the same pinned words, read without a tensor op
@@ -446,7 +451,10 @@ class BucketedGradReducer:
 
     def _host_wait(self, b):
         """Host-released mode: poll the bucket's pinned word until the replay's signal node has stored this epoch.
-        A signal that does not come within SR_SIGNAL_TIMEOUT_S raises HERE, before the collective is queued."""
+        A signal that does not come within SR_SIGNAL_TIMEOUT_S is handled like the device mode's expired wait (ADVICE r5:
+        raising HERE would leave the peers inside the collective until their RCCL timeout): the bucket's status word is
+        set, NaN goes into the bucket's guard position on the communication stream, and the collective is STILL queued
+        — it spreads the marker, every rank's guarded optimiser refuses the step and check() raises on every rank."""
         import time
 
         want = self.epoch & 0xFFFFFFFF
@@ -456,10 +464,14 @@ class BucketedGradReducer:
             spins += 1
             if spins & 0x3FF == 0:
                 if time.perf_counter() - t0 > self.timeout_us / 1e6:
-                    raise RuntimeError("BucketedGradReducer (host release): the signal of bucket %d (of %d) was not "
-                                       "published within %.0f s at epoch %d on rank %d — the replay that should produce "
-                                       "it did not run or did not finish; the bucket is NOT reduced" % (
-                                           b, len(self.buckets), self.timeout_us / 1e6, self.epoch, get_rank()))
+                    self.status[b] = b + 1
+                    lo = self.buckets[b]["lo"]
+                    with torch.cuda.stream(self.comm):
+                        self.flat[lo:lo + 1].fill_(float("nan"))
+                    _log.error("BucketedGradReducer (host release): the signal of bucket %d (of %d) was not published "
+                               "within %.0f s at epoch %d on rank %d; bucket poisoned, collective still issued",
+                               b, len(self.buckets), self.timeout_us / 1e6, self.epoch, get_rank())
+                    return
                 time.sleep(0)
 
     def finish(self):

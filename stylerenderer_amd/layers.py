@@ -109,6 +109,12 @@ def _const_rows(value, b, n, device):
     return hold_for_capture(hit)
 
 
+def _native_f32(input, weight):
+    """Device tensors take this library's kernels only as float32: they walk raw float pointers, so a .double() model, an
+    fp16 / bf16 or autocast input must never reach them (silent garbage / out-of-bounds reads)."""
+    return input.device.type == "cuda" and input.dtype == torch.float32 and weight.dtype == torch.float32
+
+
 class EqualConv2d(nn.Module):
     """Plain convolution with equalised learning rate (reference layers.py:204-221)."""
 
@@ -130,7 +136,7 @@ class EqualConv2d(nn.Module):
         (its per-(sample, channel) output scale) — ResBlock folds its 1/sqrt(2) in here instead of a separate pass."""
         geom = self._geom()
         bias = self.bias if with_bias else None
-        if input.device.type == "cuda" and geom is not None:
+        if _native_f32(input, self.weight) and geom is not None:
             wt, _ = _weight_prep_cached(self, self.weight, self.scale)
             osc = _const_rows(gain, input.shape[0], self.weight.shape[0], input.device) if gain is not None else None
             assert osc is None or bias is None
@@ -373,8 +379,13 @@ class ModulatedConv2d(nn.Module):
         return out.view(batch, self.out_channel, out.shape[2], out.shape[3])
 
     def forward(self, input, style, skip_blur=False):
-        if input.device.type == "cuda":
+        if _native_f32(input, self.weight):
             return self._forward_mfma(input, style, skip_blur)
+        if input.device.type == "cuda" and _strict_native():
+            raise RuntimeError("SR_STRICT_NATIVE: ModulatedConv2d on %s input / %s weight device tensors would run the "
+                               "grouped convolution on MIOpen (the HIP kernels are float32 only)"
+                               % (input.dtype, self.weight.dtype))
+        # CPU tensors, and device tensors of any other dtype (a .double() model, autocast): the reference's formulation
         return self._forward_grouped(input, style)
 
 
@@ -424,10 +435,15 @@ class BiasBank:
     def __enter__(self):
         if os.environ.get("SR_BIAS_BANK", "1") == "0":
             return self
-        plan = getattr(self.net, "_bias_plan", None)
-        if plan is None:
-            plan = [m for m in self.net.modules() if isinstance(m, ConvLayer) and m.merged_bias_pair() is not None]
-            self.net._bias_plan = plan
+        # the plan is keyed on the identity of the network's ConvLayers: a layer replaced, added or removed after the first
+        # forward rebuilds it (a stale plan silently dropped new layers back to the per-layer add)
+        layers = [m for m in self.net.modules() if isinstance(m, ConvLayer)]
+        key = tuple(id(m) for m in layers)
+        cached = getattr(self.net, "_bias_plan", None)
+        if cached is None or cached[0] != key:
+            cached = (key, [m for m in layers if m.merged_bias_pair() is not None])
+            object.__setattr__(self.net, "_bias_plan", cached)
+        plan = cached[1]
         pairs = [m.merged_bias_pair() for m in plan]
         live = [(m, p) for m, p in zip(plan, pairs) if p is not None and p[0].device.type == "cuda"
                 and p[0].dtype == torch.float32]

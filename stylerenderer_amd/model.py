@@ -241,13 +241,21 @@ class Generator(nn.Module):
 
         if like.device.type != "cuda" or os.environ.get("SR_NOISE_BANK", "1") == "0":
             return [None] * self.num_layers
+        # the map sizes come from the module itself — the registered noise buffers [1, 1, h, w] have exactly the shapes
+        # of the feature maps their layers see when the constant input is the 4 x 4 the module was built with; anything
+        # else (a replaced constant input, missing buffers) falls back to the per-layer draw, which sizes the noise from
+        # the image like the reference's NoiseInjection
+        const = self.input.input
+        shapes = [tuple(getattr(self.noises, "noise_%d" % i, torch.empty(0)).shape[-2:]) for i in range(self.num_layers)]
+        if (tuple(const.shape[-2:]) != (4, 4) or const.dtype != torch.float32 or any(len(sh) != 2 for sh in shapes)
+                or shapes[0] != (4, 4)):
+            return [None] * self.num_layers
         b = like.shape[0]
-        sizes = [2 ** ((i + 5) // 2) for i in range(self.num_layers)]
-        flat = torch.empty(b * sum(r * r for r in sizes), device=like.device, dtype=torch.float32).normal_()
+        flat = torch.empty(b * sum(h * w for h, w in shapes), device=like.device, dtype=torch.float32).normal_()
         out, off = [], 0
-        for r in sizes:
-            out.append(flat[off:off + b * r * r].view(b, 1, r, r))
-            off += b * r * r
+        for h, w in shapes:
+            out.append(flat[off:off + b * h * w].view(b, 1, h, w))
+            off += b * h * w
         return out
 
     def _style_layers(self):

@@ -27,6 +27,21 @@ def supported(x, w):
             and w.dim() == 4)
 
 
+def _check(what, *tensors):
+    """The kernels walk raw float32 device pointers: anything else (a .double() model, fp16 / bf16 or autocast inputs,
+    mixed devices) raises here instead of reading half- or double-sized buffers as float32."""
+    dev = None
+    for t in tensors:
+        if t is None:
+            continue
+        if t.device.type != "cuda" or t.dtype != torch.float32:
+            raise RuntimeError("%s: float32 device tensors required, got %s on %s" % (what, t.dtype, t.device))
+        if dev is None:
+            dev = t.device
+        elif t.device != dev:
+            raise RuntimeError("%s: tensors on different devices (%s, %s)" % (what, dev, t.device))
+
+
 def _geom(x_shape, w_shape, stride, padding):
     b, c, ih, iw = x_shape
     n, c2, kh, kw = w_shape
@@ -43,7 +58,9 @@ def _geom(x_shape, w_shape, stride, padding):
 
 def _fwd(x, w, bias, geo):
     b, c, n, ih, iw, oh, ow = geo[:7]
+    _check("conv2d_generic", x, w, bias)
     x, w = x.contiguous(), w.contiguous()
+    bias = bias.contiguous() if bias is not None else None
     y = torch.empty((b, n, oh, ow), dtype=x.dtype, device=x.device)
     with on_device_of(x):
         rc = _lib.lib().sr_conv2d_generic(_lib.ptr(y), _lib.ptr(x), _lib.ptr(w), _lib.ptr(bias), *geo, stream_of(x))
@@ -53,6 +70,7 @@ def _fwd(x, w, bias, geo):
 
 def _dgrad(g, w, geo):
     b, c, n, ih, iw = geo[:5]
+    _check("conv2d_generic_dgrad", g, w)
     g, w = g.contiguous(), w.contiguous()
     dx = torch.empty((b, c, ih, iw), dtype=g.dtype, device=g.device)
     with on_device_of(g):
@@ -64,6 +82,7 @@ def _dgrad(g, w, geo):
 def _wgrad(x, g, geo):
     b, c, n = geo[:3]
     kh, kw = geo[7], geo[8]
+    _check("conv2d_generic_wgrad", x, g)
     x, g = x.contiguous(), g.contiguous()
     dw = torch.empty((n, c, kh, kw), dtype=x.dtype, device=x.device)
     with on_device_of(x):

@@ -60,7 +60,9 @@ class FlatAdam:
         A step whose gradient carries NaN at one of them is REFUSED on the device (p / m / v untouched) and
         `self.skipped` (pinned host word) is raised — see sr_adam_flat_guarded and distributed.BucketedGradReducer:
         a bucket signal lost on one rank becomes a refused step on every rank instead of an update with a half-written
-        gradient."""
+        gradient.  A refused step does not advance the step count either.  NaN semantics: ONLY these positions are
+        sampled — NaN elsewhere in the buffer is not detected, and a gradient that is legitimately NaN at a guard position
+        refuses the step too (training on NaN gradients is lost anyway)."""
         import ctypes
 
         offsets = [int(o) for o in offsets]
@@ -75,12 +77,14 @@ class FlatAdam:
 
     def step(self):
         g = self.param_groups[0]
-        self.step_t.add_(1.0)
         if self.flat_p.device.type != "cuda":
             if self.guards is not None and bool(torch.isnan(self.flat_g[list(self.guards)]).any()):
-                self.skipped.fill_(1)
+                self.skipped.fill_(1)          # refused: p / m / v AND the step count stay as they were
                 return
+            self.step_t.add_(1.0)
             return self._step_host(g)
+        # (device: the guarded kernel takes this increment back when it refuses the step)
+        self.step_t.add_(1.0)
         if self.guards is not None:
             rc = _lib.lib().sr_adam_flat_guarded(self.flat_p.data_ptr(), self.flat_g.data_ptr(), self.m.data_ptr(),
                                                  self.v.data_ptr(), self.total, g["lr"], g["betas"][0], g["betas"][1],

@@ -179,6 +179,31 @@ def test_lost_signal_times_out_and_raises(monkeypatch):
     red.check()
 
 
+def test_host_release_lost_signal_poisons_and_still_issues_the_collective(monkeypatch, one_rank_group):
+    """in host-released mode a lost bucket signal must not raise BEFORE the collective is queued (the peers
+    would sit in the all-reduce): the bucket's guard position gets NaN, the collective runs, the status word is set and
+    check() raises afterwards — the same chain as the device mode's expired wait."""
+    from stylerenderer_amd import distributed as sr_dist
+
+    monkeypatch.setenv("SR_SIGNAL_TIMEOUT_S", "0.2")
+    ps = [torch.nn.Parameter(torch.zeros(64, device=DEV)) for _ in range(4)]
+    flat = torch.ones(4 * 64, device=DEV)
+    views = [flat[i * 64:(i + 1) * 64] for i in range(4)]
+    red = sr_dist.BucketedGradReducer(ps, views, [0, 64, 128, 192], flat, world=1, n_buckets=2, force=True,
+                                      release="host")
+    assert red.release == "host"
+    red.arm()                              # epoch 1 announced, but no replay publishes it
+    red.issue_all()                        # returns (does not raise): both buckets time out, are poisoned, and reduced
+    torch.cuda.synchronize()
+    lo = [b["lo"] for b in red.buckets]
+    got = flat.cpu()
+    assert all(torch.isnan(got[i]) for i in lo), got[lo]
+    assert torch.isfinite(got).sum().item() == got.numel() - len(lo)
+    with pytest.raises(RuntimeError, match=r"bucket\(s\) \[0, 1\]"):
+        red.check()
+    assert not red.status.any()
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -245,7 +270,7 @@ def test_timed_out_wait_poisons_the_bucket_and_the_guarded_step_is_refused(one_r
     opt.step()                                         # a clean gradient: applied
     torch.cuda.synchronize()
     red.check()
-    p1, m1 = opt.flat_p.clone(), opt.m.clone()
+    p1, m1, t1 = opt.flat_p.clone(), opt.m.clone(), float(opt.step_t)
     red.arm()                                          # epoch 1 announced, but nothing publishes it
     red._issue(1, replay=True)                         # wait (times out) + all-reduce of bucket 1 on the comm stream
     red.wait()
@@ -253,6 +278,7 @@ def test_timed_out_wait_poisons_the_bucket_and_the_guarded_step_is_refused(one_r
     torch.cuda.synchronize()
     assert torch.isnan(flat[red.buckets[1]["lo"]]) and torch.isfinite(flat[:red.buckets[1]["lo"]]).all()
     assert torch.equal(opt.flat_p, p1) and torch.equal(opt.m, m1)          # the step was refused on the device
+    assert float(opt.step_t) == t1                                         # ... and did not advance the step count
     with pytest.raises(RuntimeError, match=r"REFUSED.*bucket\(s\) \[1\] timed out"):
         red.check()
     red.check()                                        # reported once
