@@ -179,7 +179,7 @@ def grad_digest(named_grads):
     return names, norms, heads.astype(np.float32)
 
 
-def grad_samples(named_grads, per_tensor=256):
+def grad_samples(named_grads, per_tensor=256, dtype=np.float32):
     """Evenly spaced entries of EVERY gradient tensor (all of it when it has <= per_tensor elements): pins whole
     tensors, not only their norm and first entries.  Returns (flat values, offsets [n+1]); the test rebuilds the
     indices with sample_index()."""
@@ -188,7 +188,7 @@ def grad_samples(named_grads, per_tensor=256):
         g = named_grads[n].detach().reshape(-1).numpy()
         vals.append(g[synth.sample_index(g.size, per_tensor)])
         offs.append(offs[-1] + vals[-1].size)
-    return np.concatenate(vals).astype(np.float32), np.asarray(offs, np.int64)
+    return np.concatenate(vals).astype(dtype), np.asarray(offs, np.int64)
 
 
 # ------------------------------------------------------------------------------- LeakyReLU kink records
@@ -248,6 +248,58 @@ class KinkRecorder:
         print("   kink records: %d layers, %d flagged of %d outputs" % (
             len(keys), sum(len(self.rec[k][0]) for k in keys), sum(int(np.prod(self.rec[k][3])) for k in keys)))
         return out
+
+
+class KinkPinned:
+    """Context for a FLOAT64 run of a reference network under the sign pattern its float32 run recorded
+    (KinkRecorder.rec): inside the context the reference's CPU `fused_leaky_relu` (op/fused_act.py:87-94, as bound in
+    op.fused_act and in layers) puts every flagged pre-activation that lands on the other side of the kink on the
+    recorded side (value +-1e-30, derivative w.r.t. the input kept) — so the float64 result is the EXACT value of the
+    piecewise-linear function the float32 reference evaluated, not of a neighbouring linear piece."""
+
+    def __init__(self, net, ns, rec):
+        self.ns, self.rec, self.key, self.hooks, self.forced = ns, rec, None, [], 0
+        for name, m in net.named_modules():
+            if isinstance(m, ns.op.FusedLeakyReLU):
+                key = name.rsplit(".", 1)[0]
+            elif isinstance(m, ns.layers.EqualLinear) and m.activation == "fused_lrelu":
+                key = name
+            else:
+                continue
+            self.hooks.append(m.register_forward_pre_hook(lambda mod, inp, key=key: setattr(self, "key", key)))
+
+    def __enter__(self):
+        self.mods = [sys.modules[self.ns.op.FusedLeakyReLU.__module__], self.ns.layers]
+        self.orig = [m.fused_leaky_relu for m in self.mods]
+        F = torch.nn.functional
+
+        def pinned(input, bias, negative_slope=0.2, scale=2 ** 0.5):
+            key, self.key = self.key, None
+            assert input.device.type == "cpu" and key in self.rec, key
+            idx, pos = self.rec[key][0], self.rec[key][1]
+            pre = input + bias.view(1, bias.shape[0], *([1] * (input.dim() - 2)))
+            idx_t = torch.from_numpy(idx.astype(np.int64))
+            pos_t = torch.from_numpy(pos)
+            dis = (pre.detach().reshape(-1)[idx_t] > 0) != pos_t
+            if bool(dis.any()):
+                self.forced += int(dis.sum())
+                force = torch.zeros(pre.numel(), dtype=torch.bool)
+                target = torch.zeros(pre.numel(), dtype=pre.dtype)
+                force[idx_t[dis]] = True
+                target[idx_t[dis]] = torch.where(pos_t[dis], 1e-30, -1e-30).to(pre.dtype)
+                pre = torch.where(force.view_as(pre), target.view_as(pre) + (pre - pre.detach()), pre)
+            return F.leaky_relu(pre, negative_slope=0.2) * scale
+
+        for m in self.mods:
+            m.fused_leaky_relu = pinned
+        return self
+
+    def __exit__(self, *exc):
+        for m, f in zip(self.mods, self.orig):
+            m.fused_leaky_relu = f
+        for h in self.hooks:
+            h.remove()
+        return False
 
 
 def gold_generator(ns):
@@ -382,45 +434,188 @@ def gold_discriminator(ns):
          n_params=np.array(sum(p.numel() for p in d.parameters())))
 
 
-def _disc_case(ns, size, batch=4, sub=1):
+def _disc_case(ns, size, batch=4, sub=1, truth=False):
     """Discriminator(size) of the reference (model.py:296-336) at a size where the product runs its big kernels:
     shared-weight Winograd 3x3 convolutions, the 3x3 stride-2 convolution after Blur pad (2, 2), the decimating FIR +
     1x1 skip, minibatch-stddev.  Logits; first-order gradients of <logits, 1> w.r.t. every parameter (256 samples
     each) and the input (every `sub`-th pixel); ONE R1 evaluation the way the step weights it (reference
     train.py:110-114, 281-289: d_r1_loss -> (r1 / 2 * R1 * d_reg_every + 0 * pred[0]).backward()) with its
-    double-backward parameter gradients; and the kink records of every LeakyReLU (KinkRecorder)."""
+    double-backward parameter gradients; and the kink records of every LeakyReLU (KinkRecorder).
+    truth=True: the same sampled gradients from the reference run in FLOAT64 (`*_f64`).  The R1 gradients of the
+    biases are sums of ~1e6 cancelling second-order terms (a piecewise-linear network's input gradient depends on a
+    bias only through the minibatch-stddev layer): the reference's own float32 result is 1e-4 .. 7e-4 of the tensor's
+    scale away from the float64 value there, so a test of a second float32 implementation needs the exact value to
+    measure against (tests/util.check_grad_samples `truth=`)."""
     fn = _reference_train_functions()
-    d = ns.model.Discriminator(size)
-    synth.fill_state_dict(d.state_dict(), salt=61)
-    x = T(dn((batch, 3, size, size), 62 + size)).requires_grad_()
-    kinks = KinkRecorder(d, ns)
-    y = d(x)
-    kinks.close()
-    arrays = {"y": y.detach().numpy(), "n_params": np.array(sum(p.numel() for p in d.parameters())),
-              "sub": np.array(sub)}
-    arrays.update(kinks.arrays())
-    named = dict(d.named_parameters())
-    grads = torch.autograd.grad(y.sum(), list(named.values()) + [x], retain_graph=True)
-    gd = {n: gr for n, gr in zip(named, grads[:-1])}
-    arrays["grad_names"] = np.array(sorted(gd))
-    arrays["grad_samples"], arrays["grad_sample_offsets"] = grad_samples(gd)
-    arrays["gx"] = grads[-1].numpy()[:, :, ::sub, ::sub].copy()
-    # R1: second forward, as the step does (train.py:281-284)
-    xr = x.detach().clone().requires_grad_(True)
-    pred = d(xr)
-    r1 = fn["d_r1_loss"](pred, xr)
-    d.zero_grad()
-    (10.0 / 2 * r1 * 16 + 0 * pred[0]).backward()
-    arrays["r1"] = r1.detach().numpy()
-    g2 = {n: p.grad.clone() for n, p in d.named_parameters() if p.grad is not None}
-    arrays["r1_grad_names"] = np.array(sorted(g2))
-    arrays["r1_grad_samples"], arrays["r1_grad_sample_offsets"] = grad_samples(g2)
+
+    def run(dtype, record, rec=None):
+        d = ns.model.Discriminator(size)
+        synth.fill_state_dict(d.state_dict(), salt=61)
+        d = d.to(dtype)
+        x = T(dn((batch, 3, size, size), 62 + size)).to(dtype).requires_grad_()
+        if not record:
+            with KinkPinned(d, ns, rec) as pin:
+                out = body(d, x, None)
+            print("   float64 run under the float32 sign pattern: %d pre-activations pinned" % pin.forced)
+            return out
+        return body(d, x, KinkRecorder(d, ns))
+
+    def body(d, x, kinks):
+        y = d(x)
+        out = {}
+        if kinks is not None:
+            kinks.close()
+            out["y"] = y.detach().numpy()
+            out["rec"] = kinks.rec
+            out.update(kinks.arrays())
+        named = dict(d.named_parameters())
+        grads = torch.autograd.grad(y.sum(), list(named.values()) + [x], retain_graph=True)
+        out["gd"] = {n: gr for n, gr in zip(named, grads[:-1])}
+        out["gx"] = grads[-1].numpy()[:, :, ::sub, ::sub].copy()
+        # R1: second forward, as the step does (train.py:281-284)
+        xr = x.detach().clone().requires_grad_(True)
+        pred = d(xr)
+        r1 = fn["d_r1_loss"](pred, xr)
+        d.zero_grad()
+        (10.0 / 2 * r1 * 16 + 0 * pred[0]).backward()
+        out["r1"] = r1.detach().numpy()
+        out["g2"] = {n: p.grad.clone() for n, p in d.named_parameters() if p.grad is not None}
+        out["n_params"] = sum(p.numel() for p in d.parameters())
+        return out
+
+    r = run(torch.float32, True)
+    arrays = {k: v for k, v in r.items() if k not in ("gd", "g2", "gx", "r1", "n_params", "rec")}
+    arrays.update({"n_params": np.array(r["n_params"]), "sub": np.array(sub), "gx": r["gx"], "r1": r["r1"]})
+    arrays["grad_names"] = np.array(sorted(r["gd"]))
+    arrays["grad_samples"], arrays["grad_sample_offsets"] = grad_samples(r["gd"])
+    arrays["r1_grad_names"] = np.array(sorted(r["g2"]))
+    arrays["r1_grad_samples"], arrays["r1_grad_sample_offsets"] = grad_samples(r["g2"])
+    if truth:
+        t = run(torch.float64, False, r["rec"])
+        arrays["grad_samples_f64"] = grad_samples(t["gd"], dtype=np.float64)[0]
+        arrays["r1_grad_samples_f64"] = grad_samples(t["g2"], dtype=np.float64)[0]
+        arrays["r1_f64"] = t["r1"]
     save("discriminator_s%d" % size, **arrays)
 
 
 def gold_discriminator_big(ns):
     _disc_case(ns, 64, sub=2)
     _disc_case(ns, 128, sub=4)
+
+
+def _sub_map(a, cap=64):
+    """Every k-th pixel of a [.., h, w] map so that at most cap x cap remain (k = 1 for small maps)."""
+    k = max(1, a.shape[-1] // cap)
+    return np.ascontiguousarray(a[..., ::k, ::k]), k
+
+
+def gold_generator_with_map_256(ns):
+    """GeneratorWithMap(256, 512, 8) — the network BASELINE config[2] trains and config[4] inverts — at the size the
+    benchmark times it (reference model.py:224-295), batch 1, on the face-sized mesh of bench.py
+    (synth.face_sized_mesh: 24 770 vertices / 49 536 triangles, rebuilt from integers by the test, not stored):
+    image (every 4th pixel), the 7 rasterised normal maps (<= 64 x 64 samples each), first-order gradients of a fixed
+    linear functional w.r.t. every parameter (256 samples per tensor) and the mesh (vertex gradients IN FULL), ONE
+    g_path_regularize evaluation over [latents] + normal maps as the step calls it (train.py:118-134, 340-347) with its
+    double-backward gradients, and the kink records of every LeakyReLU (KinkRecorder; StyledMapConv tails and the
+    norm_to_style ConvLayers included)."""
+    fn = _reference_train_functions(reshape_grads=True)
+    size, sdim, nmlp, salt, zkey, nkey = 256, 512, 8, 57, 71, 6100
+    v0, tri = synth.face_sized_mesh()
+    v = synth.random_poses(v0, 1, seed=9)
+    nrm = synth.vertex_normals(v, tri)
+
+    def run(dtype, rec=None):
+        g = ns.model.GeneratorWithMap(size, sdim, nmlp)
+        synth.fill_state_dict(g.state_dict(), salt=salt)
+        g = g.to(dtype)
+        z = T(dn((1, sdim), zkey)).to(dtype)
+        noise = [x.to(dtype) for x in _noise_list(g, nkey)]
+        tv, tn = T(v).to(dtype).requires_grad_(), T(nrm).to(dtype).requires_grad_()
+        if rec is None:
+            kinks = KinkRecorder(g, ns)
+            out = body(g, z, noise, tv, tn, dtype)
+            kinks.close()
+            out["rec"], out["kink_arrays"] = kinks.rec, kinks.arrays()
+            return out
+        # the float64 run takes the float32 run's rasterised normal maps (a float64 rasterisation covers a few
+        # silhouette pixels differently — another function, not a more exact value of the same one)
+        by_res = {m.shape[-1]: m for m in maps32}
+        real_rasterize = ns.model.rasterize
+        ns.model.rasterize = lambda v_, t_, f_, h_, w_=0, *a, **k: \
+            T(by_res[int(h_)]).permute(0, 2, 3, 1).contiguous().to(dtype).requires_grad_()
+        try:
+            with KinkPinned(g, ns, rec) as pin:
+                out = body(g, z, noise, tv, tn, dtype, mesh_grads=False)
+        finally:
+            ns.model.rasterize = real_rasterize
+        print("   float64 run under the float32 sign pattern: %d pre-activations pinned" % pin.forced)
+        return out
+
+    def body(g, z, noise, tv, tn, dtype, mesh_grads=True):
+        img, lat, maps = g([z], (tv, tn, T(tri)), return_normals=True, return_latents=True, noise=noise)
+        out = {"img": img.detach().numpy(), "lat": lat.detach().numpy(), "maps": [m.detach().numpy() for m in maps],
+               "n_params": sum(p.numel() for p in g.parameters())}
+        proj = T(dn(tuple(img.shape), zkey + 4)).to(dtype)
+        named = dict(g.named_parameters())
+        grads = torch.autograd.grad((img * proj).sum(), list(named.values()) + [tv, tn], allow_unused=True,
+                                    retain_graph=True)
+        out["gd"] = {n: gr for n, gr in zip(named, grads[:-2]) if gr is not None}
+        out["unused"] = sorted(n for n, gr in zip(named, grads[:-2]) if gr is None)
+        if mesh_grads:
+            out["grad_v"], out["grad_nrm"] = grads[-2].numpy(), grads[-1].numpy()
+        torch.manual_seed(321)
+        probe = torch.randn(tuple(img.shape))             # what g_path_regularize's randn_like draws under this seed
+        out["probe_digest"] = np.array([float(probe.double().sum()), float(probe.double().abs().sum())])
+        # the reference draws the probe inside (train.py:120: torch.randn_like): float32 draw for both runs
+        real_randn_like = torch.randn_like
+        torch.randn_like = lambda t, **kw: probe.to(t.dtype)
+        try:
+            pen, mean, lengths = fn["g_path_regularize"](img, [lat] + maps, torch.tensor(0.25, dtype=dtype))
+        finally:
+            torch.randn_like = real_randn_like
+        g.zero_grad()
+        tv.grad = tn.grad = None
+        (2.0 * 4 * pen + 0 * img[0, 0, 0, 0]).backward()
+        out["pen"], out["mean"], out["lengths"] = pen.detach().numpy(), mean.numpy(), lengths.detach().numpy()
+        out["gg"] = {n: p.grad.clone() for n, p in g.named_parameters() if p.grad is not None}
+        if mesh_grads:
+            out["pl_grad_v"], out["pl_grad_nrm"] = tv.grad.numpy(), tn.grad.numpy()
+        return out
+
+    maps32 = None
+    r = run(torch.float32)
+    maps32 = r["maps"]
+    arrays = {"image": np.ascontiguousarray(r["img"][:, :, ::4, ::4]), "latent": r["lat"],
+              "mesh_digest": np.array([float(np.abs(v).sum()), float(np.abs(nrm).sum()), float(tri.sum())], np.float64),
+              "n_params": np.array(r["n_params"])}
+    arrays.update(r["kink_arrays"])
+    for i, m in enumerate(r["maps"]):
+        arrays["normmap_%d" % i], k = _sub_map(m)
+        arrays["normmap_step_%d" % i] = np.array(k)
+    arrays["unused"] = np.array(r["unused"])
+    arrays["grad_names"] = np.array(sorted(r["gd"]))
+    arrays["grad_samples"], arrays["grad_sample_offsets"] = grad_samples(r["gd"])
+    arrays["grad_v"], arrays["grad_nrm"] = r["grad_v"], r["grad_nrm"]
+    arrays["pl_probe_seed"] = np.array(321)
+    arrays["pl_probe_digest"] = r["probe_digest"]
+    # (the probe itself is not stored: the test redraws it from torch's CPU generator under the same seed and checks
+    # the digest)
+    arrays["pl_penalty"], arrays["pl_mean"], arrays["pl_lengths"] = r["pen"], r["mean"], r["lengths"]
+    arrays["pl_grad_names"] = np.array(sorted(r["gg"]))
+    arrays["pl_grad_samples"], arrays["pl_grad_sample_offsets"] = grad_samples(r["gg"])
+    arrays["pl_grad_v"], arrays["pl_grad_nrm"] = r["pl_grad_v"], r["pl_grad_nrm"]
+    # float64 truth of the sampled parameter gradients under the float32 sign pattern (see _disc_case)
+    t = run(torch.float64, r["rec"])
+    assert sorted(t["gd"]) == sorted(r["gd"]) and sorted(t["gg"]) == sorted(r["gg"])
+    arrays["grad_samples_f64"] = grad_samples(t["gd"], dtype=np.float64)[0]
+    arrays["pl_grad_samples_f64"] = grad_samples(t["gg"], dtype=np.float64)[0]
+    save("generator_map_s256", **arrays)
+
+
+def gold_discriminator_256(ns):
+    """Discriminator(256), batch 4 (= the per-GPU batch of BASELINE config[2]): the 3 -> 128 1x1 at 256^2, the first
+    128-channel Winograd pair and the 257^2 blur are reached only at this size."""
+    _disc_case(ns, 256, sub=8, truth=True)
 
 
 def gold_generator_256(ns):
@@ -861,9 +1056,9 @@ def main():
     os.makedirs(OUT, exist_ok=True)
     ns = ref_shim.load()
     torch.manual_seed(0)
-    which = sys.argv[1:] or ["fused", "ufd", "modconv", "convgeneric", "gen", "gen256", "gen256b16", "gwm", "disc", "discbig", "train", "raster", "mesh", "lpips", "contract"]
+    which = sys.argv[1:] or ["fused", "ufd", "modconv", "convgeneric", "gen", "gen256", "gen256b16", "gwm", "gwm256", "disc", "discbig", "disc256", "train", "raster", "mesh", "lpips", "contract"]
     table = {"fused": gold_fused_act, "ufd": gold_upfirdn2d, "modconv": gold_modconv, "convgeneric": gold_conv_generic,
-             "gen": gold_generator, "gen256": gold_generator_256, "gen256b16": gold_generator_256_b16, "gwm": gold_generator_with_map,
+             "gen": gold_generator, "gen256": gold_generator_256, "gen256b16": gold_generator_256_b16, "gwm": gold_generator_with_map, "gwm256": gold_generator_with_map_256, "disc256": gold_discriminator_256,
              "disc": gold_discriminator, "discbig": gold_discriminator_big, "train": gold_train_step, "raster": gold_raster, "mesh": gold_mesh, "lpips": gold_lpips,
              "contract": gold_state_dict_contract}
     with torch.no_grad():

@@ -1086,7 +1086,7 @@ extern "C" int64_t sr_conv2d_scratch_floats(int64_t B, int64_t C, int64_t N, int
     };
     if (!transposed) {
         consider(OH, OW);
-        if (ksize == 3 && stride == 2 && pad == 0 && sr_wgrad_bf16x3_enabled() &&
+        if (ksize == 3 && stride == 2 && pad == 0 && sr_wgrad_bf16x3_enabled('c') &&
             sr_conv_s2_bf16x3_eligible(B, C, N, IH, IW, OH, OW)) {
             const int64_t w = sr_conv_s2_bf16x3_scratch_floats(C, N);
             need = need > w ? need : w;
@@ -1110,7 +1110,7 @@ extern "C" int64_t sr_conv2d_scratch_floats(int64_t B, int64_t C, int64_t N, int
             need = need > w ? need : w;
             need = need > f ? need : f;
         }
-        if (ksize == 3 && stride == 2 && pad == 0 && sr_wgrad_bf16x3_enabled() && sr_convt_bf16x3_eligible(B, C, N, IH, IW)) {
+        if (ksize == 3 && stride == 2 && pad == 0 && sr_wgrad_bf16x3_enabled('t') && sr_convt_bf16x3_eligible(B, C, N, IH, IW)) {
             const int64_t w = sr_convt_bf16x3_scratch_floats(C, N);
             need = need > w ? need : w;
         }
@@ -1161,7 +1161,7 @@ extern "C" int sr_conv2d_mfma_ex(float* out, const float* in, const float* wt, c
             sr_wino_eligible(B, C, N, IH, IW, in, out))
             return sr_wino_conv3x3(out, in, wt, wt_ld, iscale, oscale, obias, B, C, N, IH, IW, scratch, st, nullptr,
                                    (flags & SR_CONV_U_READY) != 0);
-        if (ksize == 3 && stride == 2 && pad == 0 && scratch && sr_wgrad_bf16x3_enabled() &&
+        if (ksize == 3 && stride == 2 && pad == 0 && scratch && sr_wgrad_bf16x3_enabled('c') &&
             sr_conv_s2_bf16x3_eligible(B, C, N, IH, IW, OH, OW))
             // opt-in spike (SR_CONV_SPLIT_BF16=1): split-bf16 matrix path for the down-sampling convolution and the
             // data gradient of the up-sampling one
@@ -1184,7 +1184,7 @@ extern "C" int sr_conv2d_mfma_ex(float* out, const float* in, const float* wt, c
     // per-phase launches
     // small problems: nine shifted 1x1 convolutions in one launch + one reduction (k_conv_mfma<..., TAP9>)
     if (scratch && convt_taps_wanted(B, C, N, IH, IW) && convt_taps_floats(B, C, N, IH, IW) <= p.partial_floats &&
-        !(sr_wgrad_bf16x3_enabled() && sr_convt_bf16x3_eligible(B, C, N, IH, IW)))
+        !(sr_wgrad_bf16x3_enabled('t') && sr_convt_bf16x3_eligible(B, C, N, IH, IW)))
         return launch_convt_taps(p, st);
     bool fused_ok = false;
     {
@@ -1206,7 +1206,7 @@ extern "C" int sr_conv2d_mfma_ex(float* out, const float* in, const float* wt, c
                 fused_pays = true;
             }
         }
-        if (scratch && sr_wgrad_bf16x3_enabled() && sr_convt_bf16x3_eligible(B, C, N, IH, IW)) {
+        if (scratch && sr_wgrad_bf16x3_enabled('t') && sr_convt_bf16x3_eligible(B, C, N, IH, IW)) {
             // opt-in spike (SR_CONV_SPLIT_BF16=1): the interior of the map on the bf16 matrix cores (three-way operand
             // split); the border strips below stay on the exact-fp32 kernels
             const int rc = sr_convt_bf16x3_launch(out, in, wt, wt_ld, iscale, oscale, obias, B, C, N, IH, IW, scratch, st);

@@ -5,7 +5,7 @@
 
 #include <cstdlib>
 
-bool sr_wgrad_bf16x3_enabled();
+bool sr_wgrad_bf16x3_enabled(char kind);   // kind: 'w' 'g' 'c' 't', see the definition
 bool sr_wgrad_bf16x3_eligible(int64_t B, int64_t CU, int64_t CV, int64_t HW, const void* u, const void* v);
 int64_t sr_wgrad_bf16x3_scratch_floats(int64_t B, int64_t CU, int64_t CV, int64_t HW);
 int sr_wgrad_bf16x3_launch(const float* U, const float* V, const float* uscale, const float* vscale, float* partial,

@@ -416,9 +416,15 @@ __global__ __launch_bounds__(512) void k_wgrad_s2_bf16x3(const P9 p) {
 
 }  // namespace
 
-bool sr_wgrad_bf16x3_enabled() {
+// SR_CONV_SPLIT_BF16=1: all four kernel families; or a subset by letter (probes: which family moves a result):
+//   w  1x1 weight gradient    g  stride-2 3x3 weight gradient    c  stride-2 3x3 convolution    t  its transposed form
+bool sr_wgrad_bf16x3_enabled(char kind) {
     const char* e = std::getenv("SR_CONV_SPLIT_BF16");
-    return e && e[0] == '1';
+    if (!e || !e[0] || e[0] == '0') return false;
+    if (e[0] == '1') return true;
+    for (; *e; ++e)
+        if (*e == kind) return true;
+    return false;
 }
 
 bool sr_wgrad_bf16x3_eligible(int64_t B, int64_t CU, int64_t CV, int64_t HW, const void* u, const void* v) {

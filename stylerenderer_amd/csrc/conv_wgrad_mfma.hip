@@ -598,11 +598,11 @@ extern "C" int64_t sr_conv2d_wgrad_scratch_floats(int64_t B, int64_t C, int64_t 
         const int64_t w = sr_wgrad_wino_scratch_floats(B, C, N, IH, IW);
         need = need > w ? need : w;
     }
-    if (!transposed && ksize == 1 && stride == 1 && sr_wgrad_bf16x3_enabled()) {
+    if (!transposed && ksize == 1 && stride == 1 && sr_wgrad_bf16x3_enabled('w')) {
         const int64_t w = sr_wgrad_bf16x3_scratch_floats(B, C, N, IH * IW);
         need = need > w ? need : w;
     }
-    if (ksize == 3 && stride == 2 && sr_wgrad_bf16x3_enabled()) {
+    if (ksize == 3 && stride == 2 && sr_wgrad_bf16x3_enabled('g')) {
         const int64_t w = sr_wgrad_s2_bf16x3_scratch_floats(B, CUc, CVc, GH, GW);
         need = need > w ? need : w;
     }
@@ -622,7 +622,7 @@ extern "C" int sr_conv2d_wgrad_mfma(float* dwt, const float* x, const float* gy,
     if (!transposed && ksize == 3 && stride == 1 && pad == 1 && wgrad_wino_enabled() &&
         sr_wgrad_wino_eligible(B, C, N, IH, IW, x, gy))
         return sr_wgrad_wino_3x3(dwt, x, gy, xscale, gscale, B, C, N, IH, IW, scratch, st);
-    if (!transposed && ksize == 1 && stride == 1 && pad == 0 && B > 0 && sr_wgrad_bf16x3_enabled() &&
+    if (!transposed && ksize == 1 && stride == 1 && pad == 0 && B > 0 && sr_wgrad_bf16x3_enabled('w') &&
         sr_wgrad_bf16x3_eligible(B, C, N, IH * IW, x, gy)) {
         // opt-in spike (SR_CONV_SPLIT_BF16=1): split-bf16 matrix path, same partial-slab layout and reduce
         int ks3 = 0, UP3 = 0, VP3 = 0;
@@ -637,7 +637,7 @@ extern "C" int sr_conv2d_wgrad_mfma(float* dwt, const float* x, const float* gy,
         hipLaunchKernelGGL(k_wgrad_reduce, dim3(sr_stream_grid(total, 256)), dim3(256), 0, st, r);
         return sr_launch_status();
     }
-    if (ksize == 3 && is == 2 && pad == 0 && sr_wgrad_bf16x3_enabled() &&
+    if (ksize == 3 && is == 2 && pad == 0 && sr_wgrad_bf16x3_enabled('g') &&
         sr_wgrad_s2_bf16x3_eligible(B, CUc, CVc, UH, UW, GH, GW, transposed ? x : gy)) {
         // opt-in spike (SR_CONV_SPLIT_BF16=1): the up- / down-sampling layers' weight gradient on the bf16 matrix cores
         int ks3 = 0, UP3 = 0, VP3 = 0;
