@@ -340,25 +340,30 @@ int sr_rasterize_backward_f64(int64_t b, int64_t n, int64_t h, int64_t w, int re
  *            pixel order, of (grad_out . tex[vertex_i]) * dcoeff[i, :] and grad_out * coeff_k — pixel-parallel
  *            with the triangle's first pixel as its leader; workgroup-cooperative for the triangles in `big`;
  *   phase 2  per (sample, vertex): sum over its incident triangles in the order of the incidence list.
+ *   Between the phases the corner values live in VERTEX-MAJOR slots: position e of the (vertex-sorted) incidence list is
+ *   the slot of that corner, so phase 1 scatters each corner to adj_slot[k * nf + f] and phase 2 reads ONE contiguous
+ *   span per vertex (consecutive vertices: consecutive spans) instead of gathering scattered per-triangle records.
  *   grad_v  [b, nv, 3], grad_tex [b, nv, c]: every row is written (no pre-zeroing); either may be NULL.
  * v [b, nv, 3]; tex [b, nv, c]; tri int64 [nf, 3] (or [b, nf, 3] when !repeat_f); grad_out [b, h, w, c].
  * Incidence list (CSR, built once per topology by the caller): adj_off int32 [nv + 1], adj int32 [3 nf] holding
  * corner-major entries k * nf + f with tri[f][k] == vertex, ascending; per-sample topologies pass batch strides
- * (elements) adj_off_bstride / adj_bstride, shared ones pass 0.
+ * (elements) adj_off_bstride / adj_bstride, shared ones pass 0.  adj_slot int32 [3 nf] (batch stride adj_bstride) is
+ * the inverse permutation, adj_slot[adj[e]] = e, built once per topology next to the list; NULL = rebuilt by every
+ * call inside `work` (one extra launch).
  * `work`: sr_rasterize_grad_scratch_bytes(b, nf, c, is_double) bytes. */
 int64_t sr_rasterize_grad_scratch_bytes(int64_t b, int64_t nf, int64_t tex_c, int is_double);
 int sr_rasterize_grad_f32(int64_t b, int64_t nv, int64_t nf, int64_t h, int64_t w, int repeat_f,
                           int perspective, const float* v, const float* tex, int64_t tex_c,
                           const int64_t* tri, const int32_t* win, const int32_t* big, const float* grad_out,
                           const int32_t* adj_off, const int32_t* adj, int64_t adj_off_bstride,
-                          int64_t adj_bstride, float* grad_v, float* grad_tex, float eps, void* work,
-                          sr_stream_t stream);
+                          int64_t adj_bstride, const int32_t* adj_slot, float* grad_v, float* grad_tex, float eps,
+                          void* work, sr_stream_t stream);
 int sr_rasterize_grad_f64(int64_t b, int64_t nv, int64_t nf, int64_t h, int64_t w, int repeat_f,
                           int perspective, const double* v, const double* tex, int64_t tex_c,
                           const int64_t* tri, const int32_t* win, const int32_t* big, const double* grad_out,
                           const int32_t* adj_off, const int32_t* adj, int64_t adj_off_bstride,
-                          int64_t adj_bstride, double* grad_v, double* grad_tex, double eps, void* work,
-                          sr_stream_t stream);
+                          int64_t adj_bstride, const int32_t* adj_slot, double* grad_v, double* grad_tex, double eps,
+                          void* work, sr_stream_t stream);
 
 /* Host (CPU) path for HOST pointers: the reference's extension also serves CPU tensors
  * (rasterize_cpu / rasterize_cpu_backward, reference op/rasterize.cpp:21-95, dispatched at :126-150).

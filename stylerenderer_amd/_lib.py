@@ -76,14 +76,14 @@ SIGNATURES = {
     "sr_rasterize_backward_cpu_f64": (_i, [_l] * 4 + [_i] + [_p] * 3 + [_d]),
     "sr_rasterize_backward_f32": (_i, [_l] * 4 + [_i] * 2 + [_p] * 3 + [_f, _p]),
     "sr_rasterize_backward_f64": (_i, [_l] * 4 + [_i] * 2 + [_p] * 3 + [_d, _p]),
-    "sr_rasterize_grad_f32": (_i, [_l] * 5 + [_i] * 2 + [_p, _p, _l] + [_p] * 6 + [_l, _l, _p, _p, _f, _p, _p]),
+    "sr_rasterize_grad_f32": (_i, [_l] * 5 + [_i] * 2 + [_p, _p, _l] + [_p] * 6 + [_l, _l, _p, _p, _p, _f, _p, _p]),
     "sr_conv2d_wgrad_scratch_floats": (_l, [_l] * 7 + [_i] * 4),
     "sr_conv2d_wgrad_mfma": (_i, [_p] * 5 + [_l] * 7 + [_i] * 4 + [_p, _p]),
     "sr_conv2d_scratch_floats": (_l, [_l] * 7 + [_i] * 4),
     "sr_conv2d_mfma": (_i, [_p] * 6 + [_l] * 8 + [_i] * 4 + [_p, _p]),
     "sr_conv2d_uses_winograd": (_i, [_l] * 5 + [_p, _p]),
     "sr_conv2d_mfma_ex": (_i, [_p] * 6 + [_l] * 8 + [_i] * 5 + [_p, _p]),
-    "sr_rasterize_grad_f64": (_i, [_l] * 5 + [_i] * 2 + [_p, _p, _l] + [_p] * 6 + [_l, _l, _p, _p, _d, _p, _p]),
+    "sr_rasterize_grad_f64": (_i, [_l] * 5 + [_i] * 2 + [_p, _p, _l] + [_p] * 6 + [_l, _l, _p, _p, _p, _d, _p, _p]),
     "sr_pose_fwd": (_i, [_p, _p, _p, _p]),
     "sr_pose_bwd": (_i, [_p, _p, _p, _p, _p]),
     "sr_pose_batch_fwd": (_i, [_p, _p, _p, _l, _p]),

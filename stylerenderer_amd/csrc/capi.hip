@@ -3,7 +3,7 @@
 
 #include "common.h"
 
-extern "C" int sr_abi_version(void) { return 8; }
+extern "C" int sr_abi_version(void) { return 9; }   // 9: sr_rasterize_grad_* take adj_slot; sr_adam_flat_guarded rolls *step back
 
 extern "C" const char* sr_error_string(int code) {
     if (code == SR_OK) return "ok";

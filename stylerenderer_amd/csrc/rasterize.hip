@@ -1305,6 +1305,50 @@ __device__ __forceinline__ void store_row(const TriAcc<R, CT, PERSP>& acc, R* __
     }
 }
 
+// VERTEX-MAJOR corner slots (round 6).  The incidence list of a topology is sorted by vertex, so position e of the list
+// (0 <= e < 3 nf) is a slot that belongs to ONE vertex, and the slots of a vertex — and of consecutive vertices — are
+// contiguous.  Phase 1 writes the CORNER values of corner k of triangle f straight into slot e = slot_of[k * nf + f]
+// (the inverse permutation of the list) instead of a 64-byte record per triangle; phase 2 then reads one contiguous span
+// per vertex, consecutive lanes consecutive spans, instead of chasing six scattered records: same values, same summation
+// order, a coalesced stream in place of a divergent gather.  Layout: quad plane Q[b * 3 nf] (the first four values of a
+// corner, one 16-byte store / load) and TAIL scalar planes T[j][b * 3 nf] for the values behind it.
+template <typename R, int CT, bool PERSP>
+__device__ __forceinline__ void store_slots(const TriAcc<R, CT, PERSP>& acc, R* __restrict__ quad, R* __restrict__ tail,
+                                            long long plane, long long slot_base, const int* __restrict__ slot_of,
+                                            long long nf, long long ti) {
+    using S = RowShape<CT, PERSP>;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        R vals[S::CORNER < 4 ? 4 : S::CORNER];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) vals[j] = 0;
+#pragma unroll
+        for (int j = 0; j < S::NVC; ++j) vals[j] = JacTri<R, PERSP>::get(acc.gv, k, j);
+#pragma unroll
+        for (int j = 0; j < CT; ++j) vals[S::NVC + j] = acc.gt[k * CT + j];
+        const long long e = slot_base + slot_of[k * nf + ti];
+        if (sizeof(R) == 4) {
+            reinterpret_cast<float4*>(quad)[e] = make_float4((float)vals[0], (float)vals[1], (float)vals[2], (float)vals[3]);
+        } else {
+            double2* dst = reinterpret_cast<double2*>(quad) + 2 * e;
+            dst[0] = make_double2((double)vals[0], (double)vals[1]);
+            dst[1] = make_double2((double)vals[2], (double)vals[3]);
+        }
+#pragma unroll
+        for (int j = 0; j < S::TAIL; ++j) tail[j * plane + e] = vals[4 + j];
+    }
+}
+
+// slot_of[adj[e]] = e: the inverse of a topology's incidence list (one int per corner; built per call when the caller
+// does not hand a cached table over)
+__global__ __launch_bounds__(256) void k_slot_inverse(long long n3, const int* __restrict__ adj, int* __restrict__ slot_of,
+                                                      long long adj_bstride) {
+    const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= n3) return;
+    const long long s = blockIdx.y;
+    slot_of[s * n3 + adj[s * adj_bstride + e]] = (int)e;
+}
+
 // Large triangles (the list k_depth_keys recorded): one workgroup per triangle walks the box together; each lane
 // sums its pixels in order, then a fixed-order tree over the 256 lanes.
 template <typename R, int CT, bool PERSP>
@@ -1314,7 +1358,8 @@ __global__ __launch_bounds__(256) void k_grad_big(long long nv, long long nf, lo
                                                   const long long* __restrict__ f, const int* __restrict__ win,
                                                   const int* __restrict__ big, const R* __restrict__ grad_out,
                                                   bool want_v, R* __restrict__ tg,
-                                                  R eps, bool chw) {
+                                                  R eps, bool chw, const int* __restrict__ slot_of, long long slot_bs,
+                                                  R* __restrict__ tail, long long plane) {
     __shared__ R s_part[4];
     const long long hw = h * w;
     const int count = big[0];
@@ -1347,7 +1392,10 @@ __global__ __launch_bounds__(256) void k_grad_big(long long nv, long long nf, lo
         for (int j = 0; j < JacTri<R, PERSP>::NV; ++j) acc.gv[j] = block_sum_256<R>(acc.gv[j], s_part);
 #pragma unroll
         for (int j = 0; j < 3 * CT; ++j) acc.gt[j] = block_sum_256<R>(acc.gt[j], s_part);
-        if (threadIdx.x == 0 && cnt > 0) store_row<R, CT, PERSP>(acc, tg, g);
+        if (threadIdx.x == 0 && cnt > 0) {
+            if (slot_of) store_slots<R, CT, PERSP>(acc, tg, tail, plane, s * 3 * nf, slot_of + s * slot_bs, nf, ti);
+            else store_row<R, CT, PERSP>(acc, tg, g);
+        }
     }
 }
 
@@ -1391,7 +1439,8 @@ __global__ __launch_bounds__(256) void k_grad_pix(long long b, long long nv, lon
                                                   const int* __restrict__ first,
                                                   unsigned long long* __restrict__ valid,
                                                   const R* __restrict__ grad_out, bool want_v,
-                                                  R* __restrict__ tg, R eps, bool chw) {
+                                                  R* __restrict__ tg, R eps, bool chw, const int* __restrict__ slot_of,
+                                                  long long slot_bs, R* __restrict__ tail, long long plane) {
     __shared__ int s_row[256], s_pix[256];
     __shared__ int s_cnt[4];
     const long long hw = h * w;
@@ -1515,7 +1564,8 @@ __global__ __launch_bounds__(256) void k_grad_pix(long long b, long long nv, lon
                                      grad_out + s * hw * tex_c, tb + i0 * tex_c, tb + i1 * tex_c, tb + i2 * tex_c, tex_c,
                                      ch0, chw ? hw : 1);
     }
-    store_row<R, CT, PERSP>(acc, tg, row);
+    if (slot_of) store_slots<R, CT, PERSP>(acc, tg, tail, plane, s * 3 * nf, slot_of + s * slot_bs, nf, ti);
+    else store_row<R, CT, PERSP>(acc, tg, row);
 }
 
 // ---- fused gradient, phase 2: per-vertex sum over its incident corners, in incidence-list order ---------------
@@ -1563,6 +1613,53 @@ __device__ __forceinline__ void vert_gather(const int (&idx)[U], long long s, lo
     }
 }
 
+// The same step over vertex-major slots: entry u of the step is list position e0 + u, i.e. slot e0 + u — the records of a
+// lane are one contiguous span and the spans of a wave's lanes follow each other.
+// EAGER: the slot loads do not wait for the validity words (their address is the list position, known as soon as the
+// offsets are): three dependent memory levels instead of four, at the price of fetching the unwritten slots of hidden
+// triangles too — taken for small batches, where the pass is bound by that chain and not by bytes (inversion: batch 1).
+template <typename R, int CT, bool PERSP, int U, bool EAGER>
+__device__ __forceinline__ void vert_gather_slots(const int (&idx)[U], long long e0, long long s, long long nf,
+                                                  const R* __restrict__ quad, const R* __restrict__ tail, long long plane,
+                                                  const unsigned long long* __restrict__ valid, R (&av)[3], R (&at)[CT]) {
+    using S = RowShape<CT, PERSP>;
+    constexpr int NC = S::CORNER < 4 ? 4 : S::CORNER;
+    long long row[U];
+    unsigned long long word[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int i = idx[u] < 0 ? 0 : idx[u];
+        const int kk = i >= 2 * (int)nf ? 2 : (i >= (int)nf ? 1 : 0);
+        row[u] = s * nf + (i - kk * (int)nf);
+        word[u] = valid[row[u] >> 6];
+    }
+    R c[U][NC];
+    bool ok[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        ok[u] = idx[u] >= 0 && ((word[u] >> (row[u] & 63)) & 1ull);      // won a pixel: the slot was written
+        const long long e = s * 3 * nf + (EAGER ? (idx[u] >= 0 ? e0 + u : e0) : (ok[u] ? e0 + u : 0));
+        if (sizeof(R) == 4) {
+            const float4 q = reinterpret_cast<const float4*>(quad)[e];
+            c[u][0] = (R)q.x; c[u][1] = (R)q.y; c[u][2] = (R)q.z; c[u][3] = (R)q.w;
+        } else {
+            const double2 q0 = reinterpret_cast<const double2*>(quad)[2 * e];
+            const double2 q1 = reinterpret_cast<const double2*>(quad)[2 * e + 1];
+            c[u][0] = (R)q0.x; c[u][1] = (R)q0.y; c[u][2] = (R)q1.x; c[u][3] = (R)q1.y;
+        }
+#pragma unroll
+        for (int j = 4; j < S::CORNER; ++j) c[u][j] = tail[(j - 4) * plane + e];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        if (!ok[u]) continue;
+#pragma unroll
+        for (int j = 0; j < S::NVC; ++j) av[j] += c[u][j];
+#pragma unroll
+        for (int j = 0; j < CT; ++j) at[j] += c[u][S::NVC + j];
+    }
+}
+
 // 85 us at config[3] with one corner per step, 70 with six in flight.  (Round 4 tried the incidence list as fixed-width
 // rows — one aligned 32-byte load per vertex instead of offsets -> entries, a dependent level less: no change, 69-74 us;
 // the kernel is bound by the number of divergent L1 accesses, ~14 per lane at 48 % TCP utilisation, not by the chain.)
@@ -1571,24 +1668,70 @@ __global__ __launch_bounds__(256) void k_grad_vert(long long nv, long long nf, c
                                                    const int* __restrict__ adj, long long off_bstride,
                                                    long long adj_bstride, const R* __restrict__ tg,
                                                    const unsigned long long* __restrict__ valid, int tex_c, int ch0,
-                                                   R* __restrict__ grad_v, R* __restrict__ grad_tex) {
+                                                   R* __restrict__ grad_v, R* __restrict__ grad_tex, int slots,
+                                                   const R* __restrict__ tail, long long plane) {
     const long long vert = (long long)blockIdx.x * 256 + threadIdx.x;
     const long long s = blockIdx.y;
-    if (vert >= nv) return;
+    const bool live = vert < nv;
     R av[3] = {0, 0, 0};
     R at[CT];
 #pragma unroll
     for (int j = 0; j < CT; ++j) at[j] = 0;
     const int* off = adj_off + s * off_bstride;
     const int* ad = adj + s * adj_bstride;
-    const int e0 = off[vert], e1 = off[vert + 1];
+    const int e0 = live ? off[vert] : 0, e1 = live ? off[vert + 1] : 0;
     constexpr int U = 6;                        // (the valence of an interior vertex of a triangulated grid)
-    for (int base = e0; base < e1; base += U) {
-        int idx[U];
+    // A vertex of high valence (the two poles of the formula mesh: 192 corners; a fan anywhere) would be ONE lane walking
+    // 32 dependent steps while its wave waits — at batch 1 those two lanes were the whole duration of the kernel (38 us for
+    // 24 770 vertices).  Such a vertex is summed by its wave instead: lane l takes list positions e0 + l, e0 + l + 64, ...
+    // in order, then a fixed-order tree over the lanes (deterministic; the order differs from the serial one by rounding).
+    constexpr int WIDE = 4 * U;
+    const bool wide = e1 - e0 > WIDE;
+    if (!wide) {
+        for (int base = e0; base < e1; base += U) {
+            int idx[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) idx[u] = base + u < e1 ? ad[base + u] : -1;
-        vert_gather<R, CT, PERSP, U>(idx, s, nf, tg, valid, av, at);
+            for (int u = 0; u < U; ++u) idx[u] = base + u < e1 ? ad[base + u] : -1;
+            if (slots == 2) vert_gather_slots<R, CT, PERSP, U, true>(idx, base, s, nf, tg, tail, plane, valid, av, at);
+            else if (slots) vert_gather_slots<R, CT, PERSP, U, false>(idx, base, s, nf, tg, tail, plane, valid, av, at);
+            else vert_gather<R, CT, PERSP, U>(idx, s, nf, tg, valid, av, at);
+        }
     }
+    unsigned long long wm = __ballot(wide);
+    const int lane = threadIdx.x & 63;
+    while (wm) {
+        const int src = __ffsll((long long)wm) - 1;
+        wm &= wm - 1ull;
+        const int we0 = __shfl(e0, src, SR_WAVE), we1 = __shfl(e1, src, SR_WAVE);
+        R pv[3] = {0, 0, 0};
+        R pt[CT];
+#pragma unroll
+        for (int j = 0; j < CT; ++j) pt[j] = 0;
+        for (int e = we0 + lane; e < we1; e += 64) {
+            const int idx[1] = {ad[e]};
+            if (slots) vert_gather_slots<R, CT, PERSP, 1, false>(idx, e, s, nf, tg, tail, plane, valid, pv, pt);
+            else vert_gather<R, CT, PERSP, 1>(idx, s, nf, tg, valid, pv, pt);
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) pv[j] += sr_shfl_down(pv[j], o);
+#pragma unroll
+            for (int j = 0; j < CT; ++j) pt[j] += sr_shfl_down(pt[j], o);
+        }
+        // the sums sit in lane 0; hand them to the lane that owns the vertex
+#pragma unroll
+        for (int j = 0; j < 3; ++j) pv[j] = __shfl(pv[j], 0, SR_WAVE);
+#pragma unroll
+        for (int j = 0; j < CT; ++j) pt[j] = __shfl(pt[j], 0, SR_WAVE);
+        if (lane == src) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) av[j] = pv[j];
+#pragma unroll
+            for (int j = 0; j < CT; ++j) at[j] = pt[j];
+        }
+    }
+    if (!live) return;
     if (grad_v && ch0 == 0) {
         R* o = grad_v + (s * nv + vert) * 3;
         o[0] = av[0];
@@ -1734,23 +1877,28 @@ void grad_launch(long long b, long long nv, long long nf, long long h, long long
                  const R* tex, int tex_c, int ch0, const long long* tri, const int* win, const int* big,
                  const R* grad_out, const int* adj_off, const int* adj, long long off_bs, long long adj_bs,
                  R* grad_v, R* grad_tex, R eps, R* tg, const int* first, unsigned long long* valid, bool chw,
-                 hipStream_t st) {
+                 const int* slot_of, long long slot_bs, R* tail, hipStream_t st) {
     const bool want_v = grad_v != nullptr && ch0 == 0;
+    const long long plane = b * 3 * nf;
+    // few lanes: the gather is a latency chain, read the slots eagerly (SR_RASTER_GRAD_EAGER=0 / 1 forces)
+    const char* ee = getenv("SR_RASTER_GRAD_EAGER");
+    const bool eager = ee ? ee[0] == '1' : b * nv < 8 * 32768;
     hipLaunchKernelGGL((k_grad_big<R, CT, PERSP>), dim3(SR_NUM_CU * 2), dim3(256), 0, st, nv, nf, h, w, repeat_f, v,
-                       tex, tex_c, ch0, tri, win, big, grad_out, want_v, tg, eps, chw);
+                       tex, tex_c, ch0, tri, win, big, grad_out, want_v, tg, eps, chw, slot_of, slot_bs, tail, plane);
     if (b * nf > 0)
         hipLaunchKernelGGL((k_grad_pix<R, CT, PERSP>), dim3((unsigned)sr_ceil_div(b * nf, 256)), dim3(256), 0, st, b,
                            nv, nf, h, w, repeat_f, v, tex, tex_c, ch0, tri, win, first, valid, grad_out, want_v, tg, eps,
-                           chw);
+                           chw, slot_of, slot_bs, tail, plane);
     hipLaunchKernelGGL((k_grad_vert<R, CT, PERSP>), dim3((unsigned)sr_ceil_div(nv, 256), (unsigned)b), dim3(256), 0,
-                       st, nv, nf, adj_off, adj, off_bs, adj_bs, tg, valid, tex_c, ch0, grad_v, grad_tex);
+                       st, nv, nf, adj_off, adj, off_bs, adj_bs, tg, valid, tex_c, ch0, grad_v, grad_tex,
+                       slot_of == nullptr ? 0 : (eager ? 2 : 1), tail, plane);
 }
 
 template <typename R>
 int grad_impl(long long b, long long nv, long long nf, long long h, long long w, int repeat_f, int perspective,
               const R* v, const R* tex, long long tex_c, const long long* tri, const int* win, const int* big,
               const R* grad_out, const int* adj_off, const int* adj, long long off_bs, long long adj_bs,
-              R* grad_v, R* grad_tex, R eps, void* work, hipStream_t st) {
+              const int* adj_slot, R* grad_v, R* grad_tex, R eps, void* work, hipStream_t st) {
     if (b < 0 || nv < 0 || nf < 0 || h < 0 || w < 0 || tex_c <= 0) return SR_EINVAL;
     const bool chw = (perspective & SR_RASTER_CHW) != 0;        // grad_out [b, c, h, w] (see forward_impl)
     perspective &= 1;
@@ -1763,6 +1911,25 @@ int grad_impl(long long b, long long nv, long long nf, long long h, long long w,
     if (b * h * w >= 0x7FFFFFFFLL) return SR_ERANGE;
     // (records: 24 floats each, so the two tables behind them stay 8-byte aligned)
     unsigned long long* valid = reinterpret_cast<unsigned long long*>(tg + b * nf * grad_row_floats());
+    // vertex-major slots (default; SR_RASTER_GRAD_SLOTS=0: the per-triangle records of rounds 2-5): the same 24 values per
+    // triangle hold the quad plane (12) and up to three tail planes (3 each); the inverse incidence table sits behind the
+    // valid words
+    const char* slots_env = getenv("SR_RASTER_GRAD_SLOTS");
+    const bool use_slots = nf > 0 && !(slots_env && slots_env[0] == '0');
+    R* tail = tg + b * nf * 12;
+    const int* slot_of = nullptr;
+    long long slot_bs = 0;
+    if (use_slots && adj_slot) {                               // the caller's cached inverse table
+        slot_of = adj_slot;
+        slot_bs = adj_bs;
+    } else if (use_slots) {
+        int* built = reinterpret_cast<int*>(valid + (b * nf + 63) / 64 + 1);
+        const long long topo = adj_bs ? b : 1;                 // per-sample topologies carry a batch stride
+        slot_bs = adj_bs ? 3 * nf : 0;
+        hipLaunchKernelGGL(k_slot_inverse, dim3((unsigned)sr_ceil_div(3 * nf, 256), (unsigned)topo), dim3(256), 0, st, 3 * nf,
+                           adj, built, adj_bs);
+        slot_of = built;
+    }
     // leaders of all triangles, once per call (the attribute-channel chunks below share them): the table behind the
     // big-triangle list of the forward call's gradient state.  The tiled forward has built it (state word 1); the
     // global-key forward has only filled it (state word 0) and k_first_pix completes it here, in place (idempotent: a
@@ -1781,7 +1948,7 @@ int grad_impl(long long b, long long nv, long long nf, long long h, long long w,
         const long long ct = tex_c - ch0 < 4 ? tex_c - ch0 : 4;
 #define SR_GRAD_ARGS                                                                                              \
     b, nv, nf, h, w, repeat_f != 0, v, tex, (int)tex_c, (int)ch0, tri, win, big, grad_out, adj_off, adj, off_bs, \
-        adj_bs, grad_v, grad_tex, eps, tg, first, valid, chw, st
+        adj_bs, grad_v, grad_tex, eps, tg, first, valid, chw, slot_of, slot_bs, tail, st
 #define SR_GRAD_CASE(CT)                                          \
     do {                                                          \
         if (perspective) grad_launch<R, CT, true>(SR_GRAD_ARGS);  \
@@ -1881,8 +2048,8 @@ extern "C" int64_t sr_rasterize_scratch_bytes(int64_t b, int64_t nf, int64_t h, 
 extern "C" int64_t sr_rasterize_grad_scratch_bytes(int64_t b, int64_t nf, int64_t tex_c, int is_double) {
     (void)tex_c;
     const int64_t rows = (b > 0 ? b : 0) * (nf > 0 ? nf : 0);
-    // records | valid bits | leader table
-    return rows * grad_row_floats() * (is_double ? 8 : 4) + ((rows + 63) / 64 + 1) * 8 + rows * 4 + 16;
+    // records (or corner slots) | valid bits | inverse incidence table (3 ints per row at most)
+    return rows * grad_row_floats() * (is_double ? 8 : 4) + ((rows + 63) / 64 + 1) * 8 + rows * 12 + 16;
 }
 
 extern "C" int sr_rasterize_forward_f32(int64_t b, int64_t nv, int64_t nf, int64_t h, int64_t w,
@@ -1925,22 +2092,22 @@ extern "C" int sr_rasterize_grad_f32(int64_t b, int64_t nv, int64_t nf, int64_t 
                                      const int64_t* tri, const int32_t* win, const int32_t* big,
                                      const float* grad_out,
                                      const int32_t* adj_off, const int32_t* adj, int64_t adj_off_bstride,
-                                     int64_t adj_bstride, float* grad_v, float* grad_tex, float eps,
-                                     void* work, sr_stream_t stream) {
+                                     int64_t adj_bstride, const int32_t* adj_slot, float* grad_v, float* grad_tex,
+                                     float eps, void* work, sr_stream_t stream) {
     return grad_impl<float>(b, nv, nf, h, w, repeat_f, perspective, v, tex, tex_c,
                             reinterpret_cast<const long long*>(tri), win, big, grad_out, adj_off, adj,
-                            adj_off_bstride, adj_bstride, grad_v, grad_tex, eps, work, sr_stream(stream));
+                            adj_off_bstride, adj_bstride, adj_slot, grad_v, grad_tex, eps, work, sr_stream(stream));
 }
 extern "C" int sr_rasterize_grad_f64(int64_t b, int64_t nv, int64_t nf, int64_t h, int64_t w, int repeat_f,
                                      int perspective, const double* v, const double* tex, int64_t tex_c,
                                      const int64_t* tri, const int32_t* win, const int32_t* big,
                                      const double* grad_out,
                                      const int32_t* adj_off, const int32_t* adj, int64_t adj_off_bstride,
-                                     int64_t adj_bstride, double* grad_v, double* grad_tex, double eps,
-                                     void* work, sr_stream_t stream) {
+                                     int64_t adj_bstride, const int32_t* adj_slot, double* grad_v, double* grad_tex,
+                                     double eps, void* work, sr_stream_t stream) {
     return grad_impl<double>(b, nv, nf, h, w, repeat_f, perspective, v, tex, tex_c,
                              reinterpret_cast<const long long*>(tri), win, big, grad_out, adj_off, adj,
-                             adj_off_bstride, adj_bstride, grad_v, grad_tex, eps, work, sr_stream(stream));
+                             adj_off_bstride, adj_bstride, adj_slot, grad_v, grad_tex, eps, work, sr_stream(stream));
 }
 extern "C" int sr_rasterize_forward_cpu_f32(int64_t b, int64_t nv, int64_t nf, int64_t h, int64_t w, int repeat_v,
                                             int repeat_f, int perspective, const float* v, const int64_t* tri,

@@ -181,29 +181,35 @@ def _incidence_one(tri, nv):
     rasterizer skips, reference op/rasterize.cpp:30-33) are filed under the extra bucket nv."""
     flat = tri.t().reshape(-1)
     flat = torch.where((flat < 0) | (flat >= nv), torch.full_like(flat, nv), flat)
-    order = torch.sort(flat, stable=True)[1].to(torch.int32)
+    order64 = torch.sort(flat, stable=True)[1]
+    order = order64.to(torch.int32)
     counts = torch.bincount(flat, minlength=nv + 1)
     off = torch.zeros(nv + 2, dtype=torch.int32, device=tri.device)
     off[1:] = torch.cumsum(counts, 0).to(torch.int32)
-    return off, order.contiguous()
+    # the inverse permutation: corner k * nf + f sits at list position slot[k * nf + f] — the vertex-major slot the
+    # gradient's first phase writes that corner's values to (include/stylerenderer_amd.h, sr_rasterize_grad_*)
+    slot = torch.empty_like(order)
+    slot[order64] = torch.arange(order.numel(), dtype=torch.int32, device=tri.device)
+    return off, order.contiguous(), slot
 
 
 def incidence(tri, nv):
-    """(adj_off, adj, off_bstride, adj_bstride) for tri [nf, 3] (shared) or [b, nf, 3]; cached per tensor."""
+    """(adj_off, adj, off_bstride, adj_bstride, adj_slot) for tri [nf, 3] (shared) or [b, nf, 3]; cached per tensor."""
     key = (tri.data_ptr(), tuple(tri.shape), tri._version, str(tri.device), int(nv))
     hit = _INC_CACHE.get(key)
     if hit is not None:
-        return hit[:4]
+        return hit[:5]
     if tri.dim() == 2:
-        off, adj = _incidence_one(tri, nv)
-        val = (off, adj, 0, 0, tri)
+        off, adj, slot = _incidence_one(tri, nv)
+        val = (off, adj, 0, 0, slot, tri)
     else:
         parts = [_incidence_one(t, nv) for t in tri]
         off = torch.stack([p[0] for p in parts]).contiguous()
         adj = torch.stack([p[1] for p in parts]).contiguous()
-        val = (off, adj, off.shape[1], adj.shape[1], tri)
+        slot = torch.stack([p[2] for p in parts]).contiguous()
+        val = (off, adj, off.shape[1], adj.shape[1], slot, tri)
     _INC_CACHE.put(key, val)                                 # holds `tri`: the key is its address
-    return val[:4]
+    return val[:5]
 
 
 class Rasterize(Function):
@@ -255,7 +261,7 @@ class Rasterize(Function):
             raise RuntimeError("rasterize backward: batched attributes [b, n(, c)] required")
         grad_v = torch.empty_like(v) if need_v else None
         grad_t = torch.empty_like(tex_c) if need_t else None
-        off, adj, off_bs, adj_bs = incidence(tri, nv)
+        off, adj, off_bs, adj_bs, slot = incidence(tri, nv)
         L = _lib.lib()
         work = torch.empty(L.sr_rasterize_grad_scratch_bytes(b, nf, c, int(suf == "f64")), dtype=torch.uint8,
                            device=v.device)
@@ -264,7 +270,7 @@ class Rasterize(Function):
                 b, nv, nf, h, w, int(tri.dim() == 2), int(bool(ctx.perspective)) | (SR_RASTER_CHW if ctx.chw else 0),
                 _lib.ptr(v), _lib.ptr(tex_c), c,
                 _lib.ptr(tri), _lib.ptr(win), _lib.ptr(big), _lib.ptr(go), _lib.ptr(off), _lib.ptr(adj), off_bs, adj_bs,
-                _lib.ptr(grad_v), _lib.ptr(grad_t), abs(float(ctx.eps)), _lib.ptr(work), stream_of(v))
+                _lib.ptr(slot), _lib.ptr(grad_v), _lib.ptr(grad_t), abs(float(ctx.eps)), _lib.ptr(work), stream_of(v))
         _lib.check(rc, "sr_rasterize_grad")
         return grad_v, grad_t, None, None, None, None, None, None
 

@@ -49,7 +49,7 @@ def test_argument_validation_without_gpu():
                                       None, 0, None, None, None, None, None) == -1
     assert L.sr_rasterize_grad_scratch_bytes(2, 10, 3, 0) >= 2 * 10 * (9 + 9) * 4 + 20
     assert L.sr_rasterize_grad_f32(1, 3, 1, 4, 4, 1, 0, None, None, 3, None, None, None, None, None, None, 0, 0,
-                                   None, None, 1e-6, None, None) == 0          # nothing requested
+                                   None, None, None, 1e-6, None, None) == 0    # nothing requested
     assert L.sr_rasterize_forward_cpu_f32(1, 3, 1, 4, 4, 0, 1, 0, None, None, None, None, None, 1e-6) == -1
     assert L.sr_abi_version() >= 2
 
