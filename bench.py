@@ -289,6 +289,53 @@ def collect_live_pmc(timeout_s=150):
     return note
 
 
+def graph_step_traffic(probe, probe_args, tail_dispatches, per, timeout_s=240):
+    """HBM bytes per step of a hipGraph-replayed workload (the config[2] iteration, the config[4] inversion step):
+    two rocprofv3 --pmc passes (FETCH_SIZE, then WRITE_SIZE — counters only, one TCC counter per pass) over
+    scripts/<probe>, which ends with `per` steps replayed back to back = its last `tail_dispatches` kernel dispatches;
+    their counters are summed over ALL kernels (2 * FETCH_SIZE + WRITE_SIZE KB, the gfx950 correction of pmc_traffic)
+    and divided by `per`.  Returns (bytes per step or None, note)."""
+    import csv
+    import glob
+    import shutil
+    import tempfile
+
+    if any(k.startswith(("ROCPROF", "ROCP_", "ROCTRACER")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", ""):
+        return None, "this run is itself being profiled: no nested --pmc passes"
+    tool = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if tool is None or not tail_dispatches:
+        return None, "rocprofv3 not found" if tool is None else "no dispatch count"
+    out = tempfile.mkdtemp(prefix="sr_pmc_step_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    child = [sys.executable, os.path.join(ROOT, "scripts", probe)] + [str(a) for a in probe_args]
+    sums, note = {}, None
+    for c in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = os.path.join(out, c)
+        try:
+            subprocess.run([tool, "--pmc", c, "--output-format", "csv", "-d", d, "-o", "p", "--"] + child, cwd="/tmp",
+                           env=env, timeout=timeout_s, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        except Exception as e:           # noqa: BLE001
+            note = "pmc pass %s failed: %s" % (c, type(e).__name__)
+            continue
+        files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+        if not files:
+            note = "pmc pass %s wrote no counters" % c
+            continue
+        with open(files[0]) as f:
+            rows = [(int(r["Dispatch_Id"]), float(r["Counter_Value"])) for r in csv.DictReader(f) if r["Counter_Name"] == c]
+        rows.sort()
+        if len(rows) < tail_dispatches:
+            note = "pmc pass %s saw %d dispatches, fewer than the %d of the replayed steps" % (c, len(rows), tail_dispatches)
+            continue
+        sums[c] = sum(v for _i, v in rows[-int(tail_dispatches):])
+    shutil.rmtree(out, ignore_errors=True)
+    if len(sums) != 2:
+        return None, note
+    return (2.0 * sums["FETCH_SIZE"] + sums["WRITE_SIZE"]) * 1024.0 / per, None
+
+
 VALU_PEAK_GINST = 1024 * 2.4 / 4.0      # wave64 VALU instructions / ns over 1024 SIMDs at 2.4 GHz, 4 cycles each
 
 
@@ -905,6 +952,30 @@ def main():
     inversion_res = None
     if not args.no_inversion and rank == 0 and world == 1:
         inversion_res = leg(inversion_leg, dev, args.inversion_steps, args.size)
+    if rank == 0 and world == 1 and not args.no_pmc and not args.pmc_child:
+        # whole-step HBM traffic of the two replayed workloads (separate --pmc passes over their probes in scripts/)
+        if isinstance(train_res, dict) and train_res.get("roofline") and train_res.get("phases"):
+            ph = train_res["phases"]
+            per16 = {"d": 16, "r1": 1, "g": 16, "path": 4, "d_opt": 17, "g_opt": 20, "ema": 16}
+            tail = sum((ph[n].get("kernel_nodes") or 0) * c for n, c in per16.items())
+            t, note = graph_step_traffic("train_step_probe.py", [16, args.train_batch], tail, 16.0)
+            r = train_res["roofline"]
+            r["traffic"] = None if t is None else round(t)
+            r["traffic_unit"] = "bytes/iteration (all kernels of 16 consecutive iterations = one cadence cycle, / 16)"
+            r["traffic_source"] = note or ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes spawned by this run over "
+                                           "scripts/train_step_probe.py (2*FETCH_SIZE+WRITE_SIZE, KB)")
+            if t is not None:
+                r["hbm_GBps_at_measured_iteration"] = round(t / (train_res["ms_per_iter"] * 1e-3) / 1e9, 1)
+        if isinstance(inversion_res, dict) and inversion_res.get("roofline"):
+            r = inversion_res["roofline"]
+            nodes = r.get("kernel_launches_per_step") or 0
+            t, note = graph_step_traffic("inversion_replay_probe.py", [20], 20 * nodes, 20.0)
+            r["traffic"] = None if t is None else round(t)
+            r["traffic_unit"] = "bytes/step (all kernels of 20 replayed steps, / 20)"
+            r["traffic_source"] = note or ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes spawned by this run over "
+                                           "scripts/inversion_replay_probe.py (2*FETCH_SIZE+WRITE_SIZE, KB)")
+            if t is not None and r.get("ms_per_replay"):
+                r["hbm_GBps_at_measured_step"] = round(t / (r["ms_per_replay"] * 1e-3) / 1e9, 1)
     result = None
     if rank == 0:
         images = args.batch * world * args.steps

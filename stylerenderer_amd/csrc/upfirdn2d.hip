@@ -117,6 +117,25 @@ __device__ __forceinline__ void fir4_rows(const float* s_in, const float (&kf)[1
                 win[2 * h + 1] = a.y;
             }
         }
+#ifdef SR_FIR_SEP_EXPERIMENT
+        // timing experiment: separable taps, fused multiply-adds (8 per output instead of 16 mul + 16 add)
+        float hrow[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            float h = win[c] * kf[0];
+            h = __builtin_fmaf(win[c + 1], kf[1], h);
+            h = __builtin_fmaf(win[c + 2], kf[2], h);
+            h = __builtin_fmaf(win[c + 3], kf[3], h);
+            hrow[c] = h;
+        }
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int ky = t - r;
+            if (ky < 0 || ky > 3) continue;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc[r][c] = ky == 0 ? hrow[c] * kf[4] : __builtin_fmaf(hrow[c], kf[4 + ky], acc[r][c]);
+        }
+#else
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
             const int ky = t - r;
@@ -129,6 +148,7 @@ __device__ __forceinline__ void fir4_rows(const float* s_in, const float (&kf)[1
                     acc[r][c] = acc[r][c] + prod;
                 }
         }
+#endif
     }
 }
 
