@@ -111,6 +111,9 @@ def parse(argv=None):
     ap.add_argument("--no-split-bf16", action="store_true",
                     help="skip the secondary timing of the step with SR_CONV_SPLIT_BF16=1 (opt-in split-bf16 weight gradients)")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--step-traffic", nargs="?", const="1", default=None, metavar="JSON",
+                    help="collect the whole-step HBM traffic of the config[2] / config[4] legs live (minutes of "
+                         "rocprofv3 --pmc passes) and, with a path, write the summary there (profiles/rNN_step_traffic.json)")
     ap.add_argument("--plumbing", action="store_true",
                     help="CPU-only launch check (gloo, tiny model): exercises --gpus N rank spawning without a GPU")
     return ap.parse_args(argv)
@@ -289,12 +292,14 @@ def collect_live_pmc(timeout_s=150):
     return note
 
 
-def graph_step_traffic(probe, probe_args, tail_dispatches, per, timeout_s=240):
-    """HBM bytes per step of a hipGraph-replayed workload (the config[2] iteration, the config[4] inversion step):
-    two rocprofv3 --pmc passes (FETCH_SIZE, then WRITE_SIZE — counters only, one TCC counter per pass) over
-    scripts/<probe>, which ends with `per` steps replayed back to back = its last `tail_dispatches` kernel dispatches;
-    their counters are summed over ALL kernels (2 * FETCH_SIZE + WRITE_SIZE KB, the gfx950 correction of pmc_traffic)
-    and divided by `per`.  Returns (bytes per step or None, note)."""
+def graph_step_traffic(probe, probe_args, segments, timeout_s=420):
+    """HBM bytes of hipGraph-replayed work (the config[2] phases, the config[4] inversion step): two rocprofv3 --pmc passes
+    (FETCH_SIZE, then WRITE_SIZE — counters only, one TCC counter per pass) over scripts/<probe>, whose LAST kernel
+    dispatches are the replays in question.  `segments` = [(name, dispatches), ...] in execution order: the tail of the
+    process's dispatch list is cut into those pieces and every piece's counters are summed over ALL its kernels
+    (2 * FETCH_SIZE + WRITE_SIZE KB: the gfx950 correction of pmc_traffic).  Returns ({name: bytes} or None, note).
+    Counter collection costs ~10 ms per dispatch: this is run by `bench.py --step-traffic` (scripts/profile_round.sh),
+    not by the default run, which reads the committed summary profiles/r*_step_traffic.json."""
     import csv
     import glob
     import shutil
@@ -303,7 +308,8 @@ def graph_step_traffic(probe, probe_args, tail_dispatches, per, timeout_s=240):
     if any(k.startswith(("ROCPROF", "ROCP_", "ROCTRACER")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", ""):
         return None, "this run is itself being profiled: no nested --pmc passes"
     tool = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
-    if tool is None or not tail_dispatches:
+    tail = sum(n for _k, n in segments)
+    if tool is None or not tail:
         return None, "rocprofv3 not found" if tool is None else "no dispatch count"
     out = tempfile.mkdtemp(prefix="sr_pmc_step_", dir="/tmp")
     env = dict(os.environ, TMPDIR="/tmp")
@@ -326,14 +332,33 @@ def graph_step_traffic(probe, probe_args, tail_dispatches, per, timeout_s=240):
         with open(files[0]) as f:
             rows = [(int(r["Dispatch_Id"]), float(r["Counter_Value"])) for r in csv.DictReader(f) if r["Counter_Name"] == c]
         rows.sort()
-        if len(rows) < tail_dispatches:
-            note = "pmc pass %s saw %d dispatches, fewer than the %d of the replayed steps" % (c, len(rows), tail_dispatches)
+        if len(rows) < tail:
+            note = "pmc pass %s saw %d dispatches, fewer than the %d of the replays" % (c, len(rows), tail)
             continue
-        sums[c] = sum(v for _i, v in rows[-int(tail_dispatches):])
+        vals = [v for _i, v in rows[-int(tail):]]
+        per, pos = {}, 0
+        for name, n in segments:
+            per[name] = sum(vals[pos:pos + n])
+            pos += n
+        sums[c] = per
     shutil.rmtree(out, ignore_errors=True)
     if len(sums) != 2:
         return None, note
-    return (2.0 * sums["FETCH_SIZE"] + sums["WRITE_SIZE"]) * 1024.0 / per, None
+    return {k: (2.0 * sums["FETCH_SIZE"][k] + sums["WRITE_SIZE"][k]) * 1024.0 for k, _n in segments}, None
+
+
+def committed_step_traffic():
+    """The newest profiles/r*_step_traffic.json (written by `bench.py --step-traffic` in scripts/profile_round.sh)."""
+    import glob
+
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_step_traffic.json")))
+    if not files:
+        return None, None
+    try:
+        with open(files[-1]) as f:
+            return json.load(f), os.path.basename(files[-1])
+    except Exception:                    # noqa: BLE001
+        return None, None
 
 
 VALU_PEAK_GINST = 1024 * 2.4 / 4.0      # wave64 VALU instructions / ns over 1024 SIMDs at 2.4 GHz, 4 cycles each
@@ -952,30 +977,47 @@ def main():
     inversion_res = None
     if not args.no_inversion and rank == 0 and world == 1:
         inversion_res = leg(inversion_leg, dev, args.inversion_steps, args.size)
-    if rank == 0 and world == 1 and not args.no_pmc and not args.pmc_child:
-        # whole-step HBM traffic of the two replayed workloads (separate --pmc passes over their probes in scripts/)
-        if isinstance(train_res, dict) and train_res.get("roofline") and train_res.get("phases"):
-            ph = train_res["phases"]
-            per16 = {"d": 16, "r1": 1, "g": 16, "path": 4, "d_opt": 17, "g_opt": 20, "ema": 16}
-            tail = sum((ph[n].get("kernel_nodes") or 0) * c for n, c in per16.items())
-            t, note = graph_step_traffic("train_step_probe.py", [16, args.train_batch], tail, 16.0)
-            r = train_res["roofline"]
-            r["traffic"] = None if t is None else round(t)
-            r["traffic_unit"] = "bytes/iteration (all kernels of 16 consecutive iterations = one cadence cycle, / 16)"
-            r["traffic_source"] = note or ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes spawned by this run over "
-                                           "scripts/train_step_probe.py (2*FETCH_SIZE+WRITE_SIZE, KB)")
-            if t is not None:
-                r["hbm_GBps_at_measured_iteration"] = round(t / (train_res["ms_per_iter"] * 1e-3) / 1e9, 1)
-        if isinstance(inversion_res, dict) and inversion_res.get("roofline"):
-            r = inversion_res["roofline"]
-            nodes = r.get("kernel_launches_per_step") or 0
-            t, note = graph_step_traffic("inversion_replay_probe.py", [20], 20 * nodes, 20.0)
-            r["traffic"] = None if t is None else round(t)
-            r["traffic_unit"] = "bytes/step (all kernels of 20 replayed steps, / 20)"
-            r["traffic_source"] = note or ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes spawned by this run over "
-                                           "scripts/inversion_replay_probe.py (2*FETCH_SIZE+WRITE_SIZE, KB)")
-            if t is not None and r.get("ms_per_replay"):
-                r["hbm_GBps_at_measured_step"] = round(t / (r["ms_per_replay"] * 1e-3) / 1e9, 1)
+    if rank == 0 and world == 1 and not args.pmc_child:
+        # whole-step HBM traffic of the two replayed workloads: collected live with --step-traffic (separate --pmc passes
+        # over their probes in scripts/, minutes of counter collection), otherwise read from the committed summary
+        CAD = {"d": 1.0, "r1": 1.0 / 16, "g": 1.0, "path": 1.0 / 4, "d_opt": 1.0 + 1.0 / 16, "g_opt": 1.0 + 1.0 / 4, "ema": 1.0}
+        ORDER = ("d", "r1", "g", "path", "d_opt", "g_opt", "ema")
+        live = {}
+        if args.step_traffic and not args.no_pmc:
+            if isinstance(train_res, dict) and train_res.get("phases"):
+                ph = train_res["phases"]
+                per, note = graph_step_traffic("train_phase_pmc_probe.py", [args.train_batch],
+                                               [(n, int(ph[n].get("kernel_nodes") or 0)) for n in ORDER])
+                live["train_step"] = ({"phases": {k: round(v) for k, v in per.items()},
+                                       "bytes_per_iteration": round(sum(per[n] * CAD[n] for n in ORDER))} if per else
+                                      {"error": note})
+            if isinstance(inversion_res, dict) and inversion_res.get("roofline"):
+                nodes = int(inversion_res["roofline"].get("kernel_launches_per_step") or 0)
+                per, note = graph_step_traffic("inversion_replay_probe.py", [10], [("steps", 10 * nodes)])
+                live["inversion"] = {"bytes_per_step": round(per["steps"] / 10.0)} if per else {"error": note}
+            live["source"] = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes spawned by `bench.py --step-traffic` over "
+                              "scripts/train_phase_pmc_probe.py / scripts/inversion_replay_probe.py (all kernels of the "
+                              "replays, 2*FETCH_SIZE+WRITE_SIZE, KB)")
+            if args.step_traffic != "1":
+                with open(args.step_traffic, "w") as f:
+                    json.dump(live, f, indent=1)
+        table, fname = (live, None) if live else committed_step_traffic()
+        if table:
+            src = table.get("source", "") if fname is None else "profiles/%s (%s)" % (fname, table.get("source", ""))
+            t = (table.get("train_step") or {}).get("bytes_per_iteration")
+            if t and isinstance(train_res, dict) and train_res.get("roofline"):
+                r = train_res["roofline"]
+                r.update({"traffic": t, "traffic_unit": "bytes/iteration (every kernel of each captured phase x its cadence)",
+                          "traffic_measured_in_this_run": fname is None, "traffic_source": src,
+                          "traffic_by_phase": (table.get("train_step") or {}).get("phases"),
+                          "hbm_GBps_at_measured_iteration": round(t / (train_res["ms_per_iter"] * 1e-3) / 1e9, 1)})
+            t = (table.get("inversion") or {}).get("bytes_per_step")
+            if t and isinstance(inversion_res, dict) and inversion_res.get("roofline"):
+                r = inversion_res["roofline"]
+                r.update({"traffic": t, "traffic_unit": "bytes/step (every kernel of the replayed step)",
+                          "traffic_measured_in_this_run": fname is None, "traffic_source": src})
+                if r.get("ms_per_replay"):
+                    r["hbm_GBps_at_measured_step"] = round(t / (r["ms_per_replay"] * 1e-3) / 1e9, 1)
     result = None
     if rank == 0:
         images = args.batch * world * args.steps

@@ -290,11 +290,14 @@ class GraphedTrainer(Trainer):
         if name in self.PHASE_REDUCER:
             getattr(self, self.PHASE_REDUCER[name]).wait()
 
-    def build_graphs(self, warmup=3):
+    def build_graphs(self, warmup=None):
         """Eager warm-up of every phase on a side stream (lazy initialisation, incidence / tap caches, RCCL
-        communicators), state restored, then one capture per phase."""
+        communicators), state restored, then one capture per phase.  SR_GRAPH_WARMUP (default 3) = eager passes; the
+        counter-collection probes use 1 (every dispatch costs milliseconds under rocprofv3 --pmc)."""
         if not self.capture:
             return
+        if warmup is None:
+            warmup = max(1, int(os.environ.get("SR_GRAPH_WARMUP", "3")))
         snap = self._snapshot()
         for k in self.s_inject:
             self._draw_inject(k)
