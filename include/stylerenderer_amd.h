@@ -238,6 +238,31 @@ int sr_weight_adjoint_batch(int n, float* const* out, const float* const* in, co
                             const int64_t* N, const int64_t* ldn, const int64_t* ldc, const int* flip,
                             sr_stream_t stream);
 
+/* Skinny products of ALL modulated layers of a pass, one launch per call (csrc/bank_mm.hip, op/bankmm.py): the
+ * modulation s_l = EqualLinear_l(latent row) of every ModulatedConv2d and the demodulation sums q_l = s_l^2 @ Wsq_l
+ * (reference layers.py:222-248, 293-300) and their gradients of any order.  A call takes a TABLE of problems: host
+ * arrays of device pointers and extents (<= SR_BANK_MAX per launch; longer tables are cut into several launches).
+ *   sr_bank_nt: out_p[b,n] = alpha * sum_k A_p[b,k] * M_p[n,k] + bscale * bias_p[n]      A_p rows of pitch lda[p]
+ *               (a latent row of [B, n_latent, K] is read in place), M_p [N_p, K_p] dense, out_p rows of pitch ldo[p];
+ *               bias (the array or single entries) may be NULL.
+ *   sr_bank_nn: out_o[b,j] = alpha * sum over the n_terms[o] terms t of output o, in table order, of
+ *               sum_i A_t[b,i] * M_t[i,j]       (M_t [I_t, J_o] dense; the term arrays A / M / lda / I are the
+ *               concatenation of all outputs' terms).  Several layers reading one latent row add their gradients here.
+ *   sr_bank_tn: out_p[i,j] = alpha * sum_b A_p[b,i] * C_p[b,j] (dense [I_p, J_p]);  col_p[i] = bscale * sum_b A_p[b,i]
+ *               (col, or single entries, may be NULL).
+ * K, J, the pitches of A (nt) / C / out (nn) multiples of 4 and those arrays 16-byte aligned (SR_EINVAL otherwise);
+ * B <= 65535.  Fixed summation order: deterministic. */
+#define SR_BANK_MAX 48
+int sr_bank_nt(int n, float* const* out, const float* const* A, const float* const* M, const float* const* bias,
+               const int64_t* lda, const int64_t* ldo, const int64_t* K, const int64_t* N, int64_t B, float alpha,
+               float bscale, sr_stream_t stream);
+int sr_bank_nn(int n_out, float* const* out, const int64_t* ldo, const int64_t* J, const int* n_terms,
+               const float* const* A, const float* const* M, const int64_t* lda, const int64_t* I, int64_t B,
+               float alpha, sr_stream_t stream);
+int sr_bank_tn(int n, float* const* out, float* const* col, const float* const* A, const float* const* C,
+               const int64_t* lda, const int64_t* ldc, const int64_t* I, const int64_t* J, int64_t B, float alpha,
+               float bscale, sr_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------
  * upfirdn2d: zero-insert upsample -> pad/crop -> 2-D FIR (correlation with the flipped kernel)
  * -> decimate.  Replaces  bool upfirdn2d_op(float* out, const float* x, const float* k,

@@ -4,6 +4,7 @@ TorchDispatchMode + the innermost stylerenderer_amd frame of every dispatched op
 C++ autograd nodes (no Python frame) are grouped by name and shape.  usage: python scripts/aten_callsite_census.py [d|g|path|r1]"""
 import collections
 import os
+import re
 import sys
 import traceback
 
@@ -23,6 +24,10 @@ data = train.SyntheticImages(16, 256, dev)
 tr.step(data.batch(4), faces=faces, log=False)
 tr._load_inputs(data.batch(4), None, faces)
 body = tr._bodies()[phase]
+
+ANOMALY = os.environ.get("SR_CENSUS_ANOMALY", "0") == "1"
+if ANOMALY:
+    torch.autograd.set_detect_anomaly(True, check_nan=False)
 
 SKIP = ("aten::view", "aten::_unsafe_view", "aten::reshape", "aten::expand", "aten::permute", "aten::transpose", "aten::t",
         "aten::select", "aten::slice", "aten::unsqueeze", "aten::squeeze", "aten::detach", "aten::alias", "aten::as_strided",
@@ -44,7 +49,18 @@ class Census(TorchDispatchMode):
                     break
             if site is None:
                 shp = [tuple(a.shape) for a in args if isinstance(a, torch.Tensor)][:2]
-                site = "(C++ autograd node) %s" % (shp,)
+                node = torch._C._current_autograd_node()
+                origin = ""
+                if node is not None and ANOMALY:
+                    # anomaly mode keeps the forward traceback of every node: the line of this package that CREATED the
+                    # node whose backward issues this op (for the engine's fan-in adds: the node that produced the gradient)
+                    tb = node.metadata.get("traceback_") or []
+                    for line in reversed(tb):
+                        m = re.search(r'File "([^"]*stylerenderer_amd[^"]*)", line (\d+), in (\w+)', line)
+                        if m and "scripts" not in m.group(1):
+                            origin = " <- %s:%s %s" % (os.path.relpath(m.group(1), ROOT), m.group(2), m.group(3))
+                            break
+                site = "(%s) %s%s" % (type(node).__name__ if node is not None else "C++ autograd node", shp, origin)
             sites[(name, site)] += 1
         return func(*args, **(kwargs or {}))
 
@@ -54,5 +70,5 @@ with Census():
     body()
 torch.cuda.synchronize()
 print("phase %s: %d dispatched ATen ops that may launch" % (phase, sum(sites.values())))
-for (name, site), n in sites.most_common(70):
+for (name, site), n in sites.most_common(int(os.environ.get("SR_CENSUS_TOP", "70"))):
     print("%4d  %-28s %s" % (n, name, site))

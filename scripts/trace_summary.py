@@ -25,13 +25,8 @@ print("kernels/iter %.0f   wall %.2f ms/iter   GPU busy %.2f ms/iter (%.1f%%)   
       % (len(ev) / iters, wall / 1e6 / iters, busy / 1e6 / iters, 100.0 * busy / wall, 100.0 * (1 - busy / wall)))
 
 
-def family(n):
-    n = n.replace("(anonymous namespace)::", "").replace("void ", "")
-    if "at::native" in n or "rocclr" in n or "rocprim" in n or "at::cuda" in n:
-        m = re.findall(r"(\w+Functor\w*|\w+_kernel_cuda|reduce_kernel|multi_tensor_apply|fill\w*|copy\w*|CatArray\w*|"
-                       r"index\w*_kernel|distribution\w*|flip\w*)", n)
-        return "aten:" + (m[0] if m else n[:40])
-    return n.split("(")[0][:60]
+from trace_summary_names import family  # noqa: E402
+
 
 
 agg = collections.defaultdict(lambda: [0, 0])

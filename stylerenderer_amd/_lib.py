@@ -53,6 +53,9 @@ SIGNATURES = {
     "sr_weight_prep": (_i, [_p, _p, _p, _f, _l, _l, _i, _l, _p]),
     "sr_weight_prep_bwd": (_i, [_p, _p, _p, _p, _f, _l, _l, _i, _l, _p]),
     "sr_weight_adjoint": (_i, [_p, _p, _l, _l, _l, _l, _l, _i, _p]),
+    "sr_bank_nt": (_i, [_i] + [_p] * 8 + [_l, _f, _f, _p]),
+    "sr_bank_nn": (_i, [_i] + [_p] * 8 + [_l, _f, _p]),
+    "sr_bank_tn": (_i, [_i] + [_p] * 8 + [_l, _f, _f, _p]),
     "sr_weight_prep_batch": (_i, [_i] + [_p] * 9),
     "sr_weight_adjoint_batch": (_i, [_i] + [_p] * 9),
     "sr_lpips_layer_scratch_floats": (_l, [_l, _l]),

@@ -33,6 +33,7 @@ SOURCES = [
     ("fused_elem.hip", EXACT),
     ("weight_prep.hip", EXACT),
     ("style_linear.hip", EXACT),
+    ("bank_mm.hip", EXACT),
     ("mesh.hip", EXACT),
     ("lpips.hip", EXACT),
     ("conv_mfma.hip", []),
