@@ -141,6 +141,10 @@ int sr_adam_flat_guarded(float* p, const float* g, float* m, float* v, int64_t n
 int64_t sr_rowdot_scratch_floats(int64_t rows, int64_t inner);
 int sr_rowdot(float* dots, float* out_scaled, const float* a, const float* b, const float* scale,
               int64_t rows, int64_t inner, float* scratch, sr_stream_t stream);
+/* dots[r] = (sum_p a[r,p] * b[r,p]) / rdiv[r] — the demodulation gradient sum_p g * y0 / d of a modulated convolution
+ * (reference layers.py:298-300 differentiated) without a separate division launch; same sums, same order as sr_rowdot. */
+int sr_rowdot_div(float* dots, const float* a, const float* b, const float* rdiv, int64_t rows, int64_t inner,
+                  float* scratch, sr_stream_t stream);
 /* Backward of sr_rowdot in one pass (second-order sweep of the path-length regulariser): ga = gd[r] * b,
  * gb = gd[r] * a + go * scale[r], gs[r] = sum_p go * b.  ga / gb / gs / gd / go / scale may be NULL (gs needs go and
  * `scratch` of sr_rowdot_scratch_floats(rows, inner) floats). */
@@ -159,6 +163,14 @@ int sr_smallconv_dx(float* dx, const float* g, const float* ws, int64_t B, int64
 int64_t sr_smallconv_dw_scratch_floats(int64_t B, int64_t C, int64_t N, int64_t hw);
 int sr_smallconv_dw(float* dws, const float* g, const float* x, int64_t B, int64_t C, int64_t N, int64_t hw,
                     float* scratch, sr_stream_t stream);
+/* Modulated weight rows of that convolution and their pull-back (reference layers.py:293-297, demodulate=False):
+ *   sr_modrows_fwd: ws[b,j,c] = (scale * w[j,c]) * s[b,c]                       w [N, C], s [B, C], ws [B, N, C]
+ *   sr_modrows_bwd: gs[b,c] = sum_j dws[b,j,c] * (scale * w[j,c]);  gw[j,c] = scale * sum_b dws[b,j,c] * s[b,c]
+ *                   (gs or gw may be NULL).  Fixed summation order. */
+int sr_modrows_fwd(float* ws, const float* w, const float* s, float scale, int64_t B, int64_t N, int64_t C,
+                   sr_stream_t stream);
+int sr_modrows_bwd(float* gs, float* gw, const float* dws, const float* w, const float* s, float scale, int64_t B,
+                   int64_t N, int64_t C, sr_stream_t stream);
 
 /* Vertex normals of a posed mesh (replaces reference utils_3d.py:379-404 mesh_point_normal: three
  * sparse.mm scatters + layers.py:13-34 Normalize).  v [B, nv, 3]; tri [nf, 3] int64 with ids in
@@ -333,8 +345,12 @@ int sr_blur_nba_bwd(float* gx, float* gbias, float* gnoise_w, float* rowdot, con
  * `perspective` is a flags word: bit 0 = perspective projection (the reference's bool), bit 1 = SR_RASTER_CHW: the
  * interpolated attributes are written channel-major, attr[b,c,h,w] — what the generator's map heads convolve — instead of
  * the reference's [b,h,w,c] (model.py:262 permutes and every consumer re-lays it out); sr_rasterize_grad_* with the same
- * bit reads grad_out as [b,c,h,w].  Same values either way. */
+ * bit reads grad_out as [b,c,h,w].  Same values either way.  Bit 2 = SR_RASTER_GRAD_ACC (sr_rasterize_grad_* only):
+ * grad_v / grad_tex are ADDED to what the buffers hold — one mesh rasterised at several resolutions (GeneratorWithMap,
+ * reference model.py:255-262) sums its gradients inside the gather, in call order, instead of in a tensor addition per
+ * resolution. */
 #define SR_RASTER_CHW 2
+#define SR_RASTER_GRAD_ACC 4
 int64_t sr_rasterize_scratch_bytes(int64_t b, int64_t nf, int64_t h, int64_t w, int is_double);
 int sr_rasterize_forward_f32(int64_t b, int64_t nv, int64_t nf, int64_t h, int64_t w, int repeat_v,
                              int repeat_f, int perspective, const float* v, const int64_t* tri,
@@ -534,6 +550,10 @@ int sr_lpips_layer_fwd(float* d, const float* f0, const float* t, const float* l
                        int64_t t_bstride, float eps, float* scratch, sr_stream_t stream);
 int sr_lpips_layer_bwd(float* gf, const float* gd, const float* f0, const float* t, const float* lin, int64_t b,
                        int64_t c, int64_t hw, int64_t t_bstride, float eps, sr_stream_t stream);
+/* Pixel term of the inversion loss (BASELINE config[4]): out[0] = mean((a - b)^2) over n elements (one workgroup, fixed
+ * order), and ga = gout[0] * 2 / n * (a - b).  a, b 16-byte aligned for the forward. */
+int sr_mse_fwd(float* out, const float* a, const float* b, int64_t n, sr_stream_t stream);
+int sr_mse_bwd(float* ga, const float* gout, const float* a, const float* b, int64_t n, sr_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -39,11 +39,14 @@ SIGNATURES = {
     "sr_adam_flat_guarded": (_i, [_p] * 4 + [_l] + [_f] * 4 + [_p, ctypes.POINTER(_l), _i, _p, _p]),
     "sr_rowdot_scratch_floats": (_l, [_l, _l]),
     "sr_rowdot": (_i, [_p] * 5 + [_l, _l, _p, _p]),
+    "sr_rowdot_div": (_i, [_p] * 4 + [_l, _l, _p, _p]),
     "sr_rowdot_bwd": (_i, [_p] * 8 + [_l, _l, _p, _p]),
     "sr_smallconv_fwd": (_i, [_p] * 4 + [_l] * 4 + [_p]),
     "sr_smallconv_dx": (_i, [_p] * 3 + [_l] * 4 + [_p]),
     "sr_smallconv_dw_scratch_floats": (_l, [_l] * 4),
     "sr_smallconv_dw": (_i, [_p] * 3 + [_l] * 4 + [_p, _p]),
+    "sr_modrows_fwd": (_i, [_p] * 3 + [_f] + [_l] * 3 + [_p]),
+    "sr_modrows_bwd": (_i, [_p] * 5 + [_f] + [_l] * 3 + [_p]),
     "sr_vertex_normals_f32": (_i, [_p] * 6 + [_l] * 3 + [_f, _p]),
     "sr_linear_fwd": (_i, [_p] * 4 + [_l] * 4 + [_f, _f, _i, _f, _f, _p]),
     "sr_linear_bwd_x": (_i, [_p] * 4 + [_l] * 3 + [_f, _i, _f, _f, _p]),
@@ -61,6 +64,8 @@ SIGNATURES = {
     "sr_lpips_layer_scratch_floats": (_l, [_l, _l]),
     "sr_lpips_layer_fwd": (_i, [_p] * 4 + [_l] * 4 + [_f, _p, _p]),
     "sr_lpips_layer_bwd": (_i, [_p] * 5 + [_l] * 4 + [_f, _p]),
+    "sr_mse_fwd": (_i, [_p] * 3 + [_l, _p]),
+    "sr_mse_bwd": (_i, [_p] * 4 + [_l, _p]),
     "sr_upfirdn2d": (_i, [_p, _p, _p, _l] + [_i] * 14 + [_p]),
     "sr_upsample2_add": (_i, [_p] * 4 + [_l] + [_i] * 6 + [_p]),
     "sr_blur_noise_bias_act": (_i, [_p] * 6 + [_f, _f, _l, _l] + [_i] * 6 + [_l, _p]),

@@ -168,7 +168,8 @@ __global__ __launch_bounds__(64) void k_nba_finish2(float* __restrict__ gnw,
 template <bool SCALE_OUT, bool VEC>
 __global__ __launch_bounds__(EB) void k_rowdot(float* __restrict__ partial, float* __restrict__ out,
                                                const float* __restrict__ a, const float* __restrict__ b,
-                                               const float* __restrict__ s, int64_t inner, int chunks) {
+                                               const float* __restrict__ s, int64_t inner, int chunks,
+                                               const float* __restrict__ rdiv) {
     __shared__ float lds8[8];
     const int64_t row = blockIdx.y;
     const int64_t off = (int64_t)blockIdx.x * ECHUNK;
@@ -199,16 +200,18 @@ __global__ __launch_bounds__(EB) void k_rowdot(float* __restrict__ partial, floa
         }
     }
     block_sum2(acc, dummy, lds8);
-    if (threadIdx.x == 0) partial[row * chunks + blockIdx.x] = acc;
+    // rdiv (sr_rowdot_div, one chunk per row only): the row's sum divided by rdiv[row], in place
+    if (threadIdx.x == 0) partial[row * chunks + blockIdx.x] = rdiv ? acc / rdiv[row] : acc;
 }
 
 __global__ __launch_bounds__(64) void k_rowdot_finish(float* __restrict__ dots,
-                                                      const float* __restrict__ partial, int chunks) {
+                                                      const float* __restrict__ partial, int chunks,
+                                                      const float* __restrict__ rdiv = nullptr) {
     const int64_t row = blockIdx.x;
     float acc = 0.0f;
     for (int i = threadIdx.x; i < chunks; i += 64) acc += partial[row * chunks + i];
     acc = sr_wave_sum(acc);
-    if (threadIdx.x == 0) dots[row] = acc;
+    if (threadIdx.x == 0) dots[row] = rdiv ? acc / rdiv[row] : acc;
 }
 
 inline bool vec_ok(int64_t inner, const void* p0, const void* p1, const void* p2, const void* p3) {
@@ -631,13 +634,34 @@ extern "C" int sr_rowdot(float* dots, float* out_scaled, const float* a, const f
     // finish launch (the finish kernel would add it to zero)
     float* partial = chunks == 1 ? dots : scratch;
     if (out_scaled) {
-        if (vec) hipLaunchKernelGGL((k_rowdot<true, true>), grid, dim3(EB), 0, st, partial, out_scaled, a, b, scale, inner, chunks);
-        else hipLaunchKernelGGL((k_rowdot<true, false>), grid, dim3(EB), 0, st, partial, out_scaled, a, b, scale, inner, chunks);
+        if (vec) hipLaunchKernelGGL((k_rowdot<true, true>), grid, dim3(EB), 0, st, partial, out_scaled, a, b, scale, inner, chunks, (const float*)nullptr);
+        else hipLaunchKernelGGL((k_rowdot<true, false>), grid, dim3(EB), 0, st, partial, out_scaled, a, b, scale, inner, chunks, (const float*)nullptr);
     } else {
-        if (vec) hipLaunchKernelGGL((k_rowdot<false, true>), grid, dim3(EB), 0, st, partial, out_scaled, a, b, scale, inner, chunks);
-        else hipLaunchKernelGGL((k_rowdot<false, false>), grid, dim3(EB), 0, st, partial, out_scaled, a, b, scale, inner, chunks);
+        if (vec) hipLaunchKernelGGL((k_rowdot<false, true>), grid, dim3(EB), 0, st, partial, out_scaled, a, b, scale, inner, chunks, (const float*)nullptr);
+        else hipLaunchKernelGGL((k_rowdot<false, false>), grid, dim3(EB), 0, st, partial, out_scaled, a, b, scale, inner, chunks, (const float*)nullptr);
     }
-    if (chunks > 1) hipLaunchKernelGGL(k_rowdot_finish, dim3((unsigned)rows), dim3(64), 0, st, dots, scratch, chunks);
+    if (chunks > 1)
+        hipLaunchKernelGGL(k_rowdot_finish, dim3((unsigned)rows), dim3(64), 0, st, dots, scratch, chunks, (const float*)nullptr);
+    return sr_launch_status();
+}
+
+// dots[r] = (sum_p a[r,p] * b[r,p]) / rdiv[r]: the demodulation gradient of a modulated convolution,
+// sum_p g * y0 / d (op.conv.ConvFn.backward), without a separate division launch.  Same sums in the same order as
+// sr_rowdot followed by an IEEE division.
+extern "C" int sr_rowdot_div(float* dots, const float* a, const float* b, const float* rdiv, int64_t rows,
+                             int64_t inner, float* scratch, sr_stream_t stream) {
+    if (rows < 0 || inner < 0) return SR_EINVAL;
+    if (rows == 0) return SR_OK;
+    if (!dots || !a || !b || !rdiv || !scratch || rows > 65535) return SR_EINVAL;
+    const bool vec = vec_ok(inner, a, b, nullptr, nullptr);
+    hipStream_t st = sr_stream(stream);
+    const int chunks = (int)sr_ceil_div(inner > 0 ? inner : 1, ECHUNK);
+    const dim3 grid(chunks, (unsigned)rows);
+    float* partial = chunks == 1 ? dots : scratch;
+    const float* in_place = chunks == 1 ? rdiv : nullptr;
+    if (vec) hipLaunchKernelGGL((k_rowdot<false, true>), grid, dim3(EB), 0, st, partial, (float*)nullptr, a, b, (const float*)nullptr, inner, chunks, in_place);
+    else hipLaunchKernelGGL((k_rowdot<false, false>), grid, dim3(EB), 0, st, partial, (float*)nullptr, a, b, (const float*)nullptr, inner, chunks, in_place);
+    if (chunks > 1) hipLaunchKernelGGL(k_rowdot_finish, dim3((unsigned)rows), dim3(64), 0, st, dots, scratch, chunks, rdiv);
     return sr_launch_status();
 }
 
@@ -925,6 +949,68 @@ extern "C" int sr_smallconv_dw(float* dws, const float* g, const float* x, int64
     if (chunks > 1)
         hipLaunchKernelGGL(k_smallconv_dw_finish, dim3((unsigned)(B * C)), dim3(64), 0, st, dws, scratch, (int)C,
                            (int)N, chunks, B * C);
+    return sr_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------
+// Modulated weight rows of the small 1x1 convolution (ToRGB, reference layers.py:293-297 without demodulation):
+//   ws[b,j,c] = (scale * w[j,c]) * s[b,c]                                     one launch instead of two tensor products
+// and the pull-back of a gradient dws [B,N,C] (what k_smallconv_dw produces) onto both factors:
+//   gs[b,c] = sum_j dws[b,j,c] * (scale * w[j,c]);   gw[j,c] = scale * sum_b dws[b,j,c] * s[b,c]
+// (fixed order over j and b: deterministic) — one launch instead of the ~6 multiply / reduce launches autograd spends.
+namespace {
+
+__global__ __launch_bounds__(256) void k_modrows_fwd(float* __restrict__ ws, const float* __restrict__ w,
+                                                     const float* __restrict__ s, float scale, int B, int N, int C) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (int64_t)B * N * C) return;
+    const int c = (int)(i % C);
+    const int j = (int)((i / C) % N);
+    const int b = (int)(i / ((int64_t)C * N));
+    ws[i] = (w[(int64_t)j * C + c] * scale) * s[(int64_t)b * C + c];
+}
+
+__global__ __launch_bounds__(256) void k_modrows_bwd(float* __restrict__ gs, float* __restrict__ gw,
+                                                     const float* __restrict__ dws, const float* __restrict__ w,
+                                                     const float* __restrict__ s, float scale, int B, int N, int C) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    if (gs) {
+        for (int b = 0; b < B; ++b) {
+            float acc = 0.0f;
+            for (int j = 0; j < N; ++j) acc += dws[((int64_t)b * N + j) * C + c] * (w[(int64_t)j * C + c] * scale);
+            gs[(int64_t)b * C + c] = acc;
+        }
+    }
+    if (gw) {
+        for (int j = 0; j < N; ++j) {
+            float acc = 0.0f;
+            for (int b = 0; b < B; ++b) acc += dws[((int64_t)b * N + j) * C + c] * s[(int64_t)b * C + c];
+            gw[(int64_t)j * C + c] = acc * scale;
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int sr_modrows_fwd(float* ws, const float* w, const float* s, float scale, int64_t B, int64_t N, int64_t C,
+                              sr_stream_t stream) {
+    if (B == 0 || N == 0 || C == 0) return SR_OK;
+    if (!ws || !w || !s || B < 0 || N < 0 || C < 0) return SR_EINVAL;
+    if (B > 65535 || N > 65535 || C > (1 << 20)) return SR_ERANGE;
+    const int64_t total = B * N * C;
+    hipLaunchKernelGGL(k_modrows_fwd, dim3((unsigned)sr_ceil_div(total, 256)), dim3(256), 0, sr_stream(stream), ws, w, s,
+                       scale, (int)B, (int)N, (int)C);
+    return sr_launch_status();
+}
+
+extern "C" int sr_modrows_bwd(float* gs, float* gw, const float* dws, const float* w, const float* s, float scale,
+                              int64_t B, int64_t N, int64_t C, sr_stream_t stream) {
+    if (N == 0 || C == 0 || (!gs && !gw)) return SR_OK;
+    if (!dws || !w || !s || B < 0 || N < 0 || C < 0) return SR_EINVAL;
+    if (B > 65535 || N > 65535 || C > (1 << 20)) return SR_ERANGE;
+    hipLaunchKernelGGL(k_modrows_bwd, dim3((unsigned)sr_ceil_div(C, 256)), dim3(256), 0, sr_stream(stream), gs, gw, dws, w,
+                       s, scale, (int)B, (int)N, (int)C);
     return sr_launch_status();
 }
 

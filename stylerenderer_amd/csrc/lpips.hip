@@ -145,3 +145,56 @@ extern "C" int sr_lpips_layer_bwd(float* gf, const float* gd, const float* f0, c
                        f0, t, lin, (int)c, hw, t_bstride, eps, 1.0f / (float)hw);
     return sr_launch_status();
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// Pixel term of the inversion loss: mean((a - b)^2) and its gradient w.r.t. a, one launch each (the loop of BASELINE
+// config[4] runs at batch 1, where every launch is ~5 us of a 5.5 ms step: sub / pow / mean forward and their four
+// backward launches become two).  One workgroup, fixed-order tree: deterministic.
+namespace {
+
+__global__ __launch_bounds__(1024) void k_mse_fwd(float* __restrict__ out, const float* __restrict__ a,
+                                                  const float* __restrict__ b, int64_t n, float inv_n) {
+    __shared__ float part[16];
+    float acc = 0.0f;
+    const int64_t n4 = n >> 2;
+    for (int64_t i = threadIdx.x; i < n4; i += 1024) {
+        const float4 x = reinterpret_cast<const float4*>(a)[i], y = reinterpret_cast<const float4*>(b)[i];
+        const float d0 = x.x - y.x, d1 = x.y - y.y, d2 = x.z - y.z, d3 = x.w - y.w;
+        acc += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+    }
+    for (int64_t i = (n4 << 2) + threadIdx.x; i < n; i += 1024) {
+        const float d = a[i] - b[i];
+        acc += d * d;
+    }
+    acc = sr_wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = 0.0f;
+        for (int w = 0; w < 16; ++w) t += part[w];
+        out[0] = t * inv_n;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_mse_bwd(float* __restrict__ ga, const float* __restrict__ gout,
+                                                 const float* __restrict__ a, const float* __restrict__ b, int64_t n,
+                                                 float two_inv_n) {
+    const float k = gout[0] * two_inv_n;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) ga[i] = k * (a[i] - b[i]);
+}
+
+}  // namespace
+
+extern "C" int sr_mse_fwd(float* out, const float* a, const float* b, int64_t n, sr_stream_t stream) {
+    if (n <= 0 || !out || !a || !b) return SR_EINVAL;
+    if (((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b)) & 15) != 0) return SR_EINVAL;
+    hipLaunchKernelGGL(k_mse_fwd, dim3(1), dim3(1024), 0, sr_stream(stream), out, a, b, n, 1.0f / (float)n);
+    return sr_launch_status();
+}
+
+extern "C" int sr_mse_bwd(float* ga, const float* gout, const float* a, const float* b, int64_t n, sr_stream_t stream) {
+    if (n <= 0 || !ga || !gout || !a || !b) return SR_EINVAL;
+    hipLaunchKernelGGL(k_mse_bwd, dim3(sr_stream_grid(n, 256)), dim3(256), 0, sr_stream(stream), ga, gout, a, b, n,
+                       2.0f / (float)n);
+    return sr_launch_status();
+}

@@ -1669,7 +1669,7 @@ __global__ __launch_bounds__(256) void k_grad_vert(long long nv, long long nf, c
                                                    long long adj_bstride, const R* __restrict__ tg,
                                                    const unsigned long long* __restrict__ valid, int tex_c, int ch0,
                                                    R* __restrict__ grad_v, R* __restrict__ grad_tex, int slots,
-                                                   const R* __restrict__ tail, long long plane) {
+                                                   const R* __restrict__ tail, long long plane, bool accumulate) {
     const long long vert = (long long)blockIdx.x * 256 + threadIdx.x;
     const long long s = blockIdx.y;
     const bool live = vert < nv;
@@ -1733,16 +1733,18 @@ __global__ __launch_bounds__(256) void k_grad_vert(long long nv, long long nf, c
     }
     if (!live) return;
     if (grad_v && ch0 == 0) {
+        // accumulate (SR_RASTER_GRAD_ACC): the buffers hold the gradient of earlier calls — the same mesh rasterised at
+        // several resolutions sums its gradients here, in call order, instead of in one tensor addition per call
         R* o = grad_v + (s * nv + vert) * 3;
-        o[0] = av[0];
-        o[1] = av[1];
-        o[2] = av[2];
+        o[0] = accumulate ? o[0] + av[0] : av[0];
+        o[1] = accumulate ? o[1] + av[1] : av[1];
+        o[2] = accumulate ? o[2] + av[2] : av[2];
     }
     if (grad_tex) {
         R* o = grad_tex + (s * nv + vert) * tex_c + ch0;
 #pragma unroll
         for (int j = 0; j < CT; ++j)
-            if (ch0 + j < tex_c) o[j] = at[j];
+            if (ch0 + j < tex_c) o[j] = accumulate ? o[j] + at[j] : at[j];
     }
 }
 
@@ -1877,7 +1879,7 @@ void grad_launch(long long b, long long nv, long long nf, long long h, long long
                  const R* tex, int tex_c, int ch0, const long long* tri, const int* win, const int* big,
                  const R* grad_out, const int* adj_off, const int* adj, long long off_bs, long long adj_bs,
                  R* grad_v, R* grad_tex, R eps, R* tg, const int* first, unsigned long long* valid, bool chw,
-                 const int* slot_of, long long slot_bs, R* tail, hipStream_t st) {
+                 const int* slot_of, long long slot_bs, R* tail, bool accumulate, hipStream_t st) {
     const bool want_v = grad_v != nullptr && ch0 == 0;
     const long long plane = b * 3 * nf;
     // few lanes: the gather is a latency chain, read the slots eagerly (SR_RASTER_GRAD_EAGER=0 / 1 forces)
@@ -1891,7 +1893,7 @@ void grad_launch(long long b, long long nv, long long nf, long long h, long long
                            chw, slot_of, slot_bs, tail, plane);
     hipLaunchKernelGGL((k_grad_vert<R, CT, PERSP>), dim3((unsigned)sr_ceil_div(nv, 256), (unsigned)b), dim3(256), 0,
                        st, nv, nf, adj_off, adj, off_bs, adj_bs, tg, valid, tex_c, ch0, grad_v, grad_tex,
-                       slot_of == nullptr ? 0 : (eager ? 2 : 1), tail, plane);
+                       slot_of == nullptr ? 0 : (eager ? 2 : 1), tail, plane, accumulate);
 }
 
 template <typename R>
@@ -1901,6 +1903,7 @@ int grad_impl(long long b, long long nv, long long nf, long long h, long long w,
               const int* adj_slot, R* grad_v, R* grad_tex, R eps, void* work, hipStream_t st) {
     if (b < 0 || nv < 0 || nf < 0 || h < 0 || w < 0 || tex_c <= 0) return SR_EINVAL;
     const bool chw = (perspective & SR_RASTER_CHW) != 0;        // grad_out [b, c, h, w] (see forward_impl)
+    const bool accumulate = (perspective & SR_RASTER_GRAD_ACC) != 0;
     perspective &= 1;
     if (b == 0 || nv == 0 || (!grad_v && !grad_tex)) return SR_OK;
     if (b > 65535 || nf >= 0x7FFFFFFFLL / 3 || tex_c > 0x7FFFFFFF) return SR_ERANGE;
@@ -1948,7 +1951,7 @@ int grad_impl(long long b, long long nv, long long nf, long long h, long long w,
         const long long ct = tex_c - ch0 < 4 ? tex_c - ch0 : 4;
 #define SR_GRAD_ARGS                                                                                              \
     b, nv, nf, h, w, repeat_f != 0, v, tex, (int)tex_c, (int)ch0, tri, win, big, grad_out, adj_off, adj, off_bs, \
-        adj_bs, grad_v, grad_tex, eps, tg, first, valid, chw, slot_of, slot_bs, tail, st
+        adj_bs, grad_v, grad_tex, eps, tg, first, valid, chw, slot_of, slot_bs, tail, accumulate, st
 #define SR_GRAD_CASE(CT)                                          \
     do {                                                          \
         if (perspective) grad_launch<R, CT, true>(SR_GRAD_ARGS);  \

@@ -102,8 +102,10 @@ class LatentInverter:
         return img
 
     def loss(self, img):
+        from .op.lpips_layer import mse
+
         d = self.perceptual.distance_to(self.target_feats, img).mean()
-        return d + self.pixel_weight * torch.mean((img - self.target) ** 2)
+        return d + self.pixel_weight * mse(img, self.target)
 
     def _iteration(self):
         self.w.grad = None

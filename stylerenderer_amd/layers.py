@@ -271,7 +271,8 @@ class ModulatedConv2d(nn.Module):
         if (self.kernel_size == 1 and not self.demodulate and not self.upsample and not self.downsample
                 and _smallconv.supported(input, self.out_channel)):
             # ToRGB: <= 4 output channels -> streaming kernels instead of 128-wide MFMA tiles
-            return _smallconv.modulated_conv1x1_small(input, self.weight[0, :, :, 0, 0] * self.scale, s)
+            return _smallconv.modulated_conv1x1_small(input, self.weight.view(self.out_channel, self.in_channel), s,
+                                                      scale=self.scale)
         k = self.kernel_size
         if k not in (1, 3) or ((self.upsample or self.downsample) and k != 3):
             return self._forward_generic(input, s, skip_blur)

@@ -76,6 +76,10 @@ def spatial_average(x, keepdim=True):
     return x.mean([2, 3], keepdim=keepdim)
 
 
+def _fused_trunk():
+    return os.environ.get("SR_LPIPS_FUSED_TRUNK", "1") != "0"
+
+
 class _Conv3x3ReLU(nn.Module):
     """features[i] (Conv2d 3x3 pad 1) fused with features[i+1] (ReLU)."""
 
@@ -94,7 +98,12 @@ class _Conv3x3ReLU(nn.Module):
                     wt = _weight_prep(self.weight, 1.0)[0]
                     wt._sr_frozen = True                # trunk weights never train: ConvFn caches their adjoints
                     self._prepared = (tag, wt)
-            out = _conv.conv2d(x, self._prepared[1], None, None, None, "c3")
+            wt = self._prepared[1]
+            xc = x.contiguous()
+            if _fused_trunk() and _conv.conv_nba_supported(xc, wt, None):
+                # Winograd-eligible shapes (9 of the 13 layers at 256^2): bias + ReLU ride in the convolution's store
+                return _conv.conv2d_nba(xc, wt, None, None, None, None, self.bias, 0.0, 1.0)
+            out = _conv.conv2d(x, wt, None, None, None, "c3")
             return fused_leaky_relu(out, self.bias, 0.0, 1.0)                     # bias + ReLU in one pass
         return F.relu(F.conv2d(x, self.weight, self.bias, padding=1))
 

@@ -22,6 +22,7 @@ from .op import smallconv as _smallconv
 from .op import style_bank as _style_bank
 from .op import weight_bank as _weight_bank
 from .op.fused_elem import blur_noise_bias_act, noise_bias_act, noise_bias_act_affine
+from .op.rasterize import rasterize_pyramid
 from .op.upfirdn2d import upsample2_add
 
 CHANNEL_BASE = {4: 512, 8: 512, 16: 512, 32: 512, 64: 256, 128: 128, 256: 64, 512: 32, 1024: 16}
@@ -122,8 +123,8 @@ class ToRGB(nn.Module):
         if _smallconv.supported(input, conv.out_channel):
             # device tensors: the bias rides in the streaming 1x1 kernel and the skip addition in the up-sampling
             # kernel's store — two launches for conv + bias + upsample + add (reference model.py:63-69)
-            out = _smallconv.modulated_conv1x1_small(input, conv.weight.view(conv.out_channel, conv.in_channel) * conv.scale,
-                                                     conv.style_of(style), self.bias.view(-1))
+            out = _smallconv.modulated_conv1x1_small(input, conv.weight.view(conv.out_channel, conv.in_channel),
+                                                     conv.style_of(style), self.bias.view(-1), scale=conv.scale)
             if skip is not None:
                 out = upsample2_add(skip, self.upsample.kernel, self.upsample.pad, out)
             return out
@@ -332,7 +333,13 @@ class GeneratorWithMap(Generator):
         # returns and what the path-length regulariser differentiates against.  Here the rasterizer writes the maps
         # channel-major itself (SR_RASTER_CHW: same values, no re-layout pass forward or backward per resolution;
         # SR_RASTER_NCHW=0 keeps the permuted view + one contiguous copy for the map heads)
-        norm_maps = [_normal_map(vert, attr, tri, int(out.shape[2]), int(out.shape[3]))]
+        res0 = (int(out.shape[2]), int(out.shape[3]))
+        # device tensors: the normal maps of all resolutions from ONE node, whose backward adds the per-resolution mesh
+        # gradients inside the gather kernels (op.rasterize.RasterizePyramid) instead of 2 tensor additions per resolution
+        # (levels = what the loop below consumes: `to_rgbs` carries the reference's unused second half)
+        pyramid = _normal_pyramid(vert, attr, tri, [(res0[0] << k, res0[1] << k)
+                                                     for k in range(min(len(self.convs) // 2, len(self.to_rgbs)) + 1)])
+        norm_maps = [pyramid[0] if pyramid else _normal_map(vert, attr, tri, res0[0], res0[1])]
         maps = self.norm1(norm_maps[-1].contiguous())
         st = self._layer_styles(latent)
         out = self.conv1(out, st[0], maps, noise=noise[0])
@@ -341,7 +348,8 @@ class GeneratorWithMap(Generator):
         i, k = 1, 2
         for conv_up, conv, n_up, n_conv, to_rgb in zip(self.convs[::2], self.convs[1::2],
                                                        noise[1::2], noise[2::2], self.to_rgbs):
-            norm_maps.append(_normal_map(vert, attr, tri, 2 * int(out.shape[2]), 2 * int(out.shape[3])))
+            norm_maps.append(pyramid[len(norm_maps)] if pyramid else
+                             _normal_map(vert, attr, tri, 2 * int(out.shape[2]), 2 * int(out.shape[3])))
             nm = norm_maps[-1].contiguous()
             if two_stage:
                 maps = self.norm_to_style[i](self.norm_to_style[i - 1](nm))
@@ -356,6 +364,17 @@ class GeneratorWithMap(Generator):
             i += 2
             k += 3
         return skip, (latent if return_latents else None), (norm_maps if return_normals else None)
+
+
+def _normal_pyramid(vert, attr, tri, sizes):
+    """The channel-major normal maps of all `sizes` from one autograd node, or None (CPU tensors, the permuted-view layout
+    SR_RASTER_NCHW=0, SR_RASTER_PYRAMID=0: the caller rasterises per resolution)."""
+    import os
+
+    if (vert.device.type != "cuda" or vert.dim() != 3 or attr.dim() != 3 or os.environ.get("SR_RASTER_NCHW", "1") == "0"
+            or os.environ.get("SR_RASTER_PYRAMID", "1") == "0"):
+        return None
+    return rasterize_pyramid(vert, attr, tri, sizes, channel_major=True)
 
 
 def _normal_map(vert, attr, tri, h, w):

@@ -15,7 +15,7 @@ import torch
 from .. import _lib
 from ._dispatch import hold_for_capture, on_device_of, require_f32, stream_of
 from . import weight_prep as _wp
-from .fused_elem import rowdot
+from .fused_elem import rowdot, rowdot_div
 
 
 # Optional per-launch timing used by bench.py's roofline leg: when PROFILE is a list, every MFMA
@@ -228,7 +228,7 @@ class ConvFn(torch.autograd.Function):
             gw = WgradFn.apply(x, g, iscale, oscale, geom)
         if need_os:
             y0 = out - bias[None, :, None, None] if bias is not None else out
-            gos = rowdot(g, y0) / oscale
+            gos = rowdot_div(g, y0, oscale)
         if need_b:
             gb = g.sum((0, 2, 3))
         return gx, gw, gis, gos, gb, None
@@ -355,7 +355,15 @@ class ConvNBAFn(torch.autograd.Function):
                 grads = [next(got) if (nd and t is not None) else None for t, nd in zip(ins, needs[:7])]
             return tuple(grads) + (None, None)
         want_p = bool(needs[6] or (noise is not None and needs[5]))
-        g, gb, gnw, rdot = _nba_bwd_dot(gy, out, noise, noise_w, abias, slope, gain, want_p)
+        if oscale is None:
+            # no demodulation (the LPIPS trunk's plain convolution + bias + ReLU): nothing to row-dot — and with slope 0
+            # the pre-activation cannot be rebuilt from the output anyway
+            from .fused_elem import _NBABackward
+
+            g, gb, gnw = _NBABackward.apply(gy, out, noise, slope, gain, want_p)
+            rdot = None
+        else:
+            g, gb, gnw, rdot = _nba_bwd_dot(gy, out, noise, noise_w, abias, slope, gain, want_p)
         gx = gw = gis = gos = None
         if needs[0] or needs[2]:
             dxu = ConvFn.apply(g, adjoint_weight(wt, "c3", ctx.frozen, ctx.adj), oscale, None, None, "c3")

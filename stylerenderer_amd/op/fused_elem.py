@@ -351,3 +351,23 @@ def rowdot(a, b, scale=None):
         dots = (a * b).sum((2, 3))
         return dots if scale is None else (dots, b * scale[:, :, None, None])
     return _RowDot.apply(a, b, scale.contiguous() if scale is not None else None)
+
+
+def rowdot_div(a, b, div):
+    """rowdot(a, b) / div [B, C].  Outside a recorded pass (no autograd graph is being built) one kernel does both
+    (sr_rowdot_div); a recorded pass composes the two differentiable operators."""
+    ok = (not torch.is_grad_enabled() and a.device.type == "cuda" and a.dtype == torch.float32 and a.dim() == 4
+          and a.shape == b.shape and a.size(0) * a.size(1) <= 65535 and a.is_contiguous() and b.is_contiguous()
+          and div.dtype == torch.float32 and tuple(div.shape) == tuple(a.shape[:2]) and div.is_contiguous())
+    if not ok:
+        return rowdot(a, b) / div
+    rows = a.size(0) * a.size(1)
+    inner = a.numel() // max(rows, 1)
+    dots = torch.empty(a.shape[:2], dtype=a.dtype, device=a.device)
+    L = _lib.lib()
+    scratch = torch.empty(L.sr_rowdot_scratch_floats(rows, inner), dtype=a.dtype, device=a.device)
+    with on_device_of(a):
+        rc = L.sr_rowdot_div(_lib.ptr(dots), _lib.ptr(a), _lib.ptr(b), _lib.ptr(div), rows, inner, _lib.ptr(scratch),
+                             stream_of(a))
+    _lib.check(rc, "sr_rowdot_div")
+    return dots

@@ -58,3 +58,36 @@ class _LpipsLayer(Function):
 
 def lpips_layer(f0, t_normalised, lin):
     return _LpipsLayer.apply(f0, t_normalised, lin)
+
+
+class _MSE(Function):
+    """mean((a - b)^2) -> 0-d, differentiable once w.r.t. a (sr_mse_fwd / _bwd: one launch each way)."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        a, b = a.contiguous(), b.contiguous()
+        out = torch.empty((), dtype=a.dtype, device=a.device)
+        with on_device_of(a):
+            rc = _lib.lib().sr_mse_fwd(_lib.ptr(out), _lib.ptr(a), _lib.ptr(b), a.numel(), stream_of(a))
+        _lib.check(rc, "sr_mse_fwd")
+        ctx.save_for_backward(a, b)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        a, b = ctx.saved_tensors
+        ga = torch.empty_like(a)
+        with on_device_of(a):
+            rc = _lib.lib().sr_mse_bwd(_lib.ptr(ga), _lib.ptr(g.contiguous()), _lib.ptr(a), _lib.ptr(b), a.numel(), stream_of(a))
+        _lib.check(rc, "sr_mse_bwd")
+        return ga, None
+
+
+def mse(a, b):
+    """torch.mean((a - b) ** 2) with b fixed; device float32 tensors take the fused kernels."""
+    if (a.device.type == "cuda" and a.dtype == torch.float32 and b.dtype == torch.float32 and a.shape == b.shape
+            and a.numel() > 0 and not b.requires_grad and a.contiguous().data_ptr() % 16 == 0
+            and b.contiguous().data_ptr() % 16 == 0):
+        return _MSE.apply(a, b)
+    return torch.mean((a - b) ** 2)

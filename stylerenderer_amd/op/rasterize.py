@@ -19,6 +19,7 @@ CPU tensors take the library's host loops (sr_rasterize_*_cpu_*: the reference's
 CPU tensors, op/rasterize.cpp:126-150) with the interpolation / scatter in torch like the reference's
 Python; that branch is keyed on the tensors' device and never reached for `cuda` tensors.
 """
+import os
 import types
 
 import torch
@@ -57,6 +58,7 @@ def _suffix(t):
     raise RuntimeError(" type error")
 
 
+SR_RASTER_GRAD_ACC = 4     # sr_rasterize_grad_*: add to what grad_v / grad_tex hold (RasterizePyramid)
 SR_RASTER_CHW = 2          # include/stylerenderer_amd.h: attribute maps / their gradient channel-major [b, c, h, w]
 
 
@@ -212,6 +214,40 @@ def incidence(tri, nv):
     return val[:5]
 
 
+def _device_grad(v, tex, tri, win, big, grad_out, chw, perspective, eps, no_channel, need_v, need_t, into=None):
+    """One sr_rasterize_grad_* call over the gradient state (win, big) of a device forward.  `into` = (grad_v, grad_t) of
+    an earlier call over the same mesh: this call ADDS to them (SR_RASTER_GRAD_ACC)."""
+    if v.dim() != 3:
+        raise RuntimeError("rasterize backward: batched vertices [b, n, 3] required")
+    if win is None:
+        raise RuntimeError("rasterize backward: the forward pass recorded no gradient state")
+    suf = _suffix(v)
+    b, nv = v.size(0), v.size(1)
+    nf = tri.size(-2)
+    h, w = win.shape[-2], win.shape[-1]
+    c = 1 if no_channel else int(tex.shape[-1])
+    go = grad_out.contiguous()                            # [b, h, w, c], or [b, c, h, w] for a chw forward
+    tex_c = tex.contiguous()
+    if tex_c.dim() < 2 or tex_c.shape[0] != b or tex_c.shape[1] != nv:
+        raise RuntimeError("rasterize backward: batched attributes [b, n(, c)] required")
+    if into is not None:
+        grad_v, grad_t = into
+    else:
+        grad_v = torch.empty_like(v) if need_v else None
+        grad_t = torch.empty_like(tex_c) if need_t else None
+    off, adj, off_bs, adj_bs, slot = incidence(tri, nv)
+    L = _lib.lib()
+    work = torch.empty(L.sr_rasterize_grad_scratch_bytes(b, nf, c, int(suf == "f64")), dtype=torch.uint8, device=v.device)
+    flags = int(bool(perspective)) | (SR_RASTER_CHW if chw else 0) | (SR_RASTER_GRAD_ACC if into is not None else 0)
+    with on_device_of(v):
+        rc = getattr(L, "sr_rasterize_grad_" + suf)(
+            b, nv, nf, h, w, int(tri.dim() == 2), flags, _lib.ptr(v), _lib.ptr(tex_c), c,
+            _lib.ptr(tri), _lib.ptr(win), _lib.ptr(big), _lib.ptr(go), _lib.ptr(off), _lib.ptr(adj), off_bs, adj_bs,
+            _lib.ptr(slot), _lib.ptr(grad_v), _lib.ptr(grad_t), abs(float(eps)), _lib.ptr(work), stream_of(v))
+    _lib.check(rc, "sr_rasterize_grad")
+    return grad_v, grad_t
+
+
 class Rasterize(Function):
     @staticmethod
     def forward(ctx, v, tex, tri, h, w, perspective, eps, chw=False):
@@ -246,32 +282,8 @@ class Rasterize(Function):
                 grad_out = grad_out.permute(0, 2, 3, 1)
             return Rasterize._backward_host(ctx, grad_out, need_v, need_t) + (None,)
         v, tex, tri, win, big = ctx.saved_tensors
-        if v.dim() != 3:
-            raise RuntimeError("rasterize backward: batched vertices [b, n, 3] required")
-        if win is None:
-            raise RuntimeError("rasterize backward: the forward pass recorded no gradient state")
-        suf = _suffix(v)
-        b, nv = v.size(0), v.size(1)
-        nf = tri.size(-2)
-        h, w = win.shape[-2], win.shape[-1]
-        c = 1 if ctx.no_channel else int(tex.shape[-1])
-        go = grad_out.contiguous()                            # [b, h, w, c], or [b, c, h, w] for a chw forward
-        tex_c = tex.contiguous()
-        if tex_c.dim() < 2 or tex_c.shape[0] != b or tex_c.shape[1] != nv:
-            raise RuntimeError("rasterize backward: batched attributes [b, n(, c)] required")
-        grad_v = torch.empty_like(v) if need_v else None
-        grad_t = torch.empty_like(tex_c) if need_t else None
-        off, adj, off_bs, adj_bs, slot = incidence(tri, nv)
-        L = _lib.lib()
-        work = torch.empty(L.sr_rasterize_grad_scratch_bytes(b, nf, c, int(suf == "f64")), dtype=torch.uint8,
-                           device=v.device)
-        with on_device_of(v):
-            rc = getattr(L, "sr_rasterize_grad_" + suf)(
-                b, nv, nf, h, w, int(tri.dim() == 2), int(bool(ctx.perspective)) | (SR_RASTER_CHW if ctx.chw else 0),
-                _lib.ptr(v), _lib.ptr(tex_c), c,
-                _lib.ptr(tri), _lib.ptr(win), _lib.ptr(big), _lib.ptr(go), _lib.ptr(off), _lib.ptr(adj), off_bs, adj_bs,
-                _lib.ptr(slot), _lib.ptr(grad_v), _lib.ptr(grad_t), abs(float(ctx.eps)), _lib.ptr(work), stream_of(v))
-        _lib.check(rc, "sr_rasterize_grad")
+        grad_v, grad_t = _device_grad(v, tex, tri, win, big, grad_out, ctx.chw, ctx.perspective, ctx.eps, ctx.no_channel,
+                                      need_v, need_t)
         return grad_v, grad_t, None, None, None, None, None, None
 
     @staticmethod
@@ -302,3 +314,58 @@ def rasterize(v, tex, tri, h=256, w=0, perspective=False, eps=1e-6, channel_majo
     """reference op/rasterize.py `rasterize`; channel_major=True returns the interpolated attributes as [b, c, h, w]
     (= the reference's output .permute(0, 3, 1, 2), contiguous) straight from the kernel."""
     return Rasterize.apply(v, tex, tri, h, w, perspective, eps, channel_major)
+
+
+class RasterizePyramid(Function):
+    """The same posed mesh rasterised at several resolutions as ONE node (GeneratorWithMap draws a normal map per
+    synthesis resolution: reference model.py:255-262, seven calls at 256^2).  Forward: the per-resolution launches of
+    `Rasterize`, unchanged.  Backward: one gradient pass per resolution, each ADDING into the same vertex / attribute
+    gradient buffers in list order (SR_RASTER_GRAD_ACC) — autograd otherwise sums the seven [b, nv, 3] pairs with twelve
+    tensor additions per backward.  Device tensors, batched [b, nv, 3] vertices; same values as the separate calls up to
+    the order of those seven additions (fixed: deterministic)."""
+
+    @staticmethod
+    def forward(ctx, v, tex, tri, sizes, perspective, eps, chw):
+        v = v.contiguous()
+        tri = tri.contiguous()
+        need_grad = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
+        chw = bool(chw) and tex.dim() == v.dim()
+        outs, states = [], []
+        for h, w in sizes:
+            _, _, _, out, state = _forward_impl(v, tri, h, w, perspective, eps, tex=tex, want_index=False,
+                                                want_win=need_grad, chw=chw)
+            outs.append(out)
+            states += list(state) if state is not None else [None, None]
+        ctx.cfg = (chw, perspective, eps, len(sizes))
+        ctx.set_materialize_grads(False)          # a map nobody differentiated arrives as None, not as a zero-filled tensor
+        ctx.save_for_backward(v, tex, tri, *states)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        need_v, need_t = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        if not (need_v or need_t):
+            return (None,) * 7
+        chw, perspective, eps, n = ctx.cfg
+        v, tex, tri = ctx.saved_tensors[:3]
+        states = ctx.saved_tensors[3:]
+        into = None
+        for k in range(n):
+            if grads[k] is None:
+                continue
+            into = _device_grad(v, tex, tri, states[2 * k], states[2 * k + 1], grads[k], chw, perspective, eps, False,
+                                need_v, need_t, into=into)
+        if into is None:
+            return (None,) * 7
+        return into[0], into[1], None, None, None, None, None
+
+
+def rasterize_pyramid(v, tex, tri, sizes, perspective=False, eps=1e-6, channel_major=False):
+    """[rasterize(v, tex, tri, h, w) for (h, w) in sizes] — on device tensors one autograd node whose backward sums the
+    per-resolution gradients inside the gather kernels (RasterizePyramid)."""
+    sizes = [(int(h), int(w)) for h, w in sizes]
+    if (is_device_tensor(v) and v.dim() == 3 and tex.dim() == 3 and len(sizes) > 1
+            and os.environ.get("SR_RASTER_PYRAMID", "1") != "0"):
+        ctxless = RasterizePyramid.apply(v, tex, tri, tuple(sizes), perspective, eps, channel_major)
+        return list(ctxless)
+    return [rasterize(v, tex, tri, h, w, perspective, eps, channel_major) for h, w in sizes]

@@ -99,7 +99,61 @@ class SmallConvDw(Function):
         return d_g, d_x
 
 
-def modulated_conv1x1_small(x, weight_jc, style, bias=None):
-    """weight_jc [N, C] (already scaled), style [B, C], optional bias [N] -> [B, N, H, W]."""
-    ws = weight_jc[None, :, :] * style[:, None, :]
+class _ModRows(Function):
+    """ws[b,j,c] = (scale * w[j,c]) * s[b,c] in one launch (sr_modrows_fwd); its first-order pull-back in one launch too
+    (sr_modrows_bwd) instead of the six multiply / reduce launches of the differentiated tensor products.  A RECORDED
+    backward (path-length regulariser, R1) re-derives the pull-back from the defining products under autograd."""
+
+    @staticmethod
+    def forward(ctx, w, s, scale):
+        w_, s_ = w.contiguous(), s.contiguous()
+        n, c = w_.shape
+        b = s_.shape[0]
+        ws = torch.empty((b, n, c), dtype=s.dtype, device=s.device)
+        with on_device_of(s):
+            rc = _lib.lib().sr_modrows_fwd(_lib.ptr(ws), _lib.ptr(w_), _lib.ptr(s_), float(scale), b, n, c, stream_of(s))
+        _lib.check(rc, "sr_modrows_fwd")
+        ctx.save_for_backward(w, s)
+        ctx.scale = float(scale)
+        return ws
+
+    @staticmethod
+    def backward(ctx, g):
+        w, s = ctx.saved_tensors
+        need_w, need_s = ctx.needs_input_grad[:2]
+        if torch.is_grad_enabled():
+            with torch.enable_grad():
+                wa, sa = w.view_as(w), s.view_as(s)          # aliases: gradients stop at the node boundary
+                ws = (wa * ctx.scale)[None, :, :] * sa[:, None, :]
+                sel = [t for t, nd in ((wa, need_w), (sa, need_s)) if nd]
+                got = iter(torch.autograd.grad(ws, sel, g, create_graph=True)) if sel else iter(())
+                return (next(got) if need_w else None), (next(got) if need_s else None), None
+        g_, w_, s_ = g.contiguous(), w.contiguous(), s.contiguous()
+        n, c = w_.shape
+        b = s_.shape[0]
+        gw = torch.empty_like(w_) if need_w else None
+        gs = torch.empty_like(s_) if need_s else None
+        if gw is not None or gs is not None:
+            with on_device_of(s):
+                rc = _lib.lib().sr_modrows_bwd(_lib.ptr(gs), _lib.ptr(gw), _lib.ptr(g_), _lib.ptr(w_), _lib.ptr(s_),
+                                               ctx.scale, b, n, c, stream_of(s))
+            _lib.check(rc, "sr_modrows_bwd")
+        return gw, gs, None
+
+
+def modulated_rows(weight_nc, style, scale):
+    """[B, N, C] = (scale * weight_nc [N, C]) * style [B, C] — the per-sample weights of the 1x1 convolution."""
+    if (style.device.type == "cuda" and style.dtype == torch.float32 and weight_nc.dtype == torch.float32
+            and weight_nc.dim() == 2 and style.dim() == 2):
+        return _ModRows.apply(weight_nc, style, float(scale))
+    return (weight_nc * scale)[None, :, :] * style[:, None, :]
+
+
+def modulated_conv1x1_small(x, weight_jc, style, bias=None, scale=None):
+    """weight_jc [N, C], style [B, C], optional bias [N] -> [B, N, H, W].  `scale` None: weight_jc is already scaled
+    (two tensor products); a number: the raw parameter view, scaled and modulated in one launch (`modulated_rows`)."""
+    if scale is None:
+        ws = weight_jc[None, :, :] * style[:, None, :]
+    else:
+        ws = modulated_rows(weight_jc, style, scale)
     return SmallConvFwd.apply(x, ws, bias)
