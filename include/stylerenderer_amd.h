@@ -363,6 +363,20 @@ int sr_rasterize_forward_f64(int64_t b, int64_t nv, int64_t nf, int64_t h, int64
                              const double* tex, int64_t tex_c, double* attr, int32_t* win, int32_t* big,
                              void* work, sr_stream_t stream);
 
+/* The same mesh rasterised at n resolutions (GeneratorWithMap draws one normal map per synthesis resolution, reference
+ * model.py:255-262) in THREE launches instead of three per resolution: interpolated attributes only (attr[l]:
+ * [b,h_l,w_l,c] or, with SR_RASTER_CHW, [b,c,h_l,w_l]) plus the gradient state win[l] / big[l] of each level (the arrays, or
+ * single entries, may be NULL: no gradient state); work[l] >= sr_rasterize_scratch_bytes(b, nf, h_l, w_l, 0) bytes each.
+ * Same kernels' bodies as sr_rasterize_forward_f32 on its global-key path: same bits.  Levels the per-call dispatcher would
+ * give to the LDS-tiled path are not taken (sr_rasterize_levels_supported returns 0, the call SR_EINVAL): the caller then
+ * goes level by level. */
+#define SR_RASTER_MAX_LEVELS 12
+int sr_rasterize_levels_supported(int n, int64_t b, int64_t nf, const int64_t* h, const int64_t* w);
+int sr_rasterize_forward_levels_f32(int n, int64_t b, int64_t nv, int64_t nf, const int64_t* h, const int64_t* w,
+                                    int repeat_v, int repeat_f, int perspective, const float* v, const int64_t* tri,
+                                    float eps, const float* tex, int64_t tex_c, float* const* attr, int32_t* const* win,
+                                    int32_t* const* big, void* const* work, sr_stream_t stream);
+
 /* d(coeff)/d(vertex) per pixel.  Replaces  bool rasterize_gpu_backward<scalar,index>(b, n, h, w,
  *   repeat_v, perspective, const scalar* v, const index* i, scalar* dcoeff, scalar eps)
  * reference op/rasterize.cu:124-127 (arithmetic op/rasterize.h:169-228).  dcoeff [b,h,w,3,9];
@@ -554,6 +568,12 @@ int sr_lpips_layer_bwd(float* gf, const float* gd, const float* f0, const float*
  * order), and ga = gout[0] * 2 / n * (a - b).  a, b 16-byte aligned for the forward. */
 int sr_mse_fwd(float* out, const float* a, const float* b, int64_t n, sr_stream_t stream);
 int sr_mse_bwd(float* ga, const float* gout, const float* a, const float* b, int64_t n, sr_stream_t stream);
+/* 2 x 2 / stride 2 max pooling of the LPIPS trunk (reference lpips/pretrained_networks.py:97-135, torchvision VGG16
+ * features 4 / 9 / 16 / 23) over `planes` maps of ih x iw (both even), and its gradient: gx gets gy at the arg-max of
+ * every window (first maximum in row-major order, a NaN wins — torch.nn.functional.max_pool2d's rule) and zero elsewhere;
+ * every input pixel is written. */
+int sr_maxpool2_fwd(float* out, const float* x, int64_t planes, int64_t ih, int64_t iw, sr_stream_t stream);
+int sr_maxpool2_bwd(float* gx, const float* gy, const float* x, int64_t planes, int64_t ih, int64_t iw, sr_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -66,6 +66,8 @@ SIGNATURES = {
     "sr_lpips_layer_bwd": (_i, [_p] * 5 + [_l] * 4 + [_f, _p]),
     "sr_mse_fwd": (_i, [_p] * 3 + [_l, _p]),
     "sr_mse_bwd": (_i, [_p] * 4 + [_l, _p]),
+    "sr_maxpool2_fwd": (_i, [_p] * 2 + [_l] * 3 + [_p]),
+    "sr_maxpool2_bwd": (_i, [_p] * 3 + [_l] * 3 + [_p]),
     "sr_upfirdn2d": (_i, [_p, _p, _p, _l] + [_i] * 14 + [_p]),
     "sr_upsample2_add": (_i, [_p] * 4 + [_l] + [_i] * 6 + [_p]),
     "sr_blur_noise_bias_act": (_i, [_p] * 6 + [_f, _f, _l, _l] + [_i] * 6 + [_l, _p]),
@@ -76,6 +78,8 @@ SIGNATURES = {
     "sr_blur_nba_bwd": (_i, [_p] * 10 + [_f, _f, _l, _l] + [_i] * 5 + [_l, _p, _p]),
     "sr_rasterize_scratch_bytes": (_l, [_l, _l, _l, _l, _i]),
     "sr_rasterize_forward_f32": (_i, [_l] * 5 + [_i] * 3 + [_p] * 5 + [_f, _p, _l, _p, _p, _p, _p, _p]),
+    "sr_rasterize_levels_supported": (_i, [_i, _l, _l, _p, _p]),
+    "sr_rasterize_forward_levels_f32": (_i, [_i, _l, _l, _l, _p, _p, _i, _i, _i, _p, _p, _f, _p, _l, _p, _p, _p, _p, _p]),
     "sr_rasterize_forward_f64": (_i, [_l] * 5 + [_i] * 3 + [_p] * 5 + [_d, _p, _l, _p, _p, _p, _p, _p]),
     "sr_rasterize_grad_scratch_bytes": (_l, [_l, _l, _l, _i]),
     "sr_rasterize_forward_cpu_f32": (_i, [_l] * 5 + [_i] * 3 + [_p] * 5 + [_f]),

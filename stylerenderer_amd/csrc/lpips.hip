@@ -198,3 +198,78 @@ extern "C" int sr_mse_bwd(float* ga, const float* gout, const float* a, const fl
                        2.0f / (float)n);
     return sr_launch_status();
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// 2 x 2 / stride 2 max pooling of the VGG trunk (torchvision features 4 / 9 / 16 / 23, reference
+// lpips/pretrained_networks.py:97-135) and its gradient, one launch each.  The gradient recomputes the arg-max from the
+// saved input with torch's rule (the first maximum of the window in row-major order wins; a NaN wins) and writes EVERY
+// input pixel — no zero-fill launch in front of it, no index tensor kept.
+namespace {
+
+__device__ __forceinline__ int pool2_argmax(float a, float b, float c, float d) {
+    int k = 0;
+    float m = a;
+    if (b > m || b != b) { m = b; k = 1; }
+    if (c > m || c != c) { m = c; k = 2; }
+    if (d > m || d != d) { m = d; k = 3; }
+    return k;
+}
+
+__global__ __launch_bounds__(256) void k_maxpool2_fwd(float* __restrict__ out, const float* __restrict__ x, int64_t planes,
+                                                      int ih, int iw, int oh, int ow) {
+    const int64_t total = planes * oh * ow;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int ox = (int)(i % ow);
+        const int oy = (int)((i / ow) % oh);
+        const int64_t pl = i / ((int64_t)ow * oh);
+        const float* s = x + (pl * ih + 2 * oy) * iw + 2 * ox;
+        const float2 r0 = *reinterpret_cast<const float2*>(s), r1 = *reinterpret_cast<const float2*>(s + iw);
+        const float v[4] = {r0.x, r0.y, r1.x, r1.y};
+        out[i] = v[pool2_argmax(r0.x, r0.y, r1.x, r1.y)];
+    }
+}
+
+__global__ __launch_bounds__(256) void k_maxpool2_bwd(float* __restrict__ gx, const float* __restrict__ gy,
+                                                      const float* __restrict__ x, int64_t planes, int ih, int iw, int oh,
+                                                      int ow) {
+    // one lane per 2 x 2 window (the rows / columns beyond 2 * oh, 2 * ow of an odd map get zero from the last window's lane)
+    const int64_t total = planes * oh * ow;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int ox = (int)(i % ow);
+        const int oy = (int)((i / ow) % oh);
+        const int64_t pl = i / ((int64_t)ow * oh);
+        const int64_t o = (pl * ih + 2 * oy) * iw + 2 * ox;
+        const float2 r0 = *reinterpret_cast<const float2*>(x + o), r1 = *reinterpret_cast<const float2*>(x + o + iw);
+        const int k = pool2_argmax(r0.x, r0.y, r1.x, r1.y);
+        const float g = gy[i];
+        *reinterpret_cast<float2*>(gx + o) = make_float2(k == 0 ? g : 0.0f, k == 1 ? g : 0.0f);
+        *reinterpret_cast<float2*>(gx + o + iw) = make_float2(k == 2 ? g : 0.0f, k == 3 ? g : 0.0f);
+    }
+}
+
+}  // namespace
+
+extern "C" int sr_maxpool2_fwd(float* out, const float* x, int64_t planes, int64_t ih, int64_t iw, sr_stream_t stream) {
+    if (planes < 0 || ih < 0 || iw < 0) return SR_EINVAL;
+    if ((ih | iw) & 1) return SR_EINVAL;                                  // even maps (every trunk map is 2^k wide)
+    const int64_t oh = ih / 2, ow = iw / 2, total = planes * oh * ow;
+    if (total == 0) return SR_OK;
+    if (!out || !x || (reinterpret_cast<uintptr_t>(x) & 7)) return SR_EINVAL;
+    if (ih > 0x7FFFFFFF || iw > 0x7FFFFFFF) return SR_ERANGE;
+    hipLaunchKernelGGL(k_maxpool2_fwd, dim3(sr_stream_grid(total, 256)), dim3(256), 0, sr_stream(stream), out, x, planes,
+                       (int)ih, (int)iw, (int)oh, (int)ow);
+    return sr_launch_status();
+}
+
+extern "C" int sr_maxpool2_bwd(float* gx, const float* gy, const float* x, int64_t planes, int64_t ih, int64_t iw,
+                               sr_stream_t stream) {
+    if (planes < 0 || ih < 0 || iw < 0) return SR_EINVAL;
+    if ((ih | iw) & 1) return SR_EINVAL;
+    const int64_t oh = ih / 2, ow = iw / 2, total = planes * oh * ow;
+    if (total == 0) return SR_OK;
+    if (!gx || !gy || !x || ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(gx)) & 7)) return SR_EINVAL;
+    if (ih > 0x7FFFFFFF || iw > 0x7FFFFFFF) return SR_ERANGE;
+    hipLaunchKernelGGL(k_maxpool2_bwd, dim3(sr_stream_grid(total, 256)), dim3(256), 0, sr_stream(stream), gx, gy, x, planes,
+                       (int)ih, (int)iw, (int)oh, (int)ow);
+    return sr_launch_status();
+}

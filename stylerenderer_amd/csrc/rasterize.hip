@@ -374,14 +374,11 @@ __device__ __forceinline__ void depth_test(const Tri<R>& t, int x, int y, long l
 }
 
 template <typename R, int MODE>
-__global__ __launch_bounds__(256) void k_depth_keys(long long b, long long nv, long long nf,
-                                                    long long h, long long w, bool repeat_v,
-                                                    bool repeat_f, bool perspective,
-                                                    const R* __restrict__ v,
-                                                    const long long* __restrict__ f,
-                                                    unsigned long long* __restrict__ keys,
-                                                    unsigned* __restrict__ tmin, int* __restrict__ big,
-                                                    R eps) {
+__device__ __forceinline__ void depth_keys_body(long long b, long long nv, long long nf, long long h, long long w,
+                                                bool repeat_v, bool repeat_f, bool perspective,
+                                                const R* __restrict__ v, const long long* __restrict__ f,
+                                                unsigned long long* __restrict__ keys, unsigned* __restrict__ tmin,
+                                                int* __restrict__ big, R eps) {
     __shared__ int s_nbig;
     __shared__ int s_big[256];
     if (threadIdx.x == 0) s_nbig = 0;
@@ -432,17 +429,27 @@ __global__ __launch_bounds__(256) void k_depth_keys(long long b, long long nv, l
     }
 }
 
+template <typename R, int MODE>
+__global__ __launch_bounds__(256) void k_depth_keys(long long b, long long nv, long long nf,
+                                                    long long h, long long w, bool repeat_v,
+                                                    bool repeat_f, bool perspective,
+                                                    const R* __restrict__ v,
+                                                    const long long* __restrict__ f,
+                                                    unsigned long long* __restrict__ keys,
+                                                    unsigned* __restrict__ tmin, int* __restrict__ big,
+                                                    R eps) {
+    depth_keys_body<R, MODE>(b, nv, nf, h, w, repeat_v, repeat_f, perspective, v, f, keys, tmin, big, eps);
+}
+
 template <typename R>
-__global__ __launch_bounds__(256) void k_resolve(long long b, long long nv, long long nf, long long h,
-                                                 long long w, bool repeat_v, bool repeat_f,
-                                                 bool perspective, const R* __restrict__ v,
-                                                 const long long* __restrict__ f,
-                                                 const unsigned long long* __restrict__ keys,
-                                                 const unsigned* __restrict__ tmin,
-                                                 long long* __restrict__ index, R* __restrict__ coeff,
-                                                 R* __restrict__ zbuf, const R* __restrict__ tex,
-                                                 long long tex_c, R* __restrict__ attr,
-                                                 int* __restrict__ win, R eps, bool chw) {
+__device__ __forceinline__ void resolve_body(long long b, long long nv, long long nf, long long h, long long w,
+                                             bool repeat_v, bool repeat_f, bool perspective, const R* __restrict__ v,
+                                             const long long* __restrict__ f,
+                                             const unsigned long long* __restrict__ keys,
+                                             const unsigned* __restrict__ tmin, long long* __restrict__ index,
+                                             R* __restrict__ coeff, R* __restrict__ zbuf, const R* __restrict__ tex,
+                                             long long tex_c, R* __restrict__ attr, int* __restrict__ win, R eps,
+                                             bool chw) {
     const long long hw = h * w;
     const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= b * hw) return;
@@ -490,6 +497,72 @@ __global__ __launch_bounds__(256) void k_resolve(long long b, long long nv, long
             attr[chw ? (s * tex_c + ch) * hw + pix : g * tex_c + ch] = s01 + a2;     // [b,c,h,w] or [b,h,w,c]
         }
     }
+}
+
+template <typename R>
+__global__ __launch_bounds__(256) void k_resolve(long long b, long long nv, long long nf, long long h,
+                                                 long long w, bool repeat_v, bool repeat_f,
+                                                 bool perspective, const R* __restrict__ v,
+                                                 const long long* __restrict__ f,
+                                                 const unsigned long long* __restrict__ keys,
+                                                 const unsigned* __restrict__ tmin,
+                                                 long long* __restrict__ index, R* __restrict__ coeff,
+                                                 R* __restrict__ zbuf, const R* __restrict__ tex,
+                                                 long long tex_c, R* __restrict__ attr,
+                                                 int* __restrict__ win, R eps, bool chw) {
+    resolve_body<R>(b, nv, nf, h, w, repeat_v, repeat_f, perspective, v, f, keys, tmin, index, coeff, zbuf, tex, tex_c,
+                    attr, win, eps, chw);
+}
+
+// ---- the same mesh at several resolutions in three launches (GeneratorWithMap: one normal map per synthesis
+// resolution, reference model.py:255-262 — seven calls of three launches each at 256^2, every one ~5 us at the training
+// and inversion batch sizes).  blockIdx.y selects the level; its extents and buffers come from a table passed by value.
+// The bodies are the single-level kernels' (same expressions, same order: same bits).
+constexpr int RASTER_MAX_LEVELS = SR_RASTER_MAX_LEVELS;
+struct RasterLevels {
+    int n;
+    int res_h[RASTER_MAX_LEVELS], res_w[RASTER_MAX_LEVELS];
+    unsigned long long* keys[RASTER_MAX_LEVELS];
+    int* big[RASTER_MAX_LEVELS];              // gradient state of the level (or NULL)
+    int* win[RASTER_MAX_LEVELS];
+    float* attr[RASTER_MAX_LEVELS];
+};
+
+__global__ __launch_bounds__(256) void k_fill_levels(const RasterLevels t, long long b, long long nf) {
+    const int l = blockIdx.y;
+    const long long n = b * t.res_h[l] * t.res_w[l];
+    unsigned long long* p = t.keys[l];
+    int* counter = t.big[l];
+    int* first = (counter && t.win[l]) ? counter + 1 + b * nf : nullptr;
+    const long long n_first = b * nf;
+    if (counter && blockIdx.x == 0 && threadIdx.x == 0) {
+        *counter = 0;
+        if (first) first[n_first] = 0;
+    }
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    const unsigned long long v = key_init_f32();
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) p[i] = v;
+    if (first)
+        for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n_first; i += stride) first[i] = 0x7FFFFFFF;
+}
+
+__global__ __launch_bounds__(256) void k_depth_keys_levels(const RasterLevels t, long long b, long long nv, long long nf,
+                                                           bool repeat_v, bool repeat_f, bool perspective,
+                                                           const float* __restrict__ v, const long long* __restrict__ f,
+                                                           float eps) {
+    const int l = blockIdx.y;
+    depth_keys_body<float, 0>(b, nv, nf, t.res_h[l], t.res_w[l], repeat_v, repeat_f, perspective, v, f, t.keys[l], nullptr,
+                              t.big[l], eps);
+}
+
+__global__ __launch_bounds__(256) void k_resolve_levels(const RasterLevels t, long long b, long long nv, long long nf,
+                                                        bool repeat_v, bool repeat_f, bool perspective,
+                                                        const float* __restrict__ v, const long long* __restrict__ f,
+                                                        const float* __restrict__ tex, long long tex_c, float eps,
+                                                        bool chw) {
+    const int l = blockIdx.y;
+    resolve_body<float>(b, nv, nf, t.res_h[l], t.res_w[l], repeat_v, repeat_f, perspective, v, f, t.keys[l], nullptr, nullptr,
+                        nullptr, nullptr, tex, tex_c, t.attr[l], t.win[l], eps, chw);
 }
 
 // ---- fp32 forward with LDS-staged triangle tiles (square images) ------------------------------------------------
@@ -2064,6 +2137,57 @@ extern "C" int sr_rasterize_forward_f32(int64_t b, int64_t nv, int64_t nf, int64
                                reinterpret_cast<const long long*>(tri),
                                reinterpret_cast<long long*>(index), coeff, zbuf, eps, tex, tex_c, attr,
                                win, big, work, sr_stream(stream));
+}
+// n levels of the same mesh in three launches (global-key path, fp32): see k_fill_levels.  A level that the per-call
+// dispatcher would hand to the LDS-tiled path makes the call refuse (SR_EINVAL; sr_rasterize_levels_supported says so in
+// advance) — the caller then rasterises level by level.
+extern "C" int sr_rasterize_levels_supported(int n, int64_t b, int64_t nf, const int64_t* h, const int64_t* w) {
+    if (n <= 0 || n > RASTER_MAX_LEVELS || !h || !w || b <= 0 || b > 65535) return 0;
+    for (int l = 0; l < n; ++l) {
+        if (h[l] <= 0 || w[l] <= 0 || h[l] > 0x7FFFFFFF || w[l] > 0x7FFFFFFF || b * h[l] * w[l] >= 0x7FFFFFFFLL) return 0;
+        if (tiled_ok<float>(b, nf, h[l], w[l])) return 0;
+    }
+    return 1;
+}
+
+extern "C" int sr_rasterize_forward_levels_f32(int n, int64_t b, int64_t nv, int64_t nf, const int64_t* h, const int64_t* w,
+                                               int repeat_v, int repeat_f, int perspective, const float* v,
+                                               const int64_t* tri, float eps, const float* tex, int64_t tex_c,
+                                               float* const* attr, int32_t* const* win, int32_t* const* big,
+                                               void* const* work, sr_stream_t stream) {
+    if (n < 0 || b < 0 || nv < 0 || nf < 0 || tex_c <= 0) return SR_EINVAL;
+    if (n == 0 || b == 0) return SR_OK;
+    if (!h || !w || !attr || !work || !tex || (nf > 0 && (!v || !tri))) return SR_EINVAL;
+    if (!sr_rasterize_levels_supported(n, b, nf, h, w)) return SR_EINVAL;
+    const bool chw = (perspective & SR_RASTER_CHW) != 0;
+    perspective &= 1;
+    if (eps < 0) eps = -eps;
+    RasterLevels t;
+    t.n = n;
+    long long max_pix = 0;
+    for (int l = 0; l < n; ++l) {
+        if (!attr[l] || !work[l]) return SR_EINVAL;
+        t.res_h[l] = (int)h[l];
+        t.res_w[l] = (int)w[l];
+        t.keys[l] = reinterpret_cast<unsigned long long*>(work[l]);
+        t.big[l] = (big && win && big[l] && win[l]) ? big[l] : nullptr;
+        t.win[l] = (win && t.big[l]) ? win[l] : nullptr;
+        t.attr[l] = attr[l];
+        const long long npix = b * h[l] * w[l];
+        if (npix > max_pix) max_pix = npix;
+    }
+    hipStream_t st = sr_stream(stream);
+    const long long fill_items = max_pix > b * nf ? max_pix : b * nf;
+    hipLaunchKernelGGL(k_fill_levels, dim3(sr_stream_grid(fill_items, 256), (unsigned)n), dim3(256), 0, st, t, (long long)b,
+                       (long long)nf);
+    if (b * nf > 0)
+        hipLaunchKernelGGL(k_depth_keys_levels, dim3((unsigned)sr_ceil_div(b * nf, 256), (unsigned)n), dim3(256), 0, st, t,
+                           (long long)b, (long long)nv, (long long)nf, repeat_v != 0, repeat_f != 0, perspective != 0, v,
+                           reinterpret_cast<const long long*>(tri), eps);
+    hipLaunchKernelGGL(k_resolve_levels, dim3((unsigned)sr_ceil_div(max_pix, 256), (unsigned)n), dim3(256), 0, st, t,
+                       (long long)b, (long long)nv, (long long)nf, repeat_v != 0, repeat_f != 0, perspective != 0, v,
+                       reinterpret_cast<const long long*>(tri), tex, (long long)tex_c, eps, chw);
+    return sr_launch_status();
 }
 extern "C" int sr_rasterize_forward_f64(int64_t b, int64_t nv, int64_t nf, int64_t h, int64_t w,
                                         int repeat_v, int repeat_f, int perspective, const double* v,

@@ -117,7 +117,7 @@ class _Slice(nn.ModuleDict):
 
     def forward(self, x):
         if self.pool:
-            x = F.max_pool2d(x, 2, 2)
+            x = _lpips_layer.max_pool2(x)            # device tensors: sr_maxpool2_* (no MIOpen / ATen pooling kernel)
         for layer in self.values():
             x = layer(x)
         return x

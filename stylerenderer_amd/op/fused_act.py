@@ -79,6 +79,7 @@ class FusedLeakyReLUFunctionBackward(Function):
     @staticmethod
     def forward(ctx, grad_output, out, negative_slope, scale, want_bias=True):
         ctx.save_for_backward(out)
+        ctx.set_materialize_grads(False)      # an absent bias cotangent is None (no zero-fill launch), see backward
         ctx.negative_slope = negative_slope
         ctx.scale = scale
         gx, gb = _act_backward(grad_output, out, negative_slope, scale, want_bias)
@@ -89,6 +90,10 @@ class FusedLeakyReLUFunctionBackward(Function):
     @staticmethod
     def backward(ctx, gradgrad_input, gradgrad_bias):
         (out,) = ctx.saved_tensors
+        if gradgrad_input is None:
+            if gradgrad_bias is None:
+                return None, None, None, None, None
+            gradgrad_input = torch.zeros_like(out)
         gradgrad_out = fused_bias_act(gradgrad_input, gradgrad_bias, out, 3, 1,
                                       ctx.negative_slope, ctx.scale)
         return gradgrad_out, None, None, None, None

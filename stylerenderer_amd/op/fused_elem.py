@@ -147,6 +147,9 @@ class _NBAAffineBackward(Function):
                 float(slope), float(scale), n, c, inner, bstride, _lib.ptr(scratch), stream_of(out))
         _lib.check(rc, "sr_noise_bias_act_affine_bwd")
         ctx.save_for_backward(gy, out, x, smap2, noise)
+        # absent cotangents (frozen bias / noise strength, a plane nobody differentiated) arrive as None, not as
+        # zero-filled tensors: two fill launches less per layer of the recorded backward
+        ctx.set_materialize_grads(False)
         ctx.cfg = (float(slope), float(scale))
         return gx, gmap.transpose(0, 1), gb, gnw
 

@@ -91,3 +91,37 @@ def mse(a, b):
             and b.contiguous().data_ptr() % 16 == 0):
         return _MSE.apply(a, b)
     return torch.mean((a - b) ** 2)
+
+
+class _MaxPool2(Function):
+    """F.max_pool2d(x, 2, 2) on even maps — sr_maxpool2_fwd / _bwd (the arg-max is recomputed from the saved input)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = x.contiguous()
+        b, c, h, w = x.shape
+        out = torch.empty((b, c, h // 2, w // 2), dtype=x.dtype, device=x.device)
+        with on_device_of(x):
+            rc = _lib.lib().sr_maxpool2_fwd(_lib.ptr(out), _lib.ptr(x), b * c, h, w, stream_of(x))
+        _lib.check(rc, "sr_maxpool2_fwd")
+        ctx.save_for_backward(x)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        b, c, h, w = x.shape
+        gx = torch.empty_like(x)
+        with on_device_of(x):
+            rc = _lib.lib().sr_maxpool2_bwd(_lib.ptr(gx), _lib.ptr(g.contiguous()), _lib.ptr(x), b * c, h, w, stream_of(x))
+        _lib.check(rc, "sr_maxpool2_bwd")
+        return gx
+
+
+def max_pool2(x):
+    """2 x 2 / stride 2 max pooling; device float32 tensors with even maps take the library's kernels."""
+    if (x.device.type == "cuda" and x.dtype == torch.float32 and x.dim() == 4 and x.shape[2] % 2 == 0
+            and x.shape[3] % 2 == 0 and x.numel() > 0):
+        return _MaxPool2.apply(x)
+    return torch.nn.functional.max_pool2d(x, 2, 2)

@@ -316,6 +316,47 @@ def rasterize(v, tex, tri, h=256, w=0, perspective=False, eps=1e-6, channel_majo
     return Rasterize.apply(v, tex, tri, h, w, perspective, eps, channel_major)
 
 
+def _forward_levels(v, tex, tri, sizes, perspective, eps, want_win, chw):
+    """All resolutions of `sizes` in three launches (sr_rasterize_forward_levels_f32): (attribute maps, [win, big] per
+    level), or (None, None) when the call is outside that entry point (fp64, shared vertices, a level the dispatcher
+    would give to the LDS-tiled path, SR_RASTER_LEVELS=0)."""
+    import ctypes
+
+    if (v.dtype != torch.float32 or tex.dtype != torch.float32 or tri.dtype != torch.int64 or v.dim() != 3
+            or tex.dim() != 3 or os.environ.get("SR_RASTER_LEVELS", "1") == "0"):
+        return None, None
+    b, nv, nf, rv, rf = _geometry(v, tri)
+    n = len(sizes)
+    L = _lib.lib()
+    hs = (ctypes.c_int64 * n)(*[h for h, _ in sizes])
+    ws = (ctypes.c_int64 * n)(*[w for _, w in sizes])
+    if rv or not L.sr_rasterize_levels_supported(n, b, nf, hs, ws):
+        return None, None
+    dev = v.device
+    tex_c = int(tex.shape[-1])
+    tex_flat = tex.contiguous().view(-1, tex_c)
+    attrs = [torch.empty((b, tex_c, h, w) if chw else (b, h, w, tex_c), dtype=v.dtype, device=dev) for h, w in sizes]
+    wins = [torch.empty((b, h, w), dtype=torch.int32, device=dev) if want_win else None for h, w in sizes]
+    bigs = [torch.empty(2 + 2 * b * nf, dtype=torch.int32, device=dev) if want_win else None for _ in sizes]
+    sizes_b = [int(L.sr_rasterize_scratch_bytes(b, nf, h, w, 0)) for h, w in sizes]
+    offs, total = [], 0
+    for sz in sizes_b:
+        offs.append(total)
+        total += (sz + 255) // 256 * 256
+    work = torch.empty(total, dtype=torch.uint8, device=dev)
+    pa = lambda ts: (ctypes.c_void_p * n)(*[t.data_ptr() if t is not None else None for t in ts])      # noqa: E731
+    with on_device_of(v):
+        rc = L.sr_rasterize_forward_levels_f32(
+            n, b, nv, nf, hs, ws, int(rv), int(rf), int(bool(perspective)) | (SR_RASTER_CHW if chw else 0), _lib.ptr(v),
+            _lib.ptr(tri), abs(float(eps)), _lib.ptr(tex_flat), tex_c, pa(attrs), pa(wins) if want_win else None,
+            pa(bigs) if want_win else None, (ctypes.c_void_p * n)(*[work.data_ptr() + o for o in offs]), stream_of(v))
+    _lib.check(rc, "sr_rasterize_forward_levels_f32")
+    states = []
+    for wn, bg in zip(wins, bigs):
+        states += [wn, bg]
+    return attrs, states
+
+
 class RasterizePyramid(Function):
     """The same posed mesh rasterised at several resolutions as ONE node (GeneratorWithMap draws a normal map per
     synthesis resolution: reference model.py:255-262, seven calls at 256^2).  Forward: the per-resolution launches of
@@ -330,12 +371,14 @@ class RasterizePyramid(Function):
         tri = tri.contiguous()
         need_grad = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
         chw = bool(chw) and tex.dim() == v.dim()
-        outs, states = [], []
-        for h, w in sizes:
-            _, _, _, out, state = _forward_impl(v, tri, h, w, perspective, eps, tex=tex, want_index=False,
-                                                want_win=need_grad, chw=chw)
-            outs.append(out)
-            states += list(state) if state is not None else [None, None]
+        outs, states = _forward_levels(v, tex, tri, sizes, perspective, eps, need_grad, chw)
+        if outs is None:
+            outs, states = [], []
+            for h, w in sizes:
+                _, _, _, out, state = _forward_impl(v, tri, h, w, perspective, eps, tex=tex, want_index=False,
+                                                    want_win=need_grad, chw=chw)
+                outs.append(out)
+                states += list(state) if state is not None else [None, None]
         ctx.cfg = (chw, perspective, eps, len(sizes))
         ctx.set_materialize_grads(False)          # a map nobody differentiated arrives as None, not as a zero-filled tensor
         ctx.save_for_backward(v, tex, tri, *states)

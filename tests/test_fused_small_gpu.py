@@ -82,6 +82,56 @@ def test_rasterize_pyramid_equals_separate_calls(batch, monkeypatch):
     monkeypatch.setenv("SR_RASTER_PYRAMID", "0")
     off = run(True)
     assert torch.equal(off[1], gv_s)
+    monkeypatch.delenv("SR_RASTER_PYRAMID")
+    # the three-launch forward over all levels (sr_rasterize_forward_levels_f32) against the per-level launches: the maps,
+    # and the gradient state they leave (same gradients, bit for bit)
+    monkeypatch.setenv("SR_RASTER_LEVELS", "0")
+    per_level = run(True)
+    for a, b_ in zip(per_level[0], maps_p):
+        assert torch.equal(a, b_)
+    assert torch.equal(per_level[1], gv_p) and torch.equal(per_level[2], gn_p)
+
+
+def test_rasterize_levels_entry_point_matches_single_level_calls():
+    """C ABI level: attribute maps and winner maps of sr_rasterize_forward_levels_f32 == sr_rasterize_forward_f32 per level,
+    and the refusal of a level the dispatcher gives to the LDS-tiled path."""
+    import ctypes
+
+    import importlib
+
+    from stylerenderer_amd import _lib
+
+    R = importlib.import_module("stylerenderer_amd.op.rasterize")          # (op.rasterize the attribute is the function)
+    v, nrm, tri = _posed_mesh(2)
+    sizes = [(8, 8), (16, 16), (24, 40), (64, 64)]
+    got, states = R._forward_levels(v, nrm, tri, sizes, False, 1e-6, True, True)
+    assert got is not None
+    for k, (h, w) in enumerate(sizes):
+        _, _, _, ref, st = R._forward_impl(v, tri, h, w, False, 1e-6, tex=nrm, want_index=False, want_win=True, chw=True)
+        assert torch.equal(got[k], ref)
+        assert torch.equal(states[2 * k], st[0])                         # winner maps
+    L = _lib.lib()
+    one = lambda x: (ctypes.c_int64 * 1)(x)                              # noqa: E731
+    assert L.sr_rasterize_levels_supported(1, 2, tri.shape[0], one(64), one(64)) == 1
+    assert L.sr_rasterize_levels_supported(1, 64, tri.shape[0], one(256), one(256)) == 0     # 4 096 tiles: the tiled path
+
+
+@pytest.mark.parametrize("shape", [(1, 64, 256, 256), (3, 5, 6, 10)])
+def test_maxpool2_matches_torch_including_ties(shape):
+    from stylerenderer_amd.op.lpips_layer import max_pool2
+
+    g = torch.Generator(DEV).manual_seed(9)
+    x = torch.relu(torch.randn(shape, device=DEV, generator=g))            # ReLU output: windows full of equal zeros
+    x[0, 0, 0, 0] = float("nan")
+    xa = x.clone().requires_grad_(True)
+    xb = x.clone().requires_grad_(True)
+    ya = max_pool2(xa)
+    yb = torch.nn.functional.max_pool2d(xb, 2, 2)
+    assert torch.equal(torch.nan_to_num(ya.detach(), nan=-7.0), torch.nan_to_num(yb.detach(), nan=-7.0))
+    up = torch.randn(ya.shape, device=DEV, generator=g)
+    ga, = torch.autograd.grad(ya, xa, up)
+    gb, = torch.autograd.grad(yb, xb, up)
+    assert torch.equal(ga, gb)
 
 
 @pytest.mark.parametrize("shape", [(2, 8, 16, 16), (1, 64, 128, 128), (3, 5, 9, 9)])
