@@ -377,6 +377,19 @@ int sr_rasterize_forward_levels_f32(int n, int64_t b, int64_t nv, int64_t nf, co
                                     float eps, const float* tex, int64_t tex_c, float* const* attr, int32_t* const* win,
                                     int32_t* const* big, void* const* work, sr_stream_t stream);
 
+/* Gradient of those n levels in FOUR launches: grad_v / grad_tex = the sum over the levels (added in table order — the
+ * value n sr_rasterize_grad_f32 calls with SR_RASTER_GRAD_ACC from the second on produce, bit for bit) of the gradient of
+ * level l's attribute map w.r.t. the vertices / attribute rows, given grad_out[l] ([b,h_l,w_l,c], or [b,c,h_l,w_l] with
+ * SR_RASTER_CHW) and the level's gradient state win[l] / big[l].  work[l] >= sr_rasterize_grad_scratch_bytes(b, nf, c, 0)
+ * each.  fp32, c <= 4, nf > 0 and the cached inverse incidence table adj_slot are required (SR_EINVAL otherwise: the
+ * caller accumulates level by level). */
+int sr_rasterize_grad_levels_f32(int n, int64_t b, int64_t nv, int64_t nf, const int64_t* h, const int64_t* w, int repeat_f,
+                                 int perspective, const float* v, const float* tex, int64_t tex_c, const int64_t* tri,
+                                 const int32_t* const* win, int32_t* const* big, const float* const* grad_out,
+                                 const int32_t* adj_off, const int32_t* adj, int64_t off_bstride, int64_t adj_bstride,
+                                 const int32_t* adj_slot, float* grad_v, float* grad_tex, float eps, void* const* work,
+                                 sr_stream_t stream);
+
 /* d(coeff)/d(vertex) per pixel.  Replaces  bool rasterize_gpu_backward<scalar,index>(b, n, h, w,
  *   repeat_v, perspective, const scalar* v, const index* i, scalar* dcoeff, scalar eps)
  * reference op/rasterize.cu:124-127 (arithmetic op/rasterize.h:169-228).  dcoeff [b,h,w,3,9];

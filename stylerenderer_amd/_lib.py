@@ -80,6 +80,7 @@ SIGNATURES = {
     "sr_rasterize_forward_f32": (_i, [_l] * 5 + [_i] * 3 + [_p] * 5 + [_f, _p, _l, _p, _p, _p, _p, _p]),
     "sr_rasterize_levels_supported": (_i, [_i, _l, _l, _p, _p]),
     "sr_rasterize_forward_levels_f32": (_i, [_i, _l, _l, _l, _p, _p, _i, _i, _i, _p, _p, _f, _p, _l, _p, _p, _p, _p, _p]),
+    "sr_rasterize_grad_levels_f32": (_i, [_i, _l, _l, _l, _p, _p, _i, _i, _p, _p, _l] + [_p] * 6 + [_l, _l] + [_p] * 3 + [_f, _p, _p]),
     "sr_rasterize_forward_f64": (_i, [_l] * 5 + [_i] * 3 + [_p] * 5 + [_d, _p, _l, _p, _p, _p, _p, _p]),
     "sr_rasterize_grad_scratch_bytes": (_l, [_l, _l, _l, _i]),
     "sr_rasterize_forward_cpu_f32": (_i, [_l] * 5 + [_i] * 3 + [_p] * 5 + [_f]),

@@ -1425,14 +1425,12 @@ __global__ __launch_bounds__(256) void k_slot_inverse(long long n3, const int* _
 // Large triangles (the list k_depth_keys recorded): one workgroup per triangle walks the box together; each lane
 // sums its pixels in order, then a fixed-order tree over the 256 lanes.
 template <typename R, int CT, bool PERSP>
-__global__ __launch_bounds__(256) void k_grad_big(long long nv, long long nf, long long h, long long w,
-                                                  bool repeat_f, const R* __restrict__ v,
-                                                  const R* __restrict__ tex, int tex_c, int ch0,
-                                                  const long long* __restrict__ f, const int* __restrict__ win,
-                                                  const int* __restrict__ big, const R* __restrict__ grad_out,
-                                                  bool want_v, R* __restrict__ tg,
-                                                  R eps, bool chw, const int* __restrict__ slot_of, long long slot_bs,
-                                                  R* __restrict__ tail, long long plane) {
+__device__ __forceinline__ void grad_big_body(long long nv, long long nf, long long h, long long w, bool repeat_f,
+                                              const R* __restrict__ v, const R* __restrict__ tex, int tex_c, int ch0,
+                                              const long long* __restrict__ f, const int* __restrict__ win,
+                                              const int* __restrict__ big, const R* __restrict__ grad_out, bool want_v,
+                                              R* __restrict__ tg, R eps, bool chw, const int* __restrict__ slot_of,
+                                              long long slot_bs, R* __restrict__ tail, long long plane) {
     __shared__ R s_part[4];
     const long long hw = h * w;
     const int count = big[0];
@@ -1472,6 +1470,19 @@ __global__ __launch_bounds__(256) void k_grad_big(long long nv, long long nf, lo
     }
 }
 
+template <typename R, int CT, bool PERSP>
+__global__ __launch_bounds__(256) void k_grad_big(long long nv, long long nf, long long h, long long w,
+                                                  bool repeat_f, const R* __restrict__ v,
+                                                  const R* __restrict__ tex, int tex_c, int ch0,
+                                                  const long long* __restrict__ f, const int* __restrict__ win,
+                                                  const int* __restrict__ big, const R* __restrict__ grad_out,
+                                                  bool want_v, R* __restrict__ tg,
+                                                  R eps, bool chw, const int* __restrict__ slot_of, long long slot_bs,
+                                                  R* __restrict__ tail, long long plane) {
+    grad_big_body<R, CT, PERSP>(nv, nf, h, w, repeat_f, v, tex, tex_c, ch0, f, win, big, grad_out, want_v, tg, eps, chw,
+                                slot_of, slot_bs, tail, plane);
+}
+
 // first[s * nf + t] = the smallest row-major pixel index triangle t of sample s won (INT_MAX: none).  Row-major order
 // over the image restricted to a triangle's box IS box order, so that pixel is the triangle's leader.
 // A pixel whose left or upper neighbour was won by the same triangle cannot be the minimum and skips the atomic
@@ -1479,9 +1490,9 @@ __global__ __launch_bounds__(256) void k_grad_big(long long nv, long long nf, lo
 // `built` (the state word the forward pass left behind the table): non-zero = the tiled forward has already built
 // the table, every workgroup leaves at once.  The decision is the FORWARD's record, not a predicate re-evaluated at
 // backward time (environment flips, a different heuristic input: the table would be read uninitialised).
-__global__ __launch_bounds__(256) void k_first_pix(long long total, long long hw, long long w, long long nf,
-                                                   const int* __restrict__ win, int* __restrict__ first,
-                                                   const int* __restrict__ built) {
+__device__ __forceinline__ void first_pix_body(long long total, long long hw, long long w, long long nf,
+                                               const int* __restrict__ win, int* __restrict__ first,
+                                               const int* __restrict__ built) {
     if (*built) return;
     // grid-stride: the launch is capped at a few thousand workgroups, so that the common case (table already built by
     // the tiled forward: every workgroup leaves at the line above) costs ~1 us instead of retiring b*h*w/256 of them
@@ -1497,6 +1508,12 @@ __global__ __launch_bounds__(256) void k_first_pix(long long total, long long hw
     }
 }
 
+__global__ __launch_bounds__(256) void k_first_pix(long long total, long long hw, long long w, long long nf,
+                                                   const int* __restrict__ win, int* __restrict__ first,
+                                                   const int* __restrict__ built) {
+    first_pix_body(total, hw, w, nf, win, first, built);
+}
+
 // Small triangles: one lane per (sample, TRIANGLE).  The leader table says in ONE coalesced load whether the triangle
 // won a pixel at all (culled, hidden and sub-pixel triangles leave at once) and where its first pixel is; the lane
 // then sums the triangle's pixels in box order and writes the records.  Consecutive lanes own consecutive triangles:
@@ -1505,15 +1522,13 @@ __global__ __launch_bounds__(256) void k_first_pix(long long total, long long hw
 // compacted per workgroup through LDS, 122-129 us; a dense leader list, 86 us + 600 us for its single append
 // counter; this form needs neither list nor counter.)
 template <typename R, int CT, bool PERSP>
-__global__ __launch_bounds__(256) void k_grad_pix(long long b, long long nv, long long nf, long long h,
-                                                  long long w, bool repeat_f, const R* __restrict__ v,
-                                                  const R* __restrict__ tex, int tex_c, int ch0,
-                                                  const long long* __restrict__ f, const int* __restrict__ win,
-                                                  const int* __restrict__ first,
-                                                  unsigned long long* __restrict__ valid,
-                                                  const R* __restrict__ grad_out, bool want_v,
-                                                  R* __restrict__ tg, R eps, bool chw, const int* __restrict__ slot_of,
-                                                  long long slot_bs, R* __restrict__ tail, long long plane) {
+__device__ __forceinline__ void grad_pix_body(long long b, long long nv, long long nf, long long h, long long w,
+                                              bool repeat_f, const R* __restrict__ v, const R* __restrict__ tex, int tex_c,
+                                              int ch0, const long long* __restrict__ f, const int* __restrict__ win,
+                                              const int* __restrict__ first, unsigned long long* __restrict__ valid,
+                                              const R* __restrict__ grad_out, bool want_v, R* __restrict__ tg, R eps,
+                                              bool chw, const int* __restrict__ slot_of, long long slot_bs,
+                                              R* __restrict__ tail, long long plane) {
     __shared__ int s_row[256], s_pix[256];
     __shared__ int s_cnt[4];
     const long long hw = h * w;
@@ -1641,6 +1656,20 @@ __global__ __launch_bounds__(256) void k_grad_pix(long long b, long long nv, lon
     else store_row<R, CT, PERSP>(acc, tg, row);
 }
 
+template <typename R, int CT, bool PERSP>
+__global__ __launch_bounds__(256) void k_grad_pix(long long b, long long nv, long long nf, long long h,
+                                                  long long w, bool repeat_f, const R* __restrict__ v,
+                                                  const R* __restrict__ tex, int tex_c, int ch0,
+                                                  const long long* __restrict__ f, const int* __restrict__ win,
+                                                  const int* __restrict__ first,
+                                                  unsigned long long* __restrict__ valid,
+                                                  const R* __restrict__ grad_out, bool want_v,
+                                                  R* __restrict__ tg, R eps, bool chw, const int* __restrict__ slot_of,
+                                                  long long slot_bs, R* __restrict__ tail, long long plane) {
+    grad_pix_body<R, CT, PERSP>(b, nv, nf, h, w, repeat_f, v, tex, tex_c, ch0, f, win, first, valid, grad_out, want_v, tg,
+                                eps, chw, slot_of, slot_bs, tail, plane);
+}
+
 // ---- fused gradient, phase 2: per-vertex sum over its incident corners, in incidence-list order ---------------
 // One step of the gather: U list entries (already in registers; -1 = none) -> validity words -> records, every level's
 // loads in flight together (unconditional loads from clamped addresses, masked afterwards); the sums keep list order.
@@ -1736,23 +1765,15 @@ __device__ __forceinline__ void vert_gather_slots(const int (&idx)[U], long long
 // 85 us at config[3] with one corner per step, 70 with six in flight.  (Round 4 tried the incidence list as fixed-width
 // rows — one aligned 32-byte load per vertex instead of offsets -> entries, a dependent level less: no change, 69-74 us;
 // the kernel is bound by the number of divergent L1 accesses, ~14 per lane at 48 % TCP utilisation, not by the chain.)
+// The sums of one (sample, vertex) over its corner list [e0, e1) from ONE gradient state (tg / valid / tail): what
+// k_grad_vert stores, and what k_grad_vert_levels adds up over the resolutions of a pyramid.
 template <typename R, int CT, bool PERSP>
-__global__ __launch_bounds__(256) void k_grad_vert(long long nv, long long nf, const int* __restrict__ adj_off,
-                                                   const int* __restrict__ adj, long long off_bstride,
-                                                   long long adj_bstride, const R* __restrict__ tg,
-                                                   const unsigned long long* __restrict__ valid, int tex_c, int ch0,
-                                                   R* __restrict__ grad_v, R* __restrict__ grad_tex, int slots,
-                                                   const R* __restrict__ tail, long long plane, bool accumulate) {
-    const long long vert = (long long)blockIdx.x * 256 + threadIdx.x;
-    const long long s = blockIdx.y;
-    const bool live = vert < nv;
-    R av[3] = {0, 0, 0};
-    R at[CT];
+__device__ __forceinline__ void vert_sum(long long s, long long nf, const int* __restrict__ ad, int e0, int e1,
+                                         const R* __restrict__ tg, const unsigned long long* __restrict__ valid, int slots,
+                                         const R* __restrict__ tail, long long plane, R (&av)[3], R (&at)[CT]) {
+    av[0] = av[1] = av[2] = 0;
 #pragma unroll
     for (int j = 0; j < CT; ++j) at[j] = 0;
-    const int* off = adj_off + s * off_bstride;
-    const int* ad = adj + s * adj_bstride;
-    const int e0 = live ? off[vert] : 0, e1 = live ? off[vert + 1] : 0;
     constexpr int U = 6;                        // (the valence of an interior vertex of a triangulated grid)
     // A vertex of high valence (the two poles of the formula mesh: 192 corners; a fan anywhere) would be ONE lane walking
     // 32 dependent steps while its wave waits — at batch 1 those two lanes were the whole duration of the kernel (38 us for
@@ -1804,6 +1825,24 @@ __global__ __launch_bounds__(256) void k_grad_vert(long long nv, long long nf, c
             for (int j = 0; j < CT; ++j) at[j] = pt[j];
         }
     }
+}
+
+template <typename R, int CT, bool PERSP>
+__global__ __launch_bounds__(256) void k_grad_vert(long long nv, long long nf, const int* __restrict__ adj_off,
+                                                   const int* __restrict__ adj, long long off_bstride,
+                                                   long long adj_bstride, const R* __restrict__ tg,
+                                                   const unsigned long long* __restrict__ valid, int tex_c, int ch0,
+                                                   R* __restrict__ grad_v, R* __restrict__ grad_tex, int slots,
+                                                   const R* __restrict__ tail, long long plane, bool accumulate) {
+    const long long vert = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long s = blockIdx.y;
+    const bool live = vert < nv;
+    R av[3];
+    R at[CT];
+    const int* off = adj_off + s * off_bstride;
+    const int* ad = adj + s * adj_bstride;
+    const int e0 = live ? off[vert] : 0, e1 = live ? off[vert + 1] : 0;
+    vert_sum<R, CT, PERSP>(s, nf, ad, e0, e1, tg, valid, slots, tail, plane, av, at);
     if (!live) return;
     if (grad_v && ch0 == 0) {
         // accumulate (SR_RASTER_GRAD_ACC): the buffers hold the gradient of earlier calls — the same mesh rasterised at
@@ -1818,6 +1857,96 @@ __global__ __launch_bounds__(256) void k_grad_vert(long long nv, long long nf, c
 #pragma unroll
         for (int j = 0; j < CT; ++j)
             if (ch0 + j < tex_c) o[j] = accumulate ? o[j] + at[j] : at[j];
+    }
+}
+
+// ---- gradient of a pyramid (the same mesh at several resolutions, RasterLevels above) in four launches ------------------
+// blockIdx.y (k_first_pix / k_grad_big / k_grad_pix) = level; k_grad_vert_levels sums the levels' per-vertex sums in table
+// order — the value SR_RASTER_GRAD_ACC calls in that order produce, bit for bit (each level's sum is formed on its own,
+// then added to the running total).  fp32, <= 4 attribute channels, vertex-major slots from the caller's inverse table.
+struct GradLevels {
+    int n;
+    int res_h[RASTER_MAX_LEVELS], res_w[RASTER_MAX_LEVELS];
+    const int* win[RASTER_MAX_LEVELS];
+    int* big[RASTER_MAX_LEVELS];                  // [count | ids b*nf | leader table b*nf | state word]
+    const float* grad_out[RASTER_MAX_LEVELS];
+    float* tg[RASTER_MAX_LEVELS];                 // per-level scratch: corner slots (quad plane | tail planes) ...
+    unsigned long long* valid[RASTER_MAX_LEVELS]; // ... and the valid words behind them
+};
+
+__global__ __launch_bounds__(256) void k_first_pix_levels(const GradLevels t, long long b, long long nf) {
+    const int l = blockIdx.y;
+    const long long hw = (long long)t.res_h[l] * t.res_w[l];
+    int* first = t.big[l] + 1 + b * nf;
+    first_pix_body(b * hw, hw, t.res_w[l], nf, t.win[l], first, first + b * nf);
+}
+
+template <int CT, bool PERSP>
+__global__ __launch_bounds__(256) void k_grad_big_levels(const GradLevels t, long long b, long long nv, long long nf,
+                                                         bool repeat_f, const float* __restrict__ v,
+                                                         const float* __restrict__ tex, int tex_c,
+                                                         const long long* __restrict__ f, bool want_v, float eps, bool chw,
+                                                         const int* __restrict__ slot_of, long long slot_bs) {
+    const int l = blockIdx.y;
+    grad_big_body<float, CT, PERSP>(nv, nf, t.res_h[l], t.res_w[l], repeat_f, v, tex, tex_c, 0, f, t.win[l], t.big[l],
+                                    t.grad_out[l], want_v, t.tg[l], eps, chw, slot_of, slot_bs, t.tg[l] + b * nf * 12,
+                                    b * 3 * nf);
+}
+
+template <int CT, bool PERSP>
+__global__ __launch_bounds__(256) void k_grad_pix_levels(const GradLevels t, long long b, long long nv, long long nf,
+                                                         bool repeat_f, const float* __restrict__ v,
+                                                         const float* __restrict__ tex, int tex_c,
+                                                         const long long* __restrict__ f, bool want_v, float eps, bool chw,
+                                                         const int* __restrict__ slot_of, long long slot_bs) {
+    const int l = blockIdx.y;
+    grad_pix_body<float, CT, PERSP>(b, nv, nf, t.res_h[l], t.res_w[l], repeat_f, v, tex, tex_c, 0, f, t.win[l],
+                                    t.big[l] + 1 + b * nf, t.valid[l], t.grad_out[l], want_v, t.tg[l], eps, chw, slot_of,
+                                    slot_bs, t.tg[l] + b * nf * 12, b * 3 * nf);
+}
+
+template <int CT, bool PERSP>
+__global__ __launch_bounds__(256) void k_grad_vert_levels(const GradLevels t, long long b, long long nv, long long nf,
+                                                          const int* __restrict__ adj_off, const int* __restrict__ adj,
+                                                          long long off_bstride, long long adj_bstride, int tex_c,
+                                                          float* __restrict__ grad_v, float* __restrict__ grad_tex,
+                                                          int slots) {
+    const long long vert = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long s = blockIdx.y;
+    const bool live = vert < nv;
+    const int* off = adj_off + s * off_bstride;
+    const int* ad = adj + s * adj_bstride;
+    const int e0 = live ? off[vert] : 0, e1 = live ? off[vert + 1] : 0;
+    float tv[3] = {0.0f, 0.0f, 0.0f}, tt[CT];
+#pragma unroll
+    for (int j = 0; j < CT; ++j) tt[j] = 0.0f;
+    for (int l = 0; l < t.n; ++l) {
+        float av[3], at[CT];
+        vert_sum<float, CT, PERSP>(s, nf, ad, e0, e1, t.tg[l], t.valid[l], slots, t.tg[l] + b * nf * 12, b * 3 * nf, av, at);
+        if (l == 0) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) tv[j] = av[j];
+#pragma unroll
+            for (int j = 0; j < CT; ++j) tt[j] = at[j];
+        } else {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) tv[j] = tv[j] + av[j];
+#pragma unroll
+            for (int j = 0; j < CT; ++j) tt[j] = tt[j] + at[j];
+        }
+    }
+    if (!live) return;
+    if (grad_v) {
+        float* o = grad_v + (s * nv + vert) * 3;
+        o[0] = tv[0];
+        o[1] = tv[1];
+        o[2] = tv[2];
+    }
+    if (grad_tex) {
+        float* o = grad_tex + (s * nv + vert) * tex_c;
+#pragma unroll
+        for (int j = 0; j < CT; ++j)
+            if (j < tex_c) o[j] = tt[j];
     }
 }
 
@@ -2040,6 +2169,25 @@ int grad_impl(long long b, long long nv, long long nf, long long h, long long w,
     return sr_launch_status();
 }
 
+template <int CT, bool PERSP>
+void grad_levels_launch(const GradLevels& t, long long b, long long nv, long long nf, bool repeat_f, const float* v,
+                        const float* tex, int tex_c, const long long* tri, const int* adj_off, const int* adj,
+                        long long off_bs, long long adj_bs, const int* slot_of, float* grad_v, float* grad_tex, float eps,
+                        bool chw, long long max_pix, hipStream_t st) {
+    const bool want_v = grad_v != nullptr;
+    const char* ee = getenv("SR_RASTER_GRAD_EAGER");
+    const bool eager = ee ? ee[0] == '1' : b * nv < 8 * 32768;
+    const unsigned n = (unsigned)t.n;
+    hipLaunchKernelGGL(k_first_pix_levels, dim3((unsigned)std::min<long long>(sr_ceil_div(max_pix, 256), 1024), n), dim3(256),
+                       0, st, t, b, nf);
+    hipLaunchKernelGGL((k_grad_big_levels<CT, PERSP>), dim3(SR_NUM_CU * 2, n), dim3(256), 0, st, t, b, nv, nf, repeat_f, v,
+                       tex, tex_c, tri, want_v, eps, chw, slot_of, adj_bs);
+    hipLaunchKernelGGL((k_grad_pix_levels<CT, PERSP>), dim3((unsigned)sr_ceil_div(b * nf, 256), n), dim3(256), 0, st, t, b,
+                       nv, nf, repeat_f, v, tex, tex_c, tri, want_v, eps, chw, slot_of, adj_bs);
+    hipLaunchKernelGGL((k_grad_vert_levels<CT, PERSP>), dim3((unsigned)sr_ceil_div(nv, 256), (unsigned)b), dim3(256), 0, st,
+                       t, b, nv, nf, adj_off, adj, off_bs, adj_bs, tex_c, grad_v, grad_tex, eager ? 2 : 1);
+}
+
 // ---- host path: the reference's sequential loops (op/rasterize.cpp:21-67, 69-95) on the shared arithmetic ------
 template <typename R>
 int forward_cpu(long long b, long long nv, long long nf, long long h, long long w, int repeat_v, int repeat_f,
@@ -2189,6 +2337,57 @@ extern "C" int sr_rasterize_forward_levels_f32(int n, int64_t b, int64_t nv, int
                        reinterpret_cast<const long long*>(tri), tex, (long long)tex_c, eps, chw);
     return sr_launch_status();
 }
+// Gradient of n levels of one mesh (sr_rasterize_forward_levels_f32 / any forward that left win / big per level) in four
+// launches; grad_v / grad_tex receive the SUM over the levels, added in table order.  fp32, tex_c <= 4, nf > 0, the cached
+// inverse incidence table adj_slot; anything else: SR_EINVAL (the caller accumulates level by level, SR_RASTER_GRAD_ACC).
+extern "C" int sr_rasterize_grad_levels_f32(int n, int64_t b, int64_t nv, int64_t nf, const int64_t* h, const int64_t* w,
+                                            int repeat_f, int perspective, const float* v, const float* tex, int64_t tex_c,
+                                            const int64_t* tri, const int32_t* const* win, int32_t* const* big,
+                                            const float* const* grad_out, const int32_t* adj_off, const int32_t* adj,
+                                            int64_t off_bstride, int64_t adj_bstride, const int32_t* adj_slot,
+                                            float* grad_v, float* grad_tex, float eps, void* const* work,
+                                            sr_stream_t stream) {
+    if (n <= 0 || n > RASTER_MAX_LEVELS || b <= 0 || nv <= 0 || nf <= 0 || tex_c <= 0 || tex_c > 4) return SR_EINVAL;
+    if (!h || !w || !v || !tex || !tri || !win || !big || !grad_out || !adj_off || !adj || !adj_slot || !work ||
+        (!grad_v && !grad_tex))
+        return SR_EINVAL;
+    if (b > 65535 || nf >= 0x7FFFFFFFLL / 3) return SR_ERANGE;
+    const bool chw = (perspective & SR_RASTER_CHW) != 0;
+    perspective &= 1;
+    if (eps < 0) eps = -eps;
+    GradLevels t;
+    t.n = n;
+    long long max_pix = 0;
+    for (int l = 0; l < n; ++l) {
+        if (h[l] <= 0 || w[l] <= 0 || !win[l] || !big[l] || !grad_out[l] || !work[l]) return SR_EINVAL;
+        if (b * h[l] * w[l] >= 0x7FFFFFFFLL) return SR_ERANGE;
+        t.res_h[l] = (int)h[l];
+        t.res_w[l] = (int)w[l];
+        t.win[l] = win[l];
+        t.big[l] = big[l];
+        t.grad_out[l] = grad_out[l];
+        t.tg[l] = reinterpret_cast<float*>(work[l]);
+        t.valid[l] = reinterpret_cast<unsigned long long*>(t.tg[l] + b * nf * grad_row_floats());
+        if (b * h[l] * w[l] > max_pix) max_pix = b * h[l] * w[l];
+    }
+    hipStream_t st = sr_stream(stream);
+    const long long* tri_ll = reinterpret_cast<const long long*>(tri);
+#define SR_GL_ARGS t, b, nv, nf, repeat_f != 0, v, tex, (int)tex_c, tri_ll, adj_off, adj, off_bstride, adj_bstride, adj_slot, \
+                   grad_v, grad_tex, eps, chw, max_pix, st
+#define SR_GL_CASE(CT)                                             \
+    do {                                                           \
+        if (perspective) grad_levels_launch<CT, true>(SR_GL_ARGS); \
+        else grad_levels_launch<CT, false>(SR_GL_ARGS);            \
+    } while (0)
+    if (tex_c == 1) SR_GL_CASE(1);
+    else if (tex_c == 2) SR_GL_CASE(2);
+    else if (tex_c == 3) SR_GL_CASE(3);
+    else SR_GL_CASE(4);
+#undef SR_GL_CASE
+#undef SR_GL_ARGS
+    return sr_launch_status();
+}
+
 extern "C" int sr_rasterize_forward_f64(int64_t b, int64_t nv, int64_t nf, int64_t h, int64_t w,
                                         int repeat_v, int repeat_f, int perspective, const double* v,
                                         const int64_t* tri, int64_t* index, double* coeff,

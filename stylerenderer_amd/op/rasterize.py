@@ -357,6 +357,40 @@ def _forward_levels(v, tex, tri, sizes, perspective, eps, want_win, chw):
     return attrs, states
 
 
+def _grad_levels(v, tex, tri, wins, bigs, grads, chw, perspective, eps, need_v, need_t):
+    """The gradients of several levels of one mesh in four launches (sr_rasterize_grad_levels_f32): (grad_v, grad_t), or
+    None when the call is outside that entry point (fp64, > 4 attribute channels, SR_RASTER_LEVELS=0): the caller then
+    accumulates level by level."""
+    import ctypes
+
+    if (v.dtype != torch.float32 or tex.dim() != 3 or int(tex.shape[-1]) > 4 or v.dim() != 3 or tri.size(-2) == 0
+            or any(w is None or b is None for w, b in zip(wins, bigs)) or os.environ.get("SR_RASTER_LEVELS", "1") == "0"):
+        return None
+    n = len(grads)
+    L = _lib.lib()
+    b, nv = v.size(0), v.size(1)
+    nf = tri.size(-2)
+    c = int(tex.shape[-1])
+    tex_c = tex.contiguous()
+    gos = [g.contiguous() for g in grads]
+    off, adj, off_bs, adj_bs, slot = incidence(tri, nv)
+    grad_v = torch.empty_like(v) if need_v else None
+    grad_t = torch.empty_like(tex_c) if need_t else None
+    per = (int(L.sr_rasterize_grad_scratch_bytes(b, nf, c, 0)) + 255) // 256 * 256
+    work = torch.empty(per * n, dtype=torch.uint8, device=v.device)
+    pa = lambda ts: (ctypes.c_void_p * n)(*[t.data_ptr() for t in ts])                                   # noqa: E731
+    hs = (ctypes.c_int64 * n)(*[int(w.shape[-2]) for w in wins])
+    ws = (ctypes.c_int64 * n)(*[int(w.shape[-1]) for w in wins])
+    with on_device_of(v):
+        rc = L.sr_rasterize_grad_levels_f32(
+            n, b, nv, nf, hs, ws, int(tri.dim() == 2), int(bool(perspective)) | (SR_RASTER_CHW if chw else 0), _lib.ptr(v),
+            _lib.ptr(tex_c), c, _lib.ptr(tri), pa(wins), pa(bigs), pa(gos), _lib.ptr(off), _lib.ptr(adj), off_bs, adj_bs,
+            _lib.ptr(slot), _lib.ptr(grad_v), _lib.ptr(grad_t), abs(float(eps)),
+            (ctypes.c_void_p * n)(*[work.data_ptr() + per * k for k in range(n)]), stream_of(v))
+    _lib.check(rc, "sr_rasterize_grad_levels_f32")
+    return grad_v, grad_t
+
+
 class RasterizePyramid(Function):
     """The same posed mesh rasterised at several resolutions as ONE node (GeneratorWithMap draws a normal map per
     synthesis resolution: reference model.py:255-262, seven calls at 256^2).  Forward: the per-resolution launches of
@@ -392,6 +426,11 @@ class RasterizePyramid(Function):
         chw, perspective, eps, n = ctx.cfg
         v, tex, tri = ctx.saved_tensors[:3]
         states = ctx.saved_tensors[3:]
+        live = [k for k in range(n) if grads[k] is not None]
+        fused = _grad_levels(v, tex, tri, [states[2 * k] for k in live], [states[2 * k + 1] for k in live],
+                             [grads[k] for k in live], chw, perspective, eps, need_v, need_t) if len(live) > 1 else None
+        if fused is not None:
+            return fused[0], fused[1], None, None, None, None, None
         into = None
         for k in range(n):
             if grads[k] is None:

@@ -85,6 +85,8 @@ def test_rasterize_pyramid_equals_separate_calls(batch, monkeypatch):
     monkeypatch.delenv("SR_RASTER_PYRAMID")
     # the three-launch forward over all levels (sr_rasterize_forward_levels_f32) against the per-level launches: the maps,
     # and the gradient state they leave (same gradients, bit for bit)
+    # ... and the four-launch gradient over all levels (sr_rasterize_grad_levels_f32) against the accumulating per-level
+    # calls (SR_RASTER_GRAD_ACC): the same sums in the same order
     monkeypatch.setenv("SR_RASTER_LEVELS", "0")
     per_level = run(True)
     for a, b_ in zip(per_level[0], maps_p):
