@@ -422,6 +422,13 @@ class _BiasSums(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, *grads):
+        # each merged bias feeds TWO parameters.  Handing the same tensor to both makes AccumulateGrad clone it for one of
+        # them — one ~5 us copy launch per layer; one multi-tensor launch makes the second set of tensors for all layers
+        live = [g for g in grads if g is not None]
+        if live and live[0].is_cuda and not torch.is_grad_enabled():
+            copies = iter(torch._foreach_mul(live, 1.0))
+            second = tuple(next(copies) if g is not None else None for g in grads)
+            return tuple(grads) + second
         return tuple(grads) + tuple(grads)
 
 
