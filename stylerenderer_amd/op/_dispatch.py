@@ -144,3 +144,54 @@ class DerivedCache:
         """Drops the unpinned entries (tests)."""
         for k in [k for k in self.data if k not in self.pinned]:
             del self.data[k]
+
+
+# ---- gradients nobody asked for ----------------------------------------------------------------------------------------
+# `ctx.needs_input_grad` of a Python autograd Function is fixed at FORWARD time (does the input require grad at all),
+# while the engine knows per backward pass which edges it will follow: `autograd.grad(image, latents, create_graph=True)`
+# of the path-length regulariser (reference train.py:118-134) and `autograd.grad(real_pred.sum(), real_img,
+# create_graph=True)` of R1 (train.py:110-116) never use a weight / bias / noise-strength gradient, yet every layer node
+# would compute (and record) its weight-gradient kernels in that first pass.  `wanted(ctx)` is `needs_input_grad`
+# intersected with "the engine will execute the node this gradient flows to in the pass that is running now".
+def mark_inputs(ctx, *args):
+    """Call first thing in forward(ctx, *args): remembers which arguments are tensors — `ctx.next_functions` has one
+    edge per TENSOR argument, `ctx.needs_input_grad` one flag per argument."""
+    ctx._sr_tmask = tuple(isinstance(a, torch.Tensor) for a in args)
+
+
+def _prune_enabled():
+    import os
+
+    return os.environ.get("SR_PRUNE_GRADS", "1") != "0"
+
+
+def wanted(ctx):
+    """`ctx.needs_input_grad`, with False also for inputs whose gradient the running backward pass would discard.  Safe
+    by construction: anything the engine cannot answer (no mask recorded, edge count mismatch, a leaf that is itself one
+    of the `inputs=` of autograd.grad — the engine refuses that query) counts as needed."""
+    needs = tuple(ctx.needs_input_grad)
+    mask = getattr(ctx, "_sr_tmask", None)
+    if mask is None or not _prune_enabled():
+        return needs
+    try:
+        edges = ctx.next_functions
+    except Exception:                                   # not a node (a stand-in context): nothing to prune
+        return needs
+    if len(edges) != sum(mask):
+        return needs
+    out, e = [], 0
+    for i, nd in enumerate(needs):
+        is_t = mask[i] if i < len(mask) else False
+        if nd and is_t:
+            fn = edges[e][0]
+            if fn is None:
+                nd = False
+            else:
+                try:
+                    nd = bool(torch._C._will_engine_execute_node(fn))
+                except RuntimeError:
+                    nd = True
+        if is_t:
+            e += 1
+        out.append(bool(nd))
+    return tuple(out)

@@ -25,7 +25,7 @@ import torch
 from torch.autograd import Function
 
 from .. import _lib
-from ._dispatch import on_device_of, stream_of
+from ._dispatch import mark_inputs, on_device_of, stream_of, wanted
 
 
 def _arr(ctype, vals):
@@ -131,6 +131,7 @@ def _mod_tn(meta, g, x, want_bias):
 class ModNT(Function):
     @staticmethod
     def forward(ctx, meta, x, *wb):
+        mark_inputs(ctx, meta, x, *wb)
         n = len(meta[0])
         ws, bs = wb[:n], wb[n:]
         ctx.meta, ctx.has_bias = meta, len(bs) > 0
@@ -141,7 +142,7 @@ class ModNT(Function):
     def backward(ctx, g):
         x, ws = ctx.saved_tensors[0], ctx.saved_tensors[1:]
         n = len(ws)
-        need = ctx.needs_input_grad
+        need = wanted(ctx)
         gx = ModNN.apply(ctx.meta, g, tuple(x.shape), *ws) if need[1] else None
         want_w, want_b = any(need[2:2 + n]), ctx.has_bias and any(need[2 + n:])
         gws = gbs = None
@@ -158,6 +159,7 @@ class ModNT(Function):
 class ModNN(Function):
     @staticmethod
     def forward(ctx, meta, g, shape, *ws):
+        mark_inputs(ctx, meta, g, shape, *ws)
         ctx.meta, ctx.shape = meta, shape
         ctx.save_for_backward(g, *ws)
         return _mod_nn(meta, g, ws, shape)
@@ -166,7 +168,7 @@ class ModNN(Function):
     def backward(ctx, go):
         g, ws = ctx.saved_tensors[0], ctx.saved_tensors[1:]
         n = len(ws)
-        need = ctx.needs_input_grad
+        need = wanted(ctx)
         rows, widths, alpha, _ = ctx.meta
         meta = (rows, widths, alpha, 0.0)
         dg = ModNT.apply(meta, go, *ws) if need[1] else None
@@ -177,6 +179,7 @@ class ModNN(Function):
 class ModTN(Function):
     @staticmethod
     def forward(ctx, meta, g, x, want_bias):
+        mark_inputs(ctx, meta, g, x, want_bias)
         ctx.meta, ctx.want_bias = meta, bool(want_bias)
         ctx.save_for_backward(g, x)
         gws, gbs = _mod_tn(meta, g, x, want_bias)
@@ -192,7 +195,7 @@ class ModTN(Function):
         gob = ()
         if ctx.want_bias:
             gob = tuple(t if t is not None else x.new_zeros(widths[p]) for p, t in enumerate(go[n:2 * n]))
-        need = ctx.needs_input_grad
+        need = wanted(ctx)
         dg = ModNT.apply((rows, widths, alpha, bscale if gob else 0.0), x, *gow, *gob) if need[1] else None
         dx = ModNN.apply((rows, widths, alpha, 0.0), g, tuple(x.shape), *gow) if need[2] else None
         return None, dg, dx, None
@@ -279,6 +282,7 @@ def _dem_tn(meta, a, g):
 class DemNN(Function):
     @staticmethod
     def forward(ctx, meta, a, *ms):
+        mark_inputs(ctx, meta, a, *ms)
         ctx.meta = meta
         ctx.save_for_backward(a, *ms)
         return _dem_nn(meta, a, ms)
@@ -286,7 +290,7 @@ class DemNN(Function):
     @staticmethod
     def backward(ctx, g):
         a, ms = ctx.saved_tensors[0], ctx.saved_tensors[1:]
-        need = ctx.needs_input_grad
+        need = wanted(ctx)
         ga = DemNT.apply(ctx.meta, g, *ms) if need[1] else None
         gms = DemTN.apply(ctx.meta, a, g) if any(need[2:]) else None
         return (None, ga) + tuple(gms[p] if (gms is not None and need[2 + p]) else None for p in range(len(ms)))
@@ -295,6 +299,7 @@ class DemNN(Function):
 class DemNT(Function):
     @staticmethod
     def forward(ctx, meta, g, *ms):
+        mark_inputs(ctx, meta, g, *ms)
         ctx.meta = meta
         ctx.save_for_backward(g, *ms)
         return _dem_nt(meta, g, ms)
@@ -302,7 +307,7 @@ class DemNT(Function):
     @staticmethod
     def backward(ctx, go):
         g, ms = ctx.saved_tensors[0], ctx.saved_tensors[1:]
-        need = ctx.needs_input_grad
+        need = wanted(ctx)
         dg = DemNN.apply(ctx.meta, go, *ms) if need[1] else None
         dms = DemTN.apply(ctx.meta, go, g) if any(need[2:]) else None
         return (None, dg) + tuple(dms[p] if (dms is not None and need[2 + p]) else None for p in range(len(ms)))
@@ -311,6 +316,7 @@ class DemNT(Function):
 class DemTN(Function):
     @staticmethod
     def forward(ctx, meta, a, g):
+        mark_inputs(ctx, meta, a, g)
         ctx.meta = meta
         ctx.save_for_backward(a, g)
         return tuple(_dem_tn(meta, a, g))
@@ -320,7 +326,7 @@ class DemTN(Function):
         a, g = ctx.saved_tensors
         dims = ctx.meta[3]
         gom = [t if t is not None else a.new_zeros(dims[p]) for p, t in enumerate(go)]
-        need = ctx.needs_input_grad
+        need = wanted(ctx)
         da = DemNT.apply(ctx.meta, g, *gom) if need[1] else None
         dg = DemNN.apply(ctx.meta, a, *gom) if need[2] else None
         return None, da, dg

@@ -13,7 +13,7 @@ import os
 import torch
 
 from .. import _lib
-from ._dispatch import hold_for_capture, on_device_of, require_f32, stream_of
+from ._dispatch import hold_for_capture, mark_inputs, on_device_of, require_f32, stream_of, wanted
 from . import weight_prep as _wp
 from .fused_elem import rowdot, rowdot_div
 
@@ -193,6 +193,7 @@ def _bc(s):
 class ConvFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, wt, iscale, oscale, bias, geom):
+        mark_inputs(ctx, x, wt, iscale, oscale, bias, geom)
         k, stride, pad, tr = _GEOM[geom]
         out = conv2d_mfma(x, wt, iscale, oscale, bias, k, stride, pad, tr)
         ctx.frozen = bool(getattr(wt, "_sr_frozen", False))
@@ -205,7 +206,7 @@ class ConvFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         x, wt, iscale, oscale, bias, out = ctx.saved_tensors
-        need_x, need_w, need_is, need_os, need_b = ctx.needs_input_grad[:5]
+        need_x, need_w, need_is, need_os, need_b = wanted(ctx)[:5]      # minus what this pass would discard
         geom = ctx.geom
         g = g.contiguous()
         gx = gw = gis = gos = gb = None
@@ -237,6 +238,7 @@ class ConvFn(torch.autograd.Function):
 class WgradFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, g, iscale, oscale, geom):
+        mark_inputs(ctx, x, g, iscale, oscale, geom)
         k, stride, pad, tr = _GEOM[geom]
         ctx.geom = geom
         ctx.save_for_backward(x, g, iscale, oscale)
@@ -246,7 +248,7 @@ class WgradFn(torch.autograd.Function):
     def backward(ctx, gg):
         """gg = d/d(dW) [k*k, C, N]."""
         x, g, iscale, oscale = ctx.saved_tensors
-        need_x, need_g, need_is, need_os = ctx.needs_input_grad[:4]
+        need_x, need_g, need_is, need_os = wanted(ctx)[:4]
         geom = ctx.geom
         gg = gg.contiguous()
         gx = g_g = gis = gos = None
@@ -314,6 +316,7 @@ def _wt_pitch(wt):
 class ConvNBAFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, wt, iscale, oscale, noise, noise_w, abias, slope, gain):
+        mark_inputs(ctx, x, wt, iscale, oscale, noise, noise_w, abias, slope, gain)
         b, c, h, w = x.shape
         n = wt.shape[2]
         wtp, ldw = _wt_pitch(wt)
@@ -343,8 +346,12 @@ class ConvNBAFn(torch.autograd.Function):
 
         x, wt, iscale, oscale, noise, noise_w, abias, out = ctx.saved_tensors
         slope, gain = ctx.cfg
-        needs = ctx.needs_input_grad
-        if torch.is_grad_enabled():
+        needs = wanted(ctx)
+        if torch.is_grad_enabled() and oscale is not None:
+            # a recorded backward of the DEMODULATED layer needs the pre-activation as a function of its operands (the
+            # demodulation gradient is sum_p g * y0): re-derived from the separate operators.  Without demodulation (the
+            # discriminator's layers under R1, the LPIPS trunk) nothing below reads y0 — the operators of the plain
+            # branch are differentiable themselves and record the same pass without convolving again
             with torch.enable_grad():
                 xa, wa, sa, da, nwa, aba = _aliases(x, wt, iscale, oscale, noise_w, abias)
                 y0 = ConvFn.apply(xa, wa, sa, da, None, "c3")
@@ -454,6 +461,7 @@ class UpConvNBAFn(torch.autograd.Function):
     def forward(ctx, x, wt, iscale, oscale, kernel, pad, noise, noise_w, abias, slope, gain):
         from .fused_elem import _BlurNBA
 
+        mark_inputs(ctx, x, wt, iscale, oscale, kernel, pad, noise, noise_w, abias, slope, gain)
         y257 = conv2d_mfma(x, wt, iscale, oscale, None, 3, 2, 0, True)
         out = _BlurNBA.forward(_NoCtx(), y257, kernel, pad, noise, noise_w, abias, slope, gain)
         ctx.save_for_backward(x, wt, iscale, oscale, kernel, noise, noise_w, abias, out)
@@ -469,7 +477,7 @@ class UpConvNBAFn(torch.autograd.Function):
 
         x, wt, iscale, oscale, kernel, noise, noise_w, abias, out = ctx.saved_tensors
         pad, slope, gain, shape257 = ctx.cfg
-        needs = ctx.needs_input_grad
+        needs = wanted(ctx)
         if torch.is_grad_enabled():
             with torch.enable_grad():
                 xa, wa, sa, da, nwa, aba = _aliases(x, wt, iscale, oscale, noise_w, abias)

@@ -17,7 +17,7 @@ from torch.autograd import Function
 from torch.nn import functional as F
 
 from .. import _lib
-from ._dispatch import is_device_tensor, on_device_of, require_f32, stream_of
+from ._dispatch import is_device_tensor, mark_inputs, on_device_of, require_f32, stream_of, wanted
 
 
 def fused_bias_act(input, bias, refer, act, grad, alpha, scale):
@@ -102,6 +102,7 @@ class FusedLeakyReLUFunctionBackward(Function):
 class FusedLeakyReLUFunction(Function):
     @staticmethod
     def forward(ctx, input, bias, negative_slope, scale):
+        mark_inputs(ctx, input, bias, negative_slope, scale)
         out = fused_bias_act(input, bias, None, 3, 0, negative_slope, scale)
         ctx.save_for_backward(out)
         ctx.negative_slope = negative_slope
@@ -111,7 +112,7 @@ class FusedLeakyReLUFunction(Function):
     @staticmethod
     def backward(ctx, grad_output):
         (out,) = ctx.saved_tensors
-        need_bias = ctx.needs_input_grad[1]
+        need_bias = wanted(ctx)[1]
         grad_input, grad_bias = FusedLeakyReLUFunctionBackward.apply(
             grad_output, out, ctx.negative_slope, ctx.scale, need_bias)
         return grad_input, (grad_bias if need_bias else None), None, None

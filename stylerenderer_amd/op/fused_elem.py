@@ -9,7 +9,7 @@ import torch
 from torch.autograd import Function
 
 from .. import _lib
-from ._dispatch import on_device_of, stream_of
+from ._dispatch import mark_inputs, on_device_of, stream_of, wanted
 from .fused_act import fused_leaky_relu
 
 
@@ -93,6 +93,7 @@ class _NBA(Function):
         """given: the output a fused convolution node already computed for exactly these operands (its recorded
         backward re-derives the VJP from the separate operators): no launch, and the activation mask of every order
         of differentiation comes from the ONE tensor the forward pass returned."""
+        mark_inputs(ctx, x, noise, noise_w, bias, slope, scale, given)
         y = _launch_fwd(x, noise, noise_w, bias, None, slope, scale) if given is None else given.detach()
         ctx.save_for_backward(y, noise)
         ctx.slope, ctx.scale = slope, scale
@@ -101,7 +102,7 @@ class _NBA(Function):
     @staticmethod
     def backward(ctx, gy):
         y, noise = ctx.saved_tensors
-        needs = ctx.needs_input_grad
+        needs = wanted(ctx)
         want = bool(needs[3] or (noise is not None and needs[2]))
         gx, gb, gnw = _NBABackward.apply(gy, y, noise, ctx.slope, ctx.scale, want)
         return (gx, None, (gnw if noise is not None and want and needs[2] else None), (gb if want and needs[3] else None),
@@ -188,6 +189,7 @@ class _NBAAffine(Function):
 
     @staticmethod
     def forward(ctx, x, smap2, noise, noise_w, bias, slope, scale):
+        mark_inputs(ctx, x, smap2, noise, noise_w, bias, slope, scale)
         n, c, inner = _geometry(x)
         y = torch.empty_like(x)
         bstride = 0 if noise is None or noise.numel() == inner else inner
@@ -205,7 +207,7 @@ class _NBAAffine(Function):
     def backward(ctx, gy):
         x, smap2, noise, noise_w, bias, y = ctx.saved_tensors
         slope, scale = ctx.cfg
-        needs = ctx.needs_input_grad
+        needs = wanted(ctx)
         # (also when this backward is itself recorded — path-length regulariser: _NBAAffineBackward has a native
         # second-order pass, k_nba_aff_bwd2; round 2 re-derived the VJP from ~45 tensor-algebra launches per layer)
         want = bool(needs[4] or (noise is not None and needs[3]))

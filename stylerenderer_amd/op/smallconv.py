@@ -10,7 +10,7 @@ import torch
 from torch.autograd import Function
 
 from .. import _lib
-from ._dispatch import on_device_of, stream_of
+from ._dispatch import mark_inputs, on_device_of, stream_of, wanted
 
 
 def supported(x, n_out):
@@ -59,15 +59,17 @@ def _dw(g, x):
 class SmallConvFwd(Function):
     @staticmethod
     def forward(ctx, x, ws, bias=None):
+        mark_inputs(ctx, x, ws, bias)
         ctx.save_for_backward(x, ws)
         return _fwd(x, ws, bias)
 
     @staticmethod
     def backward(ctx, g):
         x, ws = ctx.saved_tensors
-        gx = SmallConvDx.apply(g, ws) if ctx.needs_input_grad[0] else None
-        gw = SmallConvDw.apply(g, x) if ctx.needs_input_grad[1] else None
-        gb = g.sum((0, 2, 3)) if len(ctx.needs_input_grad) > 2 and ctx.needs_input_grad[2] else None
+        needs = wanted(ctx)                      # (a pass that only asks for the latents' gradient: no bias sum)
+        gx = SmallConvDx.apply(g, ws) if needs[0] else None
+        gw = SmallConvDw.apply(g, x) if needs[1] else None
+        gb = g.sum((0, 2, 3)) if len(needs) > 2 and needs[2] else None
         return gx, gw, gb
 
 
@@ -106,6 +108,7 @@ class _ModRows(Function):
 
     @staticmethod
     def forward(ctx, w, s, scale):
+        mark_inputs(ctx, w, s, scale)
         w_, s_ = w.contiguous(), s.contiguous()
         n, c = w_.shape
         b = s_.shape[0]
@@ -120,7 +123,7 @@ class _ModRows(Function):
     @staticmethod
     def backward(ctx, g):
         w, s = ctx.saved_tensors
-        need_w, need_s = ctx.needs_input_grad[:2]
+        need_w, need_s = wanted(ctx)[:2]
         if torch.is_grad_enabled():
             with torch.enable_grad():
                 wa, sa = w.view_as(w), s.view_as(s)          # aliases: gradients stop at the node boundary

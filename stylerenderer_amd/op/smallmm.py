@@ -14,7 +14,7 @@ import torch
 from torch.autograd import Function
 
 from .. import _lib
-from ._dispatch import on_device_of, stream_of, strict_native
+from ._dispatch import mark_inputs, on_device_of, stream_of, strict_native, wanted
 
 _SLOPE, _GAIN = 0.2, 2 ** 0.5
 
@@ -41,6 +41,7 @@ def _fallback(what, fn, *tensors):
 class _NT(Function):
     @staticmethod
     def forward(ctx, a, w):
+        mark_inputs(ctx, a, w)
         a_, w_ = _rows(a), w.contiguous()
         b, k = a_.shape
         n = w_.size(0)
@@ -55,13 +56,14 @@ class _NT(Function):
     @staticmethod
     def backward(ctx, gy):
         a, w = ctx.saved_tensors
-        need_a, need_w = ctx.needs_input_grad
+        need_a, need_w = wanted(ctx)
         return (mm_nn(gy, w) if need_a else None), (mm_tn(gy, a) if need_w else None)
 
 
 class _NN(Function):
     @staticmethod
     def forward(ctx, g, w):
+        mark_inputs(ctx, g, w)
         g_, w_ = g.contiguous(), w.contiguous()
         b, n = g_.shape
         k = w_.size(1)
@@ -76,13 +78,14 @@ class _NN(Function):
     @staticmethod
     def backward(ctx, go):
         g, w = ctx.saved_tensors
-        need_g, need_w = ctx.needs_input_grad
+        need_g, need_w = wanted(ctx)
         return (mm_nt(go, w) if need_g else None), (mm_tn(g, go) if need_w else None)
 
 
 class _TN(Function):
     @staticmethod
     def forward(ctx, g, a):
+        mark_inputs(ctx, g, a)
         g_, a_ = g.contiguous(), _rows(a)
         b, n = g_.shape
         k = a_.size(1)
@@ -97,7 +100,7 @@ class _TN(Function):
     @staticmethod
     def backward(ctx, go):
         g, a = ctx.saved_tensors
-        need_g, need_a = ctx.needs_input_grad
+        need_g, need_a = wanted(ctx)
         return (mm_nt(a, go) if need_g else None), (mm_nn(g, go) if need_a else None)
 
 

@@ -14,7 +14,7 @@ from torch.nn import functional as F
 
 from .. import _lib
 from . import smallmm as _mm
-from ._dispatch import on_device_of, stream_of
+from ._dispatch import mark_inputs, on_device_of, stream_of, wanted
 
 LRELU_SLOPE = 0.2
 LRELU_GAIN = 2 ** 0.5
@@ -46,6 +46,7 @@ def _vjp(outputs, inputs, grads, needs):
 class _Linear(Function):
     @staticmethod
     def forward(ctx, x, weight, bias, wscale, bscale, act):
+        mark_inputs(ctx, x, weight, bias, wscale, bscale, act)
         w = weight.contiguous()
         b, k = x.shape
         n = w.size(0)
@@ -63,7 +64,7 @@ class _Linear(Function):
     def backward(ctx, gy):
         x, weight, bias, y = ctx.saved_tensors
         wscale, bscale, act = ctx.cfg
-        needs = ctx.needs_input_grad[:3]
+        needs = wanted(ctx)[:3]
         if torch.is_grad_enabled():
             with torch.enable_grad():
                 # aliases: gradients stop at the node boundary even if the inputs share history outside it
@@ -112,6 +113,7 @@ def _demod_composite(s, wsq, eps):
 class _Demod(Function):
     @staticmethod
     def forward(ctx, s, wsq, eps):
+        mark_inputs(ctx, s, wsq, eps)
         s_, w_ = s.contiguous(), wsq.contiguous()
         b, ci = s_.shape
         co = w_.size(1)
@@ -126,7 +128,7 @@ class _Demod(Function):
     @staticmethod
     def backward(ctx, gd):
         s, wsq, d = ctx.saved_tensors
-        needs = ctx.needs_input_grad[:2]
+        needs = wanted(ctx)[:2]
         if torch.is_grad_enabled():
             with torch.enable_grad():
                 sa, wa = s.view_as(s), wsq.view_as(wsq)

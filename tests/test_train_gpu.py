@@ -201,3 +201,48 @@ def test_checkpoint_moves_between_graphed_and_eager_trainers(tmp_path):
         assert torch.equal(p, q), n
     log = c.step(data.batch(4))
     assert all(np.isfinite(v) for v in log.values())
+
+
+def test_first_pass_of_the_regularisers_skips_unused_gradients_without_changing_any_value(monkeypatch):
+    """op._dispatch.wanted: the recorded first pass of the path-length regulariser (gradient of the image w.r.t. latents
+    and maps only, reference train.py:118-134) and of R1 (w.r.t. the real images, train.py:110-116) launches no weight /
+    bias gradient kernel — every parameter gradient of the penalties is bit-identical to the unpruned passes, with
+    fewer launches."""
+    from torch.profiler import ProfilerActivity, profile
+
+    from stylerenderer_amd.model import Discriminator, GeneratorWithMap
+
+    dev = torch.device("cuda")
+    torch.manual_seed(5)
+    g = GeneratorWithMap(64, 64, 2).to(dev)
+    d = Discriminator(64).to(dev)
+    m = train.synthetic_mesh(2, dev, seed=3, face_sized=False)
+    mesh = (m[0].requires_grad_(True), m[1].requires_grad_(True), m[2])      # like train.py:242-244
+    z = torch.randn(2, 64, device=dev)
+    probe = torch.randn(2, 3, 64, 64, device=dev)
+    real = torch.randn(4, 3, 64, 64, device=dev)
+
+    def run(prune):
+        monkeypatch.setenv("SR_PRUNE_GRADS", "1" if prune else "0")
+        for net in (g, d):
+            for p in net.parameters():
+                p.grad = None
+        with profile(activities=[ProfilerActivity.CUDA]) as prof:
+            img, latents, maps = g([z], mesh, return_latents=True, return_normals=True, randomize_noise=False)
+            pen, _, lengths = train.g_path_regularize(img, [latents] + list(maps), 0.0, noise=probe)
+            pen.backward()
+            x = real.clone().requires_grad_(True)
+            train.d_r1_loss(d(x), x).backward()
+            torch.cuda.synchronize()
+        launches = sum(e.count for e in prof.key_averages() if e.device_type is not None and "Memcpy" not in e.key)
+        grads = {("g." if net is g else "d.") + n: p.grad.clone() for net in (g, d) for n, p in net.named_parameters()
+                 if p.grad is not None}
+        return grads, lengths.detach().clone(), launches
+
+    full, len_full, n_full = run(False)
+    lean, len_lean, n_lean = run(True)
+    assert torch.equal(len_full, len_lean)
+    assert set(full) == set(lean) and len(full) > 40
+    differing = [k for k in full if not torch.equal(full[k], lean[k])]
+    assert not differing, differing
+    assert n_lean < n_full, (n_lean, n_full)
