@@ -562,6 +562,94 @@ int launch_wgrad_s2(const WgradParams& p, const Plan& pl, hipStream_t st) {
     return launch_wgrad_one<2, TY, TX, 8, 8, 1, 32, 128>(p, grid, st);
 }
 
+// ---- weight gradient of the map heads' 3x3 convolutions (<= 4 x <= 4 channels) ---------------------------------------
+// GeneratorWithMap turns every rasterised normal map into per-pixel affine planes with ResBlocks of 3 -> 3 -> 4 channels
+// (reference model.py:224-247).  On the 64 x 64 channel tiles of k_wgrad_mfma such a layer is 0.2 % useful work and a
+// K-split scratch of ~150 MB: 176 us at 256^2 x 4 samples.  It is a streaming reduction: a lane owns pixels, keeps the
+// 9 x 4 x 4 products in registers, the block folds them (shuffles, then LDS across its four waves) into one slab and
+// k_wgrad_small3_finish adds the slabs in block order — deterministic, 7 MB of reads.
+constexpr int WS_CM = 4, WS_NM = 4, WS_ROW = 9 * WS_NM, WS_ACC = WS_CM * WS_ROW;
+
+// blockIdx.y = input channel: 36 accumulators per lane (9 taps x <= 4 output channels), eight waves per SIMD
+__global__ __launch_bounds__(256) void k_wgrad_small3(float* __restrict__ partial, const float* __restrict__ x,
+                                                      const float* __restrict__ gy, const float* __restrict__ xs,
+                                                      const float* __restrict__ gs, int B, int C, int N, int H, int W) {
+    float acc[9][WS_NM];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int n = 0; n < WS_NM; ++n) acc[t][n] = 0.0f;
+    const int c = blockIdx.y;
+    const int64_t plane = (int64_t)H * W;
+    const int64_t total = (int64_t)B * plane;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int b = (int)(i / plane);
+        const int r = (int)(i - (int64_t)b * plane);
+        const int y = r / W, xw = r - y * W;
+        float g[WS_NM];
+#pragma unroll
+        for (int n = 0; n < WS_NM; ++n)
+            g[n] = n < N ? gy[((int64_t)b * N + n) * plane + r] * (gs ? gs[b * N + n] : 1.0f) : 0.0f;
+        const float s = xs ? xs[b * C + c] : 1.0f;
+        const float* xp = x + ((int64_t)b * C + c) * plane;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int yy = y + ky - 1;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int xx = xw + kx - 1;
+                const float v = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? xp[(int64_t)yy * W + xx] * s : 0.0f;
+#pragma unroll
+                for (int n = 0; n < WS_NM; ++n) acc[ky * 3 + kx][n] += v * g[n];
+            }
+        }
+    }
+    __shared__ float fold[4][WS_ROW];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int n = 0; n < WS_NM; ++n) {
+            float v = acc[t][n];
+#pragma unroll
+            for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+            if (lane == 0) fold[wave][t * WS_NM + n] = v;
+        }
+    __syncthreads();
+    if (threadIdx.x < WS_ROW) {
+        const int j = threadIdx.x;
+        partial[((int64_t)blockIdx.x * WS_CM + c) * WS_ROW + j] = (fold[0][j] + fold[1][j]) + (fold[2][j] + fold[3][j]);
+    }
+}
+
+// slab element j = (c, t, n).  Four lanes per element walk the slabs k = q, q + 4, ... (loads of independent slabs in
+// flight), then the four strided sums are added in a fixed order: deterministic
+__global__ __launch_bounds__(4 * WS_ACC) void k_wgrad_small3_finish(float* __restrict__ dwt, const float* __restrict__ partial,
+                                                                    int nblk, int C, int N) {
+    __shared__ float part[4][WS_ACC];
+    const int j = threadIdx.x % WS_ACC, q = threadIdx.x / WS_ACC;
+    float a = 0.0f;
+#pragma unroll 8
+    for (int k = q; k < nblk; k += 4) a += partial[(int64_t)k * WS_ACC + j];
+    part[q][j] = a;
+    __syncthreads();
+    if (q != 0) return;
+    const int n = j % WS_NM, t = (j / WS_NM) % 9, c = j / WS_ROW;
+    if (c < C && n < N) dwt[((int64_t)t * C + c) * N + n] = (part[0][j] + part[1][j]) + (part[2][j] + part[3][j]);
+}
+
+bool wgrad_small_ok(int64_t C, int64_t N, int ksize, int stride, int pad, int transposed) {
+    const char* e = std::getenv("SR_WGRAD_SMALL");
+    if (e && e[0] == '0') return false;
+    return !transposed && ksize == 3 && stride == 1 && pad == 1 && C <= WS_CM && N <= WS_NM;
+}
+
+int wgrad_small_blocks(int64_t B, int64_t IH, int64_t IW) {
+    const int64_t px = B * IH * IW;
+    const int64_t nb = (px + 1023) / 1024;                  // >= 4 pixels per lane: the fold costs a lane ~36 x 6 shuffles
+    return (int)(nb < 1 ? 1 : (nb > 256 ? 256 : nb));
+}
+
 bool geometry(int64_t B, int64_t C, int64_t N, int64_t IH, int64_t IW, int64_t OH, int64_t OW,
               int ksize, int stride, int pad, int transposed, int& is, int& GH, int& GW, int& UH,
               int& UW, int& CUc, int& CVc, int& d0) {
@@ -591,6 +679,7 @@ extern "C" int64_t sr_conv2d_wgrad_scratch_floats(int64_t B, int64_t C, int64_t 
     int is, GH, GW, UH, UW, CUc, CVc, d0;
     if (!geometry(B, C, N, IH, IW, OH, OW, ksize, stride, pad, transposed, is, GH, GW, UH, UW, CUc, CVc, d0))
         return -1;
+    if (wgrad_small_ok(C, N, ksize, stride, pad, transposed)) return (int64_t)wgrad_small_blocks(B, IH, IW) * WS_ACC + 4;
     const Plan pl = make_plan(is, (int)B, CUc, CVc, GH, GW);
     int64_t need = (int64_t)pl.ks * NG_OF(pl.pb) * ksize * ksize * (pl.tiles_u * pl.ut) * (int64_t)(pl.tiles_v * pl.vt) + 4;
     if (!transposed && ksize == 3 && stride == 1 && pad == 1 && wgrad_wino_enabled() &&
@@ -619,6 +708,15 @@ extern "C" int sr_conv2d_wgrad_mfma(float* dwt, const float* x, const float* gy,
     if (!dwt || !x || !gy || !scratch) return SR_EINVAL;
     if (B * C * IH * IW >= (1LL << 31) || B * N * OH * OW >= (1LL << 31)) return SR_ERANGE;
     hipStream_t st = sr_stream(stream);
+    if (wgrad_small_ok(C, N, ksize, stride, pad, transposed)) {
+        const int nb = B > 0 ? wgrad_small_blocks(B, IH, IW) : 0;
+        if (nb > 0) {
+            hipLaunchKernelGGL(k_wgrad_small3, dim3(nb, (unsigned)C), dim3(256), 0, st, scratch, x, gy, xscale, gscale, (int)B, (int)C,
+                               (int)N, (int)IH, (int)IW);
+        }
+        hipLaunchKernelGGL(k_wgrad_small3_finish, dim3(1), dim3(4 * WS_ACC), 0, st, dwt, scratch, nb, (int)C, (int)N);
+        return sr_launch_status();
+    }
     if (!transposed && ksize == 3 && stride == 1 && pad == 1 && wgrad_wino_enabled() &&
         sr_wgrad_wino_eligible(B, C, N, IH, IW, x, gy))
         return sr_wgrad_wino_3x3(dwt, x, gy, xscale, gscale, B, C, N, IH, IW, scratch, st);

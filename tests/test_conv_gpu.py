@@ -44,6 +44,10 @@ CASES = [
     (2, 5, 7, 16, 16, 3, 1, 1, False),
     (1, 9, 4, 37, 41, 3, 1, 1, False),
     (2, 12, 140, 64, 64, 3, 1, 1, False),
+    (4, 3, 3, 64, 64, 3, 1, 1, False),           # map-head layers: streaming weight gradient (k_wgrad_small3)
+    (2, 3, 4, 33, 47, 3, 1, 1, False),
+    (5, 4, 2, 128, 128, 3, 1, 1, False),         # more pixels than one pass of its 1024 blocks
+    (1, 1, 1, 5, 3, 3, 1, 1, False),
     (2, 8, 6, 9, 9, 3, 2, 0, False),
     (2, 10, 5, 33, 33, 3, 2, 0, False),
     (1, 7, 3, 65, 65, 3, 2, 0, False),
