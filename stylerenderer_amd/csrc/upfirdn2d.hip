@@ -16,6 +16,7 @@
 #include "common.h"
 
 #include <cstdlib>
+#include <type_traits>
 
 namespace {
 
@@ -464,6 +465,38 @@ __global__ __launch_bounds__(256) void k_fir4_resample(float* __restrict__ out, 
     if (oy >= out_h) return;
     const int my = oy * DOWN - pad_y0;
     float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    if constexpr (UP == 2) {
+        // Same taps in the same order as the loop below, without its 64 parity tests: of the four tap rows the two with
+        // (my + ky) even hold data (ky = ky0, ky0 + 2), and since ox0 + lx is a multiple of four the column parity is the
+        // same for every lane — output c reads the taps kx = ((c + PX) & 1), + 2 at compile-time offsets from one base
+        // column.  Rows / columns outside the map are zeros in the staged window: adding their 0 * tap leaves the sum as
+        // skipping them does.
+        const int ky0 = my & 1;
+        const int mx = ox0 + lx - pad_x0;
+        const int px = mx & 1;
+        const int cbase = ((mx - px) >> 1) - ix_lo;
+        auto rows = [&](auto pxc) {
+            constexpr int PX = decltype(pxc)::value;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int ky = ky0 + 2 * j;
+                const float* row = s_in + (((my + ky) >> 1) - iy_lo) * LDW + cbase;
+                const float* kr = s_k + ky * 4;
+                const float k0 = kr[0], k1 = kr[1], k2 = kr[2], k3 = kr[3];
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const int kx = ((c + PX) & 1) + 2 * i;
+                        const float kv = kx == 0 ? k0 : (kx == 1 ? k1 : (kx == 2 ? k2 : k3));
+                        const float prod = row[(PX + c + kx) >> 1] * kv;
+                        acc[c] = acc[c] + prod;
+                    }
+            }
+        };
+        if (px) rows(std::integral_constant<int, 1>{});
+        else rows(std::integral_constant<int, 0>{});
+    } else
 #pragma unroll
     for (int ky = 0; ky < 4; ++ky) {
         const int m = my + ky;
@@ -486,6 +519,19 @@ __global__ __launch_bounds__(256) void k_fir4_resample(float* __restrict__ out, 
     const int64_t o = plane * (int64_t)out_h * out_w + (int64_t)oy * out_w + ox0 + lx;
     float* q = out + o;
     // optional second operand of a following addition (ToRGB: rgb + upsample(skip), reference model.py:66-68)
+    // rows of 4-float groups on 16-byte addresses (every map of the networks): one 16-byte access per lane instead of
+    // four 4-byte ones at a 16-byte stride — the 256^2 gradient of the discriminator's skip branch is 400 MB of traffic
+    const bool vec = (out_w & 3) == 0 && ox0 + lx + 3 < out_w && ((reinterpret_cast<uintptr_t>(out) & 15) == 0) &&
+                     (!addend || (reinterpret_cast<uintptr_t>(addend) & 15) == 0);
+    if (vec) {
+        float4 r = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        if (addend) {
+            const float4 a = *reinterpret_cast<const float4*>(addend + o);
+            r.x = r.x + a.x; r.y = r.y + a.y; r.z = r.z + a.z; r.w = r.w + a.w;
+        }
+        *reinterpret_cast<float4*>(q) = r;
+        return;
+    }
 #pragma unroll
     for (int c = 0; c < 4; ++c)
         if (ox0 + lx + c < out_w) q[c] = addend ? acc[c] + addend[o + c] : acc[c];
