@@ -163,6 +163,10 @@ int sr_smallconv_dx(float* dx, const float* g, const float* ws, int64_t B, int64
 int64_t sr_smallconv_dw_scratch_floats(int64_t B, int64_t C, int64_t N, int64_t hw);
 int sr_smallconv_dw(float* dws, const float* g, const float* x, int64_t B, int64_t C, int64_t N, int64_t hw,
                     float* scratch, sr_stream_t stream);
+/* the same with the bias gradient gb[j] = sum_{b,p} g[b,j,p] of ToRGB (reference model.py:57-69) summed by the same
+ * launch (gb may be NULL); same scratch */
+int sr_smallconv_dw_bias(float* dws, float* gb, const float* g, const float* x, int64_t B, int64_t C, int64_t N, int64_t hw,
+                         float* scratch, sr_stream_t stream);
 /* Modulated weight rows of that convolution and their pull-back (reference layers.py:293-297, demodulate=False):
  *   sr_modrows_fwd: ws[b,j,c] = (scale * w[j,c]) * s[b,c]                       w [N, C], s [B, C], ws [B, N, C]
  *   sr_modrows_bwd: gs[b,c] = sum_j dws[b,j,c] * (scale * w[j,c]);  gw[j,c] = scale * sum_b dws[b,j,c] * s[b,c]

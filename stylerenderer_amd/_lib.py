@@ -45,6 +45,7 @@ SIGNATURES = {
     "sr_smallconv_dx": (_i, [_p] * 3 + [_l] * 4 + [_p]),
     "sr_smallconv_dw_scratch_floats": (_l, [_l] * 4),
     "sr_smallconv_dw": (_i, [_p] * 3 + [_l] * 4 + [_p, _p]),
+    "sr_smallconv_dw_bias": (_i, [_p] * 4 + [_l] * 4 + [_p, _p]),
     "sr_modrows_fwd": (_i, [_p] * 3 + [_f] + [_l] * 3 + [_p]),
     "sr_modrows_bwd": (_i, [_p] * 5 + [_f] + [_l] * 3 + [_p]),
     "sr_vertex_normals_f32": (_i, [_p] * 6 + [_l] * 3 + [_f, _p]),

@@ -824,8 +824,9 @@ __global__ __launch_bounds__(256) void k_smallconv_dx(float* __restrict__ dx, co
 template <int N, int CH>
 __global__ __launch_bounds__(256) void k_smallconv_dw(float* __restrict__ partial, const float* __restrict__ g,
                                                       const float* __restrict__ x, int C, int64_t hw,
-                                                      int chunks, float* __restrict__ dws) {
+                                                      int chunks, float* __restrict__ dws, float* __restrict__ gsum) {
     __shared__ float lds[CH][4 * SC_MAXN];
+    __shared__ float lds_g[4 * SC_MAXN];
     const int64_t row0 = (int64_t)blockIdx.y * CH;   // b * C + c0, CH consecutive channels of one sample
     const int64_t b = row0 / C;
     const int64_t off = (int64_t)blockIdx.x * ECHUNK;
@@ -836,11 +837,22 @@ __global__ __launch_bounds__(256) void k_smallconv_dw(float* __restrict__ partia
     for (int k = 0; k < CH; ++k)
 #pragma unroll
         for (int j = 0; j < N; ++j) acc[k][j] = 0.0f;
+    // the bias gradient sum_{b, p} g[b, j, p] rides along (ToRGB: reference model.py:57-69 adds a [1, 3, 1, 1] bias): the
+    // workgroups of a sample's FIRST channel group also sum the gradient chunk they hold anyway (was a 22 us ATen
+    // reduction with three output elements per layer)
+    const bool sum_g = gsum != nullptr && row0 == b * C;
+    float ag[N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) ag[j] = 0.0f;
 #pragma unroll 2
     for (int i = threadIdx.x; i < n4; i += 256) {
         float4 gg[N];
 #pragma unroll
         for (int j = 0; j < N; ++j) gg[j] = reinterpret_cast<const float4*>(g + (b * N + j) * hw + off)[i];
+        if (sum_g) {
+#pragma unroll
+            for (int j = 0; j < N; ++j) ag[j] += (gg[j].x + gg[j].y) + (gg[j].z + gg[j].w);
+        }
 #pragma unroll
         for (int k = 0; k < CH; ++k) {
             const float4 v = reinterpret_cast<const float4*>(x + (row0 + k) * hw + off)[i];
@@ -857,7 +869,18 @@ __global__ __launch_bounds__(256) void k_smallconv_dw(float* __restrict__ partia
             const float r = sr_wave_sum(acc[k][j]);
             if (lane == 0) lds[k][j * 4 + wave] = r;
         }
+    if (sum_g) {
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            const float r = sr_wave_sum(ag[j]);
+            if (lane == 0) lds_g[j * 4 + wave] = r;
+        }
+    }
     __syncthreads();
+    if (sum_g && threadIdx.x >= 64 && threadIdx.x < 64 + N) {
+        const int j = threadIdx.x - 64;
+        gsum[(b * chunks + blockIdx.x) * N + j] = (lds_g[j * 4] + lds_g[j * 4 + 1]) + (lds_g[j * 4 + 2] + lds_g[j * 4 + 3]);
+    }
     if (threadIdx.x < CH * N) {
         const int k = threadIdx.x / N, j = threadIdx.x % N;
         const float r = (lds[k][j * 4] + lds[k][j * 4 + 1]) + (lds[k][j * 4 + 2] + lds[k][j * 4 + 3]);
@@ -879,6 +902,18 @@ __global__ __launch_bounds__(64) void k_smallconv_dw_finish(float* __restrict__ 
         for (int i = threadIdx.x; i < chunks; i += 64) acc += partial[(row * chunks + i) * N + j];
         acc = sr_wave_sum(acc);
         if (threadIdx.x == 0) dws[(b * N + j) * C + c] = acc;
+    }
+}
+
+// gb[j] = sum over (sample, chunk) of gsum[(b * chunks + chunk) * N + j]: lane i takes entries i, i + 64, ..., then the
+// wave's fixed-order sum
+__global__ __launch_bounds__(64) void k_smallconv_gb_finish(float* __restrict__ gb, const float* __restrict__ gsum, int N,
+                                                            int entries) {
+    for (int j = 0; j < N; ++j) {
+        float acc = 0.0f;
+        for (int i = threadIdx.x; i < entries; i += 64) acc += gsum[(int64_t)i * N + j];
+        acc = sr_wave_sum(acc);
+        if (threadIdx.x == 0) gb[j] = acc;
     }
 }
 
@@ -920,36 +955,46 @@ extern "C" int sr_smallconv_dx(float* dx, const float* g, const float* ws, int64
 
 extern "C" int64_t sr_smallconv_dw_scratch_floats(int64_t B, int64_t C, int64_t N, int64_t hw) {
     if (B <= 0 || C <= 0 || N <= 0 || hw <= 0) return 1;
-    return B * C * sr_ceil_div(hw, ECHUNK) * N + 1;
+    // the weight-gradient partials, then the bias-gradient partials of sr_smallconv_dw_bias
+    return B * C * sr_ceil_div(hw, ECHUNK) * N + B * sr_ceil_div(hw, ECHUNK) * N + 1;
 }
 
-extern "C" int sr_smallconv_dw(float* dws, const float* g, const float* x, int64_t B, int64_t C, int64_t N,
-                               int64_t hw, float* scratch, sr_stream_t stream) {
+// gb (optional): the bias gradient sum_{b, p} g[b, j, p] [N], summed by the same launch (+ one 64-lane finish)
+extern "C" int sr_smallconv_dw_bias(float* dws, float* gb, const float* g, const float* x, int64_t B, int64_t C, int64_t N,
+                                    int64_t hw, float* scratch, sr_stream_t stream) {
     if (!dws || !g || !x || !scratch || !smallconv_ok(B, C, N, hw, g, x) || B * C > 65535) return SR_EINVAL;
     const int chunks = (int)sr_ceil_div(hw, ECHUNK);
     hipStream_t st = sr_stream(stream);
     float* direct = chunks == 1 ? dws : nullptr;
+    float* gsum = gb ? scratch + B * C * chunks * N : nullptr;
     if (C % 4 == 0) {
         const dim3 grid((unsigned)chunks, (unsigned)(B * C / 4));
         switch (N) {
-            case 1: hipLaunchKernelGGL((k_smallconv_dw<1, 4>), grid, dim3(256), 0, st, scratch, g, x, (int)C, hw, chunks, direct); break;
-            case 2: hipLaunchKernelGGL((k_smallconv_dw<2, 4>), grid, dim3(256), 0, st, scratch, g, x, (int)C, hw, chunks, direct); break;
-            case 3: hipLaunchKernelGGL((k_smallconv_dw<3, 4>), grid, dim3(256), 0, st, scratch, g, x, (int)C, hw, chunks, direct); break;
-            default: hipLaunchKernelGGL((k_smallconv_dw<4, 4>), grid, dim3(256), 0, st, scratch, g, x, (int)C, hw, chunks, direct); break;
+            case 1: hipLaunchKernelGGL((k_smallconv_dw<1, 4>), grid, dim3(256), 0, st, scratch, g, x, (int)C, hw, chunks, direct, gsum); break;
+            case 2: hipLaunchKernelGGL((k_smallconv_dw<2, 4>), grid, dim3(256), 0, st, scratch, g, x, (int)C, hw, chunks, direct, gsum); break;
+            case 3: hipLaunchKernelGGL((k_smallconv_dw<3, 4>), grid, dim3(256), 0, st, scratch, g, x, (int)C, hw, chunks, direct, gsum); break;
+            default: hipLaunchKernelGGL((k_smallconv_dw<4, 4>), grid, dim3(256), 0, st, scratch, g, x, (int)C, hw, chunks, direct, gsum); break;
         }
     } else {
         const dim3 grid((unsigned)chunks, (unsigned)(B * C));
         switch (N) {
-            case 1: hipLaunchKernelGGL((k_smallconv_dw<1, 1>), grid, dim3(256), 0, st, scratch, g, x, (int)C, hw, chunks, direct); break;
-            case 2: hipLaunchKernelGGL((k_smallconv_dw<2, 1>), grid, dim3(256), 0, st, scratch, g, x, (int)C, hw, chunks, direct); break;
-            case 3: hipLaunchKernelGGL((k_smallconv_dw<3, 1>), grid, dim3(256), 0, st, scratch, g, x, (int)C, hw, chunks, direct); break;
-            default: hipLaunchKernelGGL((k_smallconv_dw<4, 1>), grid, dim3(256), 0, st, scratch, g, x, (int)C, hw, chunks, direct); break;
+            case 1: hipLaunchKernelGGL((k_smallconv_dw<1, 1>), grid, dim3(256), 0, st, scratch, g, x, (int)C, hw, chunks, direct, gsum); break;
+            case 2: hipLaunchKernelGGL((k_smallconv_dw<2, 1>), grid, dim3(256), 0, st, scratch, g, x, (int)C, hw, chunks, direct, gsum); break;
+            case 3: hipLaunchKernelGGL((k_smallconv_dw<3, 1>), grid, dim3(256), 0, st, scratch, g, x, (int)C, hw, chunks, direct, gsum); break;
+            default: hipLaunchKernelGGL((k_smallconv_dw<4, 1>), grid, dim3(256), 0, st, scratch, g, x, (int)C, hw, chunks, direct, gsum); break;
         }
     }
     if (chunks > 1)
         hipLaunchKernelGGL(k_smallconv_dw_finish, dim3((unsigned)(B * C)), dim3(64), 0, st, dws, scratch, (int)C,
                            (int)N, chunks, B * C);
+    if (gb)
+        hipLaunchKernelGGL(k_smallconv_gb_finish, dim3(1), dim3(64), 0, st, gb, gsum, (int)N, (int)(B * chunks));
     return sr_launch_status();
+}
+
+extern "C" int sr_smallconv_dw(float* dws, const float* g, const float* x, int64_t B, int64_t C, int64_t N,
+                               int64_t hw, float* scratch, sr_stream_t stream) {
+    return sr_smallconv_dw_bias(dws, nullptr, g, x, B, C, N, hw, scratch, stream);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -970,24 +1015,27 @@ __global__ __launch_bounds__(256) void k_modrows_fwd(float* __restrict__ ws, con
     ws[i] = (w[(int64_t)j * C + c] * scale) * s[(int64_t)b * C + c];
 }
 
+// blockIdx.y < B: the style row of sample b;  otherwise weight row j = blockIdx.y - B (batch added in ascending order:
+// deterministic).  One lane per (row, channel): the first form walked B x N products in each of C lanes of TWO
+// workgroups — 26 us for 100 KB at batch 16.
 __global__ __launch_bounds__(256) void k_modrows_bwd(float* __restrict__ gs, float* __restrict__ gw,
                                                      const float* __restrict__ dws, const float* __restrict__ w,
                                                      const float* __restrict__ s, float scale, int B, int N, int C) {
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c >= C) return;
-    if (gs) {
-        for (int b = 0; b < B; ++b) {
-            float acc = 0.0f;
-            for (int j = 0; j < N; ++j) acc += dws[((int64_t)b * N + j) * C + c] * (w[(int64_t)j * C + c] * scale);
-            gs[(int64_t)b * C + c] = acc;
-        }
-    }
-    if (gw) {
-        for (int j = 0; j < N; ++j) {
-            float acc = 0.0f;
-            for (int b = 0; b < B; ++b) acc += dws[((int64_t)b * N + j) * C + c] * s[(int64_t)b * C + c];
-            gw[(int64_t)j * C + c] = acc * scale;
-        }
+    const int r = blockIdx.y;
+    if (r < B) {
+        if (!gs) return;
+        float acc = 0.0f;
+        for (int j = 0; j < N; ++j) acc += dws[((int64_t)r * N + j) * C + c] * (w[(int64_t)j * C + c] * scale);
+        gs[(int64_t)r * C + c] = acc;
+    } else {
+        if (!gw) return;
+        const int j = r - B;
+        float acc = 0.0f;
+#pragma unroll 4
+        for (int b = 0; b < B; ++b) acc += dws[((int64_t)b * N + j) * C + c] * s[(int64_t)b * C + c];
+        gw[(int64_t)j * C + c] = acc * scale;
     }
 }
 
@@ -1008,8 +1056,8 @@ extern "C" int sr_modrows_bwd(float* gs, float* gw, const float* dws, const floa
                               int64_t B, int64_t N, int64_t C, sr_stream_t stream) {
     if (N == 0 || C == 0 || (!gs && !gw)) return SR_OK;
     if (!dws || !w || !s || B < 0 || N < 0 || C < 0) return SR_EINVAL;
-    if (B > 65535 || N > 65535 || C > (1 << 20)) return SR_ERANGE;
-    hipLaunchKernelGGL(k_modrows_bwd, dim3((unsigned)sr_ceil_div(C, 256)), dim3(256), 0, sr_stream(stream), gs, gw, dws, w,
+    if (B > 65535 || N > 65535 || B + N > 65535 || C > (1 << 20)) return SR_ERANGE;
+    hipLaunchKernelGGL(k_modrows_bwd, dim3((unsigned)sr_ceil_div(C, 256), (unsigned)(B + N)), dim3(256), 0, sr_stream(stream), gs, gw, dws, w,
                        s, scale, (int)B, (int)N, (int)C);
     return sr_launch_status();
 }

@@ -42,18 +42,20 @@ def _dx(g, ws):
     return dx
 
 
-def _dw(g, x):
+def _dw(g, x, want_bias=False):
+    """dws [B, N, C] (and, with want_bias, gb [N] = sum over samples and pixels of g — summed by the same launch)."""
     g, x = g.contiguous(), x.contiguous()
     b, n, h, w = g.shape
     c = x.size(1)
     L = _lib.lib()
     dws = torch.empty((b, n, c), dtype=g.dtype, device=g.device)
+    gb = torch.empty(n, dtype=g.dtype, device=g.device) if want_bias else None
     scratch = torch.empty(L.sr_smallconv_dw_scratch_floats(b, c, n, h * w), dtype=g.dtype, device=g.device)
     with on_device_of(g):
-        rc = L.sr_smallconv_dw(_lib.ptr(dws), _lib.ptr(g), _lib.ptr(x), b, c, n, h * w, _lib.ptr(scratch),
-                               stream_of(g))
-    _lib.check(rc, "sr_smallconv_dw")
-    return dws
+        rc = L.sr_smallconv_dw_bias(_lib.ptr(dws), _lib.ptr(gb), _lib.ptr(g), _lib.ptr(x), b, c, n, h * w,
+                                    _lib.ptr(scratch), stream_of(g))
+    _lib.check(rc, "sr_smallconv_dw_bias")
+    return (dws, gb) if want_bias else dws
 
 
 class SmallConvFwd(Function):
@@ -68,8 +70,14 @@ class SmallConvFwd(Function):
         x, ws = ctx.saved_tensors
         needs = wanted(ctx)                      # (a pass that only asks for the latents' gradient: no bias sum)
         gx = SmallConvDx.apply(g, ws) if needs[0] else None
-        gw = SmallConvDw.apply(g, x) if needs[1] else None
-        gb = g.sum((0, 2, 3)) if len(needs) > 2 and needs[2] else None
+        want_b = len(needs) > 2 and needs[2]
+        gw = gb = None
+        if needs[1] and want_b:
+            gw, gb = SmallConvDwBias.apply(g, x)          # the bias gradient rides in the weight-gradient launch
+        elif needs[1]:
+            gw = SmallConvDw.apply(g, x)
+        elif want_b:
+            gb = g.sum((0, 2, 3))
         return gx, gw, gb
 
 
@@ -98,6 +106,29 @@ class SmallConvDw(Function):
         g, x = ctx.saved_tensors
         d_g = SmallConvFwd.apply(x, gw) if ctx.needs_input_grad[0] else None
         d_x = SmallConvDx.apply(g, gw) if ctx.needs_input_grad[1] else None
+        return d_g, d_x
+
+
+class SmallConvDwBias(Function):
+    """(dws, gb) = (sum_p g x, sum_{b,p} g) in one launch; both linear in g, so the pull-back is the convolution of the
+    cotangents with the bias cotangent as its bias."""
+
+    @staticmethod
+    def forward(ctx, g, x):
+        ctx.save_for_backward(g, x)
+        return _dw(g, x, True)
+
+    @staticmethod
+    def backward(ctx, gw, ggb):
+        g, x = ctx.saved_tensors
+        d_g = d_x = None
+        if ctx.needs_input_grad[0]:
+            if gw is None:
+                d_g = ggb.view(1, -1, 1, 1).expand_as(g) if ggb is not None else None
+            else:
+                d_g = SmallConvFwd.apply(x, gw, ggb)
+        if ctx.needs_input_grad[1] and gw is not None:
+            d_x = SmallConvDx.apply(g, gw)
         return d_g, d_x
 
 
