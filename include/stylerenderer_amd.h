@@ -160,6 +160,10 @@ int sr_smallconv_fwd(float* out, const float* x, const float* ws, const float* b
                      int64_t N, int64_t hw, sr_stream_t stream);
 int sr_smallconv_dx(float* dx, const float* g, const float* ws, int64_t B, int64_t C, int64_t N, int64_t hw,
                     sr_stream_t stream);
+/* dx = addend + W^T g: the feature map that feeds ToRGB also feeds the next layer (reference model.py:206-219); its two
+ * gradients are added in this pass (addend [B, C, hw] or NULL, may alias dx) */
+int sr_smallconv_dx_add(float* dx, const float* g, const float* ws, const float* addend, int64_t B, int64_t C, int64_t N,
+                        int64_t hw, sr_stream_t stream);
 int64_t sr_smallconv_dw_scratch_floats(int64_t B, int64_t C, int64_t N, int64_t hw);
 int sr_smallconv_dw(float* dws, const float* g, const float* x, int64_t B, int64_t C, int64_t N, int64_t hw,
                     float* scratch, sr_stream_t stream);

@@ -43,6 +43,7 @@ SIGNATURES = {
     "sr_rowdot_bwd": (_i, [_p] * 8 + [_l, _l, _p, _p]),
     "sr_smallconv_fwd": (_i, [_p] * 4 + [_l] * 4 + [_p]),
     "sr_smallconv_dx": (_i, [_p] * 3 + [_l] * 4 + [_p]),
+    "sr_smallconv_dx_add": (_i, [_p] * 4 + [_l] * 4 + [_p]),
     "sr_smallconv_dw_scratch_floats": (_l, [_l] * 4),
     "sr_smallconv_dw": (_i, [_p] * 3 + [_l] * 4 + [_p, _p]),
     "sr_smallconv_dw_bias": (_i, [_p] * 4 + [_l] * 4 + [_p, _p]),

@@ -795,9 +795,11 @@ __global__ __launch_bounds__(256) void k_smallconv_fwd(float* __restrict__ out, 
 
 template <int N>
 __global__ __launch_bounds__(256) void k_smallconv_dx(float* __restrict__ dx, const float* __restrict__ g,
-                                                      const float* __restrict__ ws, int C, int64_t hw4) {
+                                                      const float* __restrict__ ws, int C, int64_t hw4,
+                                                      const float* __restrict__ addend, int cgroup) {
     extern __shared__ float s_ws[];
     const int b = blockIdx.y;
+    const int c0 = blockIdx.z * cgroup, c1 = (c0 + cgroup < C) ? c0 + cgroup : C;
     for (int i = threadIdx.x; i < N * C; i += 256) s_ws[i] = ws[(int64_t)b * N * C + i];
     __syncthreads();
     const int64_t p4 = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -806,8 +808,43 @@ __global__ __launch_bounds__(256) void k_smallconv_dx(float* __restrict__ dx, co
 #pragma unroll
     for (int j = 0; j < N; ++j) gv[j] = reinterpret_cast<const float4*>(g)[((int64_t)b * N + j) * hw4 + p4];
     float4* dst = reinterpret_cast<float4*>(dx) + (int64_t)b * C * hw4 + p4;
+    if (addend) {
+        // the other gradient of a feature map that also feeds the next convolution (SmallConvFork): one pass instead
+        // of this store + autograd's read-read-write addition.  Eight addend loads in flight per lane: a loop that
+        // waits for one load per channel is latency-bound on the small maps
+        const float4* add = reinterpret_cast<const float4*>(addend) + (int64_t)b * C * hw4 + p4;
+        int c = c0;
+        for (; c + 8 <= c1; c += 8) {
+            float4 a[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) a[u] = add[(int64_t)(c + u) * hw4];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int j = 0; j < N; ++j) {
+                    const float w = s_ws[j * C + c + u];
+                    r.x += w * gv[j].x; r.y += w * gv[j].y; r.z += w * gv[j].z; r.w += w * gv[j].w;
+                }
+                r.x = a[u].x + r.x; r.y = a[u].y + r.y; r.z = a[u].z + r.z; r.w = a[u].w + r.w;
+                dst[(int64_t)(c + u) * hw4] = r;
+            }
+        }
+        for (; c < c1; ++c) {
+            const float4 a = add[(int64_t)c * hw4];
+            float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+                const float w = s_ws[j * C + c];
+                r.x += w * gv[j].x; r.y += w * gv[j].y; r.z += w * gv[j].z; r.w += w * gv[j].w;
+            }
+            r.x = a.x + r.x; r.y = a.y + r.y; r.z = a.z + r.z; r.w = a.w + r.w;
+            dst[(int64_t)c * hw4] = r;
+        }
+        return;
+    }
 #pragma unroll 4
-    for (int c = 0; c < C; ++c) {
+    for (int c = c0; c < c1; ++c) {
         float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int j = 0; j < N; ++j) {
@@ -942,14 +979,29 @@ extern "C" int sr_smallconv_fwd(float* out, const float* x, const float* ws, con
     return sr_launch_status();
 }
 
+extern "C" int sr_smallconv_dx_add(float* dx, const float* g, const float* ws, const float* addend, int64_t B, int64_t C,
+                                   int64_t N, int64_t hw, sr_stream_t stream);
+
 extern "C" int sr_smallconv_dx(float* dx, const float* g, const float* ws, int64_t B, int64_t C, int64_t N,
                                int64_t hw, sr_stream_t stream) {
-    if (!dx || !g || !ws || !smallconv_ok(B, C, N, hw, dx, g)) return SR_EINVAL;
+    return sr_smallconv_dx_add(dx, g, ws, nullptr, B, C, N, hw, stream);
+}
+
+// dx = addend + W^T g  (addend [B, C, hw] or NULL; may alias dx: every element is read and written by the same lane)
+extern "C" int sr_smallconv_dx_add(float* dx, const float* g, const float* ws, const float* addend, int64_t B, int64_t C,
+                                   int64_t N, int64_t hw, sr_stream_t stream) {
+    if (!dx || !g || !ws || !smallconv_ok(B, C, N, hw, dx, g) || ((uintptr_t)addend & 15)) return SR_EINVAL;
     const int64_t hw4 = hw / 4;
-    const dim3 grid((unsigned)sr_ceil_div(hw4, 256), (unsigned)B);
+    // channel groups (multiples of 8) so that the launch has ~2048 workgroups: a 64^2 map at batch 16 is 64 pixel blocks
+    const int64_t wgs = sr_ceil_div(hw4, 256) * B;
+    int64_t groups = sr_ceil_div(2048, wgs);
+    if (groups > sr_ceil_div(C, 8)) groups = sr_ceil_div(C, 8);
+    if (groups < 1) groups = 1;
+    const int cgroup = (int)(sr_ceil_div(sr_ceil_div(C, groups), 8) * 8);
+    const dim3 grid((unsigned)sr_ceil_div(hw4, 256), (unsigned)B, (unsigned)sr_ceil_div(C, cgroup));
     const size_t lds = (size_t)N * C * sizeof(float);
     hipStream_t st = sr_stream(stream);
-    SR_SMALLCONV_DISPATCH(k_smallconv_dx, grid, dim3(256), lds, st, dx, g, ws, (int)C, hw4);
+    SR_SMALLCONV_DISPATCH(k_smallconv_dx, grid, dim3(256), lds, st, dx, g, ws, (int)C, hw4, addend, cgroup);
     return sr_launch_status();
 }
 

@@ -110,6 +110,13 @@ class StyledMapConv(nn.Module):
         return self.activate(out)
 
 
+def _fork_enabled():
+    """SR_TORGB_FORK=0: ToRGB as a second consumer of the feature map (A/B)."""
+    import os
+
+    return os.environ.get("SR_TORGB_FORK", "1") != "0"
+
+
 class ToRGB(nn.Module):
     def __init__(self, in_channel, style_dim, upsample=True, blur_kernel=[1, 3, 3, 1]):
         super().__init__()
@@ -118,20 +125,26 @@ class ToRGB(nn.Module):
         self.conv = ModulatedConv2d(in_channel, 3, 1, style_dim, demodulate=False)
         self.bias = nn.Parameter(torch.zeros(1, 3, 1, 1))
 
-    def forward(self, input, style, skip=None):
+    def forward(self, input, style, skip=None, fork=False):
+        """fork (the synthesis loops): returns (input', rgb) with input' = input for the NEXT layer to consume — on device
+        tensors the feature map then has one consumer node, whose backward adds the two gradients inside the
+        data-gradient kernel (op.smallconv.SmallConvFork); elsewhere input' is input."""
         conv = self.conv
         if _smallconv.supported(input, conv.out_channel):
             # device tensors: the bias rides in the streaming 1x1 kernel and the skip addition in the up-sampling
             # kernel's store — two launches for conv + bias + upsample + add (reference model.py:63-69)
             out = _smallconv.modulated_conv1x1_small(input, conv.weight.view(conv.out_channel, conv.in_channel),
-                                                     conv.style_of(style), self.bias.view(-1), scale=conv.scale)
+                                                     conv.style_of(style), self.bias.view(-1), scale=conv.scale,
+                                                     fork=fork and _fork_enabled())
+            if fork and _fork_enabled():
+                input, out = out
             if skip is not None:
                 out = upsample2_add(skip, self.upsample.kernel, self.upsample.pad, out)
-            return out
+            return (input, out) if fork else out
         out = self.conv(input, style) + self.bias
         if skip is not None:
             out = out + self.upsample(skip)
-        return out
+        return (input, out) if fork else out
 
 
 class Generator(nn.Module):
@@ -288,13 +301,13 @@ class Generator(nn.Module):
             out = self.input(latent)
             st = self._layer_styles(latent)
             out = self.conv1(out, st[0], noise=noise[0])
-            skip = self.to_rgb1(out, st[1])
+            out, skip = self.to_rgb1(out, st[1], fork=True)      # `out` goes on to the next layer through the ToRGB node
             k = 2
             for conv_up, conv, n_up, n_conv, to_rgb in zip(self.convs[::2], self.convs[1::2],
                                                            noise[1::2], noise[2::2], self.to_rgbs):
                 out = conv_up(out, st[k], noise=n_up)
                 out = conv(out, st[k + 1], noise=n_conv)
-                skip = to_rgb(out, st[k + 2], skip)
+                out, skip = to_rgb(out, st[k + 2], skip, fork=True)
                 k += 3
         return skip, (latent if return_latents else None)
 
@@ -343,7 +356,7 @@ class GeneratorWithMap(Generator):
         maps = self.norm1(norm_maps[-1].contiguous())
         st = self._layer_styles(latent)
         out = self.conv1(out, st[0], maps, noise=noise[0])
-        skip = self.to_rgb1(out, st[1])
+        out, skip = self.to_rgb1(out, st[1], fork=True)          # `out` goes on to the next layer through the ToRGB node
         two_stage = len(self.convs) == len(self.norm_to_style)
         i, k = 1, 2
         for conv_up, conv, n_up, n_conv, to_rgb in zip(self.convs[::2], self.convs[1::2],
@@ -360,7 +373,7 @@ class GeneratorWithMap(Generator):
             maps_up, maps_conv = maps.split([2, maps.shape[1] - 2], 1)
             out = conv_up(out, st[k], maps_up, noise=n_up)
             out = conv(out, st[k + 1], maps_conv, noise=n_conv)
-            skip = to_rgb(out, st[k + 2], skip)
+            out, skip = to_rgb(out, st[k + 2], skip, fork=True)
             i += 2
             k += 3
         return skip, (latent if return_latents else None), (norm_maps if return_normals else None)

@@ -31,14 +31,16 @@ def _fwd(x, ws, bias=None):
     return out
 
 
-def _dx(g, ws):
+def _dx(g, ws, addend=None):
+    """W^T g (+ addend [B, C, H, W]: the other gradient of the same feature map, added in the same pass)."""
     g, ws = g.contiguous(), ws.contiguous()
     b, n, h, w = g.shape
     c = ws.size(2)
     dx = torch.empty((b, c, h, w), dtype=g.dtype, device=g.device)
     with on_device_of(g):
-        rc = _lib.lib().sr_smallconv_dx(_lib.ptr(dx), _lib.ptr(g), _lib.ptr(ws), b, c, n, h * w, stream_of(g))
-    _lib.check(rc, "sr_smallconv_dx")
+        rc = _lib.lib().sr_smallconv_dx_add(_lib.ptr(dx), _lib.ptr(g), _lib.ptr(ws), _lib.ptr(addend), b, c, n, h * w,
+                                            stream_of(g))
+    _lib.check(rc, "sr_smallconv_dx_add")
     return dx
 
 
@@ -74,6 +76,46 @@ class SmallConvFwd(Function):
         gw = gb = None
         if needs[1] and want_b:
             gw, gb = SmallConvDwBias.apply(g, x)          # the bias gradient rides in the weight-gradient launch
+        elif needs[1]:
+            gw = SmallConvDw.apply(g, x)
+        elif want_b:
+            gb = g.sum((0, 2, 3))
+        return gx, gw, gb
+
+
+class SmallConvFork(Function):
+    """(x, rgb) = (x handed on unchanged, conv1x1(x, ws) + bias): the feature map that feeds ToRGB also feeds the next
+    layer (reference model.py:206-219).  As two consumers of one tensor, autograd adds their gradients in a
+    read-read-write pass of the full map; as the two outputs of ONE node both arrive together and the addition rides
+    in the data-gradient kernel (sr_smallconv_dx_add)."""
+
+    @staticmethod
+    def forward(ctx, x, ws, bias=None):
+        mark_inputs(ctx, x, ws, bias)
+        ctx.save_for_backward(x, ws)
+        ctx.set_materialize_grads(False)                 # an unused output's cotangent stays None (no zero-fill)
+        return x.view_as(x), _fwd(x, ws, bias)
+
+    @staticmethod
+    def backward(ctx, g_x, g):
+        x, ws = ctx.saved_tensors
+        needs = wanted(ctx)
+        if g is None:
+            return (g_x if needs[0] else None), None, None
+        gx = None
+        if needs[0]:
+            fused = (g_x is not None and not torch.is_grad_enabled() and g_x.is_contiguous() and g_x.data_ptr() % 16 == 0
+                     and g_x.dtype == g.dtype and g_x.shape == x.shape)
+            if fused:
+                gx = _dx(g, ws, g_x)
+            else:
+                gx = SmallConvDx.apply(g, ws)
+                if g_x is not None:
+                    gx = gx + g_x
+        want_b = len(needs) > 2 and needs[2]
+        gw = gb = None
+        if needs[1] and want_b:
+            gw, gb = SmallConvDwBias.apply(g, x)
         elif needs[1]:
             gw = SmallConvDw.apply(g, x)
         elif want_b:
@@ -183,11 +225,14 @@ def modulated_rows(weight_nc, style, scale):
     return (weight_nc * scale)[None, :, :] * style[:, None, :]
 
 
-def modulated_conv1x1_small(x, weight_jc, style, bias=None, scale=None):
+def modulated_conv1x1_small(x, weight_jc, style, bias=None, scale=None, fork=False):
     """weight_jc [N, C], style [B, C], optional bias [N] -> [B, N, H, W].  `scale` None: weight_jc is already scaled
-    (two tensor products); a number: the raw parameter view, scaled and modulated in one launch (`modulated_rows`)."""
+    (two tensor products); a number: the raw parameter view, scaled and modulated in one launch (`modulated_rows`).
+    fork: returns (x', out) with x' = x for the next layer to consume — see SmallConvFork."""
     if scale is None:
         ws = weight_jc[None, :, :] * style[:, None, :]
     else:
         ws = modulated_rows(weight_jc, style, scale)
+    if fork:
+        return SmallConvFork.apply(x, ws, bias)
     return SmallConvFwd.apply(x, ws, bias)
