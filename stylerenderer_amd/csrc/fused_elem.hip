@@ -743,14 +743,15 @@ namespace {
 
 constexpr int SC_MAXN = 4;
 
-template <int N>
-__global__ __launch_bounds__(256) void k_smallconv_fwd(float* __restrict__ out, const float* __restrict__ x,
-                                                       const float* __restrict__ ws,
-                                                       const float* __restrict__ bias, int C, int64_t hw4) {
-    // A workgroup covers 64 float4 (256 pixels) of one sample; its four waves split the channel
-    // loop (short serial chains and enough workgroups even for 64x64 maps) and are summed through
-    // LDS in a fixed order.  Weights are wave-uniform -> scalar loads.
-    __shared__ float4 s_part[3][64][N];
+template <int N, int NW>
+__global__ __launch_bounds__(64 * NW) void k_smallconv_fwd(float* __restrict__ out, const float* __restrict__ x,
+                                                           const float* __restrict__ ws,
+                                                           const float* __restrict__ bias, int C, int64_t hw4) {
+    // A workgroup covers 64 float4 (256 pixels) of one sample; its NW waves split the channel
+    // loop (short serial chains) and are summed through LDS in a fixed order.  Weights are wave-uniform -> scalar
+    // loads.  NW = 4 where the map alone gives >= 1024 workgroups; NW = 16 below that (a 64^2 map at batch 16 is 256
+    // workgroups: four waves each walking 128 channels were latency-bound at 2.6 TB/s).
+    __shared__ float4 s_part[NW - 1][64][N];
     const int b = blockIdx.y;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const float* __restrict__ wsb = ws + (int64_t)b * N * C;
@@ -760,7 +761,7 @@ __global__ __launch_bounds__(256) void k_smallconv_fwd(float* __restrict__ out, 
     float4 acc[N];
 #pragma unroll
     for (int j = 0; j < N; ++j) acc[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-    const int c_per = (C + 3) / 4;
+    const int c_per = (C + NW - 1) / NW;
     const int c_lo = __builtin_amdgcn_readfirstlane(wave * c_per);
     const int c_hi = min(C, c_lo + c_per);
 #pragma unroll 8
@@ -782,7 +783,7 @@ __global__ __launch_bounds__(256) void k_smallconv_fwd(float* __restrict__ out, 
         for (int j = 0; j < N; ++j) {
             float4 r = acc[j];
 #pragma unroll
-            for (int k = 0; k < 3; ++k) {
+            for (int k = 0; k < NW - 1; ++k) {
                 const float4 t = s_part[k][lane][j];
                 r.x += t.x; r.y += t.y; r.z += t.z; r.w += t.w;
             }
@@ -975,7 +976,17 @@ extern "C" int sr_smallconv_fwd(float* out, const float* x, const float* ws, con
     const int64_t hw4 = hw / 4;
     const dim3 grid((unsigned)sr_ceil_div(hw4, 64), (unsigned)B);
     hipStream_t st = sr_stream(stream);
-    SR_SMALLCONV_DISPATCH(k_smallconv_fwd, grid, dim3(256), 0, st, out, x, ws, bias, (int)C, hw4);
+    const bool wide = sr_ceil_div(hw4, 64) * B < 1024 && C >= 64;
+#define SR_SMALLCONV_FWD(NN)                                                                                          \
+    if (wide) hipLaunchKernelGGL((k_smallconv_fwd<NN, 16>), grid, dim3(1024), 0, st, out, x, ws, bias, (int)C, hw4);  \
+    else hipLaunchKernelGGL((k_smallconv_fwd<NN, 4>), grid, dim3(256), 0, st, out, x, ws, bias, (int)C, hw4);
+    switch (N) {
+        case 1: SR_SMALLCONV_FWD(1) break;
+        case 2: SR_SMALLCONV_FWD(2) break;
+        case 3: SR_SMALLCONV_FWD(3) break;
+        default: SR_SMALLCONV_FWD(4) break;
+    }
+#undef SR_SMALLCONV_FWD
     return sr_launch_status();
 }
 
