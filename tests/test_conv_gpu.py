@@ -65,6 +65,8 @@ CASES = [
     (2, 32, 128, 33, 33, 3, 2, 0, False),        # same kernel, down-sampling convolution
     (2, 8, 3, 8, 8, 1, 1, 0, False),
     (2, 16, 5, 32, 32, 1, 1, 0, False),
+    (4, 3, 128, 32, 32, 1, 1, 0, False),         # from-RGB layer: weight gradient on the streaming row-product kernel
+    (2, 3, 64, 16, 8, 1, 1, 0, False),
     (2, 6, 4, 9, 9, 1, 2, 0, False),
 ]
 
