@@ -43,6 +43,7 @@ SOURCES = [
     ("conv_wgrad_bf16x3.hip", []),
     ("conv_s2_bf16x3.hip", []),
     ("conv_generic.hip", []),
+    ("conv1x1_gemm.hip", []),
 ]
 
 

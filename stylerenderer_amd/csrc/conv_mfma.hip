@@ -35,6 +35,7 @@
 // The stride-1 3x3 case of maps >= 32 wide is normally taken by the Winograd kernel (conv_wino.hip);
 // this file then serves the strided / transposed / 1x1 / small-map launches and SR_WINOGRAD=0.
 #include "common.h"
+#include "conv1x1_gemm.h"
 #include "conv_s2_bf16x3.h"
 #include "conv_wgrad_bf16x3.h"
 #include "conv_wino.h"
@@ -1168,7 +1169,12 @@ extern "C" int sr_conv2d_mfma_ex(float* out, const float* in, const float* wt, c
             return sr_conv_s2_bf16x3_launch(out, in, wt, wt_ld, iscale, oscale, obias, B, C, N, IH, IW, OH, OW, scratch, st);
         if (ksize == 3 && stride == 1) rc = launch_by_patch<1, 3, 3>(p, st);
         else if (ksize == 3 && stride == 2) rc = launch_by_patch<2, 3, 3>(p, st);
-        else if (ksize == 1 && stride == 1) rc = launch_by_patch<1, 1, 1>(p, st);
+        else if (ksize == 1 && stride == 1) {
+            // no window: a plain GEMM with both operands K-major (csrc/conv1x1_gemm.hip) where its tiles fill the chip
+            if (pad == 0 && sr_conv1x1_gemm_eligible(B, C, N, wt_ld, IH * IW, in, wt, out))
+                return sr_conv1x1_gemm_launch(out, in, wt, wt_ld, iscale, oscale, obias, B, C, N, IH * IW, st);
+            rc = launch_by_patch<1, 1, 1>(p, st);
+        }
         else if (ksize == 1 && stride == 2) rc = launch_by_patch<2, 1, 1>(p, st);
         else return SR_EINVAL;
         return rc;

@@ -1007,3 +1007,31 @@ def test_generic_geometry_layers_vs_reference(golden):
         grads = torch.autograd.grad(y, [x, m.weight, m.bias], T(synth.det_normal(tuple(y.shape), 41)))
         for a, kk in zip(grads, ("gx", "gw", "gb")):
             assert rel(a.cpu().numpy(), gold[tag + "_" + kk]) < 2e-6, (tag, kk)
+
+
+@pytest.mark.parametrize("b,c,n,h,w", [(2, 32, 128, 16, 32), (3, 48, 256, 8, 16), (1, 16, 128, 32, 64)])
+@pytest.mark.parametrize("scaled", [True, False])
+def test_conv1x1_gemm_vs_float64_and_window_kernel(b, c, n, h, w, scaled, monkeypatch):
+    """csrc/conv1x1_gemm.hip (the discriminator's skip convolutions as a plain GEMM: reference model.py:296-336) against
+    float64 and against the 1x1 instantiation of k_conv_mfma it replaces."""
+    from stylerenderer_amd.op.conv import conv2d_mfma
+
+    g = torch.Generator().manual_seed(b * 31 + c + n + h)
+    x = torch.randn(b, c, h, w, generator=g)
+    wgt = torch.randn(n, c, 1, 1, generator=g) / np.sqrt(c)
+    isc = torch.randn(b, c, generator=g) if scaled else None
+    osc = (torch.rand(b, n, generator=g) + 0.5) if scaled else None
+    bias = torch.randn(n, generator=g) if scaled else None
+    want = ref_conv(x, wgt, isc, osc, bias, 1, 0, False)
+    dev = lambda t: None if t is None else t.to(DEV)  # noqa: E731
+    args = [dev(x), dev(to_taps(wgt, False)), dev(isc), dev(osc), dev(bias)]
+    monkeypatch.setenv("SR_CONV1X1_GEMM", "force")
+    got = conv2d_mfma(*args, 1, 1, 0, False)
+    mag = F.conv2d(x.abs().double() * (isc.abs().double()[:, :, None, None] if scaled else 1.0), wgt.abs().double())
+    if scaled:
+        mag = mag * osc.abs().double()[:, :, None, None] + bias.abs().double()[None, :, None, None]
+    assert float(((got.cpu().double() - want).abs() / (mag + 1e-30)).max()) < 2e-6
+    assert torch.equal(got, conv2d_mfma(*args, 1, 1, 0, False))
+    monkeypatch.setenv("SR_CONV1X1_GEMM", "0")
+    old = conv2d_mfma(*args, 1, 1, 0, False)
+    assert float(((old - got).abs().cpu().double() / (mag + 1e-30)).max()) < 2e-6
