@@ -14,6 +14,7 @@ def child():
 
     tag = {"1": "fused ", "0": "phases"}.get(os.environ.get("SR_CONVT_FUSED", ""), "auto  ")
     tag += {"0": " taps off", "1": " taps forced"}.get(os.environ.get("SR_CONVT_TAPS", ""), " taps auto")
+    tag += {"0": " (patch form)"}.get(os.environ.get("SR_CONVT_TAPS_GEMM", ""), " (flattened)")
     for (b, c, n, res) in ((1, 512, 512, 32), (2, 512, 512, 32), (4, 512, 512, 32), (8, 512, 512, 32), (1, 512, 256, 64),
                            (2, 512, 256, 64), (4, 512, 256, 64), (1, 256, 128, 128), (2, 256, 128, 128), (4, 256, 128, 128),
                            (4, 512, 512, 16), (8, 512, 512, 16), (4, 512, 512, 8), (4, 512, 512, 4)):
@@ -48,6 +49,7 @@ if __name__ == "__main__":
     else:
         # fused four-phase kernel forced; per-phase launches; the default choice (tap-split for small maps)
         for env in ({"SR_CONVT_FUSED": "1", "SR_CONVT_TAPS": "0"}, {"SR_CONVT_FUSED": "0", "SR_CONVT_TAPS": "0"},
+                    {"SR_CONVT_FUSED": "0", "SR_CONVT_TAPS": "1", "SR_CONVT_TAPS_GEMM": "0"},
                     {"SR_CONVT_FUSED": "0", "SR_CONVT_TAPS": "1"}, {}):
             subprocess.run([sys.executable, os.path.abspath(__file__), "child"], env=dict(os.environ, **env),
                            check=False, timeout=600)

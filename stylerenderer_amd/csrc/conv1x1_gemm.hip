@@ -127,6 +127,131 @@ __global__ __launch_bounds__(256, 2) void k_conv1x1_gemm(const GemmParams q) {
 #endif
 }
 
+// ---- tap-split transposed convolution on the same tile ------------------------------------------------------------------
+// The stride-2 transposed 3x3 convolution of a small map is nine shifted 1x1 convolutions over the common (IH+1) x (IW+1)
+// phase grid (conv_mfma.hip, TAP9).  On 32 x 4 / 16 x 8 pixel PATCHES a 17 x 17 grid fills 45 % of its tiles (32-wide rows
+// for 17 columns, 20 rows for 17): 43 TFLOP/s for the 16^2 -> 32^2 layer at batch 4.  Here the pixel dimension of a tile is
+// 128 consecutive points of the FLATTENED (sample, grid point) index — only the last tile of a launch is partial — and the
+// shifted, border-clipped window is a per-lane base pointer + mask computed once (a lane stages ONE pixel column of the
+// tile for all chunks).  Raw sums go to partial[slice * 9 + tap][b][n][grid point]: the layout k_convt_tap_reduce adds up.
+struct TapParams {
+    const float* x;
+    const float* wt;        // [9][C][ldw]
+    const float* iscale;
+    float* partial;
+    int B, C, N, ldw, IH, IW, GW, region;
+    int tiles_q, tiles_n, c_per_slice;
+    int64_t total_q;        // B * region
+};
+
+__global__ __launch_bounds__(256, 2) void k_convt_taps_gemm(const TapParams q) {
+#if __HIP_DEVICE_COMPILE__
+    __shared__ float s_a[2][KC][TN];
+    __shared__ float s_b[2][KC][TP];
+    int bid = blockIdx.x;
+    const int tap = bid % 9;                    // the taps of a tile are neighbours: one input patch in L2
+    bid /= 9;
+    const int tn = bid % q.tiles_n;
+    bid /= q.tiles_n;
+    const int tq = bid % q.tiles_q;
+    const int slice = bid / q.tiles_q;
+    const int c_beg = slice * q.c_per_slice;
+    const int c_end = min(q.C, c_beg + q.c_per_slice);
+    const int n0 = tn * TN;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, half = lane >> 5;
+    const int wn = (wave >> 1) * 64, wp = (wave & 1) * 64;
+    const int ky = tap / 3, kx = tap - 3 * ky;
+
+    // weights: rows r0, r0 + 8 of the chunk, 16 bytes per lane
+    const int r0 = tid >> 5, c4 = (tid & 31) * 4;
+    const float* wsrc = q.wt + ((int64_t)tap * q.C + c_beg + r0) * q.ldw + n0 + c4;
+    const int64_t wstep8 = (int64_t)8 * q.ldw;
+    // activations: this lane's pixel column, rows rb0 + 2 i
+    const int col = tid & 127, rb0 = tid >> 7;
+    const int64_t qi = (int64_t)tq * TP + col;
+    const int plane = q.IH * q.IW;
+    bool ok = qi < q.total_q;
+    const int bq = ok ? (int)(qi / q.region) : 0;
+    const int g = ok ? (int)(qi - (int64_t)bq * q.region) : 0;
+    const int yy = g / q.GW - (ky >> 1), xx = g % q.GW - (kx >> 1);
+    ok = ok && yy >= 0 && yy < q.IH && xx >= 0 && xx < q.IW;
+    const float* xsrc = q.x + ((int64_t)bq * q.C + c_beg + rb0) * plane + (ok ? yy * q.IW + xx : 0);
+    const float* isc = q.iscale ? q.iscale + (int64_t)bq * q.C + c_beg + rb0 : nullptr;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    float4 ra0, ra1;
+    float rb[8];
+    auto fetch = [&](int kc) {
+        const float* w = wsrc + (int64_t)kc * KC * q.ldw;
+        ra0 = *reinterpret_cast<const float4*>(w);
+        ra1 = *reinterpret_cast<const float4*>(w + wstep8);
+        const float* xx_ = xsrc + (int64_t)kc * KC * plane;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            float v = ok ? xx_[(int64_t)(2 * i) * plane] : 0.0f;
+            if (isc) v *= isc[kc * KC + 2 * i];
+            rb[i] = v;
+        }
+    };
+    auto stash = [&](int buf) {
+        *reinterpret_cast<float4*>(&s_a[buf][r0][c4]) = ra0;
+        *reinterpret_cast<float4*>(&s_a[buf][r0 + 8][c4]) = ra1;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) s_b[buf][rb0 + 2 * i][col] = rb[i];
+    };
+
+    const int nchunks = (c_end - c_beg) / KC;
+    if (nchunks > 0) {
+        fetch(0);
+        stash(0);
+    }
+    __syncthreads();
+    for (int kc = 0; kc < nchunks; ++kc) {
+        const int buf = kc & 1;
+        const bool more = kc + 1 < nchunks;
+        if (more) fetch(kc + 1);
+#pragma unroll
+        for (int kk = 0; kk < KC / 2; ++kk) {
+            const int k = 2 * kk + half;
+            const float a0 = s_a[buf][k][wn + l31], a1 = s_a[buf][k][wn + 32 + l31];
+            const float b0 = s_b[buf][k][wp + l31], b1 = s_b[buf][k][wp + 32 + l31];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        if (more) stash(buf ^ 1);
+        __syncthreads();
+    }
+
+    // raw sums: partial[((slice * 9 + tap) * B + b) * N + n][grid point]
+    float* base = q.partial + ((int64_t)slice * 9 + tap) * q.B * q.N * q.region;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int64_t qo = (int64_t)tq * TP + wp + j * 32 + l31;
+        if (qo >= q.total_q) continue;
+        const int bo = (int)(qo / q.region);
+        const int go = (int)(qo - (int64_t)bo * q.region);
+        float* d = base + ((int64_t)bo * q.N + n0 + wn) * q.region + go;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                d[(int64_t)row * q.region] = acc[i][j][r];
+            }
+    }
+#endif
+}
+
 // SR_CONV1X1_GEMM: "0" off, "force" also below the tile count that fills the chip (tests)
 int mode() {
     const char* e = std::getenv("SR_CONV1X1_GEMM");
@@ -159,5 +284,30 @@ int sr_conv1x1_gemm_launch(float* out, const float* in, const float* wt, int64_t
     q.tiles_p = (int)(P / TP); q.tiles_n = (int)(N / TN);
     const int64_t tiles = (int64_t)q.tiles_p * q.tiles_n * B;
     hipLaunchKernelGGL(k_conv1x1_gemm, dim3((unsigned)tiles), dim3(256), 0, st, q);
+    return sr_launch_status();
+}
+
+bool sr_convt_taps_gemm_eligible(int64_t B, int64_t C, int64_t N, int64_t IW, int64_t ldw, int c_per_slice,
+                                 const void* wt) {
+    const char* e = std::getenv("SR_CONVT_TAPS_GEMM");
+    if (e && e[0] == '0') return false;
+    // maps up to 32 wide: their (2^k + 1)-wide grids fill half of a 32-wide patch row; from 64 up the patch form's
+    // aligned 16-byte DMA wins (batch 1, scripts/bench_convt_small.py: 0.169 against 0.180 ms at 64^2, 0.172 / 0.188 at 128^2)
+    if (IW > 32 && !(e && e[0] == 'f')) return false;
+    return B > 0 && C % KC == 0 && c_per_slice % KC == 0 && N % TN == 0 && ldw % 4 == 0 &&
+           (reinterpret_cast<uintptr_t>(wt) & 15) == 0;
+}
+
+int sr_convt_taps_gemm_launch(float* partial, const float* in, const float* wt, int64_t ldw, const float* iscale, int64_t B,
+                              int64_t C, int64_t N, int64_t IH, int64_t IW, int ks, int c_per_slice, hipStream_t st) {
+    TapParams q;
+    q.x = in; q.wt = wt; q.iscale = iscale; q.partial = partial;
+    q.B = (int)B; q.C = (int)C; q.N = (int)N; q.ldw = (int)ldw; q.IH = (int)IH; q.IW = (int)IW;
+    q.GW = (int)IW + 1; q.region = (int)((IH + 1) * (IW + 1));
+    q.total_q = B * q.region;
+    q.tiles_q = (int)((q.total_q + TP - 1) / TP); q.tiles_n = (int)(N / TN); q.c_per_slice = c_per_slice;
+    const int64_t blocks = (int64_t)q.tiles_q * q.tiles_n * 9 * ks;
+    if (blocks > 0x7FFFFFFFLL) return SR_ERANGE;
+    hipLaunchKernelGGL(k_convt_taps_gemm, dim3((unsigned)blocks), dim3(256), 0, st, q);
     return sr_launch_status();
 }

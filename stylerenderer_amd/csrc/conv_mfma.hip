@@ -855,6 +855,21 @@ int convt_taps_mode() {
 // K slices of the tap-split launch: enough workgroups for ~2 per CU (the nine taps already multiply the tiles by 9),
 // >= 32 channels (a multiple of 16) per slice
 void convt_taps_plan(int IH, int IW, int B, int N, int C, int& ks, int& c_per_slice) {
+    if (sr_convt_taps_gemm_eligible(B, C, N, IW, 4, 16, nullptr)) {
+        // flattened-pixel form (csrc/conv1x1_gemm.hip): 128-point tiles of the (sample, grid point) index; ~3 workgroups
+        // per CU (each a wave per SIMD: the other workgroups' MFMAs cover a chunk's load latency)
+        const int64_t tiles = sr_ceil_div((int64_t)B * (IH + 1) * (IW + 1), 128) * (N / 128) * 9;
+        int want = (int)sr_ceil_div(3 * SR_NUM_CU, tiles);
+        if (want > 8) want = 8;
+        if (want < 1) want = 1;
+        int per = (C + want - 1) / want;
+        per = (per + 15) / 16 * 16;
+        if (per < 64) per = 64;
+        if (per > C) per = C;
+        c_per_slice = per;
+        ks = (C + per - 1) / per;
+        return;
+    }
     int pw, ph, pb;
     patch_shape(IW + 1, pw, ph, pb);
     const int64_t blocks = (int64_t)((IW + pw) / pw) * ((IH + ph) / ph) * ((B + pb - 1) / pb) * ((N + BN - 1) / BN) * 9;
@@ -911,7 +926,10 @@ int launch_convt_taps(ConvParams p, hipStream_t st) {
     const dim3 grid((unsigned)blocks);
     const bool v4 = taps_v4(p);
     int rc;
-    if (pw == 32) rc = v4 ? launch_one<1, 1, 1, 32, 4, 1, true, true>(p, grid, st)
+    if (sr_convt_taps_gemm_eligible(p.B, p.C, p.N, p.IW, p.ldw, p.c_per_slice, p.wt))
+        // pixels = the flattened (sample, grid point) index instead of 32 x 4 patches of a (2^k + 1)-wide grid
+        rc = sr_convt_taps_gemm_launch(p.partial, p.in, p.wt, p.ldw, p.iscale, p.B, p.C, p.N, p.IH, p.IW, p.ks, p.c_per_slice, st);
+    else if (pw == 32) rc = v4 ? launch_one<1, 1, 1, 32, 4, 1, true, true>(p, grid, st)
                           : launch_one<1, 1, 1, 32, 4, 1, false, true>(p, grid, st);
     else if (pw == 16) rc = v4 ? launch_one<1, 1, 1, 16, 8, 1, true, true>(p, grid, st)
                                : launch_one<1, 1, 1, 16, 8, 1, false, true>(p, grid, st);

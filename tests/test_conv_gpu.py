@@ -1035,3 +1035,33 @@ def test_conv1x1_gemm_vs_float64_and_window_kernel(b, c, n, h, w, scaled, monkey
     monkeypatch.setenv("SR_CONV1X1_GEMM", "0")
     old = conv2d_mfma(*args, 1, 1, 0, False)
     assert float(((old - got).abs().cpu().double() / (mag + 1e-30)).max()) < 2e-6
+
+
+@pytest.mark.parametrize("b,c,n,h,w", [(4, 64, 128, 4, 4), (2, 128, 256, 8, 8), (3, 96, 128, 16, 16), (1, 32, 128, 32, 32),
+                                       (2, 48, 128, 5, 9)])
+@pytest.mark.parametrize("scaled", [True, False])
+def test_convt_taps_gemm_vs_float64_and_patch_kernel(b, c, n, h, w, scaled, monkeypatch):
+    """Tap-split transposed convolution with the flattened (sample, grid point) pixel dimension (csrc/conv1x1_gemm.hip
+    k_convt_taps_gemm) against float64 and against the patch form it replaces (same K slices, same reduction)."""
+    from stylerenderer_amd.op.conv import conv2d_mfma
+
+    g = torch.Generator().manual_seed(b * 131 + c + n + h * 7 + w)
+    x = torch.randn(b, c, h, w, generator=g)
+    wgt = torch.randn(c, n, 3, 3, generator=g) / (3 * c ** 0.5)
+    isc = torch.randn(b, c, generator=g) if scaled else None
+    osc = torch.randn(b, n, generator=g) if scaled else None
+    bias = torch.randn(n, generator=g) if scaled else None
+    want = ref_conv(x, wgt, isc, osc, bias, 2, 0, True)
+    dev = lambda t: None if t is None else t.to(DEV)  # noqa: E731
+    args = [dev(x), dev(to_taps(wgt, True)), dev(isc), dev(osc), dev(bias)]
+    monkeypatch.setenv("SR_CONVT_TAPS", "1")
+    got = conv2d_mfma(*args, 3, 2, 0, True)
+    mag = F.conv_transpose2d(x.abs().double() * (isc.abs().double()[:, :, None, None] if scaled else 1.0), wgt.abs().double(),
+                             stride=2)
+    if scaled:
+        mag = mag * osc.abs().double()[:, :, None, None] + bias.abs().double()[None, :, None, None]
+    assert float(((got.cpu().double() - want).abs() / (mag + 1e-30)).max()) < 2e-6
+    assert torch.equal(got, conv2d_mfma(*args, 3, 2, 0, True))
+    monkeypatch.setenv("SR_CONVT_TAPS_GEMM", "0")
+    old = conv2d_mfma(*args, 3, 2, 0, True)
+    assert float(((old - got).abs().cpu().double() / (mag + 1e-30)).max()) < 2e-6
