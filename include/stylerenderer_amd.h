@@ -520,6 +520,14 @@ int sr_conv2d_mfma_ex(float* out, const float* in, const float* wt, const float*
                       const float* oscale, const float* obias, int64_t B, int64_t C, int64_t N,
                       int64_t wt_ld, int64_t IH, int64_t IW, int64_t OH, int64_t OW, int ksize,
                       int stride, int pad, int transposed, int flags, float* scratch, sr_stream_t stream);
+/* out = oscale[b,n] * conv1x1(in, wt)[b,n,p] + addend[b,n,p]  (stride 1, no window; P = pixels per plane): the skip branch of the
+ * discriminator's ResBlock with the sum of the two branches in its store (reference model.py: ResBlock.forward
+ * `(out + skip) / sqrt(2)`, the factor folded into oscale and the other branch's gain).  _supported: 1 when the GEMM-shaped
+ * kernel takes the call (C % 16, N % 128, P % 128, 16-byte aligned operands, enough tiles), else the caller adds separately. */
+int sr_conv1x1_add_supported(int64_t B, int64_t C, int64_t N, int64_t wt_ld, int64_t P, const float* in, const float* wt,
+                             const float* out, const float* addend);
+int sr_conv1x1_add(float* out, const float* in, const float* wt, const float* oscale, const float* addend, int64_t B,
+                   int64_t C, int64_t N, int64_t wt_ld, int64_t P, sr_stream_t stream);
 int sr_conv2d_nba_ex(float* out, const float* in, const float* wt, const float* iscale, const float* oscale,
                      const float* noise, const float* noise_w, const float* abias, float alpha, float gain,
                      int64_t B, int64_t C, int64_t N, int64_t wt_ld, int64_t H, int64_t W, int64_t noise_bstride,

@@ -98,6 +98,8 @@ SIGNATURES = {
     "sr_conv2d_mfma": (_i, [_p] * 6 + [_l] * 8 + [_i] * 4 + [_p, _p]),
     "sr_conv2d_uses_winograd": (_i, [_l] * 5 + [_p, _p]),
     "sr_conv2d_mfma_ex": (_i, [_p] * 6 + [_l] * 8 + [_i] * 5 + [_p, _p]),
+    "sr_conv1x1_add_supported": (_i, [_l] * 5 + [_p] * 4),
+    "sr_conv1x1_add": (_i, [_p] * 5 + [_l] * 5 + [_p]),
     "sr_rasterize_grad_f64": (_i, [_l] * 5 + [_i] * 2 + [_p, _p, _l] + [_p] * 6 + [_l, _l, _p, _p, _p, _d, _p, _p]),
     "sr_pose_fwd": (_i, [_p, _p, _p, _p]),
     "sr_pose_bwd": (_i, [_p, _p, _p, _p, _p]),

@@ -8,7 +8,7 @@ bool sr_conv1x1_gemm_eligible(int64_t B, int64_t C, int64_t N, int64_t ldw, int6
                               const void* out);
 int sr_conv1x1_gemm_launch(float* out, const float* in, const float* wt, int64_t ldw, const float* iscale,
                            const float* oscale, const float* obias, int64_t B, int64_t C, int64_t N, int64_t P,
-                           hipStream_t st);
+                           hipStream_t st, const float* addend = nullptr);
 
 // tap-split stride-2 transposed 3x3 convolution (nine shifted 1x1 convolutions over the (IH+1) x (IW+1) phase grid) on the
 // same tile, pixels = the flattened (sample, grid point) index; raw sums to partial[slice * 9 + tap][b][n][grid point]

@@ -30,6 +30,7 @@ struct GemmParams {
     const float* iscale;
     const float* oscale;
     const float* obias;
+    const float* addend;    // optional [B, N, P]: out = conv + addend (ResBlock: conv2(conv1(x)) + skip(x), reference model.py)
     float* out;
     int C, N, ldw;
     int64_t P;
@@ -121,8 +122,14 @@ __global__ __launch_bounds__(256, 2) void k_conv1x1_gemm(const GemmParams q) {
             const float s = osc ? osc[row] : 1.0f;
             const float t = bia ? bia[row] : 0.0f;
             float* d = dst + (int64_t)row * q.P;
-            d[0] = acc[i][0][r] * s + t;
-            d[32] = acc[i][1][r] * s + t;
+            float v0 = acc[i][0][r] * s + t, v1 = acc[i][1][r] * s + t;
+            if (q.addend) {
+                const float* a = q.addend + (d - q.out);
+                v0 += a[0];
+                v1 += a[32];
+            }
+            d[0] = v0;
+            d[32] = v1;
         }
 #endif
 }
@@ -277,9 +284,9 @@ bool sr_conv1x1_gemm_eligible(int64_t B, int64_t C, int64_t N, int64_t ldw, int6
 
 int sr_conv1x1_gemm_launch(float* out, const float* in, const float* wt, int64_t ldw, const float* iscale,
                            const float* oscale, const float* obias, int64_t B, int64_t C, int64_t N, int64_t P,
-                           hipStream_t st) {
+                           hipStream_t st, const float* addend) {
     GemmParams q;
-    q.x = in; q.wt = wt; q.iscale = iscale; q.oscale = oscale; q.obias = obias; q.out = out;
+    q.x = in; q.wt = wt; q.iscale = iscale; q.oscale = oscale; q.obias = obias; q.out = out; q.addend = addend;
     q.C = (int)C; q.N = (int)N; q.ldw = (int)ldw; q.P = P;
     q.tiles_p = (int)(P / TP); q.tiles_n = (int)(N / TN);
     const int64_t tiles = (int64_t)q.tiles_p * q.tiles_n * B;
@@ -310,4 +317,19 @@ int sr_convt_taps_gemm_launch(float* partial, const float* in, const float* wt, 
     if (blocks > 0x7FFFFFFFLL) return SR_ERANGE;
     hipLaunchKernelGGL(k_convt_taps_gemm, dim3((unsigned)blocks), dim3(256), 0, st, q);
     return sr_launch_status();
+}
+
+// C ABI: the fused form  out = oscale * conv1x1(in, wt) + addend  (no window, stride 1).  _supported says whether the
+// GEMM-shaped kernel takes the call (shape / alignment / tile count, SR_CONV1X1_GEMM); otherwise the caller adds separately.
+extern "C" int sr_conv1x1_add_supported(int64_t B, int64_t C, int64_t N, int64_t wt_ld, int64_t P, const float* in,
+                                        const float* wt, const float* out, const float* addend) {
+    return sr_conv1x1_gemm_eligible(B, C, N, wt_ld, P, in, wt, out) && (reinterpret_cast<uintptr_t>(addend) & 15) == 0 ? 1 : 0;
+}
+
+extern "C" int sr_conv1x1_add(float* out, const float* in, const float* wt, const float* oscale, const float* addend,
+                              int64_t B, int64_t C, int64_t N, int64_t wt_ld, int64_t P, sr_stream_t stream) {
+    if (!out || !in || !wt || !addend) return SR_EINVAL;
+    if (!sr_conv1x1_add_supported(B, C, N, wt_ld, P, in, wt, out, addend)) return SR_EINVAL;
+    if (B * C * P >= (1LL << 31)) return SR_ERANGE;
+    return sr_conv1x1_gemm_launch(out, in, wt, wt_ld, nullptr, oscale, nullptr, B, C, N, P, sr_stream(stream), addend);
 }

@@ -151,12 +151,17 @@ class EqualConv2d(nn.Module):
         out = F.conv2d(input, self.weight * self.scale, bias=bias, stride=self.stride, padding=self.padding)
         return out * gain if gain is not None else out
 
-    def forward_stride1(self, input, gain=None):
-        """The 1x1 convolution applied to an input that is already decimated (see ConvLayer.forward)."""
+    def forward_stride1(self, input, gain=None, addend=None):
+        """The 1x1 convolution applied to an input that is already decimated (see ConvLayer.forward).  addend (bias-free
+        layers): a tensor of the output's shape added in the convolution's store where the GEMM-shaped kernel takes the
+        call (op.conv.conv1x1_add) — ResBlock's sum of its two branches."""
         wt, _ = _weight_prep_cached(self, self.weight, self.scale)
         osc = _const_rows(gain, input.shape[0], self.weight.shape[0], input.device) if gain is not None else None
         assert osc is None or self.bias is None
-        return _conv.conv2d(input, wt, None, osc, self.bias, "c1")
+        if addend is not None and self.bias is None:
+            return _conv.conv1x1_add(input.contiguous(), wt, osc, addend.contiguous())
+        out = _conv.conv2d(input, wt, None, osc, self.bias, "c1")
+        return out if addend is None else out + addend
 
     def __repr__(self):
         return "%s(%d, %d, %d, stride=%d, padding=%d)" % (
@@ -583,7 +588,8 @@ class ResBlock(nn.Module):
                 # (a + b) / sqrt(2) = a / sqrt(2) + b / sqrt(2): the factor rides in conv2's activation gain
                 # (sqrt(2) * 1/sqrt(2)) and in the skip convolution's store — one full-size pass (the add) instead
                 # of two, forward and backward
-                return self.conv2(self.conv1(same), gain=RSQRT2) + mods[1].forward_stride1(down, gain=RSQRT2)
+                # ... and the sum itself in the skip convolution's store
+                return mods[1].forward_stride1(down, gain=RSQRT2, addend=self.conv2(self.conv1(same), gain=RSQRT2))
             out = self.conv2(self.conv1(same))
             return (out + mods[1].forward_stride1(down)) / math.sqrt(2)
         if input.device.type == "cuda" and input.dtype == torch.float32 and _resblock_fold():

@@ -542,6 +542,56 @@ def conv2d_nba(x, wt, iscale, oscale, noise, noise_w, abias, slope=0.2, gain=2 *
     return ConvNBAFn.apply(x, wt, iscale, oscale, noise, noise_w, abias, slope, gain)
 
 
+class Conv1x1AddFn(torch.autograd.Function):
+    """out = oscale * conv1x1(x, wt) + addend in one launch (csrc/conv1x1_gemm.hip, sr_conv1x1_add): the skip branch of the
+    discriminator's ResBlock with the sum of the two branches in its store (reference model.py ResBlock.forward) — the
+    separate addition was a read-read-write pass of the block's output.  Backward: the 1x1 operators of ConvFn (so any
+    order of differentiation stays on them) and the cotangent itself for the addend."""
+
+    @staticmethod
+    def forward(ctx, x, wt, oscale, addend):
+        mark_inputs(ctx, x, wt, oscale, addend)
+        b, c, h, w = x.shape
+        n = wt.shape[2]
+        out = torch.empty((b, n, h, w), dtype=x.dtype, device=x.device)
+        with on_device_of(x):
+            rc = _lib.lib().sr_conv1x1_add(_lib.ptr(out), _lib.ptr(x), _lib.ptr(wt), _lib.ptr(oscale), _lib.ptr(addend),
+                                           b, c, n, wt.stride(1), h * w, stream_of(x))
+        _lib.check(rc, "sr_conv1x1_add")
+        ctx.frozen = bool(getattr(wt, "_sr_frozen", False))
+        ctx.adj = getattr(wt, "_sr_adj", None)
+        ctx.save_for_backward(x, wt, oscale)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, wt, oscale = ctx.saved_tensors
+        need_x, need_w, _, need_a = wanted(ctx)[:4]
+        g = g.contiguous()
+        gx = gw = None
+        if need_x:
+            gx = ConvFn.apply(g, adjoint_weight(wt, "c1", ctx.frozen, ctx.adj), oscale, None, None, "c1")
+        if need_w:
+            gw = WgradFn.apply(x, g, None, oscale, "c1")
+        return gx, gw, None, (g if need_a else None)
+
+
+def conv1x1_add(x, wt, oscale, addend):
+    """oscale * conv1x1(x, wt) + addend: fused where the GEMM-shaped kernel takes the shape, else the two operators.
+    `oscale` is a constant table (no gradient flows to it)."""
+    ok = (x.device.type == "cuda" and x.dtype == torch.float32 and addend.dtype == torch.float32 and x.is_contiguous()
+          and addend.is_contiguous() and wt.dim() == 3 and wt.shape[0] == 1 and wt.stride(2) == 1
+          and wt.stride(1) % 4 == 0 and (oscale is None or (oscale.is_contiguous() and not oscale.requires_grad))
+          and tuple(addend.shape) == (x.shape[0], wt.shape[2], x.shape[2], x.shape[3]))
+    if ok:
+        b, c, h, w = x.shape
+        ok = bool(_lib.lib().sr_conv1x1_add_supported(b, c, wt.shape[2], wt.stride(1), h * w, _lib.ptr(x), _lib.ptr(wt),
+                                                      _lib.ptr(addend), _lib.ptr(addend)))
+    if not ok:
+        return ConvFn.apply(x, wt, None, oscale, None, "c1") + addend
+    return Conv1x1AddFn.apply(x, wt, oscale, addend)
+
+
 def conv2d(x, wt, iscale=None, oscale=None, bias=None, geom="c3"):
     """Differentiable (to any order) MFMA convolution; see ConvFn."""
     return ConvFn.apply(x, wt, iscale, oscale, bias, geom)

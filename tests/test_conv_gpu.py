@@ -1065,3 +1065,29 @@ def test_convt_taps_gemm_vs_float64_and_patch_kernel(b, c, n, h, w, scaled, monk
     monkeypatch.setenv("SR_CONVT_TAPS_GEMM", "0")
     old = conv2d_mfma(*args, 3, 2, 0, True)
     assert float(((old - got).abs().cpu().double() / (mag + 1e-30)).max()) < 2e-6
+
+
+def test_conv1x1_add_fused_equals_the_two_operators_incl_gradients(monkeypatch):
+    """op.conv.conv1x1_add (ResBlock: skip convolution + the other branch in one store, reference model.py ResBlock.forward):
+    output and all first-order gradients equal the separate convolution + addition bit for bit; a second-order probe
+    (R1-style: gradient of the input gradient's square) agrees too."""
+    from stylerenderer_amd.op import conv as C
+
+    monkeypatch.setenv("SR_CONV1X1_GEMM", "force")
+    g = torch.Generator().manual_seed(3)
+    b, c, n, h, w = 2, 32, 128, 16, 16
+    wt0 = (torch.randn(1, c, n, generator=g) / c ** 0.5).to(DEV)
+    osc = torch.full((b, n), 0.70710678, device=DEV)
+    x0, a0 = torch.randn(b, c, h, w, generator=g).to(DEV), torch.randn(b, n, h, w, generator=g).to(DEV)
+    gy = torch.randn(b, n, h, w, generator=g).to(DEV)
+
+    def run(fused):
+        x, wt, a = x0.clone().requires_grad_(True), wt0.clone().requires_grad_(True), a0.clone().requires_grad_(True)
+        out = C.conv1x1_add(x, wt, osc, a) if fused else C.ConvFn.apply(x, wt, None, osc, None, "c1") + a
+        gx, gw, ga = torch.autograd.grad(out, (x, wt, a), gy, create_graph=True)
+        (g2,) = torch.autograd.grad((gx * gx).sum(), wt)
+        return out.detach(), gx.detach(), gw.detach(), ga.detach(), g2
+
+    assert isinstance(C.conv1x1_add(x0.clone().requires_grad_(True), wt0, osc, a0).grad_fn, C.Conv1x1AddFn.apply.__self__._backward_cls)
+    for got, want in zip(run(True), run(False)):
+        assert torch.equal(got, want)
