@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Per-iteration summary of a rocprofv3 kernel trace CSV: GPU busy / idle and time by kernel family.
 usage: scripts/trace_summary.py <kernel_trace.csv> <iterations in trace> [skip_fraction_at_start | --after-gap]
---after-gap: keep only the kernels behind the longest idle gap of the trace (scripts/phase_trace.py sleeps there)"""
+--after-gap [ms]: keep only the kernels behind the last idle gap of at least that many ms (scripts/phase_trace.py sleeps there)"""
 import collections
 import csv
 import re
@@ -14,8 +14,12 @@ skip = float(sys.argv[3]) if len(sys.argv) > 3 and not after_gap else 0.0
 ev = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in rows)
 ev = ev[int(len(ev) * skip):]
 if after_gap:
+    # the LAST idle gap of at least `--after-gap <ms>` (default 400): the probe sleeps 1 s right before the replays it wants
+    # summarised; a longer stall earlier in the run (graph instantiation on a cold box) must not win
+    min_gap = float(sys.argv[4]) * 1e6 if len(sys.argv) > 4 else 400e6
     gaps = [(ev[i + 1][0] - ev[i][1], i) for i in range(len(ev) - 1)]
-    ev = ev[max(gaps)[1] + 1:]
+    long_gaps = [i for gap, i in gaps if gap >= min_gap]
+    ev = ev[(long_gaps[-1] if long_gaps else max(gaps)[1]) + 1:]
 wall = ev[-1][1] - ev[0][0]
 busy, cur = 0, ev[0][0]
 for s, e, _ in ev:
