@@ -856,10 +856,16 @@ int convt_taps_mode() {
 // >= 32 channels (a multiple of 16) per slice
 void convt_taps_plan(int IH, int IW, int B, int N, int C, int& ks, int& c_per_slice) {
     if (sr_convt_taps_gemm_eligible(B, C, N, IW, 4, 16, nullptr)) {
-        // flattened-pixel form (csrc/conv1x1_gemm.hip): 128-point tiles of the (sample, grid point) index; ~3 workgroups
-        // per CU (each a wave per SIMD: the other workgroups' MFMAs cover a chunk's load latency)
+        // flattened-pixel form (csrc/conv1x1_gemm.hip): 128-point tiles of the (sample, grid point) index; ~2 workgroups
+        // per CU (scripts/taps_wgs_sweep.sh: 16^2 at batch 4 0.148 / 0.104 / 0.126 / 0.127 ms for 1 / 2 / 3 / 4 — more slices
+        // cover a chunk's load latency with other workgroups' MFMAs but multiply the partial sums the reduction reads)
         const int64_t tiles = sr_ceil_div((int64_t)B * (IH + 1) * (IW + 1), 128) * (N / 128) * 9;
-        int want = (int)sr_ceil_div(3 * SR_NUM_CU, tiles);
+        static const int per_cu = [] {
+            const char* e = std::getenv("SR_TAPS_WGS");       // workgroups per CU the K slices aim at (measurements)
+            const int v = e ? std::atoi(e) : 0;
+            return v >= 1 && v <= 8 ? v : 2;
+        }();
+        int want = (int)sr_ceil_div((int64_t)per_cu * SR_NUM_CU, tiles);
         if (want > 8) want = 8;
         if (want < 1) want = 1;
         int per = (C + want - 1) / want;
