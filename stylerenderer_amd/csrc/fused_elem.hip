@@ -439,7 +439,10 @@ __global__ __launch_bounds__(EB) void k_plane_sum(float* __restrict__ out0, cons
 inline int aff_cgroup(int64_t n, int64_t c, int64_t inner) {
     const int64_t wgs = sr_ceil_div(inner, APIX) * n;
     int64_t groups = sr_ceil_div(2048, wgs);
-    if (groups > 16) groups = 16;        // k_plane_sum walks the group planes serially
+    // k_plane_sum walks the group planes serially: 16, or up to 64 where even 16 groups leave the launch under one
+    // workgroup per CU (a 64^2 map at batch 1 — the inversion loop — was 64 workgroups walking 32 channels each)
+    const int64_t cap = wgs * 16 < SR_NUM_CU ? 64 : 16;
+    if (groups > cap) groups = cap;
     if (groups > c) groups = c;
     if (groups < 1) groups = 1;
     return (int)sr_ceil_div(c, groups);
