@@ -418,21 +418,39 @@ __global__ __launch_bounds__(EB) void k_nba_aff_bwd(float* __restrict__ gx, floa
     }
 }
 
-// out[i] = sum over g (ascending) of part[g * plane + i]; blockIdx.y selects one of two (out, part) pairs, so the two
-// map planes of the StyledMapConv tail are finished by ONE launch
+// out[i] = sum over g of part[g * plane + i]; blockIdx.y selects one of two (out, part) pairs, so the two map planes of the
+// StyledMapConv tail are finished by ONE launch.  A workgroup covers 64 float4 of the plane; its four waves take a quarter
+// of the groups each (ascending) and the four partial sums are added in wave order: a fixed order, and the 64 groups of a
+// small map (aff_cgroup) are 16 loads deep instead of 64 (one lane walking 64 planes: 16 us for a 32^2 map).
 __global__ __launch_bounds__(EB) void k_plane_sum(float* __restrict__ out0, const float* __restrict__ part0,
                                                   float* __restrict__ out1, const float* __restrict__ part1,
                                                   int64_t plane, int groups) {
+    __shared__ float4 s_q[3][64];
     float* out = blockIdx.y ? out1 : out0;
     const float* part = blockIdx.y ? part1 : part0;
-    const int64_t i = ((int64_t)blockIdx.x * EB + threadIdx.x) * 4;
-    if (i >= plane) return;
-    float4 acc = *reinterpret_cast<const float4*>(part + i);
-    for (int g = 1; g < groups; ++g) {
-        const float4 v = *reinterpret_cast<const float4*>(part + g * plane + i);
-        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t i = ((int64_t)blockIdx.x * 64 + lane) * 4;
+    const bool live = i < plane;
+    const int per = (groups + 3) / 4;
+    const int g0 = wave * per, g1 = min(groups, g0 + per);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (live) {
+#pragma unroll 4
+        for (int g = g0; g < g1; ++g) {
+            const float4 v = *reinterpret_cast<const float4*>(part + g * plane + i);
+            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
     }
-    *reinterpret_cast<float4*>(out + i) = acc;
+    if (wave > 0) s_q[wave - 1][lane] = acc;
+    __syncthreads();
+    if (wave == 0 && live) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float4 v = s_q[k][lane];
+            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
+        *reinterpret_cast<float4*>(out + i) = acc;
+    }
 }
 
 // channel groups so that the launch has a few thousand workgroups
@@ -496,7 +514,7 @@ extern "C" int sr_noise_bias_act_affine_bwd(float* gx, float* gamap, float* gsma
                        ga_part, gs_part, scratch, gy, out, x, amap, map_bstride, noise, alpha, scale, (int)c, inner,
                        noise_bstride, chunks, cg, plane);
     if (groups > 1) {
-        const unsigned g1 = (unsigned)sr_ceil_div(plane, EB * 4);
+        const unsigned g1 = (unsigned)sr_ceil_div(plane, 64 * 4);
         hipLaunchKernelGGL(k_plane_sum, dim3(g1, 2), dim3(EB), 0, st, gamap, ga_part, gsmap, gs_part, plane, groups);
     }
     if (gbias) {                                            // (NULL: frozen bias / noise strength)
@@ -568,19 +586,36 @@ __global__ __launch_bounds__(EB) void k_nba_aff_bwd2(float* __restrict__ d_gy, f
     *reinterpret_cast<float4*>(d_amap + b * inner + p) = da;
 }
 
-// out[b * out_bstride + i] = sum over g (ascending) of part[g * plane + b * inner + i]
+// out[b * out_bstride + i] = sum over g of part[g * plane + b * inner + i]; four waves take a quarter of the groups each
+// (ascending), partial sums added in wave order — see k_plane_sum
 __global__ __launch_bounds__(EB) void k_plane_sum_strided(float* __restrict__ out, int64_t out_bstride,
                                                           const float* __restrict__ part, int64_t plane,
                                                           int64_t inner, int groups) {
-    const int64_t i = ((int64_t)blockIdx.x * EB + threadIdx.x) * 4;
+    __shared__ float4 s_q[3][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t i = ((int64_t)blockIdx.x * 64 + lane) * 4;
     const int64_t b = blockIdx.y;
-    if (i >= inner) return;
-    float4 acc = *reinterpret_cast<const float4*>(part + b * inner + i);
-    for (int g = 1; g < groups; ++g) {
-        const float4 v = *reinterpret_cast<const float4*>(part + g * plane + b * inner + i);
-        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    const bool live = i < inner;
+    const int per = (groups + 3) / 4;
+    const int g0 = wave * per, g1 = min(groups, g0 + per);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (live) {
+#pragma unroll 4
+        for (int g = g0; g < g1; ++g) {
+            const float4 v = *reinterpret_cast<const float4*>(part + g * plane + b * inner + i);
+            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
     }
-    *reinterpret_cast<float4*>(out + b * out_bstride + i) = acc;
+    if (wave > 0) s_q[wave - 1][lane] = acc;
+    __syncthreads();
+    if (wave == 0 && live) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float4 v = s_q[k][lane];
+            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
+        *reinterpret_cast<float4*>(out + b * out_bstride + i) = acc;
+    }
 }
 
 }  // namespace
@@ -613,7 +648,7 @@ extern "C" int sr_noise_bias_act_affine_bwd2(float* d_gy, float* d_x, float* d_a
     hipLaunchKernelGGL(k_nba_aff_bwd2, dim3((unsigned)chunks, (unsigned)n, (unsigned)groups), dim3(EB), 0, st, d_gy,
                        d_x, scratch, Gx, Gmap, gmap_bstride, Gb, Gnw, gy, out, x, amap, map_bstride, noise, alpha, scale,
                        (int)c, inner, noise_bstride, cg, plane);
-    hipLaunchKernelGGL(k_plane_sum_strided, dim3((unsigned)sr_ceil_div(inner, EB * 4), (unsigned)n), dim3(EB), 0, st,
+    hipLaunchKernelGGL(k_plane_sum_strided, dim3((unsigned)sr_ceil_div(inner, 64 * 4), (unsigned)n), dim3(EB), 0, st,
                        d_amap, d_amap_bstride, scratch, plane, inner, groups);
     return sr_launch_status();
 }
