@@ -157,6 +157,8 @@ __global__ __launch_bounds__(1024) void k_mse_fwd(float* __restrict__ out, const
     __shared__ float part[16];
     float acc = 0.0f;
     const int64_t n4 = n >> 2;
+    // (sixteen loads in flight per lane: one workgroup walking a 256^2 image 48 dependent steps deep took 30 us)
+#pragma unroll 8
     for (int64_t i = threadIdx.x; i < n4; i += 1024) {
         const float4 x = reinterpret_cast<const float4*>(a)[i], y = reinterpret_cast<const float4*>(b)[i];
         const float d0 = x.x - y.x, d1 = x.y - y.y, d2 = x.z - y.z, d3 = x.w - y.w;

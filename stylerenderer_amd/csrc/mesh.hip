@@ -129,7 +129,8 @@ __global__ __launch_bounds__(1024) void k_affine3_bwd(float* __restrict__ gm, fl
     float a[12];
 #pragma unroll
     for (int k = 0; k < 12; ++k) a[k] = 0.f;
-    for (int64_t i = threadIdx.x; i < nv; i += 1024) {
+#pragma unroll 4
+    for (int64_t i = threadIdx.x; i < nv; i += 1024) {          // (loads of four vertices in flight per lane)
         const float* p = v + b * v_bstride + 3 * i;
         const float* q = g + (b * nv + i) * 3;
         const float x = p[0], y = p[1], z = p[2], g0 = q[0], g1 = q[1], g2 = q[2];
