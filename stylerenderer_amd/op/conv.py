@@ -141,20 +141,16 @@ def conv2d_wgrad_mfma(x, gy, xscale=None, gscale=None, ksize=3, stride=1, pad=1,
     for t, shape, name in ((xscale, (b, c), "xscale"), (gscale, (b, n), "gscale")):
         if t is not None and (tuple(t.shape) != shape or not t.is_contiguous() or t.dtype != torch.float32):
             raise RuntimeError("conv2d_wgrad_mfma: %s must be contiguous float32 %s" % (name, shape))
-    if (ksize == 1 and stride == 1 and pad == 0 and not transposed and c <= 4
+    if (ksize == 1 and stride == 1 and pad == 0 and not transposed and c <= 4 and xscale is None and gscale is None
             and (ih * iw) % 4 == 0 and b * n <= 65535 and n <= 4096 and os.environ.get("SR_WGRAD_SMALL", "1") != "0"):
-        # the discriminator's from-RGB layer (3 -> 128 channels, 1x1, reference model.py:304) and the map heads' skip
-        # convolutions (3 -> 4): on 64-channel MFMA tiles that is 5 % useful work; it IS the streaming row-product kernel
-        # of ToRGB with the roles of the two operands swapped — dws[b, c, n] = sum_p x[b, c, p] * gy[b, n, p] — followed
-        # by the (scaled) sum over the batch
+        # the discriminator's from-RGB layer (3 -> 128 channels, 1x1, reference model.py:304): on 64-channel MFMA tiles
+        # that is 5 % useful work; it IS the streaming row-product kernel of ToRGB with the roles of the two operands
+        # swapped — dws[b, c, n] = sum_p x[b, c, p] * gy[b, n, p] — followed by the sum over the batch.  (With operand
+        # scales — the map heads' 3 -> 4 skip layers — the two extra element-wise launches cost what the kernel saves:
+        # measured, left on the MFMA path.)
         from .smallconv import _dw
 
-        dws = _dw(x, gy)
-        if xscale is not None:
-            dws = dws * xscale[:, :, None]
-        if gscale is not None:
-            dws = dws * gscale[:, None, :]
-        return dws.sum(0).view(1, c, n)
+        return _dw(x, gy).sum(0).view(1, c, n)
     L = _lib.lib()
     nfl = L.sr_conv2d_wgrad_scratch_floats(b, c, n, ih, iw, oh, ow, ksize, stride, pad, int(bool(transposed)))
     if nfl < 0:
