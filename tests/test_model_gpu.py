@@ -399,3 +399,32 @@ def test_resblock_fork_node_equals_two_consumers(monkeypatch):
     assert torch.equal(res["1"][2], res["0"][2])
     for a, b in zip(res["1"][3], res["0"][3]):
         assert torch.equal(a, b)
+
+
+def test_torgb_fork_equals_two_consumers_bit_for_bit(monkeypatch):
+    """op.smallconv.SmallConvFork (the feature map goes on to the next layer through the ToRGB node, whose backward adds
+    the map's two gradients inside the data-gradient kernel) against ToRGB as a second consumer with autograd's own
+    addition (reference model.py:206-219): image and every parameter gradient identical."""
+    import torch
+
+    from stylerenderer_amd.model import Generator
+
+    dev = torch.device("cuda")
+    torch.manual_seed(9)
+    g = Generator(64, 64, 2).to(dev)
+    z = torch.randn(3, 64, device=dev)
+    probe = torch.randn(3, 3, 64, 64, device=dev)
+
+    def run(fork):
+        monkeypatch.setenv("SR_TORGB_FORK", "1" if fork else "0")
+        for p in g.parameters():
+            p.grad = None
+        img, _ = g([z], randomize_noise=False)
+        (img * probe).sum().backward()
+        return img.detach().clone(), {n: p.grad.clone() for n, p in g.named_parameters() if p.grad is not None}
+
+    img_a, ga = run(True)
+    img_b, gb = run(False)
+    assert torch.equal(img_a, img_b)
+    assert set(ga) == set(gb) and len(ga) > 30
+    assert not [k for k in ga if not torch.equal(ga[k], gb[k])]
