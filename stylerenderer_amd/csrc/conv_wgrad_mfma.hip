@@ -472,6 +472,37 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(const ReduceParams p) {
     }
 }
 
+// The same reduction for FEW outputs over MANY slices (the tiny-channel layers of the map heads: 12 ... 144 outputs, up to
+// 512 slices): one wave per output, lane l adds slices l, l + 64, ... in order, then the wave's fixed-order sum — instead of
+// one lane walking 512 slices (10 us in a single workgroup).
+__global__ __launch_bounds__(256) void k_wgrad_reduce_wave(const ReduceParams p) {
+    const int64_t total = (int64_t)p.nt * p.CU * p.CV;
+    const int64_t stride_s = (int64_t)p.nt * p.UP * p.VP;
+    const int lane = threadIdx.x & 63;
+    const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= total) return;
+    const int v = (int)(i % p.CV);
+    const int u = (int)((i / p.CV) % p.CU);
+    const int t = (int)(i / ((int64_t)p.CV * p.CU));
+    const float* src = p.partial + ((int64_t)t * p.UP + u) * p.VP + v;
+    float acc = 0.0f;
+    for (int s = lane; s < p.ks; s += 64) acc += src[s * stride_s];
+    acc = sr_wave_sum(acc);
+    if (lane != 0) return;
+    int slab = 0;
+#pragma unroll
+    for (int k = 0; k < 9; ++k)
+        if (t == k) slab = p.tmap[k];
+    p.out[slab * p.slab + u * p.su + v * p.sv] = acc;
+}
+
+inline void launch_wgrad_reduce(const ReduceParams& r, int64_t total, hipStream_t st) {
+    if (total <= 1024 && r.ks >= 32)
+        hipLaunchKernelGGL(k_wgrad_reduce_wave, dim3((unsigned)sr_ceil_div(total, 4)), dim3(256), 0, st, r);
+    else
+        hipLaunchKernelGGL(k_wgrad_reduce, dim3(sr_stream_grid(total, 256)), dim3(256), 0, st, r);
+}
+
 struct Plan {
     int pw, ph, pb, ut, vt;
     int tiles_x, tiles_y, tiles_b, tiles_u, tiles_v, ks, pps;
@@ -732,7 +763,7 @@ extern "C" int sr_conv2d_wgrad_mfma(float* dwt, const float* x, const float* gy,
         r.slab = C * N; r.su = N; r.sv = 1;
         for (int t = 0; t < 9; ++t) r.tmap[t] = t;
         const int64_t total = (int64_t)CUc * CVc;
-        hipLaunchKernelGGL(k_wgrad_reduce, dim3(sr_stream_grid(total, 256)), dim3(256), 0, st, r);
+        launch_wgrad_reduce(r, total, st);
         return sr_launch_status();
     }
     if (ksize == 3 && is == 2 && pad == 0 && sr_wgrad_bf16x3_enabled('g') &&
@@ -751,7 +782,7 @@ extern "C" int sr_conv2d_wgrad_mfma(float* dwt, const float* x, const float* gy,
         r.sv = transposed ? N : 1;
         for (int t = 0; t < 9; ++t) r.tmap[t] = t;
         const int64_t total = (int64_t)9 * CUc * CVc;
-        hipLaunchKernelGGL(k_wgrad_reduce, dim3(sr_stream_grid(total, 256)), dim3(256), 0, st, r);
+        launch_wgrad_reduce(r, total, st);
         return sr_launch_status();
     }
     const Plan pl = make_plan(is, (int)B, CUc, CVc, GH, GW);
@@ -783,6 +814,6 @@ extern "C" int sr_conv2d_wgrad_mfma(float* dwt, const float* x, const float* gy,
     r.sv = transposed ? N : 1;
     for (int t = 0; t < 9; ++t) r.tmap[t] = t;
     const int64_t total = (int64_t)r.nt * CUc * CVc;
-    hipLaunchKernelGGL(k_wgrad_reduce, dim3(sr_stream_grid(total, 256)), dim3(256), 0, st, r);
+    launch_wgrad_reduce(r, total, st);
     return sr_launch_status();
 }
