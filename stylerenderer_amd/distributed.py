@@ -288,6 +288,16 @@ class BucketedGradReducer:
                 self.buckets.append({"lo": lo, "hi": hi, "members": members})
                 members = []
         self.bucket_of = {i: b for b, bk in enumerate(self.buckets) for i in bk["members"]}
+        # A producer whose LAST kernel writes a parameter's whole gradient (op.weight_prep._WPrepBwd: every convolution
+        # weight, ~90 % of the bytes) may write it straight into the parameter's slot of the flat buffer: `claim` hands out
+        # a fresh view of the slot once per backward (a second contribution in the same backward gets None and autograd
+        # adds as usual); _flush then has nothing to copy for that parameter.  SR_GRAD_INPLACE=0 disables.
+        import os
+
+        self.claimed = set()
+        if os.environ.get("SR_GRAD_INPLACE", "1") != "0":
+            for i, prm in enumerate(self.params):
+                prm._sr_grad_slot = (lambda i=i: self._claim(i))
         self.single = FlatGradReducer(flat, self.world) if (len(self.buckets) == 1 and self.world > 1) else None
         self.comm = None
         self.counters, self.runs, self.eager_events = None, [], []
@@ -364,9 +374,17 @@ class BucketedGradReducer:
         return optimiser
 
     # ---- one backward ---------------------------------------------------------------------------------------
+    def _claim(self, i):
+        if not getattr(self, "active", False) or i in self.claimed:
+            return None
+        self.claimed.add(i)
+        v = self.views[i]
+        return v.view_as(v)              # a fresh tensor object over the slot: AccumulateGrad can take it as it is
+
     def begin(self):
         for p in self.params:
             p.grad = None                # autograd then ASSIGNS: no zero fill, no accumulate kernel
+        self.claimed = set()
         self.pending = [len(b["members"]) for b in self.buckets]
         self.done = [False] * len(self.buckets)
         self.next_issue = 0
@@ -393,6 +411,8 @@ class BucketedGradReducer:
     def _flush(self, b):
         members = self.buckets[b]["members"]
         have = [(self.views[i], self.params[i].grad) for i in members if self.params[i].grad is not None]
+        # gradients their producer wrote in place (see __init__): nothing to copy
+        have = [(v, g) for v, g in have if not (g.data_ptr() == v.data_ptr() and g.shape == v.shape and g.is_contiguous())]
         miss = [self.views[i] for i in members if self.params[i].grad is None]
         with torch.no_grad():
             if have:

@@ -68,7 +68,18 @@ class _WPrepBwd(Function):
             gwt = gwt.contiguous()
         if gwsq is not None:
             gwsq = gwsq.contiguous()
-        gw = torch.empty_like(w)
+        gw = None
+        slot = getattr(weight, "_sr_grad_slot", None)
+        if slot is not None and not torch.is_grad_enabled() and w is weight:
+            # the parameter's slot of a flat gradient buffer (distributed.BucketedGradReducer): this kernel writes the
+            # whole gradient, so it can write it THERE — no copy into the buffer afterwards (first contribution of a
+            # backward only; a recorded pass keeps its own tensor)
+            gw = slot()
+            if gw is not None and (gw.shape != w.shape or gw.dtype != w.dtype or gw.device != w.device
+                                   or not gw.is_contiguous()):
+                gw = None
+        if gw is None:
+            gw = torch.empty_like(w)
         with on_device_of(w):
             rc = _lib.lib().sr_weight_prep_bwd(_lib.ptr(gw), _lib.ptr(gwt), _lib.ptr(gwsq), _lib.ptr(w),
                                                float(scale), co, ci, k, co, stream_of(w))

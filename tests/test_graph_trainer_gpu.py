@@ -323,3 +323,27 @@ def test_host_released_overlap_orders_buckets_before_the_replay_ends(one_rank_gr
         assert len(done) == 4 and done == sorted(done) and t["release"] == "host"
     assert any(t["bucket_done_ms_after_replay_end"][0] < -0.25 * t["replay_ms"] for t in tries), tries
     assert a.reduce_d.counters.tolist() == [a.reduce_d.epoch] * 4
+
+
+def test_gradients_written_into_the_flat_buffer_equal_the_copied_ones(monkeypatch):
+    """distributed.BucketedGradReducer hands the convolution weights' slots of the flat gradient buffer to the kernel that
+    writes their whole gradient (op.weight_prep._WPrepBwd): the parameters after three iterations (all four phases on the
+    first) equal those of the copy-after-backward form bit for bit."""
+    dev = torch.device("cuda")
+
+    def run(inplace):
+        monkeypatch.setenv("SR_GRAD_INPLACE", "1" if inplace else "0")
+        faces = train.SyntheticFaceSource(dev, shape_dim=6, expression_dim=4, seed=3, face_sized=False)
+        tr = graph_train.GraphedTrainer(size=32, latent=32, n_mlp=2, use_mesh=True, device=dev, seed=1, batch=4,
+                                        mesh_vertices=faces.model.dim[2] // 3)
+        data = train.SyntheticImages(8, 32, dev)
+        for _ in range(3):
+            tr.step(data.batch(4), faces=faces, log=False)
+        torch.cuda.synchronize()
+        claimed = len(tr.reduce_g.claimed) + len(tr.reduce_d.claimed)
+        return tr.g_optim.flat_p.clone(), tr.d_optim.flat_p.clone(), claimed
+
+    g1, d1, n1 = run(True)
+    g0, d0, n0 = run(False)
+    assert n0 == 0 and n1 > 10
+    assert torch.equal(g1, g0) and torch.equal(d1, d0)
